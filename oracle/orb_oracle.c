@@ -1,0 +1,1152 @@
+/*
+ * orb_oracle.c -- CPU ORACLE (test infrastructure, see orb_oracle.h header note).
+ * PARITY UNPINNED at the OpenCV boundary; constants pinned by known-answer tests.
+ *
+ * Every function cites the reference file:line it restates
+ * (paths relative to the reference root).  Build with -ffp-contract=off:
+ * float expressions must not be FMA-contracted (hard part 2).
+ */
+#include "orb_oracle.h"
+#include "orb_pattern_data.h"
+
+#include <float.h>
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* ------------------------------------------------------------------ */
+/* arithmetic primitives                                               */
+/* ------------------------------------------------------------------ */
+
+/* cvRound: SSE cvtsd2si / lrint semantics = round half to even (default FP env). */
+int orc_cvround(double v) { return (int)nearbyint(v); }
+
+static int cvfloor_f(float v) { return (int)floorf(v); }
+
+/* cv::fastAtan2 polynomial (OpenCV 2.4.9+/3.x scalar path), called at
+ * src/ORBextractor.cc:105.  All fp32, no FMA. */
+float orc_fast_atan2(float y, float x) {
+  static const float p1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795);
+  static const float p3 = -0.3258083974640975f * (float)(180 / 3.1415926535897932384626433832795);
+  static const float p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795);
+  static const float p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
+  float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + (float)DBL_EPSILON);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + (float)DBL_EPSILON);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+/* Project-owned sincos replacing libm cosf/sinf at src/ORBextractor.cc:116.
+ * Double Cody-Waite reduction by pi/2 + fdlibm-degree kernels, rounded once
+ * to float: equals the correctly rounded result except when the double value
+ * sits within ~1e-16 of a float rounding tie.  Only IEEE +,-,* on doubles, so
+ * the HIP device code reproduces it bit for bit.  Valid for |rad| < 1e4. */
+void orc_sincos(float rad, float *c, float *s) {
+  const double x = (double)rad;
+  const double k = nearbyint(x * 6.36619772367581382433e-01); /* 2/pi */
+  double r = x - k * 1.57079632673412561417e+00;             /* pi/2 hi (33 bits) */
+  r = r - k * 6.07710050650619224932e-11;                     /* pi/2 lo */
+  const double z = r * r;
+  double ps = 1.58969099521155010221e-10;
+  ps = -2.50507602534068634195e-08 + z * ps;
+  ps = 2.75573137070700676789e-06 + z * ps;
+  ps = -1.98412698298579493134e-04 + z * ps;
+  ps = 8.33333333332248946124e-03 + z * ps;
+  ps = -1.66666666666666324348e-01 + z * ps;
+  const double sr = r + (r * z) * ps;
+  double pc = -1.13596475577881948265e-11;
+  pc = 2.08757232129817482790e-09 + z * pc;
+  pc = -2.75573143513906633035e-07 + z * pc;
+  pc = 2.48015872894767294178e-05 + z * pc;
+  pc = -1.38888888888741095749e-03 + z * pc;
+  pc = 4.16666666666666019037e-02 + z * pc;
+  const double cr = (1.0 - 0.5 * z) + (z * z) * pc;
+  const int n = (int)((long long)k & 3);
+  double cs, sn;
+  switch (n) {
+    case 0: cs = cr; sn = sr; break;
+    case 1: cs = -sr; sn = cr; break;
+    case 2: cs = -cr; sn = -sr; break;
+    default: cs = sr; sn = -cr; break;
+  }
+  *c = (float)cs;
+  *s = (float)sn;
+}
+
+const signed char *orc_pattern(void) { return ORC_BIT_PATTERN_31; }
+
+/* ------------------------------------------------------------------ */
+/* constructor tables: src/ORBextractor.cc:415-486                     */
+/* ------------------------------------------------------------------ */
+void orc_extractor_init(orc_extractor *e, int nfeatures, float scaleFactor, int nlevels,
+                        int iniThFAST, int minThFAST) {
+  memset(e, 0, sizeof(*e));
+  if (nlevels > ORC_MAX_LEVELS) nlevels = ORC_MAX_LEVELS;
+  e->nfeatures = nfeatures;
+  e->scaleFactor = (double)scaleFactor;
+  e->nlevels = nlevels;
+  e->iniThFAST = iniThFAST;
+  e->minThFAST = minThFAST;
+  e->mvScaleFactor[0] = 1.0f;
+  e->mvLevelSigma2[0] = 1.0f;
+  for (int i = 1; i < nlevels; i++) { /* :424-428, float*double -> float */
+    e->mvScaleFactor[i] = (float)((double)e->mvScaleFactor[i - 1] * e->scaleFactor);
+    e->mvLevelSigma2[i] = e->mvScaleFactor[i] * e->mvScaleFactor[i];
+  }
+  for (int i = 0; i < nlevels; i++) { /* :432-436 */
+    e->mvInvScaleFactor[i] = 1.0f / e->mvScaleFactor[i];
+    e->mvInvLevelSigma2[i] = 1.0f / e->mvLevelSigma2[i];
+  }
+  /* :448-458 */
+  float factor = (float)(1.0 / e->scaleFactor); /* 1.0f / double */
+  float nDesired = (float)nfeatures * (1 - factor) /
+                   (1 - (float)pow((double)factor, (double)nlevels));
+  int sum = 0;
+  for (int level = 0; level < nlevels - 1; level++) {
+    e->mnFeaturesPerLevel[level] = orc_cvround(nDesired);
+    sum += e->mnFeaturesPerLevel[level];
+    nDesired *= factor;
+  }
+  e->mnFeaturesPerLevel[nlevels - 1] = nfeatures - sum > 0 ? nfeatures - sum : 0;
+  /* umax, :471-485 */
+  const int HP = 15;
+  int v, v0;
+  int vmax = cvfloor_f(HP * sqrtf(2.f) / 2 + 1);
+  int vmin = (int)ceilf(HP * sqrtf(2.f) / 2);
+  const double hp2 = HP * HP;
+  for (v = 0; v <= vmax; ++v) e->umax[v] = orc_cvround(sqrt(hp2 - v * v));
+  for (v = HP, v0 = 0; v >= vmin; --v) {
+    while (e->umax[v0] == e->umax[v0 + 1]) ++v0;
+    e->umax[v] = v0;
+    ++v0;
+  }
+}
+
+/* src/ORBextractor.cc:1207-1208 */
+void orc_level_size(const orc_extractor *e, int W, int H, int level, int *w, int *h) {
+  float scale = e->mvInvScaleFactor[level];
+  *w = orc_cvround((float)W * scale);
+  *h = orc_cvround((float)H * scale);
+}
+
+/* ------------------------------------------------------------------ */
+/* cv::resize INTER_LINEAR, 8UC1 (OpenCV imgproc fixed-point path)      */
+/* called at src/ORBextractor.cc:1219                                  */
+/* ------------------------------------------------------------------ */
+static short sat_short_round(float v) {
+  int i = orc_cvround(v);
+  if (i > 32767) i = 32767;
+  if (i < -32768) i = -32768;
+  return (short)i;
+}
+
+void orc_resize_linear(const uint8_t *src, int sw, int sh, int sstride, uint8_t *dst, int dw,
+                       int dh, int dstride) {
+  const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+  const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+  int *xofs = (int *)malloc(sizeof(int) * dw);
+  short *ialpha = (short *)malloc(sizeof(short) * 2 * dw);
+  int *rows[2];
+  rows[0] = (int *)malloc(sizeof(int) * dw);
+  rows[1] = (int *)malloc(sizeof(int) * dw);
+  for (int dx = 0; dx < dw; dx++) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = cvfloor_f(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    xofs[dx] = sx;
+    ialpha[2 * dx] = sat_short_round((1.f - fx) * 2048);
+    ialpha[2 * dx + 1] = sat_short_round(fx * 2048);
+  }
+  for (int dy = 0; dy < dh; dy++) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = cvfloor_f(fy);
+    fy -= sy;
+    short b0 = sat_short_round((1.f - fy) * 2048);
+    short b1 = sat_short_round(fy * 2048);
+    for (int k = 0; k < 2; k++) { /* rows clamped, weights are not */
+      int r = sy + k;
+      if (r < 0) r = 0;
+      if (r >= sh) r = sh - 1;
+      const uint8_t *S = src + (size_t)r * sstride;
+      for (int dx = 0; dx < dw; dx++) {
+        int sx = xofs[dx];
+        int s1 = sx + 1 < sw ? S[sx + 1] : S[sx];
+        rows[k][dx] = S[sx] * ialpha[2 * dx] + s1 * ialpha[2 * dx + 1];
+      }
+    }
+    uint8_t *D = dst + (size_t)dy * dstride;
+    for (int x = 0; x < dw; x++)
+      D[x] = (uint8_t)((((b0 * (rows[0][x] >> 4)) >> 16) + ((b1 * (rows[1][x] >> 4)) >> 16) + 2) >> 2);
+  }
+  free(xofs);
+  free(ialpha);
+  free(rows[0]);
+  free(rows[1]);
+}
+
+/* ------------------------------------------------------------------ */
+/* cv::GaussianBlur 7x7 sigma=2 reflect-101, 8U fixed-point            */
+/* (OpenCV >= 4 bit-exact path; kernel by error diffusion, sums to 256) */
+/* called at src/ORBextractor.cc:1175                                  */
+/* ------------------------------------------------------------------ */
+static int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) {
+    if (i < 0) i = -i;
+    else i = 2 * (n - 1) - i;
+  }
+  return i;
+}
+
+void orc_gaussian_blur7(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride) {
+  static const int K[7] = {18, 34, 48, 56, 48, 34, 18};
+  uint16_t *hs = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)w * h);
+  uint8_t *row = (uint8_t *)malloc((size_t)w + 6);
+  for (int y = 0; y < h; y++) { /* horizontal pass into 8.8 fixed point (<= 65280) */
+    const uint8_t *S = src + (size_t)y * sstride;
+    memcpy(row + 3, S, w);
+    for (int i = 1; i <= 3; i++) { row[3 - i] = S[reflect101(-i, w)]; row[3 + w - 1 + i] = S[reflect101(w - 1 + i, w)]; }
+    uint16_t *H = hs + (size_t)y * w;
+    for (int x = 0; x < w; x++) {
+      const uint8_t *r = row + x;
+      H[x] = (uint16_t)(K[0] * (r[0] + r[6]) + K[1] * (r[1] + r[5]) + K[2] * (r[2] + r[4]) + K[3] * r[3]);
+    }
+  }
+  for (int y = 0; y < h; y++) { /* vertical pass, 16.16 -> u8 with round-half-up */
+    const uint16_t *r[7];
+    for (int j = 0; j < 7; j++) r[j] = hs + (size_t)reflect101(y + j - 3, h) * w;
+    uint8_t *D = dst + (size_t)y * dstride;
+    for (int x = 0; x < w; x++) {
+      uint32_t acc = (uint32_t)K[0] * ((uint32_t)r[0][x] + r[6][x]) + (uint32_t)K[1] * ((uint32_t)r[1][x] + r[5][x]) +
+                     (uint32_t)K[2] * ((uint32_t)r[2][x] + r[4][x]) + (uint32_t)K[3] * r[3][x];
+      D[x] = (uint8_t)((acc + (1u << 15)) >> 16);
+    }
+  }
+  free(row);
+  free(hs);
+}
+
+/* ------------------------------------------------------------------ */
+/* cv::FAST (FAST-9/16) with non-max suppression                       */
+/* called at src/ORBextractor.cc:874,880                               */
+/* ------------------------------------------------------------------ */
+static const int kCircle[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},   {3, 0},  {3, -1},
+                                   {2, -2}, {1, -3},  {0, -3},  {-1, -3}, {-2, -2}, {-3, -1},
+                                   {-3, 0}, {-3, 1},  {-2, 2},  {-1, 3}};
+
+static int fast_is_corner(const uint8_t *p, int stride, int t) {
+  int v = p[0];
+  int dark[16], bright[16];
+  for (int k = 0; k < 16; k++) {
+    int x = p[kCircle[k][0] + kCircle[k][1] * stride];
+    dark[k] = x < v - t;
+    bright[k] = x > v + t;
+  }
+  for (int s = 0; s < 16; s++) {
+    int cd = 0, cb = 0;
+    for (int j = 0; j < 9; j++) {
+      cd += dark[(s + j) & 15];
+      cb += bright[(s + j) & 15];
+    }
+    if (cd == 9 || cb == 9) return 1;
+  }
+  return 0;
+}
+
+/* cornerScore<16>: max(thr, max_arc min(d), max_arc min(-d)) - 1 */
+int orc_fast_score_pixel(const uint8_t *p, int stride, int threshold) {
+  int v = p[0], d[16];
+  for (int k = 0; k < 16; k++) d[k] = v - p[kCircle[k][0] + kCircle[k][1] * stride];
+  int a0 = threshold;
+  for (int s = 0; s < 16; s++) {
+    int a = INT_MAX;
+    for (int j = 0; j < 9; j++) if (d[(s + j) & 15] < a) a = d[(s + j) & 15];
+    if (a > a0) a0 = a;
+  }
+  int b0 = -a0;
+  for (int s = 0; s < 16; s++) {
+    int b = INT_MIN;
+    for (int j = 0; j < 9; j++) if (d[(s + j) & 15] > b) b = d[(s + j) & 15];
+    if (b < b0) b0 = b;
+  }
+  return -b0 - 1;
+}
+
+/* Brute-force statement of cv::FAST(...,nonmax=true): kept as the readable spec and
+ * as the cross-check of the optimized orc_fast_nms below (tests/test_oracle_*.py). */
+int orc_fast_nms_bruteforce(const uint8_t *img, int w, int h, int stride, int threshold, int *xs,
+                            int *ys, int *scores, int cap) {
+  if (w < 7 || h < 7) return 0;
+  if (threshold < 0) threshold = 0;
+  if (threshold > 255) threshold = 255;
+  uint8_t *sc = (uint8_t *)calloc((size_t)w * h, 1);
+  uint8_t *is = (uint8_t *)calloc((size_t)w * h, 1);
+  for (int i = 3; i < h - 3; i++)
+    for (int j = 3; j < w - 3; j++) {
+      const uint8_t *p = img + (size_t)i * stride + j;
+      if (fast_is_corner(p, stride, threshold)) {
+        is[(size_t)i * w + j] = 1;
+        sc[(size_t)i * w + j] = (uint8_t)orc_fast_score_pixel(p, stride, threshold);
+      }
+    }
+  int n = 0;
+  for (int i = 3; i < h - 3; i++)
+    for (int j = 3; j < w - 3; j++) {
+      if (!is[(size_t)i * w + j]) continue;
+      int s = sc[(size_t)i * w + j];
+      const uint8_t *r0 = sc + (size_t)(i - 1) * w + j, *r1 = sc + (size_t)i * w + j,
+                    *r2 = sc + (size_t)(i + 1) * w + j;
+      if (s > r1[-1] && s > r1[1] && s > r0[-1] && s > r0[0] && s > r0[1] && s > r2[-1] &&
+          s > r2[0] && s > r2[1]) {
+        if (n < cap) { xs[n] = j; ys[n] = i; scores[n] = s; }
+        n++;
+      }
+    }
+  free(sc);
+  free(is);
+  return n;
+}
+
+/* cornerScore<16> with OpenCV's early-outs (same value as orc_fast_score_pixel). */
+static int corner_score16(const uint8_t *ptr, const int pixel[25], int threshold) {
+  const int K = 8, N = K * 3 + 1;
+  int k, v = ptr[0];
+  short d[25];
+  for (k = 0; k < N; k++) d[k] = (short)(v - ptr[pixel[k]]);
+  int a0 = threshold;
+  for (k = 0; k < 16; k += 2) {
+    int a = d[k + 1] < d[k + 2] ? d[k + 1] : d[k + 2];
+    if (d[k + 3] < a) a = d[k + 3];
+    if (a <= a0) continue;
+    for (int j = 4; j <= 8; j++) if (d[k + j] < a) a = d[k + j];
+    int t = a < d[k] ? a : d[k];
+    if (t > a0) a0 = t;
+    t = a < d[k + 9] ? a : d[k + 9];
+    if (t > a0) a0 = t;
+  }
+  int b0 = -a0;
+  for (k = 0; k < 16; k += 2) {
+    int b = d[k + 1] > d[k + 2] ? d[k + 1] : d[k + 2];
+    for (int j = 3; j <= 5; j++) if (d[k + j] > b) b = d[k + j];
+    if (b >= b0) continue;
+    for (int j = 6; j <= 8; j++) if (d[k + j] > b) b = d[k + j];
+    int t = b > d[k] ? b : d[k];
+    if (t < b0) b0 = t;
+    t = b > d[k + 9] ? b : d[k + 9];
+    if (t < b0) b0 = t;
+  }
+  return -b0 - 1;
+}
+
+/* FAST_t<16> as OpenCV runs it: threshold table quick-reject, 9-of-16 arc test,
+ * 3 rolling score rows for the 3x3 non-max suppression, raster emission. */
+int orc_fast_nms(const uint8_t *img, int w, int h, int stride, int threshold, int *xs, int *ys,
+                 int *scores, int cap) {
+  if (w < 7 || h < 7) return 0;
+  const int K = 8, N = 16 + K + 1;
+  int pixel[25];
+  for (int k = 0; k < 16; k++) pixel[k] = kCircle[k][0] + kCircle[k][1] * stride;
+  for (int k = 16; k < 25; k++) pixel[k] = pixel[k - 16];
+  if (threshold < 0) threshold = 0;
+  if (threshold > 255) threshold = 255;
+  uint8_t tab[512];
+  for (int i = -255; i <= 255; i++) tab[i + 255] = (uint8_t)(i < -threshold ? 1 : i > threshold ? 2 : 0);
+  uint8_t *bufmem = (uint8_t *)calloc((size_t)w * 3, 1);
+  int *cpmem = (int *)malloc(sizeof(int) * (size_t)(w + 1) * 3);
+  uint8_t *buf[3] = {bufmem, bufmem + w, bufmem + 2 * w};
+  int *cpbuf[3] = {cpmem + 1, cpmem + 1 + (w + 1), cpmem + 1 + 2 * (w + 1)};
+  int n = 0;
+  for (int i = 3; i < h - 2; i++) {
+    const uint8_t *ptr = img + (size_t)i * stride + 3;
+    uint8_t *curr = buf[(i - 3) % 3];
+    int *cornerpos = cpbuf[(i - 3) % 3];
+    memset(curr, 0, w);
+    int ncorners = 0;
+    if (i < h - 3) {
+      for (int j = 3; j < w - 3; j++, ptr++) {
+        int v = ptr[0];
+        const uint8_t *t = &tab[0] - v + 255;
+        int d = t[ptr[pixel[0]]] | t[ptr[pixel[8]]];
+        if (d == 0) continue;
+        d &= t[ptr[pixel[2]]] | t[ptr[pixel[10]]];
+        d &= t[ptr[pixel[4]]] | t[ptr[pixel[12]]];
+        d &= t[ptr[pixel[6]]] | t[ptr[pixel[14]]];
+        if (d == 0) continue;
+        d &= t[ptr[pixel[1]]] | t[ptr[pixel[9]]];
+        d &= t[ptr[pixel[3]]] | t[ptr[pixel[11]]];
+        d &= t[ptr[pixel[5]]] | t[ptr[pixel[13]]];
+        d &= t[ptr[pixel[7]]] | t[ptr[pixel[15]]];
+        if (d & 1) {
+          int vt = v - threshold, count = 0;
+          for (int k = 0; k < N; k++) {
+            int x = ptr[pixel[k]];
+            if (x < vt) {
+              if (++count > K) { cornerpos[ncorners++] = j; curr[j] = (uint8_t)corner_score16(ptr, pixel, threshold); break; }
+            } else count = 0;
+          }
+        }
+        if (d & 2) {
+          int vt = v + threshold, count = 0;
+          for (int k = 0; k < N; k++) {
+            int x = ptr[pixel[k]];
+            if (x > vt) {
+              if (++count > K) { cornerpos[ncorners++] = j; curr[j] = (uint8_t)corner_score16(ptr, pixel, threshold); break; }
+            } else count = 0;
+          }
+        }
+      }
+    }
+    cornerpos[-1] = ncorners;
+    if (i == 3) continue;
+    const uint8_t *prev = buf[(i - 4 + 3) % 3];
+    const uint8_t *pprev = buf[(i - 5 + 3) % 3];
+    cornerpos = cpbuf[(i - 4 + 3) % 3];
+    ncorners = cornerpos[-1];
+    for (int k = 0; k < ncorners; k++) {
+      int j = cornerpos[k];
+      int score = prev[j];
+      if (score > prev[j + 1] && score > prev[j - 1] && score > pprev[j - 1] && score > pprev[j] &&
+          score > pprev[j + 1] && score > curr[j - 1] && score > curr[j] && score > curr[j + 1]) {
+        if (n < cap) { xs[n] = j; ys[n] = i - 1; scores[n] = score; }
+        n++;
+      }
+    }
+  }
+  free(bufmem);
+  free(cpmem);
+  return n;
+}
+
+/* ------------------------------------------------------------------ */
+/* grid stage: src/ORBextractor.cc:815-896                             */
+/* ------------------------------------------------------------------ */
+int orc_grid_candidates(const orc_extractor *e, const uint8_t *img, int cols, int rows, int stride,
+                        float *xs, float *ys, float *resp, int cap) {
+  const float W = 30;
+  const int minBorderX = 19 - 3, minBorderY = minBorderX;
+  const int maxBorderX = cols - 19 + 3, maxBorderY = rows - 19 + 3;
+  const float width = (float)(maxBorderX - minBorderX);
+  const float height = (float)(maxBorderY - minBorderY);
+  const int nCols = (int)(width / W);
+  const int nRows = (int)(height / W);
+  if (nCols <= 0 || nRows <= 0) return 0; /* reference would divide by zero */
+  const int wCell = (int)ceilf(width / nCols);
+  const int hCell = (int)ceilf(height / nRows);
+  int tmpcap = (wCell + 6) * (hCell + 6);
+  int *tx = (int *)malloc(sizeof(int) * tmpcap * 3), *ty = tx + tmpcap, *ts = ty + tmpcap;
+  int n = 0;
+  for (int i = 0; i < nRows; i++) {
+    const float iniY = (float)(minBorderY + i * hCell);
+    float maxY = iniY + hCell + 6;
+    if (iniY >= maxBorderY - 3) continue;
+    if (maxY > maxBorderY) maxY = (float)maxBorderY;
+    for (int j = 0; j < nCols; j++) {
+      const float iniX = (float)(minBorderX + j * wCell);
+      float maxX = iniX + wCell + 6;
+      if (iniX >= maxBorderX - 6) continue;
+      if (maxX > maxBorderX) maxX = (float)maxBorderX;
+      const int y0 = (int)iniY, y1 = (int)maxY, x0 = (int)iniX, x1 = (int)maxX;
+      const uint8_t *sub = img + (size_t)y0 * stride + x0;
+      int c = orc_fast_nms(sub, x1 - x0, y1 - y0, stride, e->iniThFAST, tx, ty, ts, tmpcap);
+      if (c == 0) c = orc_fast_nms(sub, x1 - x0, y1 - y0, stride, e->minThFAST, tx, ty, ts, tmpcap);
+      for (int k = 0; k < c; k++) {
+        if (n < cap) {
+          xs[n] = (float)tx[k] + (float)(j * wCell);
+          ys[n] = (float)ty[k] + (float)(i * hCell);
+          resp[n] = (float)ts[k];
+        }
+        n++;
+      }
+    }
+  }
+  free(tx);
+  return n;
+}
+
+/* ------------------------------------------------------------------ */
+/* DistributeOctTree + DivideNode: src/ORBextractor.cc:498-558,566-808 */
+/* std::list emulated with a node pool (index = creation order); the    */
+/* reference's (count, pointer) sort key becomes (count, creation order)*/
+/* -- documented deviation, SURVEY.md 7 hard part 4.                    */
+/* ------------------------------------------------------------------ */
+typedef struct {
+  int ULx, ULy, URx, URy, BLx, BLy, BRx, BRy;
+  int *keys; /* indices into the input arrays */
+  int nkeys;
+  int noMore;
+  int prev, next; /* list links, -1 = none */
+} onode;
+
+typedef struct {
+  onode *pool;
+  int npool, cappool;
+  int head, tail, size;
+} olist;
+
+static int ol_new(olist *L) {
+  if (L->npool == L->cappool) {
+    L->cappool = L->cappool ? L->cappool * 2 : 256;
+    L->pool = (onode *)realloc(L->pool, sizeof(onode) * L->cappool);
+  }
+  memset(&L->pool[L->npool], 0, sizeof(onode));
+  return L->npool++;
+}
+static void ol_push_back(olist *L, int i) {
+  L->pool[i].prev = L->tail;
+  L->pool[i].next = -1;
+  if (L->tail >= 0) L->pool[L->tail].next = i; else L->head = i;
+  L->tail = i;
+  L->size++;
+}
+static void ol_push_front(olist *L, int i) {
+  L->pool[i].next = L->head;
+  L->pool[i].prev = -1;
+  if (L->head >= 0) L->pool[L->head].prev = i; else L->tail = i;
+  L->head = i;
+  L->size++;
+}
+static int ol_erase(olist *L, int i) { /* returns next */
+  int p = L->pool[i].prev, n = L->pool[i].next;
+  if (p >= 0) L->pool[p].next = n; else L->head = n;
+  if (n >= 0) L->pool[n].prev = p; else L->tail = p;
+  L->size--;
+  return n;
+}
+
+/* DivideNode :498-558.  Children are allocated in the pool (c[0..3]) but not linked. */
+static void divide_node(olist *L, int pi, const float *xs, const float *ys, int c[4]) {
+  for (int k = 0; k < 4; k++) c[k] = ol_new(L);
+  onode *P = &L->pool[pi];
+  const int halfX = (int)ceilf((float)(P->URx - P->ULx) / 2);
+  const int halfY = (int)ceilf((float)(P->BRy - P->ULy) / 2);
+  onode *n1 = &L->pool[c[0]], *n2 = &L->pool[c[1]], *n3 = &L->pool[c[2]], *n4 = &L->pool[c[3]];
+  n1->ULx = P->ULx; n1->ULy = P->ULy;
+  n1->URx = P->ULx + halfX; n1->URy = P->ULy;
+  n1->BLx = P->ULx; n1->BLy = P->ULy + halfY;
+  n1->BRx = P->ULx + halfX; n1->BRy = P->ULy + halfY;
+  n2->ULx = n1->URx; n2->ULy = n1->URy;
+  n2->URx = P->URx; n2->URy = P->URy;
+  n2->BLx = n1->BRx; n2->BLy = n1->BRy;
+  n2->BRx = P->URx; n2->BRy = P->ULy + halfY;
+  n3->ULx = n1->BLx; n3->ULy = n1->BLy;
+  n3->URx = n1->BRx; n3->URy = n1->BRy;
+  n3->BLx = P->BLx; n3->BLy = P->BLy;
+  n3->BRx = n1->BRx; n3->BRy = P->BLy;
+  n4->ULx = n3->URx; n4->ULy = n3->URy;
+  n4->URx = n2->BRx; n4->URy = n2->BRy;
+  n4->BLx = n3->BRx; n4->BLy = n3->BRy;
+  n4->BRx = P->BRx; n4->BRy = P->BRy;
+  for (int k = 0; k < 4; k++) {
+    L->pool[c[k]].keys = (int *)malloc(sizeof(int) * (P->nkeys > 0 ? P->nkeys : 1));
+    L->pool[c[k]].nkeys = 0;
+  }
+  for (int i = 0; i < P->nkeys; i++) {
+    int id = P->keys[i];
+    onode *t;
+    if (xs[id] < (float)n1->URx) t = (ys[id] < (float)n1->BRy) ? n1 : n3;
+    else if (ys[id] < (float)n1->BRy) t = n2;
+    else t = n4;
+    t->keys[t->nkeys++] = id;
+  }
+  for (int k = 0; k < 4; k++)
+    if (L->pool[c[k]].nkeys == 1) L->pool[c[k]].noMore = 1;
+}
+
+typedef struct { int count, seq; } szptr;
+static int szptr_cmp(const void *a, const void *b) {
+  const szptr *A = (const szptr *)a, *B = (const szptr *)b;
+  if (A->count != B->count) return A->count < B->count ? -1 : 1;
+  return A->seq < B->seq ? -1 : (A->seq > B->seq ? 1 : 0);
+}
+
+int orc_distribute_octtree(const float *xs, const float *ys, const float *resp, int n, int minX,
+                           int maxX, int minY, int maxY, int N, int *out_idx, int cap) {
+  const int nIni = (int)roundf((float)(maxX - minX) / (float)(maxY - minY));
+  const float hX = (float)(maxX - minX) / (float)nIni;
+  olist L;
+  memset(&L, 0, sizeof(L));
+  L.head = L.tail = -1;
+  if (nIni <= 0) return 0; /* reference assumes width>height (:560) */
+  int *ini = (int *)malloc(sizeof(int) * nIni);
+  for (int i = 0; i < nIni; i++) {
+    int ni = ol_new(&L);
+    onode *nd = &L.pool[ni];
+    nd->ULx = (int)(hX * (float)i); nd->ULy = 0;
+    nd->URx = (int)(hX * (float)(i + 1)); nd->URy = 0;
+    nd->BLx = nd->ULx; nd->BLy = maxY - minY;
+    nd->BRx = nd->URx; nd->BRy = maxY - minY;
+    nd->keys = (int *)malloc(sizeof(int) * (n > 0 ? n : 1));
+    nd->nkeys = 0;
+    ol_push_back(&L, ni);
+    ini[i] = ni;
+  }
+  for (int i = 0; i < n; i++) {
+    int b = (int)(xs[i] / hX);
+    if (b >= nIni) b = nIni - 1; /* reference: out-of-range write (UB); clamp */
+    onode *nd = &L.pool[ini[b]];
+    nd->keys[nd->nkeys++] = i;
+  }
+  for (int lit = L.head; lit >= 0;) { /* :608-619 */
+    if (L.pool[lit].nkeys == 1) { L.pool[lit].noMore = 1; lit = L.pool[lit].next; }
+    else if (L.pool[lit].nkeys == 0) lit = ol_erase(&L, lit);
+    else lit = L.pool[lit].next;
+  }
+  int bFinish = 0;
+  szptr *vSize = NULL; int nSize = 0, capSize = 0;
+#define VS_PUSH(cnt, sq) do { if (nSize == capSize) { capSize = capSize ? capSize * 2 : 256; \
+      vSize = (szptr *)realloc(vSize, sizeof(szptr) * capSize); } \
+      vSize[nSize].count = (cnt); vSize[nSize].seq = (sq); nSize++; } while (0)
+  while (!bFinish) {
+    int prevSize = L.size;
+    int lit = L.head;
+    int nToExpand = 0;
+    nSize = 0;
+    while (lit >= 0) {
+      if (L.pool[lit].noMore) { lit = L.pool[lit].next; continue; }
+      int c[4];
+      divide_node(&L, lit, xs, ys, c);
+      for (int k = 0; k < 4; k++) {
+        if (L.pool[c[k]].nkeys > 0) {
+          ol_push_front(&L, c[k]);
+          if (L.pool[c[k]].nkeys > 1) { nToExpand++; VS_PUSH(L.pool[c[k]].nkeys, c[k]); }
+        }
+      }
+      lit = ol_erase(&L, lit);
+    }
+    if (L.size >= N || L.size == prevSize) {
+      bFinish = 1;
+    } else if (L.size + nToExpand * 3 > N) {
+      while (!bFinish) {
+        prevSize = L.size;
+        int nPrev = nSize;
+        szptr *vPrev = (szptr *)malloc(sizeof(szptr) * (nPrev > 0 ? nPrev : 1));
+        memcpy(vPrev, vSize, sizeof(szptr) * nPrev);
+        nSize = 0;
+        qsort(vPrev, nPrev, sizeof(szptr), szptr_cmp);
+        for (int j = nPrev - 1; j >= 0; j--) {
+          int c[4];
+          int pi = vPrev[j].seq;
+          divide_node(&L, pi, xs, ys, c);
+          for (int k = 0; k < 4; k++) {
+            if (L.pool[c[k]].nkeys > 0) {
+              ol_push_front(&L, c[k]);
+              if (L.pool[c[k]].nkeys > 1) VS_PUSH(L.pool[c[k]].nkeys, c[k]);
+            }
+          }
+          ol_erase(&L, pi);
+          if (L.size >= N) break;
+        }
+        free(vPrev);
+        if (L.size >= N || L.size == prevSize) bFinish = 1;
+      }
+    }
+  }
+#undef VS_PUSH
+  int nout = 0;
+  for (int lit = L.head; lit >= 0; lit = L.pool[lit].next) { /* :787-805 */
+    onode *nd = &L.pool[lit];
+    int best = nd->keys[0];
+    float maxR = resp[best];
+    for (int k = 1; k < nd->nkeys; k++)
+      if (resp[nd->keys[k]] > maxR) { best = nd->keys[k]; maxR = resp[best]; }
+    if (nout < cap) out_idx[nout] = best;
+    nout++;
+  }
+  for (int i = 0; i < L.npool; i++) free(L.pool[i].keys);
+  free(L.pool);
+  free(vSize);
+  free(ini);
+  return nout;
+}
+
+/* ------------------------------------------------------------------ */
+/* IC_Angle: src/ORBextractor.cc:78-106                                */
+/* ------------------------------------------------------------------ */
+float orc_ic_angle(const uint8_t *img, int stride, int x, int y, const int *umax) {
+  int m_01 = 0, m_10 = 0;
+  const uint8_t *center = img + (size_t)y * stride + x;
+  for (int u = -15; u <= 15; ++u) m_10 += u * center[u];
+  for (int v = 1; v <= 15; ++v) {
+    int v_sum = 0;
+    int d = umax[v];
+    for (int u = -d; u <= d; ++u) {
+      int val_plus = center[u + v * stride], val_minus = center[u - v * stride];
+      v_sum += (val_plus - val_minus);
+      m_10 += u * (val_plus + val_minus);
+    }
+    m_01 += v * v_sum;
+  }
+  return orc_fast_atan2((float)m_01, (float)m_10);
+}
+
+/* ------------------------------------------------------------------ */
+/* computeOrbDescriptor: src/ORBextractor.cc:111-152                   */
+/* ------------------------------------------------------------------ */
+void orc_descriptor(const uint8_t *blur, int stride, int x, int y, float angle_deg,
+                    uint8_t desc[32]) {
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+  float angle = angle_deg * factorPI;
+  float a, b;
+  orc_sincos(angle, &a, &b);
+  const uint8_t *center = blur + (size_t)y * stride + x;
+  const signed char *pat = ORC_BIT_PATTERN_31;
+  for (int i = 0; i < 32; ++i, pat += 32) {
+    int val = 0;
+    for (int k = 0; k < 8; k++) {
+      float x0 = (float)pat[4 * k], y0 = (float)pat[4 * k + 1];
+      float x1 = (float)pat[4 * k + 2], y1 = (float)pat[4 * k + 3];
+      int t0 = center[orc_cvround(x0 * b + y0 * a) * stride + orc_cvround(x0 * a - y0 * b)];
+      int t1 = center[orc_cvround(x1 * b + y1 * a) * stride + orc_cvround(x1 * a - y1 * b)];
+      val |= (t0 < t1) << k;
+    }
+    desc[i] = (uint8_t)val;
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* ORBextractor::operator(): src/ORBextractor.cc:1119-1197             */
+/* ------------------------------------------------------------------ */
+int orc_extract(orc_extractor *e, const uint8_t *img, int W, int H, int stride, orc_keypoint *kps,
+                uint8_t *desc, int capacity, int *n_out, uint8_t *pyr_out) {
+  *n_out = 0;
+  if (!img || W <= 0 || H <= 0) return 0; /* :1122 empty image -> silent return */
+  const int nl = e->nlevels;
+  int lw[ORC_MAX_LEVELS], lh[ORC_MAX_LEVELS];
+  uint8_t *lev[ORC_MAX_LEVELS];
+  double t0 = now_s();
+  /* ComputePyramid :1203-1234 (the 19-px border is never read: SURVEY.md 8) */
+  for (int l = 0; l < nl; l++) {
+    orc_level_size(e, W, H, l, &lw[l], &lh[l]);
+    lev[l] = (uint8_t *)malloc((size_t)lw[l] * lh[l] > 0 ? (size_t)lw[l] * lh[l] : 1);
+    if (l == 0) {
+      for (int y = 0; y < H; y++) memcpy(lev[0] + (size_t)y * W, img + (size_t)y * stride, W);
+    } else {
+      orc_resize_linear(lev[l - 1], lw[l - 1], lh[l - 1], lw[l - 1], lev[l], lw[l], lh[l], lw[l]);
+    }
+  }
+  double t1 = now_s();
+  e->t_pyramid += t1 - t0;
+  if (pyr_out) {
+    size_t off = 0;
+    for (int l = 0; l < nl; l++) { memcpy(pyr_out + off, lev[l], (size_t)lw[l] * lh[l]); off += (size_t)lw[l] * lh[l]; }
+  }
+  /* ComputeKeyPointsOctTree :815-922 */
+  orc_keypoint *lk[ORC_MAX_LEVELS];
+  int ln[ORC_MAX_LEVELS];
+  int total = 0;
+  for (int l = 0; l < nl; l++) {
+    double ta = now_s();
+    const int minBX = 16, minBY = 16, maxBX = lw[l] - 16, maxBY = lh[l] - 16;
+    int cap = (lw[l] * lh[l]) / 4 + 16;
+    float *xs = (float *)malloc(sizeof(float) * cap * 3), *ys = xs + cap, *rs = ys + cap;
+    int nc = (lw[l] > 32 && lh[l] > 32) ? orc_grid_candidates(e, lev[l], lw[l], lh[l], lw[l], xs, ys, rs, cap) : 0;
+    double tb = now_s();
+    e->t_fast += tb - ta;
+    int *sel = (int *)malloc(sizeof(int) * (nc + 4));
+    int ns = nc > 0 ? orc_distribute_octtree(xs, ys, rs, nc, minBX, maxBX, minBY, maxBY,
+                                             e->mnFeaturesPerLevel[l], sel, nc + 4) : 0;
+    e->t_octree += now_s() - tb;
+    lk[l] = (orc_keypoint *)malloc(sizeof(orc_keypoint) * (ns > 0 ? ns : 1));
+    ln[l] = ns;
+    const int scaledPatchSize = (int)(31 * e->mvScaleFactor[l]);
+    for (int i = 0; i < ns; i++) {
+      orc_keypoint *k = &lk[l][i];
+      k->x = xs[sel[i]] + (float)minBX;
+      k->y = ys[sel[i]] + (float)minBY;
+      k->size = (float)scaledPatchSize;
+      k->angle = -1;
+      k->response = rs[sel[i]];
+      k->octave = l;
+      k->class_id = -1;
+    }
+    free(sel);
+    free(xs);
+    total += ns;
+  }
+  double t2 = now_s();
+  for (int l = 0; l < nl; l++) /* :920-921 */
+    for (int i = 0; i < ln[l]; i++)
+      lk[l][i].angle = orc_ic_angle(lev[l], lw[l], orc_cvround(lk[l][i].x), orc_cvround(lk[l][i].y), e->umax);
+  e->t_orient += now_s() - t2;
+  int rc = 0;
+  if (total > capacity) rc = -1;
+  int offset = 0;
+  for (int l = 0; l < nl && rc == 0; l++) {
+    if (ln[l] == 0) continue;
+    double ta = now_s();
+    uint8_t *blur = (uint8_t *)malloc((size_t)lw[l] * lh[l]);
+    orc_gaussian_blur7(lev[l], lw[l], lh[l], lw[l], blur, lw[l]);
+    double tb = now_s();
+    e->t_blur += tb - ta;
+    for (int i = 0; i < ln[l]; i++) {
+      orc_keypoint *k = &lk[l][i];
+      orc_descriptor(blur, lw[l], orc_cvround(k->x), orc_cvround(k->y), k->angle, desc + (size_t)(offset + i) * 32);
+    }
+    if (l != 0) {
+      float scale = e->mvScaleFactor[l];
+      for (int i = 0; i < ln[l]; i++) { lk[l][i].x *= scale; lk[l][i].y *= scale; }
+    }
+    memcpy(kps + offset, lk[l], sizeof(orc_keypoint) * ln[l]);
+    offset += ln[l];
+    free(blur);
+    e->t_desc += now_s() - tb;
+  }
+  for (int l = 0; l < nl; l++) { free(lk[l]); free(lev[l]); }
+  *n_out = rc == 0 ? total : 0;
+  return rc;
+}
+
+/* ------------------------------------------------------------------ */
+/* matcher: src/ORBmatcher.cc                                          */
+/* ------------------------------------------------------------------ */
+int orc_descriptor_distance(const uint8_t *a, const uint8_t *b) { /* :1828-1844 */
+  int dist = 0;
+  for (int i = 0; i < 8; i++) {
+    uint32_t pa, pb;
+    memcpy(&pa, a + 4 * i, 4);
+    memcpy(&pb, b + 4 * i, 4);
+    uint32_t v = pa ^ pb;
+    v = v - ((v >> 1) & 0x55555555);
+    v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+    dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+  }
+  return dist;
+}
+
+void orc_three_maxima(const int *hs, int L, int *ind1, int *ind2, int *ind3) { /* :1777-1821 */
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = hs[i];
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; *ind3 = *ind2; *ind2 = *ind1; *ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; *ind3 = *ind2; *ind2 = i; }
+    else if (s > max3) { max3 = s; *ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { *ind2 = -1; *ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { *ind3 = -1; }
+}
+
+#define HISTO_LENGTH 30
+#define TH_LOW 50
+#define TH_HIGH 100
+
+typedef struct { int *v[HISTO_LENGTH]; int n[HISTO_LENGTH]; } rothist;
+static void rh_init(rothist *h, int cap) { for (int i = 0; i < HISTO_LENGTH; i++) { h->v[i] = (int *)malloc(sizeof(int) * (cap > 0 ? cap : 1)); h->n[i] = 0; } }
+static void rh_free(rothist *h) { for (int i = 0; i < HISTO_LENGTH; i++) free(h->v[i]); }
+static void rh_push(rothist *h, float a1, float a2, int idx) { /* :272-281 */
+  const float factor = 1.0f / HISTO_LENGTH;
+  float rot = a1 - a2;
+  if (rot < 0.0) rot += 360.0f;
+  int bin = (int)roundf(rot * factor);
+  if (bin == HISTO_LENGTH) bin = 0;
+  h->v[bin][h->n[bin]++] = idx;
+}
+static int rh_prune(rothist *h, int32_t *arr) { /* :303-322; returns removed count */
+  int i1 = -1, i2 = -1, i3 = -1, removed = 0;
+  orc_three_maxima(h->n, HISTO_LENGTH, &i1, &i2, &i3);
+  for (int i = 0; i < HISTO_LENGTH; i++) {
+    if (i == i1 || i == i2 || i == i3) continue;
+    for (int j = 0; j < h->n[i]; j++) { arr[h->v[i][j]] = -1; removed++; }
+  }
+  return removed;
+}
+
+/* merge-walk of two ascending node lists (std::map iteration + lower_bound, :211-300) */
+#define FV_WALK_BEGIN(fv1, fv2) \
+  { int a_ = 0, b_ = 0; \
+    while (a_ < (fv1)->n_nodes && b_ < (fv2)->n_nodes) { \
+      if ((fv1)->node_ids[a_] == (fv2)->node_ids[b_]) {
+#define FV_WALK_END(fv1, fv2) \
+        a_++; b_++; \
+      } else if ((fv1)->node_ids[a_] < (fv2)->node_ids[b_]) { \
+        while (a_ < (fv1)->n_nodes && (fv1)->node_ids[a_] < (fv2)->node_ids[b_]) a_++; \
+      } else { \
+        while (b_ < (fv2)->n_nodes && (fv2)->node_ids[b_] < (fv1)->node_ids[a_]) b_++; \
+      } } }
+
+int orc_search_by_bow(const uint8_t *desc1, const uint8_t *has_mp1, const float *ang1, int n1,
+                      const orc_featvec *fv1, const uint8_t *desc2, const float *ang2, int n2,
+                      const orc_featvec *fv2, float nnratio, int check_ori, int32_t *match_f) {
+  (void)n1;
+  for (int i = 0; i < n2; i++) match_f[i] = -1;
+  int nmatches = 0;
+  rothist rh;
+  rh_init(&rh, n2);
+  FV_WALK_BEGIN(fv1, fv2)
+    for (int iKF = fv1->offsets[a_]; iKF < fv1->offsets[a_ + 1]; iKF++) {
+      const unsigned realIdxKF = fv1->indices[iKF];
+      if (!has_mp1[realIdxKF]) continue;
+      const uint8_t *dKF = desc1 + (size_t)realIdxKF * 32;
+      int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+      for (int iF = fv2->offsets[b_]; iF < fv2->offsets[b_ + 1]; iF++) {
+        const unsigned realIdxF = fv2->indices[iF];
+        if (match_f[realIdxF] >= 0) continue;
+        const int dist = orc_descriptor_distance(dKF, desc2 + (size_t)realIdxF * 32);
+        if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = (int)realIdxF; }
+        else if (dist < bestDist2) bestDist2 = dist;
+      }
+      if (bestDist1 <= TH_LOW) {
+        if ((float)bestDist1 < nnratio * (float)bestDist2) {
+          match_f[bestIdxF] = (int32_t)realIdxKF;
+          if (check_ori) rh_push(&rh, ang1[realIdxKF], ang2[bestIdxF], bestIdxF);
+          nmatches++;
+        }
+      }
+    }
+  FV_WALK_END(fv1, fv2)
+  if (check_ori) nmatches -= rh_prune(&rh, match_f);
+  rh_free(&rh);
+  return nmatches;
+}
+
+int orc_search_by_bow_kf(const uint8_t *desc1, const uint8_t *has_mp1, const float *ang1, int n1,
+                         const orc_featvec *fv1, const uint8_t *desc2, const uint8_t *has_mp2,
+                         const float *ang2, int n2, const orc_featvec *fv2, float nnratio,
+                         int check_ori, int32_t *match12) {
+  for (int i = 0; i < n1; i++) match12[i] = -1;
+  uint8_t *matched2 = (uint8_t *)calloc(n2 > 0 ? n2 : 1, 1);
+  int nmatches = 0;
+  rothist rh;
+  rh_init(&rh, n1);
+  FV_WALK_BEGIN(fv1, fv2)
+    for (int i1 = fv1->offsets[a_]; i1 < fv1->offsets[a_ + 1]; i1++) {
+      const unsigned idx1 = fv1->indices[i1];
+      if (!has_mp1[idx1]) continue;
+      const uint8_t *d1 = desc1 + (size_t)idx1 * 32;
+      int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+      for (int i2 = fv2->offsets[b_]; i2 < fv2->offsets[b_ + 1]; i2++) {
+        const unsigned idx2 = fv2->indices[i2];
+        if (matched2[idx2] || !has_mp2[idx2]) continue;
+        int dist = orc_descriptor_distance(d1, desc2 + (size_t)idx2 * 32);
+        if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = (int)idx2; }
+        else if (dist < bestDist2) bestDist2 = dist;
+      }
+      if (bestDist1 < TH_LOW) {
+        if ((float)bestDist1 < nnratio * (float)bestDist2) {
+          match12[idx1] = bestIdx2;
+          matched2[bestIdx2] = 1;
+          if (check_ori) rh_push(&rh, ang1[idx1], ang2[bestIdx2], (int)idx1);
+          nmatches++;
+        }
+      }
+    }
+  FV_WALK_END(fv1, fv2)
+  if (check_ori) nmatches -= rh_prune(&rh, match12);
+  rh_free(&rh);
+  free(matched2);
+  return nmatches;
+}
+
+/* CheckDistEpipolarLine :156-175 */
+static int check_epipolar(float x1, float y1, float x2, float y2, const float *F, float sigma2) {
+  const float a = x1 * F[0] + y1 * F[3] + F[6];
+  const float b = x1 * F[1] + y1 * F[4] + F[7];
+  const float c = x1 * F[2] + y1 * F[5] + F[8];
+  const float num = a * x2 + b * y2 + c;
+  const float den = a * a + b * b;
+  if (den == 0) return 0;
+  const float dsqr = num * num / den;
+  return (double)dsqr < 3.84 * (double)sigma2;
+}
+
+int orc_search_for_triangulation(const uint8_t *desc1, const uint8_t *has_mp1, const float *x1,
+                                 const float *y1, const float *ang1, const uint8_t *stereo1, int n1,
+                                 const orc_featvec *fv1, const uint8_t *desc2,
+                                 const uint8_t *has_mp2, const float *x2, const float *y2,
+                                 const float *ang2, const int32_t *oct2, const uint8_t *stereo2,
+                                 int n2, const orc_featvec *fv2, const float *F12, float ex,
+                                 float ey, const float *scale_factors2, const float *level_sigma2_2,
+                                 int only_stereo, int check_ori, int32_t *match12) {
+  (void)n2;
+  for (int i = 0; i < n1; i++) match12[i] = -1;
+  int nmatches = 0;
+  rothist rh;
+  rh_init(&rh, n1);
+  FV_WALK_BEGIN(fv1, fv2)
+    for (int i1 = fv1->offsets[a_]; i1 < fv1->offsets[a_ + 1]; i1++) {
+      const unsigned idx1 = fv1->indices[i1];
+      if (has_mp1[idx1]) continue;
+      const int bStereo1 = stereo1[idx1];
+      if (only_stereo && !bStereo1) continue;
+      const uint8_t *d1 = desc1 + (size_t)idx1 * 32;
+      int bestDist = TH_LOW, bestIdx2 = -1;
+      for (int i2 = fv2->offsets[b_]; i2 < fv2->offsets[b_ + 1]; i2++) {
+        const unsigned idx2 = fv2->indices[i2];
+        if (has_mp2[idx2]) continue; /* vbMatched2 is never set (:774,827) */
+        const int bStereo2 = stereo2[idx2];
+        if (only_stereo && !bStereo2) continue;
+        const int dist = orc_descriptor_distance(d1, desc2 + (size_t)idx2 * 32);
+        if (dist > TH_LOW || dist > bestDist) continue;
+        if (!bStereo1 && !bStereo2) {
+          const float distex = ex - x2[idx2];
+          const float distey = ey - y2[idx2];
+          if (distex * distex + distey * distey < 100 * scale_factors2[oct2[idx2]]) continue;
+        }
+        if (check_epipolar(x1[idx1], y1[idx1], x2[idx2], y2[idx2], F12, level_sigma2_2[oct2[idx2]])) {
+          bestIdx2 = (int)idx2;
+          bestDist = dist;
+        }
+      }
+      if (bestIdx2 >= 0) {
+        match12[idx1] = bestIdx2;
+        nmatches++;
+        if (check_ori) rh_push(&rh, ang1[idx1], ang2[bestIdx2], (int)idx1);
+      }
+    }
+  FV_WALK_END(fv1, fv2)
+  if (check_ori) nmatches -= rh_prune(&rh, match12);
+  rh_free(&rh);
+  return nmatches;
+}
+
+/* ------------------------------------------------------------------ */
+/* Frame::ComputeStereoMatches: src/Frame.cc:512-686                   */
+/* ------------------------------------------------------------------ */
+typedef struct { int d, i; } distidx;
+static int distidx_cmp(const void *a, const void *b) {
+  const distidx *A = (const distidx *)a, *B = (const distidx *)b;
+  if (A->d != B->d) return A->d < B->d ? -1 : 1;
+  return A->i < B->i ? -1 : (A->i > B->i ? 1 : 0);
+}
+
+int orc_compute_stereo_matches(const orc_extractor *e, int W, int H, const orc_keypoint *kpL,
+                               const uint8_t *descL, int N, const orc_keypoint *kpR,
+                               const uint8_t *descR, int Nr, const uint8_t *pyrL,
+                               const uint8_t *pyrR, float mbf, float mb, float *uRight,
+                               float *depth) {
+  for (int i = 0; i < N; i++) { uRight[i] = -1.0f; depth[i] = -1.0f; }
+  const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+  const int nRows = H;
+  int lw[ORC_MAX_LEVELS], lh[ORC_MAX_LEVELS];
+  size_t loff[ORC_MAX_LEVELS];
+  size_t off = 0;
+  for (int l = 0; l < e->nlevels; l++) { orc_level_size(e, W, H, l, &lw[l], &lh[l]); loff[l] = off; off += (size_t)lw[l] * lh[l]; }
+  /* vRowIndices :519-539 */
+  int *rowCnt = (int *)calloc(nRows, sizeof(int));
+  int **rowIdx = (int **)calloc(nRows, sizeof(int *));
+  for (int pass = 0; pass < 2; pass++) {
+    for (int iR = 0; iR < Nr; iR++) {
+      const float kpY = kpR[iR].y;
+      const float r = 2.0f * e->mvScaleFactor[kpR[iR].octave];
+      const int maxr = (int)ceilf(kpY + r);
+      const int minr = (int)floorf(kpY - r);
+      for (int yi = minr; yi <= maxr; yi++) {
+        if (yi < 0 || yi >= nRows) continue; /* reference: unchecked (A13) */
+        if (pass == 0) rowCnt[yi]++;
+        else rowIdx[yi][rowCnt[yi]++] = iR;
+      }
+    }
+    if (pass == 0)
+      for (int y = 0; y < nRows; y++) { rowIdx[y] = (int *)malloc(sizeof(int) * (rowCnt[y] > 0 ? rowCnt[y] : 1)); rowCnt[y] = 0; }
+  }
+  const float minZ = mb, minD = 0, maxD = mbf / minZ;
+  distidx *vDistIdx = (distidx *)malloc(sizeof(distidx) * (N > 0 ? N : 1));
+  int nDist = 0;
+  for (int iL = 0; iL < N; iL++) {
+    const orc_keypoint *kl = &kpL[iL];
+    const int levelL = kl->octave;
+    const float vL = kl->y, uL = kl->x;
+    const int row = (int)vL;
+    if (row < 0 || row >= nRows) continue;
+    if (rowCnt[row] == 0) continue;
+    const float minU = uL - maxD, maxU = uL - minD;
+    if (maxU < 0) continue;
+    int bestDist = TH_HIGH;
+    int bestIdxR = 0;
+    const uint8_t *dL = descL + (size_t)iL * 32;
+    for (int iC = 0; iC < rowCnt[row]; iC++) {
+      const int iR = rowIdx[row][iC];
+      const orc_keypoint *kr = &kpR[iR];
+      if (kr->octave < levelL - 1 || kr->octave > levelL + 1) continue;
+      const float uR = kr->x;
+      if (uR >= minU && uR <= maxU) {
+        const int dist = orc_descriptor_distance(dL, descR + (size_t)iR * 32);
+        if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+      }
+    }
+    if (bestDist < thOrbDist) {
+      const float uR0 = kpR[bestIdxR].x;
+      const float scaleFactor = e->mvInvScaleFactor[kl->octave];
+      const float scaleduL = roundf(kl->x * scaleFactor);
+      const float scaledvL = roundf(kl->y * scaleFactor);
+      const float scaleduR0 = roundf(uR0 * scaleFactor);
+      const int w = 5, L = 5;
+      const int lv = kl->octave;
+      const uint8_t *IL = pyrL + loff[lv], *IR = pyrR + loff[lv];
+      const int st = lw[lv];
+      const int cy = (int)scaledvL, cxL = (int)scaleduL;
+      int bestD = INT_MAX, bestincR = 0;
+      float vDists[11];
+      const float iniu = scaleduR0 + L - w;
+      const float endu = scaleduR0 + L + w + 1;
+      if (iniu < 0 || endu >= (float)lw[lv]) continue;
+      const int cL = IL[(size_t)cy * st + cxL];
+      for (int incR = -L; incR <= +L; incR++) {
+        const int cxR = (int)(scaleduR0 + (float)incR);
+        const int cR = IR[(size_t)cy * st + cxR];
+        double acc = 0; /* cv::norm(NORM_L1) on CV_32F accumulates in double */
+        for (int dy = -w; dy <= w; dy++)
+          for (int dx = -w; dx <= w; dx++) {
+            float a = (float)IL[(size_t)(cy + dy) * st + cxL + dx] - (float)cL;
+            float b = (float)IR[(size_t)(cy + dy) * st + cxR + dx] - (float)cR;
+            acc += fabs((double)(a - b));
+          }
+        float dist = (float)acc;
+        if (dist < (float)bestD) { bestD = (int)dist; bestincR = incR; }
+        vDists[L + incR] = dist;
+      }
+      if (bestincR == -L || bestincR == L) continue;
+      const float dist1 = vDists[L + bestincR - 1];
+      const float dist2 = vDists[L + bestincR];
+      const float dist3 = vDists[L + bestincR + 1];
+      const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+      if (deltaR < -1 || deltaR > 1) continue;
+      float bestuR = e->mvScaleFactor[kl->octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+      float disparity = (uL - bestuR);
+      if (disparity >= minD && disparity < maxD) {
+        if (disparity <= 0) { disparity = 0.01f; bestuR = (float)((double)uL - 0.01); }
+        depth[iL] = mbf / disparity;
+        uRight[iL] = bestuR;
+        vDistIdx[nDist].d = bestD;
+        vDistIdx[nDist].i = iL;
+        nDist++;
+      }
+    }
+  }
+  if (nDist > 0) { /* :672-685; empty case is UB in the reference -- guarded */
+    qsort(vDistIdx, nDist, sizeof(distidx), distidx_cmp);
+    const float median = (float)vDistIdx[nDist / 2].d;
+    const float thDist = 1.5f * 1.4f * median;
+    for (int i = nDist - 1; i >= 0; i--) {
+      if ((float)vDistIdx[i].d < thDist) break;
+      uRight[vDistIdx[i].i] = -1;
+      depth[vDistIdx[i].i] = -1;
+    }
+  }
+  int cnt = 0;
+  for (int i = 0; i < N; i++) cnt += uRight[i] >= 0 || depth[i] >= 0;
+  for (int y = 0; y < nRows; y++) free(rowIdx[y]);
+  free(rowIdx);
+  free(rowCnt);
+  free(vDistIdx);
+  return cnt;
+}

@@ -1,0 +1,141 @@
+/*
+ * orb_oracle.h -- CPU ORACLE for the ORB front-end hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C restatement of the reference's CPU algorithm (saber/ORB_SLAM2_Annotate,
+ * src/ORBextractor.cc, src/ORBmatcher.cc, src/Frame.cc:512-686) used by tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg as the CHECKER.
+ * Nothing under orb_slam2_annotate_amd/ may include, link or call this.
+ *
+ * PARITY UNPINNED: the reference ships no tests, no golden vectors and cannot be
+ * built here (OpenCV/Eigen absent, version unpinned; see DESIGN.md "Oracle").
+ * The pixel primitives that live in OpenCV (resize, FAST, GaussianBlur,
+ * fastAtan2, cvRound) are restated from their published algorithm as the
+ * "canonical spec" frozen in SURVEY.md section 8(c); cos/sin is this project's
+ * own correctly-rounded-double routine (documented deviation from glibc cosf).
+ * What IS pinned: every constant derivable from the reference source
+ * (pattern table, umax, quotas, scale tables, thresholds) -- see
+ * tests/test_oracle_known_answers.py.
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_LEVELS 16
+
+/* Layout-compatible with cv::KeyPoint (28 bytes). */
+typedef struct orc_keypoint {
+  float x, y;     /* pt */
+  float size;
+  float angle;
+  float response;
+  int32_t octave;
+  int32_t class_id;
+} orc_keypoint;
+
+/* include/ORBextractor.h:52-114 -- constructor-derived constant tables. */
+typedef struct orc_extractor {
+  int nfeatures;
+  double scaleFactor; /* (double)(float)1.2 -- the member is double, include/ORBextractor.h:100 */
+  int nlevels, iniThFAST, minThFAST;
+  float mvScaleFactor[ORC_MAX_LEVELS];
+  float mvInvScaleFactor[ORC_MAX_LEVELS];
+  float mvLevelSigma2[ORC_MAX_LEVELS];
+  float mvInvLevelSigma2[ORC_MAX_LEVELS];
+  int mnFeaturesPerLevel[ORC_MAX_LEVELS];
+  int umax[16];
+  /* per-stage wall-clock accumulators (seconds), filled by orc_extract */
+  double t_pyramid, t_fast, t_octree, t_orient, t_blur, t_desc;
+} orc_extractor;
+
+/* ---- arithmetic primitives (canonical spec) ---- */
+int orc_cvround(double v);                          /* round half to even */
+float orc_fast_atan2(float y, float x);             /* degrees in [0,360) */
+void orc_sincos(float rad, float *c, float *s);     /* shared-spec sincos */
+const signed char *orc_pattern(void);               /* 1024 int8 */
+
+/* ---- extractor ---- */
+void orc_extractor_init(orc_extractor *e, int nfeatures, float scaleFactor, int nlevels,
+                        int iniThFAST, int minThFAST);        /* src/ORBextractor.cc:415-486 */
+void orc_level_size(const orc_extractor *e, int W, int H, int level, int *w, int *h);
+/* cv::resize(INTER_LINEAR) 8UC1, src/ORBextractor.cc:1219 */
+void orc_resize_linear(const uint8_t *src, int sw, int sh, int sstride, uint8_t *dst, int dw,
+                       int dh, int dstride);
+/* cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101), src/ORBextractor.cc:1175 */
+void orc_gaussian_blur7(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride);
+/* cv::FAST(sub-image, thr, nonmax=true) -> keypoints relative to the sub-image.
+ * Returns count; writes up to cap (x,y,score) triples. */
+int orc_fast_nms(const uint8_t *img, int w, int h, int stride, int threshold, int *xs, int *ys,
+                 int *scores, int cap);
+int orc_fast_nms_bruteforce(const uint8_t *img, int w, int h, int stride, int threshold, int *xs,
+                            int *ys, int *scores, int cap);
+/* FAST corner score S-1 for one pixel (>= threshold iff corner at threshold). */
+int orc_fast_score_pixel(const uint8_t *p, int stride, int threshold);
+/* Grid stage only (src/ORBextractor.cc:815-896): candidates in emission order,
+ * coordinates relative to (minBorderX,minBorderY). Returns count. */
+int orc_grid_candidates(const orc_extractor *e, const uint8_t *img, int w, int h, int stride,
+                        float *xs, float *ys, float *resp, int cap);
+/* DistributeOctTree (src/ORBextractor.cc:566-808). In/out arrays of (x,y,response);
+ * returns number selected; out_idx receives indices into the input in list order. */
+int orc_distribute_octtree(const float *xs, const float *ys, const float *resp, int n, int minX,
+                           int maxX, int minY, int maxY, int N, int *out_idx, int cap);
+float orc_ic_angle(const uint8_t *img, int stride, int x, int y, const int *umax);
+void orc_descriptor(const uint8_t *blur, int stride, int x, int y, float angle_deg,
+                    uint8_t desc[32]);
+
+/* Whole ORBextractor::operator() (src/ORBextractor.cc:1119-1197).
+ * pyr_out (optional): receives nlevels contiguous images, level l of w_l*h_l bytes
+ * (stride w_l), back to back (= mvImagePyramid contents).
+ * Returns 0 on success, -1 if capacity too small. */
+int orc_extract(orc_extractor *e, const uint8_t *img, int w, int h, int stride, orc_keypoint *kps,
+                uint8_t *desc, int capacity, int *n_out, uint8_t *pyr_out);
+
+/* ---- matcher (src/ORBmatcher.cc) ---- */
+int orc_descriptor_distance(const uint8_t *a, const uint8_t *b); /* :1828-1844 */
+void orc_three_maxima(const int *histo_sizes, int L, int *ind1, int *ind2, int *ind3); /* :1777-1821 */
+
+/* A DBoW2::FeatureVector flattened: node_ids ascending, CSR offsets into indices. */
+typedef struct orc_featvec {
+  int n_nodes;
+  const uint32_t *node_ids;
+  const int32_t *offsets; /* n_nodes+1 */
+  const uint32_t *indices;
+} orc_featvec;
+
+/* SearchByBoW(KeyFrame*,Frame&,...) :185-325.  has_mp1[i]!=0 <=> KF feature i has a
+ * good MapPoint.  match_f[j] = KF feature index matched to frame feature j, or -1. */
+int orc_search_by_bow(const uint8_t *desc1, const uint8_t *has_mp1, const float *ang1, int n1,
+                      const orc_featvec *fv1, const uint8_t *desc2, const float *ang2, int n2,
+                      const orc_featvec *fv2, float nnratio, int check_ori, int32_t *match_f);
+/* SearchByBoW(KeyFrame*,KeyFrame*,...) :610-743.  match12[i] = KF2 index or -1. */
+int orc_search_by_bow_kf(const uint8_t *desc1, const uint8_t *has_mp1, const float *ang1, int n1,
+                         const orc_featvec *fv1, const uint8_t *desc2, const uint8_t *has_mp2,
+                         const float *ang2, int n2, const orc_featvec *fv2, float nnratio,
+                         int check_ori, int32_t *match12);
+/* SearchForTriangulation :754-928.  kp = (x,y,angle,octave) SoA; F12 row-major 3x3;
+ * stereo flags = mvuRight>=0.  match12[i] = KF2 index or -1 (pairs ascending in i). */
+int orc_search_for_triangulation(const uint8_t *desc1, const uint8_t *has_mp1, const float *x1,
+                                 const float *y1, const float *ang1, const uint8_t *stereo1, int n1,
+                                 const orc_featvec *fv1, const uint8_t *desc2,
+                                 const uint8_t *has_mp2, const float *x2, const float *y2,
+                                 const float *ang2, const int32_t *oct2, const uint8_t *stereo2,
+                                 int n2, const orc_featvec *fv2, const float *F12, float ex,
+                                 float ey, const float *scale_factors2, const float *level_sigma2_2,
+                                 int only_stereo, int check_ori, int32_t *match12);
+
+/* Frame::ComputeStereoMatches, src/Frame.cc:512-686.  pyrL/pyrR: level images
+ * packed as orc_extract's pyr_out.  Outputs uRight[N], depth[N] (-1 = none). */
+int orc_compute_stereo_matches(const orc_extractor *e, int W, int H, const orc_keypoint *kpL,
+                               const uint8_t *descL, int N, const orc_keypoint *kpR,
+                               const uint8_t *descR, int Nr, const uint8_t *pyrL,
+                               const uint8_t *pyrR, float mbf, float mb, float *uRight,
+                               float *depth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

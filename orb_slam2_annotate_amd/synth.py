@@ -1,0 +1,154 @@
+"""Seeded synthetic grayscale frames / stereo pairs / sequences.
+
+The datasets named in BASELINE.json (TUM fr1_xyz, KITTI 00-07, EuRoC MH_01) are
+not available offline, so tests and bench.py render
+scenes with the statistics the ORB front-end cares about: corners at many
+scales (random rectangles / rotated rectangles / triangles of uniform
+intensity over low-frequency value noise) plus sensor noise.  Everything is a
+pure function of the integer seed, so the GPU box regenerates the same bytes.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+__all__ = ["render_frame", "render_stereo", "render_sequence", "adversarial"]
+
+
+def _background(rng: np.random.Generator, w: int, h: int) -> np.ndarray:
+    cell = 48
+    gw, gh = w // cell + 3, h // cell + 3
+    g = rng.uniform(50.0, 200.0, size=(gh, gw))
+    xs = np.arange(w) / cell
+    ys = np.arange(h) / cell
+    x0 = xs.astype(int)
+    y0 = ys.astype(int)
+    fx = (xs - x0)[None, :]
+    fy = (ys - y0)[:, None]
+    a = g[y0][:, x0]
+    b = g[y0][:, x0 + 1]
+    c = g[y0 + 1][:, x0]
+    d = g[y0 + 1][:, x0 + 1]
+    return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
+
+
+def _make_shapes(rng: np.random.Generator, w: int, h: int, n: int, max_disp: int):
+    """Returns list of (poly[k,2] float, intensity, disparity)."""
+    shapes = []
+    kinds = rng.integers(0, 3, size=n)
+    cx = rng.uniform(-20, w + 20, size=n)
+    cy = rng.uniform(-20, h + 20, size=n)
+    size = np.exp(rng.uniform(np.log(5.0), np.log(90.0), size=n))
+    aspect = rng.uniform(0.4, 1.0, size=n)
+    theta = rng.uniform(0, np.pi, size=n)
+    inten = rng.integers(0, 256, size=n)
+    disp = rng.integers(0, max_disp + 1, size=n) if max_disp > 0 else np.zeros(n, dtype=int)
+    tri = rng.uniform(-1.0, 1.0, size=(n, 3, 2))
+    for i in range(n):
+        if kinds[i] == 0:  # axis-aligned rectangle
+            hw, hh = size[i] / 2, size[i] * aspect[i] / 2
+            poly = np.array([[-hw, -hh], [hw, -hh], [hw, hh], [-hw, hh]])
+        elif kinds[i] == 1:  # rotated rectangle
+            hw, hh = size[i] / 2, size[i] * aspect[i] / 2
+            base = np.array([[-hw, -hh], [hw, -hh], [hw, hh], [-hw, hh]])
+            c, s = np.cos(theta[i]), np.sin(theta[i])
+            poly = base @ np.array([[c, s], [-s, c]])
+        else:  # triangle
+            poly = tri[i] * size[i] / 2
+            # make it counter-clockwise consistent for the half-plane test
+            e1, e2 = poly[1] - poly[0], poly[2] - poly[0]
+            if e1[0] * e2[1] - e1[1] * e2[0] < 0:
+                poly = poly[::-1].copy()
+        poly = poly + np.array([cx[i], cy[i]])
+        shapes.append((poly, int(inten[i]), int(disp[i])))
+    return shapes
+
+
+def _paint(canvas: np.ndarray, shapes, shift_sign: float, ox: float = 0.0, oy: float = 0.0):
+    h, w = canvas.shape
+    for poly, inten, disp in shapes:
+        p = poly.copy()
+        p[:, 0] -= shift_sign * disp + ox
+        p[:, 1] -= oy
+        x0 = max(int(np.floor(p[:, 0].min())), 0)
+        x1 = min(int(np.ceil(p[:, 0].max())) + 1, w)
+        y0 = max(int(np.floor(p[:, 1].min())), 0)
+        y1 = min(int(np.ceil(p[:, 1].max())) + 1, h)
+        if x0 >= x1 or y0 >= y1:
+            continue
+        xs = np.arange(x0, x1)[None, :] + 0.5
+        ys = np.arange(y0, y1)[:, None] + 0.5
+        k = len(p)
+        # orientation sign of polygon
+        area = 0.0
+        for j in range(k):
+            a, b = p[j], p[(j + 1) % k]
+            area += a[0] * b[1] - a[1] * b[0]
+        sgn = 1.0 if area >= 0 else -1.0
+        mask = np.ones((y1 - y0, x1 - x0), dtype=bool)
+        for j in range(k):
+            a, b = p[j], p[(j + 1) % k]
+            mask &= sgn * ((b[0] - a[0]) * (ys - a[1]) - (b[1] - a[1]) * (xs - a[0])) >= 0
+        canvas[y0:y1, x0:x1][mask] = inten
+
+
+def _finish(canvas: np.ndarray, rng: np.random.Generator, sigma: float) -> np.ndarray:
+    noisy = canvas + rng.normal(0.0, sigma, size=canvas.shape)
+    return np.clip(np.rint(noisy), 0, 255).astype(np.uint8)
+
+
+def render_frame(seed: int, w: int = 640, h: int = 480, n_shapes: int | None = None,
+                 sigma: float = 3.0) -> np.ndarray:
+    rng = np.random.default_rng([0x0B5EED, int(seed)])
+    if n_shapes is None:
+        n_shapes = int(rng.integers(400, 1500) * (w * h) / (640 * 480))
+    canvas = _background(rng, w, h)
+    _paint(canvas, _make_shapes(rng, w, h, n_shapes, 0), 0.0)
+    return _finish(canvas, rng, sigma)
+
+
+def render_stereo(seed: int, w: int = 1241, h: int = 376, n_shapes: int | None = None,
+                  max_disp: int = 96, sigma: float = 3.0):
+    """Left/right pair: every object is re-rendered in the right view shifted left
+    by its own integer disparity (0..max_disp); the background has disparity 0."""
+    rng = np.random.default_rng([0x57E8E0, int(seed)])
+    if n_shapes is None:
+        n_shapes = int(rng.integers(400, 1500) * (w * h) / (640 * 480))
+    bg = _background(rng, w, h)
+    shapes = _make_shapes(rng, w, h, n_shapes, max_disp)
+    # paint far objects first so near ones (large disparity) occlude them
+    shapes.sort(key=lambda s: s[2])
+    left, right = bg.copy(), bg.copy()
+    _paint(left, shapes, 0.0)
+    _paint(right, shapes, 1.0)
+    return _finish(left, rng, sigma), _finish(right, rng, sigma)
+
+
+def render_sequence(seed: int, n_frames: int, w: int = 640, h: int = 480,
+                    n_shapes: int | None = None, sigma: float = 3.0, step: float = 1.5):
+    """Same scene under a small per-frame camera translation (fresh noise per frame)."""
+    rng = np.random.default_rng([0x5E0CE, int(seed)])
+    if n_shapes is None:
+        n_shapes = int(rng.integers(400, 1500) * (w * h) / (640 * 480))
+    margin = int(step * n_frames) + 8
+    bg = _background(rng, w + margin, h + margin)
+    shapes = _make_shapes(rng, w + margin, h + margin, int(n_shapes * (1 + margin / w)), 0)
+    big = bg.copy()
+    _paint(big, shapes, 0.0)
+    frames = []
+    for f in range(n_frames):
+        ox = int(round(step * f))
+        oy = int(round(0.5 * step * f))
+        frames.append(_finish(big[oy:oy + h, ox:ox + w], rng, sigma))
+    return frames
+
+
+def adversarial(kind: str, w: int = 640, h: int = 480, seed: int = 0) -> np.ndarray:
+    """Edge-case images: 'constant' (0 keypoints), 'noise', 'checker' (ties everywhere)."""
+    if kind == "constant":
+        return np.full((h, w), 127, dtype=np.uint8)
+    if kind == "noise":
+        return np.random.default_rng([0xA0153, int(seed)]).integers(0, 256, size=(h, w), dtype=np.uint8)
+    if kind == "checker":
+        yy, xx = np.mgrid[0:h, 0:w]
+        return np.where(((xx // 8) + (yy // 8)) % 2 == 0, 30, 220).astype(np.uint8)
+    raise ValueError(kind)

@@ -1,0 +1,257 @@
+"""ctypes binding of the CPU oracle (oracle/liborb_oracle.so) -- test infrastructure only."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+ORACLE_DIR = ROOT / "oracle"
+MAX_LEVELS = 16
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+class OrcExtractor(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scaleFactor", C.c_double), ("nlevels", C.c_int),
+                ("iniThFAST", C.c_int), ("minThFAST", C.c_int),
+                ("mvScaleFactor", C.c_float * MAX_LEVELS), ("mvInvScaleFactor", C.c_float * MAX_LEVELS),
+                ("mvLevelSigma2", C.c_float * MAX_LEVELS), ("mvInvLevelSigma2", C.c_float * MAX_LEVELS),
+                ("mnFeaturesPerLevel", C.c_int * MAX_LEVELS), ("umax", C.c_int * 16),
+                ("t_pyramid", C.c_double), ("t_fast", C.c_double), ("t_octree", C.c_double),
+                ("t_orient", C.c_double), ("t_blur", C.c_double), ("t_desc", C.c_double)]
+
+
+class OrcFeatVec(C.Structure):
+    _fields_ = [("n_nodes", C.c_int), ("node_ids", C.c_void_p), ("offsets", C.c_void_p),
+                ("indices", C.c_void_p)]
+
+
+_lib = None
+
+
+def build_oracle() -> Path:
+    so = ORACLE_DIR / "liborb_oracle.so"
+    srcs = [ORACLE_DIR / n for n in ("orb_oracle.c", "orb_oracle.h", "orb_pattern_data.h", "Makefile")]
+    if not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
+        subprocess.run(["make", "-C", str(ORACLE_DIR)], check=True, capture_output=True)
+    return so
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(str(build_oracle()))
+        _lib.orc_fast_atan2.restype = C.c_float
+        _lib.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        _lib.orc_cvround.argtypes = [C.c_double]
+        _lib.orc_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        _lib.orc_pattern.restype = C.POINTER(C.c_byte)
+        _lib.orc_ic_angle.restype = C.c_float
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Oracle:
+    """Mirror of ORB_SLAM2::ORBextractor on the CPU oracle."""
+
+    def __init__(self, nfeatures=1000, scale=1.2, nlevels=8, ini=20, minth=7):
+        self.L = lib()
+        self.e = OrcExtractor()
+        self.L.orc_extractor_init(C.byref(self.e), int(nfeatures), C.c_float(scale), int(nlevels),
+                                  int(ini), int(minth))
+        self.nlevels = self.e.nlevels
+
+    # tables
+    def scale_factors(self):
+        return np.array(self.e.mvScaleFactor[: self.nlevels], dtype=np.float32)
+
+    def inv_scale_factors(self):
+        return np.array(self.e.mvInvScaleFactor[: self.nlevels], dtype=np.float32)
+
+    def level_sigma2(self):
+        return np.array(self.e.mvLevelSigma2[: self.nlevels], dtype=np.float32)
+
+    def inv_level_sigma2(self):
+        return np.array(self.e.mvInvLevelSigma2[: self.nlevels], dtype=np.float32)
+
+    def features_per_level(self):
+        return list(self.e.mnFeaturesPerLevel[: self.nlevels])
+
+    def umax(self):
+        return list(self.e.umax)
+
+    def level_sizes(self, W, H):
+        out = []
+        for l in range(self.nlevels):
+            w, h = C.c_int(), C.c_int()
+            self.L.orc_level_size(C.byref(self.e), W, H, l, C.byref(w), C.byref(h))
+            out.append((w.value, h.value))
+        return out
+
+    def extract(self, img: np.ndarray, capacity: int | None = None, want_pyramid=False):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        H, W = img.shape
+        cap = capacity or (self.e.nfeatures * 2 + 64)
+        kps = np.zeros(cap, dtype=KP_DTYPE)
+        desc = np.zeros((cap, 32), dtype=np.uint8)
+        n = C.c_int()
+        pyr = None
+        if want_pyramid:
+            tot = sum(w * h for w, h in self.level_sizes(W, H))
+            pyr = np.zeros(tot, dtype=np.uint8)
+        rc = self.L.orc_extract(C.byref(self.e), _p(img), W, H, W, _p(kps), _p(desc), cap,
+                                C.byref(n), _p(pyr))
+        if rc != 0:
+            raise RuntimeError("oracle capacity too small")
+        if want_pyramid:
+            return kps[: n.value].copy(), desc[: n.value].copy(), pyr
+        return kps[: n.value].copy(), desc[: n.value].copy()
+
+    def split_pyramid(self, pyr, W, H):
+        out, off = [], 0
+        for w, h in self.level_sizes(W, H):
+            out.append(pyr[off: off + w * h].reshape(h, w))
+            off += w * h
+        return out
+
+    def stage_times(self):
+        e = self.e
+        return dict(pyramid=e.t_pyramid, fast=e.t_fast, octree=e.t_octree, orient=e.t_orient,
+                    blur=e.t_blur, desc=e.t_desc)
+
+    def stereo(self, W, H, kpL, dL, kpR, dR, pyrL, pyrR, mbf, mb):
+        N, Nr = len(kpL), len(kpR)
+        u = np.zeros(max(N, 1), dtype=np.float32)
+        d = np.zeros(max(N, 1), dtype=np.float32)
+        kpL = np.ascontiguousarray(kpL); kpR = np.ascontiguousarray(kpR)
+        dL = np.ascontiguousarray(dL); dR = np.ascontiguousarray(dR)
+        self.L.orc_compute_stereo_matches(C.byref(self.e), W, H, _p(kpL), _p(dL), N, _p(kpR), _p(dR), Nr,
+                                          _p(pyrL), _p(pyrR), C.c_float(mbf), C.c_float(mb), _p(u), _p(d))
+        return u[:N], d[:N]
+
+
+def resize_linear(src, dw, dh):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    sh, sw = src.shape
+    dst = np.zeros((dh, dw), dtype=np.uint8)
+    lib().orc_resize_linear(_p(src), sw, sh, sw, _p(dst), dw, dh, dw)
+    return dst
+
+
+def gaussian_blur7(src):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    h, w = src.shape
+    dst = np.zeros_like(src)
+    lib().orc_gaussian_blur7(_p(src), w, h, w, _p(dst), w)
+    return dst
+
+
+def fast_nms(sub, threshold):
+    sub = np.ascontiguousarray(sub, dtype=np.uint8)
+    h, w = sub.shape
+    cap = w * h
+    xs = np.zeros(cap, dtype=np.int32); ys = np.zeros(cap, dtype=np.int32); sc = np.zeros(cap, dtype=np.int32)
+    n = lib().orc_fast_nms(_p(sub), w, h, w, int(threshold), _p(xs), _p(ys), _p(sc), cap)
+    return xs[:n].copy(), ys[:n].copy(), sc[:n].copy()
+
+
+def grid_candidates(orc: Oracle, img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    cap = w * h // 4 + 16
+    xs = np.zeros(cap, dtype=np.float32); ys = np.zeros(cap, dtype=np.float32); rs = np.zeros(cap, dtype=np.float32)
+    n = lib().orc_grid_candidates(C.byref(orc.e), _p(img), w, h, w, _p(xs), _p(ys), _p(rs), cap)
+    return xs[:n].copy(), ys[:n].copy(), rs[:n].copy()
+
+
+def distribute_octtree(xs, ys, rs, minX, maxX, minY, maxY, N):
+    xs = np.ascontiguousarray(xs, dtype=np.float32); ys = np.ascontiguousarray(ys, dtype=np.float32)
+    rs = np.ascontiguousarray(rs, dtype=np.float32)
+    n = len(xs)
+    out = np.zeros(n + 8, dtype=np.int32)
+    k = lib().orc_distribute_octtree(_p(xs), _p(ys), _p(rs), n, minX, maxX, minY, maxY, N, _p(out), n + 8)
+    return out[:k].copy()
+
+
+def fast_atan2(y, x):
+    return float(lib().orc_fast_atan2(C.c_float(y), C.c_float(x)))
+
+
+def sincos(rad):
+    c, s = C.c_float(), C.c_float()
+    lib().orc_sincos(C.c_float(rad), C.byref(c), C.byref(s))
+    return c.value, s.value
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, dtype=np.uint8); b = np.ascontiguousarray(b, dtype=np.uint8)
+    return lib().orc_descriptor_distance(_p(a), _p(b))
+
+
+def three_maxima(sizes):
+    s = np.ascontiguousarray(sizes, dtype=np.int32)
+    i1, i2, i3 = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+    lib().orc_three_maxima(_p(s), len(s), C.byref(i1), C.byref(i2), C.byref(i3))
+    return i1.value, i2.value, i3.value
+
+
+class FeatVec:
+    """Flattened DBoW2::FeatureVector (node ids ascending, CSR)."""
+
+    def __init__(self, node_of_feature: np.ndarray):
+        node_of_feature = np.asarray(node_of_feature)
+        ids = np.unique(node_of_feature)
+        self.node_ids = ids.astype(np.uint32)
+        order = np.argsort(node_of_feature, kind="stable")
+        self.indices = order.astype(np.uint32)
+        counts = np.array([(node_of_feature == i).sum() for i in ids], dtype=np.int64)
+        self.offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        self.c = OrcFeatVec(len(ids), _p(self.node_ids), _p(self.offsets), _p(self.indices))
+
+
+def search_by_bow(d1, has_mp1, ang1, fv1: FeatVec, d2, ang2, fv2: FeatVec, nnratio, check_ori):
+    n1, n2 = len(d1), len(d2)
+    out = np.zeros(max(n2, 1), dtype=np.int32)
+    d1 = np.ascontiguousarray(d1); d2 = np.ascontiguousarray(d2)
+    has_mp1 = np.ascontiguousarray(has_mp1, dtype=np.uint8)
+    ang1 = np.ascontiguousarray(ang1, dtype=np.float32); ang2 = np.ascontiguousarray(ang2, dtype=np.float32)
+    n = lib().orc_search_by_bow(_p(d1), _p(has_mp1), _p(ang1), n1, C.byref(fv1.c), _p(d2), _p(ang2), n2,
+                                C.byref(fv2.c), C.c_float(nnratio), int(check_ori), _p(out))
+    return n, out[:n2].copy()
+
+
+def search_by_bow_kf(d1, has_mp1, ang1, fv1, d2, has_mp2, ang2, fv2, nnratio, check_ori):
+    n1, n2 = len(d1), len(d2)
+    out = np.zeros(max(n1, 1), dtype=np.int32)
+    d1 = np.ascontiguousarray(d1); d2 = np.ascontiguousarray(d2)
+    has_mp1 = np.ascontiguousarray(has_mp1, dtype=np.uint8); has_mp2 = np.ascontiguousarray(has_mp2, dtype=np.uint8)
+    ang1 = np.ascontiguousarray(ang1, dtype=np.float32); ang2 = np.ascontiguousarray(ang2, dtype=np.float32)
+    n = lib().orc_search_by_bow_kf(_p(d1), _p(has_mp1), _p(ang1), n1, C.byref(fv1.c), _p(d2), _p(has_mp2),
+                                   _p(ang2), n2, C.byref(fv2.c), C.c_float(nnratio), int(check_ori), _p(out))
+    return n, out[:n1].copy()
+
+
+def search_for_triangulation(d1, has_mp1, x1, y1, ang1, st1, fv1, d2, has_mp2, x2, y2, ang2, oct2, st2, fv2,
+                             F12, ex, ey, sf2, sig2, only_stereo, check_ori):
+    n1, n2 = len(d1), len(d2)
+    out = np.zeros(max(n1, 1), dtype=np.int32)
+    f = lambda a, t: np.ascontiguousarray(a, dtype=t)
+    d1, d2 = f(d1, np.uint8), f(d2, np.uint8)
+    a = [f(has_mp1, np.uint8), f(x1, np.float32), f(y1, np.float32), f(ang1, np.float32), f(st1, np.uint8)]
+    b = [f(has_mp2, np.uint8), f(x2, np.float32), f(y2, np.float32), f(ang2, np.float32), f(oct2, np.int32),
+         f(st2, np.uint8)]
+    F12 = f(F12, np.float32).reshape(9); sf2 = f(sf2, np.float32); sig2 = f(sig2, np.float32)
+    n = lib().orc_search_for_triangulation(_p(d1), *[_p(v) for v in a], n1, C.byref(fv1.c), _p(d2),
+                                           *[_p(v) for v in b], n2, C.byref(fv2.c), _p(F12), C.c_float(ex),
+                                           C.c_float(ey), _p(sf2), _p(sig2), int(only_stereo), int(check_ori),
+                                           _p(out))
+    return n, out[:n1].copy()
