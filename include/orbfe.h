@@ -1,0 +1,223 @@
+/*
+ * orbfe.h -- C-ABI of the MI355X-native ORB front-end (liborbfe.so).
+ *
+ * Drop-in boundary for the ONE hot path of saber/ORB_SLAM2_Annotate:
+ * ORBextractor::operator() + Hamming matchers + Frame::ComputeStereoMatches.
+ * Plain pointers and sizes only; no C++/torch/OpenCV types; no exceptions cross
+ * this boundary.  Every entry point cites the reference interface it replaces
+ * (paths relative to the reference root).  INTEGRATION.md shows the thin C++
+ * classes (include/ORBextractor.h, include/ORBmatcher.h of this repo) that keep
+ * the reference's class API on top of these calls.
+ *
+ * Threading contract (reference: src/Frame.cc:78-81, src/LocalMapping.cc:261,
+ * src/LoopClosing.cc:294): one extractor handle per thread, handles are fully
+ * independent (own HIP stream + workspace); matcher entry points are re-entrant.
+ *
+ * There is NO CPU fallback: every call needs a gfx950 device and returns
+ * ORBFE_ERR_HIP when the HIP runtime reports none.
+ */
+#ifndef ORBFE_H
+#define ORBFE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBFE_MAX_LEVELS 16
+
+enum {
+  ORBFE_OK = 0,
+  ORBFE_ERR_INVALID = -1,  /* bad argument (null pointer, non-positive size, ...) */
+  ORBFE_ERR_CAPACITY = -2, /* caller-provided output buffer too small */
+  ORBFE_ERR_HIP = -3,      /* HIP runtime / device failure (see orbfe_last_error) */
+  ORBFE_ERR_NOMEM = -4
+};
+
+/* Layout-identical to cv::KeyPoint (28 bytes): pt.x, pt.y, size, angle, response,
+ * octave, class_id -- what ORBextractor::operator() fills (src/ORBextractor.cc:905-916,1187-1195). */
+typedef struct orbfe_keypoint {
+  float x, y;
+  float size;
+  float angle;
+  float response;
+  int32_t octave;
+  int32_t class_id;
+} orbfe_keypoint;
+
+typedef struct orbfe_extractor orbfe_extractor;
+
+/* Thread-local text of the last failure (never NULL). */
+const char *orbfe_last_error(void);
+/* Number of visible HIP devices (0 if none / runtime error). */
+int orbfe_device_count(void);
+
+/* ------------------------------------------------------------------------- */
+/* Extractor                                                                  */
+/* ------------------------------------------------------------------------- */
+
+/* Replaces ORBextractor::ORBextractor(int nfeatures, float scaleFactor, int nlevels,
+ * int iniThFAST, int minThFAST)  (include/ORBextractor.h:52-53, src/ORBextractor.cc:415-486).
+ * `device` = HIP device ordinal. */
+int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST,
+                           int minThFAST, int device, orbfe_extractor **out);
+void orbfe_extractor_destroy(orbfe_extractor *e);
+
+/* GetLevels / GetScaleFactor / GetScaleFactors / GetInverseScaleFactors /
+ * GetScaleSigmaSquares / GetInverseScaleSigmaSquares (include/ORBextractor.h:66-87).
+ * Each `out` receives nlevels floats. */
+int orbfe_extractor_get_levels(const orbfe_extractor *e);
+float orbfe_extractor_get_scale_factor(const orbfe_extractor *e);
+int orbfe_extractor_get_scale_factors(const orbfe_extractor *e, float *out);
+int orbfe_extractor_get_inverse_scale_factors(const orbfe_extractor *e, float *out);
+int orbfe_extractor_get_scale_sigma_squares(const orbfe_extractor *e, float *out);
+int orbfe_extractor_get_inverse_scale_sigma_squares(const orbfe_extractor *e, float *out);
+/* mnFeaturesPerLevel (src/ORBextractor.cc:448-458) and umax (:471-485), for tests. */
+int orbfe_extractor_get_features_per_level(const orbfe_extractor *e, int32_t *out);
+int orbfe_extractor_get_umax(const orbfe_extractor *e, int32_t *out16);
+/* Upper bound on keypoints one frame can return (quota + octree overshoot, Appendix A3). */
+int orbfe_extractor_max_keypoints(const orbfe_extractor *e);
+
+/* Replaces ORBextractor::operator()(InputArray image, InputArray mask (ignored),
+ * vector<KeyPoint>&, OutputArray descriptors)  (src/ORBextractor.cc:1119-1197).
+ * `image`: host, 8-bit single channel, row-major, `stride` bytes per row.
+ * Writes up to `capacity` keypoints and capacity*32 descriptor bytes (row i <-> keypoint i);
+ * *n_out = count.  Empty image (NULL or w/h<=0) -> ORBFE_OK with *n_out = 0
+ * (the reference returns silently, :1122-1123). */
+int orbfe_extract(orbfe_extractor *e, const uint8_t *image, int width, int height, int stride,
+                  orbfe_keypoint *keypoints, uint8_t *descriptors, int capacity, int *n_out);
+
+/* Batched form of the same call for n_frames equally-sized frames (frame f starts at
+ * images + f*frame_stride).  Per-frame outputs are packed at fixed slots of
+ * `capacity` entries: keypoints[f*capacity + i], descriptors[(f*capacity + i)*32];
+ * n_out[f] = count of frame f.  This is how a stereo Frame (2 images, src/Frame.cc:78-81)
+ * or a whole sequence shard is pushed through the GPU in one pass. */
+int orbfe_extract_batch(orbfe_extractor *e, const uint8_t *images, int n_frames, int width,
+                        int height, int stride, size_t frame_stride, orbfe_keypoint *keypoints,
+                        uint8_t *descriptors, int capacity, int *n_out);
+
+/* Same, but `d_images`, `d_keypoints`, `d_descriptors`, `d_n_out` are DEVICE pointers
+ * (HBM-resident in, HBM-resident out; nothing crosses PCIe except per-batch control words).
+ * The call returns after the work is complete on the handle's stream. */
+int orbfe_extract_batch_device(orbfe_extractor *e, const uint8_t *d_images, int n_frames,
+                               int width, int height, int stride, size_t frame_stride,
+                               orbfe_keypoint *d_keypoints, uint8_t *d_descriptors, int capacity,
+                               int32_t *d_n_out);
+
+/* Replaces reads of the public member `mvImagePyramid[level]` (include/ORBextractor.h:86;
+ * read by Frame::ComputeStereoMatches, src/Frame.cc:519,609,621,626): copies level `level`
+ * of frame `frame` of the LAST extract call into `dst` (host, dst_stride bytes per row).
+ * level_size gives the dimensions for any input size. */
+int orbfe_extractor_level_size(const orbfe_extractor *e, int width, int height, int level,
+                               int *w, int *h);
+int orbfe_extractor_get_pyramid_level(orbfe_extractor *e, int frame, int level, uint8_t *dst,
+                                      int dst_stride);
+/* Device view of the same (valid until the next extract call on this handle). */
+int orbfe_extractor_pyramid_level_device(orbfe_extractor *e, int frame, int level,
+                                         const uint8_t **d_ptr, int *pitch, int *w, int *h);
+
+/* Stage diagnostics used by tests: raw grid-stage candidates of one level of frame 0 of
+ * the last call, in emission order (src/ORBextractor.cc:846-896), coordinates relative to
+ * (minBorderX,minBorderY).  Returns count or a negative status. */
+int orbfe_extractor_debug_candidates(orbfe_extractor *e, int frame, int level, float *xs,
+                                     float *ys, float *resp, int cap);
+/* Blurred level (the `workingMat` of src/ORBextractor.cc:1169-1175) of the last call. */
+int orbfe_extractor_debug_blurred_level(orbfe_extractor *e, int frame, int level, uint8_t *dst,
+                                        int dst_stride);
+
+/* Per-kernel timing, measured with HIP events on the handle's own stream.
+ * enable!=0 starts accumulating; get returns, per stage, total milliseconds and the
+ * number of launches since the last reset. */
+enum {
+  ORBFE_STAGE_H2D = 0,
+  ORBFE_STAGE_PYRAMID,
+  ORBFE_STAGE_FAST,
+  ORBFE_STAGE_OCTREE,
+  ORBFE_STAGE_BLUR,
+  ORBFE_STAGE_ORIENT_DESC,
+  ORBFE_STAGE_D2H,
+  ORBFE_STAGE_COUNT
+};
+int orbfe_extractor_profile(orbfe_extractor *e, int enable);
+int orbfe_extractor_profile_get(orbfe_extractor *e, double *ms_out /*[ORBFE_STAGE_COUNT]*/,
+                                int64_t *launches_out /*[ORBFE_STAGE_COUNT]*/);
+const char *orbfe_stage_name(int stage);
+
+/* Standalone primitives on host buffers (tests of the individual kernels). */
+int orbfe_resize_linear(int device, const uint8_t *src, int sw, int sh, int sstride, uint8_t *dst,
+                        int dw, int dh, int dstride);
+int orbfe_gaussian_blur7(int device, const uint8_t *src, int w, int h, int sstride, uint8_t *dst,
+                         int dstride);
+
+/* ------------------------------------------------------------------------- */
+/* Matcher                                                                    */
+/* ------------------------------------------------------------------------- */
+
+/* DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned>>, ascending node id;
+ * Thirdparty/DBoW2/DBoW2/FeatureVector.cpp:31-45) flattened to CSR. */
+typedef struct orbfe_featvec {
+  int32_t n_nodes;
+  const uint32_t *node_ids; /* ascending */
+  const int32_t *offsets;   /* n_nodes + 1 */
+  const uint32_t *indices;  /* feature indices, grouped by node in insertion order */
+} orbfe_featvec;
+
+/* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1828-1844) for n pairs:
+ * out[i] = popcount(a[i] ^ b[i]) over 256 bits. Host buffers. */
+int orbfe_descriptor_distance(int device, const uint8_t *a, const uint8_t *b, int n, int32_t *out);
+
+/* Dense n1 x n2 Hamming matrix (row-major int16 would do; int32 for simplicity). Host buffers. */
+int orbfe_hamming_matrix(int device, const uint8_t *desc1, int n1, const uint8_t *desc2, int n2,
+                         int32_t *out);
+
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>&)  (src/ORBmatcher.cc:185-325).
+ * has_mp1[i] != 0 <=> KF feature i has a non-bad MapPoint.  match_f[j] (size n2) = index of the KF
+ * feature whose MapPoint the wrapper assigns to frame feature j, or -1.  Returns nmatches >= 0,
+ * or a negative status. */
+int orbfe_search_by_bow(int device, const uint8_t *desc1, const uint8_t *has_mp1,
+                        const float *angle1, int n1, const orbfe_featvec *fv1,
+                        const uint8_t *desc2, const float *angle2, int n2,
+                        const orbfe_featvec *fv2, float nnratio, int check_orientation,
+                        int32_t *match_f);
+
+/* ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&)  (src/ORBmatcher.cc:610-743).
+ * match12[i] (size n1) = KF2 feature index or -1. */
+int orbfe_search_by_bow_kf(int device, const uint8_t *desc1, const uint8_t *has_mp1,
+                           const float *angle1, int n1, const orbfe_featvec *fv1,
+                           const uint8_t *desc2, const uint8_t *has_mp2, const float *angle2,
+                           int n2, const orbfe_featvec *fv2, float nnratio, int check_orientation,
+                           int32_t *match12);
+
+/* ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat F12,
+ * vector<pair<size_t,size_t>>&, bool bOnlyStereo)  (src/ORBmatcher.cc:754-928).
+ * Keypoints are mvKeysUn as SoA; stereo flags are (mvuRight[i] >= 0); F12 is row-major 3x3;
+ * (ex,ey) the epipole computed by the caller as at :766-769; scale_factors2 / level_sigma2_2 are
+ * KF2's mvScaleFactors / mvLevelSigma2.  match12[i] = KF2 index or -1; the wrapper emits the
+ * pairs in ascending i exactly as :920-925. */
+int orbfe_search_for_triangulation(int device, const uint8_t *desc1, const uint8_t *has_mp1,
+                                   const float *x1, const float *y1, const float *angle1,
+                                   const uint8_t *stereo1, int n1, const orbfe_featvec *fv1,
+                                   const uint8_t *desc2, const uint8_t *has_mp2, const float *x2,
+                                   const float *y2, const float *angle2, const int32_t *octave2,
+                                   const uint8_t *stereo2, int n2, const orbfe_featvec *fv2,
+                                   const float *F12, float ex, float ey,
+                                   const float *scale_factors2, const float *level_sigma2_2,
+                                   int n_levels2, int only_stereo, int check_orientation,
+                                   int32_t *match12);
+
+/* Frame::ComputeStereoMatches()  (src/Frame.cc:512-686).  `left`/`right` are the two extractor
+ * handles whose LAST extract call produced the keypoints (their pyramids are read on the device,
+ * replacing mpORBextractorLeft/Right->mvImagePyramid); frameL/frameR select the frame of that
+ * batch.  kp/desc are host arrays exactly as returned by orbfe_extract.  Outputs mvuRight / mvDepth
+ * (N floats each, -1 = no stereo).  mbf, mb as in src/Frame.cc:114,542-544. */
+int orbfe_compute_stereo_matches(orbfe_extractor *left, int frameL, orbfe_extractor *right,
+                                 int frameR, const orbfe_keypoint *kpL, const uint8_t *descL,
+                                 int N, const orbfe_keypoint *kpR, const uint8_t *descR, int Nr,
+                                 float mbf, float mb, float *uRight, float *depth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBFE_H */

@@ -1,0 +1,7 @@
+"""MI355X-native ORB front-end: the ORBextractor / ORBmatcher hot path of ORB-SLAM2 as
+hand-written HIP (gfx950) behind a C-ABI (include/orbfe.h).  This package is the host-side
+mirror of the reference's class interface; it binds liborbfe.so with ctypes and has no
+compute of its own (and no CPU fallback)."""
+from ._lib import KP_DTYPE, OrbfeError, LIB_PATH  # noqa: F401
+from .extractor import ORBextractor, gaussian_blur7, resize_linear  # noqa: F401
+from .matcher import ComputeStereoMatches, FeatureVector, ORBmatcher  # noqa: F401

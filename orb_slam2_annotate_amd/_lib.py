@@ -1,0 +1,110 @@
+"""Loader of liborbfe.so (the HIP/gfx950 product library) and its ctypes prototypes.
+
+There is no CPU fallback: if the library is missing the import fails loudly, and every
+compute entry point returns ORBFE_ERR_HIP on a machine without a gfx950 device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "liborbfe.so"
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+STAGES = ["h2d", "pyramid", "fast", "octree", "blur", "orient_desc", "d2h"]
+ORBFE_OK, ERR_INVALID, ERR_CAPACITY, ERR_HIP, ERR_NOMEM = 0, -1, -2, -3, -4
+
+
+class OrbfeError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"liborbfe error {code}: {msg}")
+        self.code = code
+
+
+class FeatVecC(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("node_ids", C.c_void_p), ("offsets", C.c_void_p),
+                ("indices", C.c_void_p)]
+
+
+# every symbol include/orbfe.h declares (tests/test_cabi_symbols.py checks the header against this)
+EXPORTS = [
+    "orbfe_last_error", "orbfe_device_count", "orbfe_extractor_create", "orbfe_extractor_destroy",
+    "orbfe_extractor_get_levels", "orbfe_extractor_get_scale_factor", "orbfe_extractor_get_scale_factors",
+    "orbfe_extractor_get_inverse_scale_factors", "orbfe_extractor_get_scale_sigma_squares",
+    "orbfe_extractor_get_inverse_scale_sigma_squares", "orbfe_extractor_get_features_per_level",
+    "orbfe_extractor_get_umax", "orbfe_extractor_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
+    "orbfe_extract_batch_device", "orbfe_extractor_level_size", "orbfe_extractor_get_pyramid_level",
+    "orbfe_extractor_pyramid_level_device", "orbfe_extractor_debug_candidates",
+    "orbfe_extractor_debug_blurred_level", "orbfe_extractor_profile", "orbfe_extractor_profile_get",
+    "orbfe_stage_name", "orbfe_resize_linear", "orbfe_gaussian_blur7", "orbfe_descriptor_distance",
+    "orbfe_hamming_matrix", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",
+    "orbfe_search_for_triangulation", "orbfe_compute_stereo_matches",
+]
+
+_lib = None
+
+
+def load():
+    """Load liborbfe.so; raises (never falls back) when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(str(LIB_PATH))
+    L.orbfe_last_error.restype = C.c_char_p
+    L.orbfe_stage_name.restype = C.c_char_p
+    L.orbfe_extractor_get_scale_factor.restype = C.c_float
+    L.orbfe_extractor_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.POINTER(C.c_void_p)]
+    L.orbfe_extractor_destroy.argtypes = [C.c_void_p]
+    L.orbfe_extractor_destroy.restype = None
+    vp, ci, cf, cs = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    L.orbfe_extractor_get_levels.argtypes = [vp]
+    L.orbfe_extractor_get_scale_factor.argtypes = [vp]
+    for n in ("scale_factors", "inverse_scale_factors", "scale_sigma_squares", "inverse_scale_sigma_squares",
+              "features_per_level", "umax"):
+        getattr(L, f"orbfe_extractor_get_{n}").argtypes = [vp, vp]
+    L.orbfe_extractor_max_keypoints.argtypes = [vp]
+    L.orbfe_extract.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, vp]
+    L.orbfe_extract_batch.argtypes = [vp, vp, ci, ci, ci, ci, cs, vp, vp, ci, vp]
+    L.orbfe_extract_batch_device.argtypes = [vp, vp, ci, ci, ci, ci, cs, vp, vp, ci, vp]
+    L.orbfe_extractor_level_size.argtypes = [vp, ci, ci, ci, vp, vp]
+    L.orbfe_extractor_get_pyramid_level.argtypes = [vp, ci, ci, vp, ci]
+    L.orbfe_extractor_pyramid_level_device.argtypes = [vp, ci, ci, vp, vp, vp, vp]
+    L.orbfe_extractor_debug_candidates.argtypes = [vp, ci, ci, vp, vp, vp, ci]
+    L.orbfe_extractor_debug_blurred_level.argtypes = [vp, ci, ci, vp, ci]
+    L.orbfe_extractor_profile.argtypes = [vp, ci]
+    L.orbfe_extractor_profile_get.argtypes = [vp, vp, vp]
+    L.orbfe_stage_name.argtypes = [ci]
+    L.orbfe_resize_linear.argtypes = [ci, vp, ci, ci, ci, vp, ci, ci, ci]
+    L.orbfe_gaussian_blur7.argtypes = [ci, vp, ci, ci, ci, vp, ci]
+    L.orbfe_descriptor_distance.argtypes = [ci, vp, vp, ci, vp]
+    L.orbfe_hamming_matrix.argtypes = [ci, vp, ci, vp, ci, vp]
+    fvp = C.POINTER(FeatVecC)
+    L.orbfe_search_by_bow.argtypes = [ci, vp, vp, vp, ci, fvp, vp, vp, ci, fvp, cf, ci, vp]
+    L.orbfe_search_by_bow_kf.argtypes = [ci, vp, vp, vp, ci, fvp, vp, vp, vp, ci, fvp, cf, ci, vp]
+    L.orbfe_search_for_triangulation.argtypes = [ci, vp, vp, vp, vp, vp, vp, ci, fvp, vp, vp, vp, vp, vp, vp, vp,
+                                                 ci, fvp, vp, cf, cf, vp, vp, ci, ci, ci, vp]
+    L.orbfe_compute_stereo_matches.argtypes = [vp, ci, vp, ci, vp, vp, ci, vp, vp, ci, cf, cf, vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise OrbfeError(rc, load().orbfe_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def ptr(a):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,593 @@
+// extractor.hip -- the extractor handle, its HBM workspace and the batch pipeline behind the
+// C-ABI of include/orbfe.h (replacing ORBextractor::operator(), src/ORBextractor.cc:1119-1197).
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/orbfe.h"
+#include "kernels.h"
+#include "octree_host.h"
+#include "orb_params.h"
+#include "orb_pattern.inc"
+
+using namespace orbfe;
+
+static thread_local std::string g_err = "";
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess)                                                              \
+      return fail(ORBFE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));   \
+  } while (0)
+
+extern "C" const char* orbfe_last_error(void) { return g_err.c_str(); }
+int orbfe_set_error_(int code, const char* msg) { return fail(code, msg); }  // used by matcher.hip
+extern "C" int orbfe_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static_assert(sizeof(orbfe_keypoint) == 28, "cv::KeyPoint layout");
+
+struct orbfe_extractor {
+  ExtractorTables tab;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[ORBFE_STAGE_COUNT + 1] = {};
+  bool profiling = false;
+  double stageMs[ORBFE_STAGE_COUNT] = {};
+  int64_t stageLaunches[ORBFE_STAGE_COUNT] = {};
+
+  FrameGeom geom;
+  int capFrames = 0;  // frames the workspace is sized for
+  // constant device tables
+  uint32_t* d_pattern = nullptr;
+  int32_t* d_umax = nullptr;
+  CellDesc* d_cells = nullptr;
+  LevelGeom* d_lvgeom = nullptr;
+  int32_t* d_xofs[kMaxLevels] = {};
+  int16_t* d_alpha[kMaxLevels] = {};
+  int32_t* d_yofs[kMaxLevels] = {};
+  int16_t* d_beta[kMaxLevels] = {};
+  // per-batch workspace
+  uint8_t* d_pyr = nullptr;
+  uint8_t* d_blur = nullptr;
+  Candidate* d_slots = nullptr;
+  Candidate* d_cand = nullptr;
+  uint16_t* d_cellCount = nullptr;
+  int32_t* d_cellPrefix = nullptr;
+  int32_t* d_candCount = nullptr;
+  LevelKp* d_levelKp = nullptr;
+  int32_t* d_levelCount = nullptr;
+  // device-side outputs used by the host-buffer API
+  orbfe_keypoint* d_kpOut = nullptr;
+  uint8_t* d_descOut = nullptr;
+  int32_t* d_nOut = nullptr;
+  int outCap = 0;
+  // host staging
+  std::vector<int32_t> h_candCount, h_levelCount;
+  std::vector<Candidate> h_cand;
+  std::vector<LevelKp> h_levelKp;
+  // description of the last call (for mvImagePyramid-style reads)
+  PyramidViews lastPyr = {};
+  PyramidViews lastBlur = {};
+  int lastFrames = 0;
+  bool haveLast = false;
+};
+
+namespace {
+
+template <typename T>
+int dalloc(T** p, size_t n) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (n == 0) n = 1;
+  HIPCHK(hipMalloc((void**)p, n * sizeof(T)));
+  return ORBFE_OK;
+}
+template <typename T>
+void dfree(T** p) {
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+}
+
+void free_geometry(orbfe_extractor* e) {
+  dfree(&e->d_cells);
+  dfree(&e->d_lvgeom);
+  for (int l = 0; l < kMaxLevels; l++) { dfree(&e->d_xofs[l]); dfree(&e->d_alpha[l]); dfree(&e->d_yofs[l]); dfree(&e->d_beta[l]); }
+}
+void free_workspace(orbfe_extractor* e) {
+  dfree(&e->d_pyr); dfree(&e->d_blur); dfree(&e->d_slots); dfree(&e->d_cand);
+  dfree(&e->d_cellCount); dfree(&e->d_cellPrefix); dfree(&e->d_candCount);
+  dfree(&e->d_levelKp); dfree(&e->d_levelCount);
+  e->capFrames = 0;
+}
+void free_outputs(orbfe_extractor* e) {
+  dfree(&e->d_kpOut); dfree(&e->d_descOut); dfree(&e->d_nOut);
+  e->outCap = 0;
+}
+
+int ensure_geometry(orbfe_extractor* e, int W, int H) {
+  if (e->geom.W == W && e->geom.H == H && e->d_lvgeom) return ORBFE_OK;
+  free_geometry(e);
+  free_workspace(e);
+  e->haveLast = false;
+  e->geom.build(e->tab, W, H);
+  const FrameGeom& g = e->geom;
+  for (const CellDesc& c : g.cells)
+    if (c.w > 60 || c.h > 60) return fail(ORBFE_ERR_INVALID, "FAST grid cell larger than 60 px");
+  for (int l = 0; l < g.nlevels; l++)
+    if (g.lv[l].w < 1 || g.lv[l].h < 1) return fail(ORBFE_ERR_INVALID, "image too small for the pyramid");
+  int rc;
+  if ((rc = dalloc(&e->d_cells, g.cells.size()))) return rc;
+  if (!g.cells.empty()) HIPCHK(hipMemcpy(e->d_cells, g.cells.data(), g.cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
+  if ((rc = dalloc(&e->d_lvgeom, (size_t)kMaxLevels))) return rc;
+  HIPCHK(hipMemcpy(e->d_lvgeom, g.lv, sizeof(LevelGeom) * kMaxLevels, hipMemcpyHostToDevice));
+  for (int l = 1; l < g.nlevels; l++) {
+    const ResizeTables& t = g.rz[l];
+    if ((rc = dalloc(&e->d_xofs[l], t.xofs.size()))) return rc;
+    if ((rc = dalloc(&e->d_alpha[l], t.alpha.size()))) return rc;
+    if ((rc = dalloc(&e->d_yofs[l], t.yofs.size()))) return rc;
+    if ((rc = dalloc(&e->d_beta[l], t.beta.size()))) return rc;
+    HIPCHK(hipMemcpy(e->d_xofs[l], t.xofs.data(), t.xofs.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_alpha[l], t.alpha.data(), t.alpha.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_yofs[l], t.yofs.data(), t.yofs.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_beta[l], t.beta.data(), t.beta.size() * 2, hipMemcpyHostToDevice));
+  }
+  return ORBFE_OK;
+}
+
+int ensure_workspace(orbfe_extractor* e, int nFrames) {
+  if (nFrames <= e->capFrames) return ORBFE_OK;
+  free_workspace(e);
+  const FrameGeom& g = e->geom;
+  const size_t B = (size_t)nFrames;
+  int rc;
+  if ((rc = dalloc(&e->d_pyr, B * g.pyrBytes))) return rc;
+  if ((rc = dalloc(&e->d_blur, B * g.pyrBytes))) return rc;
+  if ((rc = dalloc(&e->d_slots, B * (size_t)g.totalSlots))) return rc;
+  if ((rc = dalloc(&e->d_cand, B * (size_t)g.totalSlots))) return rc;
+  if ((rc = dalloc(&e->d_cellCount, B * g.cells.size()))) return rc;
+  if ((rc = dalloc(&e->d_cellPrefix, B * g.cells.size()))) return rc;
+  if ((rc = dalloc(&e->d_candCount, B * (size_t)g.nlevels))) return rc;
+  if ((rc = dalloc(&e->d_levelKp, B * (size_t)g.totalKpCap))) return rc;
+  if ((rc = dalloc(&e->d_levelCount, B * (size_t)g.nlevels))) return rc;
+  e->capFrames = nFrames;
+  return ORBFE_OK;
+}
+
+int ensure_outputs(orbfe_extractor* e, int nFrames, int capacity) {
+  const int need = nFrames * capacity;
+  if (need <= e->outCap && e->d_nOut) return ORBFE_OK;
+  free_outputs(e);
+  int rc;
+  if ((rc = dalloc(&e->d_kpOut, (size_t)need))) return rc;
+  if ((rc = dalloc(&e->d_descOut, (size_t)need * 32))) return rc;
+  if ((rc = dalloc(&e->d_nOut, (size_t)(nFrames > 4096 ? nFrames : 4096)))) return rc;
+  e->outCap = need;
+  return ORBFE_OK;
+}
+
+struct StageTimer {
+  orbfe_extractor* e;
+  int stage;
+  int launches;
+  StageTimer(orbfe_extractor* e_, int st, int n = 1) : e(e_), stage(st), launches(n) {
+    if (e->profiling) (void)hipEventRecord(e->ev[0], e->stream);
+  }
+  ~StageTimer() {
+    if (!e->profiling) return;
+    (void)hipEventRecord(e->ev[1], e->stream);
+    (void)hipEventSynchronize(e->ev[1]);
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e->ev[0], e->ev[1]) == hipSuccess) {
+      e->stageMs[stage] += ms;
+      e->stageLaunches[stage] += launches;
+    }
+  }
+};
+
+// The device pipeline.  level0: view of the input frames in HBM.
+int run_pipeline(orbfe_extractor* e, LevelView level0, int nFrames, orbfe_keypoint* d_kp,
+                 uint8_t* d_desc, int capacity, int32_t* d_nOut) {
+  const FrameGeom& g = e->geom;
+  hipStream_t s = e->stream;
+  PyramidViews pyr = {}, blur = {};
+  pyr.nlevels = blur.nlevels = g.nlevels;
+  pyr.lv[0] = level0;
+  for (int l = 0; l < g.nlevels; l++) {
+    if (l > 0) pyr.lv[l] = LevelView{e->d_pyr + g.lv[l].off, g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
+    blur.lv[l] = LevelView{e->d_blur + g.lv[l].off, g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
+  }
+  {  // ComputePyramid, :1203-1234
+    StageTimer t(e, ORBFE_STAGE_PYRAMID, g.nlevels - 1);
+    for (int l = 1; l < g.nlevels; l++) {
+      LevelViewMut dst{e->d_pyr + g.lv[l].off, g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
+      launch_resize(s, pyr.lv[l - 1], dst, e->d_xofs[l], e->d_alpha[l], e->d_yofs[l], e->d_beta[l], nFrames);
+    }
+  }
+  {  // FAST grid stage, :846-896
+    StageTimer t(e, ORBFE_STAGE_FAST, 2);
+    launch_fast_cells(s, pyr, e->d_cells, (int)g.cells.size(), nFrames, e->tab.iniThFAST, e->tab.minThFAST,
+                      e->d_slots, g.totalSlots, e->d_cellCount);
+    launch_gather_candidates(s, e->d_cells, e->d_lvgeom, g.nlevels, nFrames, e->d_slots, g.totalSlots,
+                             e->d_cellCount, (int)g.cells.size(), e->d_cand, e->d_candCount, e->d_cellPrefix);
+  }
+  {  // GaussianBlur of every level, :1169-1175 (queued before the host octree so it overlaps it)
+    StageTimer t(e, ORBFE_STAGE_BLUR, g.nlevels);
+    for (int l = 0; l < g.nlevels; l++) {
+      LevelViewMut dst{e->d_blur + g.lv[l].off, g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
+      launch_blur7(s, pyr.lv[l], dst, nFrames);
+    }
+  }
+  {  // DistributeOctTree, :566-808 (host, flat arrays; device version replaces this)
+    StageTimer t(e, ORBFE_STAGE_OCTREE, 0);
+    const int nl = g.nlevels;
+    e->h_candCount.resize((size_t)nFrames * nl);
+    HIPCHK(hipMemcpyAsync(e->h_candCount.data(), e->d_candCount, sizeof(int32_t) * nFrames * nl, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    std::vector<size_t> off((size_t)nFrames * nl + 1, 0);
+    for (size_t i = 0; i < (size_t)nFrames * nl; i++) off[i + 1] = off[i] + (size_t)e->h_candCount[i];
+    e->h_cand.resize(off.back() + 1);
+    for (int f = 0; f < nFrames; f++)
+      for (int l = 0; l < nl; l++) {
+        const size_t i = (size_t)f * nl + l;
+        if (e->h_candCount[i] > 0)
+          HIPCHK(hipMemcpyAsync(e->h_cand.data() + off[i], e->d_cand + (size_t)f * g.totalSlots + g.lv[l].slotStart,
+                                sizeof(Candidate) * e->h_candCount[i], hipMemcpyDeviceToHost, s));
+      }
+    HIPCHK(hipStreamSynchronize(s));
+    e->h_levelKp.assign((size_t)nFrames * g.totalKpCap, LevelKp{0, 0, 0});
+    e->h_levelCount.assign((size_t)nFrames * nl, 0);
+    std::atomic<int> next{0};
+    const int nTasks = nFrames * nl;
+    auto worker = [&]() {
+      for (;;) {
+        const int i = next.fetch_add(1);
+        if (i >= nTasks) break;
+        const int f = i / nl, l = i % nl;
+        const LevelGeom& lg = g.lv[l];
+        const int n = distribute_octree_host(e->h_cand.data() + off[i], e->h_candCount[i], kMinBorder,
+                                             lg.w - kEdgeThreshold + 3, kMinBorder, lg.h - kEdgeThreshold + 3,
+                                             lg.quota, e->h_levelKp.data() + (size_t)f * g.totalKpCap + lg.kpStart, lg.kpCap);
+        e->h_levelCount[i] = n > lg.kpCap ? lg.kpCap : n;
+      }
+    };
+    unsigned hw = std::thread::hardware_concurrency();
+    int nThreads = (int)(hw ? hw : 4);
+    if (nThreads > 16) nThreads = 16;
+    if (nThreads > nTasks) nThreads = nTasks;
+    std::vector<std::thread> pool;
+    for (int i = 1; i < nThreads; i++) pool.emplace_back(worker);
+    worker();
+    for (auto& th : pool) th.join();
+    HIPCHK(hipMemcpyAsync(e->d_levelKp, e->h_levelKp.data(), sizeof(LevelKp) * e->h_levelKp.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->d_levelCount, e->h_levelCount.data(), sizeof(int32_t) * e->h_levelCount.size(), hipMemcpyHostToDevice, s));
+  }
+  {  // computeOrientation + computeDescriptors + output records
+    StageTimer t(e, ORBFE_STAGE_ORIENT_DESC, 1);
+    OrientDescArgs a = {};
+    a.pyr = pyr;
+    a.blur = blur;
+    a.nlevels = g.nlevels;
+    a.kpSlotsPerFrame = g.totalKpCap;
+    a.outCapacity = capacity;
+    for (int l = 0; l < g.nlevels; l++) {
+      a.kpStart[l] = g.lv[l].kpStart;
+      a.kpCap[l] = g.lv[l].kpCap;
+      a.scale[l] = e->tab.scale[l];
+      a.kpSize[l] = (float)(int)(kPatchSize * e->tab.scale[l]);  // :905
+    }
+    launch_orient_desc(s, a, e->d_levelKp, e->d_levelCount, e->d_pattern, e->d_umax, nFrames, d_kp, d_desc, d_nOut);
+  }
+  HIPCHK(hipGetLastError());
+  e->lastPyr = pyr;
+  e->lastBlur = blur;
+  e->lastFrames = nFrames;
+  e->haveLast = true;
+  return ORBFE_OK;
+}
+
+}  // namespace
+
+extern "C" int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST,
+                                      int minThFAST, int device, orbfe_extractor** out) {
+  if (!out) return fail(ORBFE_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (nfeatures < 0 || nlevels < 1 || nlevels > ORBFE_MAX_LEVELS || !(scaleFactor > 1.0f))
+    return fail(ORBFE_ERR_INVALID, "bad extractor parameters");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(ORBFE_ERR_HIP, "no such HIP device");
+  HIPCHK(hipSetDevice(device));
+  orbfe_extractor* e = new (std::nothrow) orbfe_extractor();
+  if (!e) return fail(ORBFE_ERR_NOMEM, "out of memory");
+  e->device = device;
+  e->tab.init(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST);
+  hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  if (err == hipSuccess) err = hipEventCreate(&e->ev[0]);
+  if (err == hipSuccess) err = hipEventCreate(&e->ev[1]);
+  if (err == hipSuccess) err = hipMalloc((void**)&e->d_pattern, 1024);
+  if (err == hipSuccess) err = hipMemcpy(e->d_pattern, kOrbBitPattern31, 1024, hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMalloc((void**)&e->d_umax, 16 * sizeof(int32_t));
+  if (err == hipSuccess) err = hipMemcpy(e->d_umax, e->tab.umax, 16 * sizeof(int32_t), hipMemcpyHostToDevice);
+  if (err != hipSuccess) {
+    orbfe_extractor_destroy(e);
+    return fail(ORBFE_ERR_HIP, std::string("extractor_create: ") + hipGetErrorString(err));
+  }
+  *out = e;
+  return ORBFE_OK;
+}
+
+extern "C" void orbfe_extractor_destroy(orbfe_extractor* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  free_geometry(e);
+  free_workspace(e);
+  free_outputs(e);
+  dfree(&e->d_pattern);
+  dfree(&e->d_umax);
+  if (e->ev[0]) (void)hipEventDestroy(e->ev[0]);
+  if (e->ev[1]) (void)hipEventDestroy(e->ev[1]);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+extern "C" int orbfe_extractor_get_levels(const orbfe_extractor* e) { return e ? e->tab.nlevels : 0; }
+extern "C" float orbfe_extractor_get_scale_factor(const orbfe_extractor* e) { return e ? (float)e->tab.scaleFactor : 0.f; }
+#define GETTER(name, field)                                                       \
+  extern "C" int name(const orbfe_extractor* e, float* out) {                     \
+    if (!e || !out) return fail(ORBFE_ERR_INVALID, #name ": NULL argument");      \
+    for (int i = 0; i < e->tab.nlevels; i++) out[i] = e->tab.field[i];            \
+    return ORBFE_OK;                                                              \
+  }
+GETTER(orbfe_extractor_get_scale_factors, scale)
+GETTER(orbfe_extractor_get_inverse_scale_factors, invScale)
+GETTER(orbfe_extractor_get_scale_sigma_squares, sigma2)
+GETTER(orbfe_extractor_get_inverse_scale_sigma_squares, invSigma2)
+extern "C" int orbfe_extractor_get_features_per_level(const orbfe_extractor* e, int32_t* out) {
+  if (!e || !out) return fail(ORBFE_ERR_INVALID, "NULL argument");
+  for (int i = 0; i < e->tab.nlevels; i++) out[i] = e->tab.quota[i];
+  return ORBFE_OK;
+}
+extern "C" int orbfe_extractor_get_umax(const orbfe_extractor* e, int32_t* out16) {
+  if (!e || !out16) return fail(ORBFE_ERR_INVALID, "NULL argument");
+  for (int i = 0; i < 16; i++) out16[i] = e->tab.umax[i];
+  return ORBFE_OK;
+}
+extern "C" int orbfe_extractor_max_keypoints(const orbfe_extractor* e) {
+  if (!e) return 0;
+  // quota + 3 per level, or 4 root children per level on very wide images (nIni <= 16 assumed)
+  int n = 0;
+  for (int l = 0; l < e->tab.nlevels; l++) n += (e->tab.quota[l] + 3 > 64 ? e->tab.quota[l] + 3 : 64);
+  return n;
+}
+extern "C" int orbfe_extractor_level_size(const orbfe_extractor* e, int width, int height, int level, int* w, int* h) {
+  if (!e || !w || !h || level < 0 || level >= e->tab.nlevels) return fail(ORBFE_ERR_INVALID, "bad argument");
+  const float s = e->tab.invScale[level];
+  *w = cv_round((float)width * s);
+  *h = cv_round((float)height * s);
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_extract_batch_device(orbfe_extractor* e, const uint8_t* d_images, int n_frames,
+                                          int width, int height, int stride, size_t frame_stride,
+                                          orbfe_keypoint* d_keypoints, uint8_t* d_descriptors,
+                                          int capacity, int32_t* d_n_out) {
+  if (!e || !d_keypoints || !d_descriptors || !d_n_out || capacity <= 0 || n_frames < 0)
+    return fail(ORBFE_ERR_INVALID, "extract_batch_device: bad argument");
+  if (n_frames == 0) return ORBFE_OK;
+  if (!d_images || width <= 0 || height <= 0 || stride < width)
+    return fail(ORBFE_ERR_INVALID, "extract_batch_device: bad image");
+  HIPCHK(hipSetDevice(e->device));
+  int rc;
+  if ((rc = ensure_geometry(e, width, height))) return rc;
+  if ((rc = ensure_workspace(e, n_frames))) return rc;
+  LevelView l0{d_images, frame_stride, stride, width, height};
+  if ((rc = run_pipeline(e, l0, n_frames, d_keypoints, d_descriptors, capacity, d_n_out))) return rc;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* images, int n_frames, int width,
+                                   int height, int stride, size_t frame_stride,
+                                   orbfe_keypoint* keypoints, uint8_t* descriptors, int capacity,
+                                   int* n_out) {
+  if (!e || !n_out || n_frames < 0) return fail(ORBFE_ERR_INVALID, "extract_batch: bad argument");
+  for (int f = 0; f < n_frames; f++) n_out[f] = 0;
+  if (n_frames == 0) return ORBFE_OK;
+  if (!images || width <= 0 || height <= 0) return ORBFE_OK;  // empty image: silent return (:1122)
+  if (!keypoints || !descriptors || capacity <= 0 || stride < width)
+    return fail(ORBFE_ERR_INVALID, "extract_batch: bad output buffers");
+  HIPCHK(hipSetDevice(e->device));
+  int rc;
+  if ((rc = ensure_geometry(e, width, height))) return rc;
+  if ((rc = ensure_workspace(e, n_frames))) return rc;
+  if ((rc = ensure_outputs(e, n_frames, capacity))) return rc;
+  const FrameGeom& g = e->geom;
+  {
+    StageTimer t(e, ORBFE_STAGE_H2D, 0);
+    // level 0 lives at the head of the per-frame pyramid slab (pitch-aligned copy)
+    for (int f = 0; f < n_frames; f++)
+      HIPCHK(hipMemcpy2DAsync(e->d_pyr + (size_t)f * g.pyrBytes + g.lv[0].off, g.lv[0].pitch,
+                              images + (size_t)f * frame_stride, stride, width, height,
+                              hipMemcpyHostToDevice, e->stream));
+  }
+  LevelView l0{e->d_pyr + g.lv[0].off, g.pyrBytes, g.lv[0].pitch, width, height};
+  if ((rc = run_pipeline(e, l0, n_frames, e->d_kpOut, e->d_descOut, capacity, e->d_nOut))) return rc;
+  {
+    StageTimer t(e, ORBFE_STAGE_D2H, 0);
+    std::vector<int32_t> cnt(n_frames);
+    HIPCHK(hipMemcpyAsync(cnt.data(), e->d_nOut, sizeof(int32_t) * n_frames, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    bool overflow = false;
+    for (int f = 0; f < n_frames; f++) {
+      int n = cnt[f];
+      if (n > capacity) { overflow = true; n = capacity; }
+      n_out[f] = n;
+      if (n > 0) {
+        HIPCHK(hipMemcpyAsync(keypoints + (size_t)f * capacity, e->d_kpOut + (size_t)f * capacity,
+                              sizeof(orbfe_keypoint) * n, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(descriptors + (size_t)f * capacity * 32, e->d_descOut + (size_t)f * capacity * 32,
+                              (size_t)n * 32, hipMemcpyDeviceToHost, e->stream));
+      }
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (overflow) return fail(ORBFE_ERR_CAPACITY, "keypoint capacity too small");
+  }
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_extract(orbfe_extractor* e, const uint8_t* image, int width, int height, int stride,
+                             orbfe_keypoint* keypoints, uint8_t* descriptors, int capacity, int* n_out) {
+  return orbfe_extract_batch(e, image, 1, width, height, stride, (size_t)stride * (size_t)(height > 0 ? height : 0),
+                             keypoints, descriptors, capacity, n_out);
+}
+
+static int copy_level_out(orbfe_extractor* e, const PyramidViews& pv, int frame, int level, uint8_t* dst, int dst_stride) {
+  if (!e || !dst) return fail(ORBFE_ERR_INVALID, "NULL argument");
+  if (!e->haveLast) return fail(ORBFE_ERR_INVALID, "no extract call yet");
+  if (frame < 0 || frame >= e->lastFrames || level < 0 || level >= pv.nlevels)
+    return fail(ORBFE_ERR_INVALID, "frame/level out of range");
+  const LevelView& v = pv.lv[level];
+  if (dst_stride < v.w) return fail(ORBFE_ERR_INVALID, "dst_stride too small");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipMemcpy2DAsync(dst, dst_stride, v.base + (size_t)frame * v.frameStride, v.pitch, v.w, v.h,
+                          hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return ORBFE_OK;
+}
+extern "C" int orbfe_extractor_get_pyramid_level(orbfe_extractor* e, int frame, int level, uint8_t* dst, int dst_stride) {
+  if (!e) return fail(ORBFE_ERR_INVALID, "NULL handle");
+  return copy_level_out(e, e->lastPyr, frame, level, dst, dst_stride);
+}
+extern "C" int orbfe_extractor_debug_blurred_level(orbfe_extractor* e, int frame, int level, uint8_t* dst, int dst_stride) {
+  if (!e) return fail(ORBFE_ERR_INVALID, "NULL handle");
+  return copy_level_out(e, e->lastBlur, frame, level, dst, dst_stride);
+}
+extern "C" int orbfe_extractor_pyramid_level_device(orbfe_extractor* e, int frame, int level, const uint8_t** d_ptr,
+                                                    int* pitch, int* w, int* h) {
+  if (!e || !d_ptr || !pitch || !w || !h) return fail(ORBFE_ERR_INVALID, "NULL argument");
+  if (!e->haveLast || frame < 0 || frame >= e->lastFrames || level < 0 || level >= e->lastPyr.nlevels)
+    return fail(ORBFE_ERR_INVALID, "frame/level out of range");
+  const LevelView& v = e->lastPyr.lv[level];
+  *d_ptr = v.base + (size_t)frame * v.frameStride;
+  *pitch = v.pitch;
+  *w = v.w;
+  *h = v.h;
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_extractor_debug_candidates(orbfe_extractor* e, int frame, int level, float* xs, float* ys,
+                                                float* resp, int cap) {
+  if (!e || !xs || !ys || !resp) return fail(ORBFE_ERR_INVALID, "NULL argument");
+  if (!e->haveLast || frame < 0 || frame >= e->lastFrames || level < 0 || level >= e->geom.nlevels)
+    return fail(ORBFE_ERR_INVALID, "frame/level out of range");
+  HIPCHK(hipSetDevice(e->device));
+  int32_t n = 0;
+  HIPCHK(hipMemcpy(&n, e->d_candCount + (size_t)frame * e->geom.nlevels + level, 4, hipMemcpyDeviceToHost));
+  std::vector<Candidate> c((size_t)(n > 0 ? n : 1));
+  if (n > 0)
+    HIPCHK(hipMemcpy(c.data(), e->d_cand + (size_t)frame * e->geom.totalSlots + e->geom.lv[level].slotStart,
+                     sizeof(Candidate) * n, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n && i < cap; i++) {
+    xs[i] = (float)(c[i].xy & 0xffffu);
+    ys[i] = (float)(c[i].xy >> 16);
+    resp[i] = (float)c[i].score;
+  }
+  return n;
+}
+
+extern "C" int orbfe_extractor_profile(orbfe_extractor* e, int enable) {
+  if (!e) return fail(ORBFE_ERR_INVALID, "NULL handle");
+  e->profiling = enable != 0;
+  for (int i = 0; i < ORBFE_STAGE_COUNT; i++) { e->stageMs[i] = 0; e->stageLaunches[i] = 0; }
+  return ORBFE_OK;
+}
+extern "C" int orbfe_extractor_profile_get(orbfe_extractor* e, double* ms_out, int64_t* launches_out) {
+  if (!e || !ms_out || !launches_out) return fail(ORBFE_ERR_INVALID, "NULL argument");
+  for (int i = 0; i < ORBFE_STAGE_COUNT; i++) { ms_out[i] = e->stageMs[i]; launches_out[i] = e->stageLaunches[i]; }
+  return ORBFE_OK;
+}
+extern "C" const char* orbfe_stage_name(int stage) {
+  static const char* names[ORBFE_STAGE_COUNT] = {"h2d", "pyramid", "fast", "octree", "blur", "orient_desc", "d2h"};
+  return (stage >= 0 && stage < ORBFE_STAGE_COUNT) ? names[stage] : "?";
+}
+
+// ---- standalone primitives on host buffers ----
+extern "C" int orbfe_resize_linear(int device, const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst,
+                                   int dw, int dh, int dstride) {
+  if (!src || !dst || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || sstride < sw || dstride < dw)
+    return fail(ORBFE_ERR_INVALID, "resize: bad argument");
+  HIPCHK(hipSetDevice(device));
+  ResizeTables t;
+  build_resize_tables(sw, sh, dw, dh, &t);
+  const int sp = (sw + 63) & ~63, dp = (dw + 63) & ~63;
+  uint8_t *d_src = nullptr, *d_dst = nullptr;
+  int32_t *d_xofs = nullptr, *d_yofs = nullptr;
+  int16_t *d_alpha = nullptr, *d_beta = nullptr;
+  int rc = ORBFE_OK;
+  auto cleanup = [&]() { dfree(&d_src); dfree(&d_dst); dfree(&d_xofs); dfree(&d_yofs); dfree(&d_alpha); dfree(&d_beta); };
+  if ((rc = dalloc(&d_src, (size_t)sp * sh)) || (rc = dalloc(&d_dst, (size_t)dp * dh)) ||
+      (rc = dalloc(&d_xofs, t.xofs.size())) || (rc = dalloc(&d_yofs, t.yofs.size())) ||
+      (rc = dalloc(&d_alpha, t.alpha.size())) || (rc = dalloc(&d_beta, t.beta.size()))) { cleanup(); return rc; }
+  hipError_t err = hipMemcpy2D(d_src, sp, src, sstride, sw, sh, hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMemcpy(d_xofs, t.xofs.data(), t.xofs.size() * 4, hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMemcpy(d_yofs, t.yofs.data(), t.yofs.size() * 4, hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMemcpy(d_alpha, t.alpha.data(), t.alpha.size() * 2, hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMemcpy(d_beta, t.beta.data(), t.beta.size() * 2, hipMemcpyHostToDevice);
+  if (err == hipSuccess) {
+    launch_resize(nullptr, LevelView{d_src, 0, sp, sw, sh}, LevelViewMut{d_dst, 0, dp, dw, dh}, d_xofs, d_alpha, d_yofs, d_beta, 1);
+    err = hipGetLastError();
+  }
+  if (err == hipSuccess) err = hipDeviceSynchronize();
+  if (err == hipSuccess) err = hipMemcpy2D(dst, dstride, d_dst, dp, dw, dh, hipMemcpyDeviceToHost);
+  cleanup();
+  if (err != hipSuccess) return fail(ORBFE_ERR_HIP, std::string("resize: ") + hipGetErrorString(err));
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_gaussian_blur7(int device, const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride) {
+  if (!src || !dst || w <= 0 || h <= 0 || sstride < w || dstride < w) return fail(ORBFE_ERR_INVALID, "blur: bad argument");
+  HIPCHK(hipSetDevice(device));
+  const int p = (w + 63) & ~63;
+  uint8_t *d_src = nullptr, *d_dst = nullptr;
+  int rc;
+  if ((rc = dalloc(&d_src, (size_t)p * h))) return rc;
+  if ((rc = dalloc(&d_dst, (size_t)p * h))) { dfree(&d_src); return rc; }
+  hipError_t err = hipMemcpy2D(d_src, p, src, sstride, w, h, hipMemcpyHostToDevice);
+  if (err == hipSuccess) {
+    launch_blur7(nullptr, LevelView{d_src, 0, p, w, h}, LevelViewMut{d_dst, 0, p, w, h}, 1);
+    err = hipGetLastError();
+  }
+  if (err == hipSuccess) err = hipDeviceSynchronize();
+  if (err == hipSuccess) err = hipMemcpy2D(dst, dstride, d_dst, p, w, h, hipMemcpyDeviceToHost);
+  dfree(&d_src);
+  dfree(&d_dst);
+  if (err != hipSuccess) return fail(ORBFE_ERR_HIP, std::string("blur: ") + hipGetErrorString(err));
+  return ORBFE_OK;
+}
+
+// internal (matcher.hip): pyramid views + scale tables of the last extract call
+extern "C" int orbfe_stereo_views_(orbfe_extractor* e, int frame, PyramidViews* pv, float* scale, float* invScale,
+                                   int* nlevels, int* device) {
+  if (!e->haveLast) return fail(ORBFE_ERR_INVALID, "compute_stereo_matches: extractor has no pyramid yet");
+  if (frame < 0 || frame >= e->lastFrames) return fail(ORBFE_ERR_INVALID, "compute_stereo_matches: frame out of range");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  *pv = e->lastPyr;
+  for (int l = 0; l < e->tab.nlevels; l++) { scale[l] = e->tab.scale[l]; invScale[l] = e->tab.invScale[l]; }
+  *nlevels = e->tab.nlevels;
+  *device = e->device;
+  return ORBFE_OK;
+}

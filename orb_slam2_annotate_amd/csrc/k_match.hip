@@ -1,0 +1,413 @@
+// k_match.hip -- 256-bit Hamming matching kernels (ORBmatcher, src/ORBmatcher.cc; stereo,
+// src/Frame.cc:512-686).  Pure XOR + v_bcnt popcount work, no MFMA: one 64-lane wavefront
+// owns a query descriptor (held in 8 SGPR/VGPR dwords), its lanes stride over the candidate
+// descriptors (32 B each, two 16-B loads per lane) and the best/second-best bookkeeping of
+// the reference's sequential scan is reproduced by an order-preserving wave reduction:
+// keys are (distance << 16 | scan position), so "first minimum wins" / "last minimum wins"
+// are a plain min over the wave.
+#include "kernels.h"
+#include "match_kernels.h"
+
+namespace orbfe {
+
+namespace {
+struct Desc { uint32_t w[8]; };
+
+__device__ __forceinline__ Desc load_desc(const uint8_t* base, uint32_t idx) {
+  const uint4* p = reinterpret_cast<const uint4*>(base + (size_t)idx * 32);
+  const uint4 a = p[0], b = p[1];
+  Desc d;
+  d.w[0] = a.x; d.w[1] = a.y; d.w[2] = a.z; d.w[3] = a.w;
+  d.w[4] = b.x; d.w[5] = b.y; d.w[6] = b.z; d.w[7] = b.w;
+  return d;
+}
+__device__ __forceinline__ int hdist(const Desc& a, const Desc& b) {
+  int d = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) d += __popc(a.w[i] ^ b.w[i]);
+  return d;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// rotation-histogram bin, src/ORBmatcher.cc:272-279 (C round(): half away from zero)
+__device__ __forceinline__ int rot_bin(float a1, float a2) {
+  const float factor = 1.0f / 30;
+  float rot = __fsub_rn(a1, a2);
+  if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+  int bin = (int)roundf(__fmul_rn(rot, factor));
+  if (bin == 30) bin = 0;
+  return bin;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_hamming_pairs(const uint8_t* __restrict__ a,
+                                                       const uint8_t* __restrict__ b, int n,
+                                                       int32_t* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  out[i] = hdist(load_desc(a, i), load_desc(b, i));
+}
+void launch_hamming_pairs(hipStream_t s, const uint8_t* a, const uint8_t* b, int n, int32_t* out) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_hamming_pairs, dim3((n + 255) / 256), dim3(256), 0, s, a, b, n, out);
+}
+
+__global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t* __restrict__ d1, int n1,
+                                                        const uint8_t* __restrict__ d2, int n2,
+                                                        int32_t* __restrict__ out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int i0 = blockIdx.y * 16;
+  if (j >= n2) return;
+  const Desc b = load_desc(d2, j);
+  for (int i = i0; i < i0 + 16 && i < n1; i++) {
+    const Desc a = load_desc(d1, i);  // wave-uniform address: one broadcast load
+    out[(size_t)i * n2 + j] = hdist(a, b);
+  }
+}
+void launch_hamming_matrix(hipStream_t s, const uint8_t* d1, int n1, const uint8_t* d2, int n2, int32_t* out) {
+  if (n1 <= 0 || n2 <= 0) return;
+  hipLaunchKernelGGL(k_hamming_matrix, dim3((n2 + 255) / 256, (n1 + 15) / 16), dim3(256), 0, s, d1, n1, d2, n2, out);
+}
+
+// ---------------------------------------------------------------------------------------
+// SearchByBoW (src/ORBmatcher.cc:185-325 and :610-743): one wavefront per shared vocabulary
+// node.  Queries inside a node are sequential (a frame feature claimed by an earlier query is
+// skipped by later ones, :242-244/:664,691); different nodes never interact.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_search_by_bow(BowArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t claimed[];  // per position in node 2
+  const int lane = threadIdx.x;
+  const NodePair np = a.pairs[blockIdx.x];
+  for (int i = lane; i < np.cnt2; i += 64) claimed[i] = 0;
+  __syncthreads();
+  for (int q = 0; q < np.cnt1; q++) {
+    const uint32_t idx1 = a.indices1[np.off1 + q];
+    if (!a.hasMp1[idx1]) continue;  // wave-uniform
+    const Desc d1 = load_desc(a.desc1, idx1);
+    uint32_t key1 = (256u << 16) | 0xffffu;  // (bestDist1, position) -- first minimum wins
+    uint32_t best2 = 256u;
+    for (int p = lane; p < np.cnt2; p += 64) {
+      const uint32_t idx2 = a.indices2[np.off2 + p];
+      if (claimed[p]) continue;
+      if (a.hasMp2 && !a.hasMp2[idx2]) continue;  // KF-KF form, :664
+      const uint32_t dist = (uint32_t)hdist(d1, load_desc(a.desc2, idx2));
+      const uint32_t key = (dist << 16) | (uint32_t)p;
+      if (dist < (key1 >> 16)) { best2 = key1 >> 16; key1 = key; }
+      else if (dist < best2) best2 = dist;
+    }
+    // two smallest of the multiset, first position of the minimum
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t ok1 = (uint32_t)__shfl_xor((int)key1, o, 64);
+      const uint32_t ob2 = (uint32_t)__shfl_xor((int)best2, o, 64);
+      const uint32_t lo = ok1 < key1 ? ok1 : key1, hi = ok1 < key1 ? key1 : ok1;
+      const uint32_t m2 = ob2 < best2 ? ob2 : best2;
+      key1 = lo;
+      best2 = (hi >> 16) < m2 ? (hi >> 16) : m2;
+    }
+    const uint32_t bestDist1 = key1 >> 16, pos = key1 & 0xffffu;
+    const bool pass1 = a.strictLow ? (bestDist1 < 50u) : (bestDist1 <= 50u);  // :263 vs :686
+    if (pass1 && (float)bestDist1 < __fmul_rn(a.nnratio, (float)best2)) {
+      if (lane == 0) {
+        claimed[pos] = 1;
+        const uint32_t idx2 = a.indices2[np.off2 + pos];
+        if (a.strictLow) {  // KF-KF: vpMatches12[idx1] = MapPoint of idx2; histogram holds idx1
+          a.match[idx1] = (int32_t)idx2;
+          a.bin[idx1] = (int8_t)rot_bin(a.angle1[idx1], a.angle2[idx2]);
+        } else {            // KF-Frame: vpMapPointMatches[idxF] = MapPoint of idxKF; histogram holds idxF
+          a.match[idx2] = (int32_t)idx1;
+          a.bin[idx2] = (int8_t)rot_bin(a.angle1[idx1], a.angle2[idx2]);
+        }
+      }
+      __syncthreads();  // single-wave block: orders the LDS claim before the next query
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// SearchForTriangulation (src/ORBmatcher.cc:754-928): queries are independent (vbMatched2 is
+// never written, :774,827) -> one wavefront per KF1 feature.  A candidate replaces the best
+// when dist <= bestDist, so among equal distances the LAST scanned one wins (:840).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_search_triangulation(TriArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= a.nQueries) return;
+  const TriQuery tq = a.queries[q];
+  const uint32_t idx1 = tq.idx1;
+  const Desc d1 = load_desc(a.desc1, idx1);
+  const float x1 = a.x1[idx1], y1 = a.y1[idx1];
+  const bool st1 = a.stereo1[idx1] != 0;
+  // epipolar line of kp1 in image 2, CheckDistEpipolarLine :158-160
+  const float* F = a.F12;
+  const float la = __fadd_rn(__fadd_rn(__fmul_rn(x1, F[0]), __fmul_rn(y1, F[3])), F[6]);
+  const float lb = __fadd_rn(__fadd_rn(__fmul_rn(x1, F[1]), __fmul_rn(y1, F[4])), F[7]);
+  const float lc = __fadd_rn(__fadd_rn(__fmul_rn(x1, F[2]), __fmul_rn(y1, F[5])), F[8]);
+  const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
+  uint32_t best = 0xffffffffu;  // (dist << 16) | (0xffff - position): min dist, last position
+  for (int p = lane; p < tq.cnt2; p += 64) {
+    const uint32_t idx2 = a.indices2[tq.off2 + p];
+    if (a.hasMp2[idx2]) continue;
+    const bool st2 = a.stereo2[idx2] != 0;
+    if (a.onlyStereo && !st2) continue;
+    const uint32_t dist = (uint32_t)hdist(d1, load_desc(a.desc2, idx2));
+    if (dist > 50u) continue;
+    const float x2 = a.x2[idx2], y2 = a.y2[idx2];
+    const int oc = a.octave2[idx2];
+    if (!st1 && !st2) {  // :845-854
+      const float dex = __fsub_rn(a.ex, x2), dey = __fsub_rn(a.ey, y2);
+      if (__fadd_rn(__fmul_rn(dex, dex), __fmul_rn(dey, dey)) < __fmul_rn(100.0f, a.scaleFactors2[oc])) continue;
+    }
+    const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, x2), __fmul_rn(lb, y2)), lc);
+    if (den == 0) continue;
+    const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+    if (!((double)dsqr < __dmul_rn(3.84, (double)a.levelSigma2_2[oc]))) continue;
+    const uint32_t key = (dist << 16) | (0xffffu - (uint32_t)p);
+    best = key < best ? key : best;
+  }
+  best = wave_min_u32(best);
+  if (lane == 0) {
+    if (best != 0xffffffffu) {
+      const uint32_t pos = 0xffffu - (best & 0xffffu);
+      const uint32_t idx2 = a.indices2[tq.off2 + pos];
+      a.match[idx1] = (int32_t)idx2;
+      a.bin[idx1] = (int8_t)rot_bin(a.angle1[idx1], a.angle2[idx2]);
+    }
+  }
+}
+
+// Rotation-consistency pruning shared by the three searches (:303-322, ComputeThreeMaxima
+// :1777-1821): one workgroup histograms the accepted matches, keeps the three dominant bins.
+__global__ __launch_bounds__(256) void k_rot_prune(int32_t* __restrict__ match, const int8_t* __restrict__ bin,
+                                                   int n, int checkOri, int32_t* __restrict__ nMatches) {
+  __shared__ int hist[30];
+  __shared__ int keep[3];
+  __shared__ int total;
+  const int tid = threadIdx.x;
+  if (tid < 30) hist[tid] = 0;
+  if (tid == 0) total = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int i = tid; i < n; i += 256)
+    if (match[i] >= 0) { mine++; atomicAdd(&hist[bin[i]], 1); }
+  if (mine) atomicAdd(&total, mine);
+  __syncthreads();
+  if (!checkOri) { if (tid == 0) *nMatches = total; return; }
+  if (tid == 0) {
+    int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+    for (int i = 0; i < 30; i++) {
+      const int s = hist[i];
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+      else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+      else if (s > max3) { max3 = s; i3 = i; }
+    }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { i2 = -1; i3 = -1; }
+    else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { i3 = -1; }
+    keep[0] = i1; keep[1] = i2; keep[2] = i3;
+    int kept = 0;
+    for (int i = 0; i < 30; i++)
+      if (i == i1 || i == i2 || i == i3) kept += hist[i];
+    *nMatches = kept;
+  }
+  __syncthreads();
+  const int k0 = keep[0], k1 = keep[1], k2 = keep[2];
+  for (int i = tid; i < n; i += 256)
+    if (match[i] >= 0) {
+      const int b = bin[i];
+      if (b != k0 && b != k1 && b != k2) match[i] = -1;
+    }
+}
+
+void launch_search_by_bow(hipStream_t s, const BowArgs& a, int nPairs, int maxCnt2) {
+  if (nPairs <= 0) return;
+  const size_t lds = (size_t)((maxCnt2 + 15) & ~15);
+  hipLaunchKernelGGL(k_search_by_bow, dim3(nPairs), dim3(64), lds, s, a);
+}
+void launch_search_triangulation(hipStream_t s, const TriArgs& a) {
+  if (a.nQueries <= 0) return;
+  hipLaunchKernelGGL(k_search_triangulation, dim3((a.nQueries + 3) / 4), dim3(256), 0, s, a);
+}
+void launch_rot_prune(hipStream_t s, int32_t* match, const int8_t* bin, int n, int checkOri, int32_t* nMatches) {
+  hipLaunchKernelGGL(k_rot_prune, dim3(1), dim3(256), 0, s, match, bin, n, checkOri, nMatches);
+}
+
+// ---------------------------------------------------------------------------------------
+// Frame::ComputeStereoMatches (src/Frame.cc:512-686)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (iL >= a.N) return;
+  const float* kl = a.kpL + (size_t)iL * 7;
+  const float uL = kl[0], vL = kl[1];
+  const int levelL = reinterpret_cast<const int32_t*>(kl)[5];
+  if (lane == 0) { a.uRight[iL] = -1.0f; a.depth[iL] = -1.0f; a.sad[iL] = -1; }
+  const int row = (int)vL;
+  const float minU = __fsub_rn(uL, a.maxD), maxU = uL;  // minD = 0
+  if (maxU < 0) return;
+  const Desc dL = load_desc(a.descL, iL);
+  // candidates: right keypoints whose row band [floor(y-r), ceil(y+r)], r = 2*scale[octave],
+  // contains `row` (:522-539), octave within +-1 (:579), uR in [minU, maxU] (:584);
+  // best = strictly smaller distance, i.e. first minimum in ascending iR (:589-593)
+  uint32_t best = 0xffffffffu;  // dist << 20 | iR
+  for (int iR = lane; iR < a.Nr; iR += 64) {
+    const float* kr = a.kpR + (size_t)iR * 7;
+    const int octR = reinterpret_cast<const int32_t*>(kr)[5];
+    const float yR = kr[1];
+    const float r = __fmul_rn(2.0f, a.scale[octR]);
+    const int maxr = (int)ceilf(__fadd_rn(yR, r));
+    const int minr = (int)floorf(__fsub_rn(yR, r));
+    if (row < minr || row > maxr) continue;
+    if (octR < levelL - 1 || octR > levelL + 1) continue;
+    const float uR = kr[0];
+    if (!(uR >= minU && uR <= maxU)) continue;
+    const uint32_t dist = (uint32_t)hdist(dL, load_desc(a.descR, iR));
+    if (dist >= 100u) continue;  // bestDist starts at TH_HIGH, strict <
+    const uint32_t key = (dist << 20) | (uint32_t)iR;
+    best = key < best ? key : best;
+  }
+  best = wave_min_u32(best);
+  if (best == 0xffffffffu) return;
+  const int bestDist = (int)(best >> 20), bestIdxR = (int)(best & 0xfffffu);
+  if (bestDist >= 75) return;  // thOrbDist = (TH_HIGH+TH_LOW)/2, :517,598
+  // ---- SAD refinement on the left keypoint's pyramid level (:600-638) ----
+  const float uR0 = a.kpR[(size_t)bestIdxR * 7];
+  const float sf = a.invScale[levelL];
+  const float scaleduL = roundf(__fmul_rn(uL, sf));
+  const float scaledvL = roundf(__fmul_rn(vL, sf));
+  const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
+  const LevelView L = a.pyrL.lv[levelL], R = a.pyrR.lv[levelL];
+  const float iniu = scaleduR0 + 5 - 5;
+  const float endu = scaleduR0 + 5 + 5 + 1;
+  if (iniu < 0 || endu >= (float)R.w) return;
+  const int cy = (int)scaledvL, cxL = (int)scaleduL, cxR0 = (int)scaleduR0;
+  const uint8_t* IL = L.base + (size_t)a.frameL * L.frameStride;
+  const uint8_t* IR = R.base + (size_t)a.frameR * R.frameStride;
+  const int cL = IL[(size_t)cy * L.pitch + cxL];
+  // lanes own patch pixels p = lane, lane+64 of the 11x11 window
+  int pl[2], py[2], px[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int p = lane + 64 * k;
+    py[k] = p / 11 - 5;
+    px[k] = p % 11 - 5;
+    pl[k] = p < 121 ? (int)IL[(size_t)(cy + py[k]) * L.pitch + cxL + px[k]] - cL : 0;
+  }
+  int dists[11];
+#pragma unroll
+  for (int inc = -5; inc <= 5; inc++) {
+    const int cxR = cxR0 + inc;
+    const int cR = IR[(size_t)cy * R.pitch + cxR];
+    int acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      if (lane + 64 * k < 121) {
+        const int v = (int)IR[(size_t)(cy + py[k]) * R.pitch + cxR + px[k]] - cR;
+        const int d = pl[k] - v;
+        acc += d < 0 ? -d : d;
+      }
+    }
+    dists[inc + 5] = wave_sum_i32(acc);
+  }
+  int bestSad = 0x7fffffff, bestinc = 0;
+#pragma unroll
+  for (int i = 0; i < 11; i++)
+    if (dists[i] < bestSad) { bestSad = dists[i]; bestinc = i - 5; }
+  if (bestinc == -5 || bestinc == 5) return;
+  float d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll
+  for (int i = 1; i < 10; i++)
+    if (i == bestinc + 5) { d1 = (float)dists[i - 1]; d2 = (float)dists[i]; d3 = (float)dists[i + 1]; }
+  // parabola sub-pixel (:644-651)
+  const float deltaR = __fdiv_rn(__fsub_rn(d1, d3),
+                                 __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2))));
+  if (deltaR < -1 || deltaR > 1) return;
+  float bestuR = __fmul_rn(a.scale[levelL], __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));
+  float disparity = __fsub_rn(uL, bestuR);
+  if (disparity >= 0 && disparity < a.maxD) {
+    if (disparity <= 0) {
+      disparity = 0.01f;
+      bestuR = (float)__dsub_rn((double)uL, 0.01);
+    }
+    if (lane == 0) {
+      a.depth[iL] = __fdiv_rn(a.mbf, disparity);
+      a.uRight[iL] = bestuR;
+      a.sad[iL] = bestSad;
+    }
+  }
+}
+
+// Median cut (:672-685): drop matches whose SAD >= 1.5*1.4*median, median = sorted[size/2].
+// SAD <= 121*510 < 65536 -> two-level 8+8 bit radix select in one workgroup.
+__global__ __launch_bounds__(256) void k_stereo_median_cut(int N, const int32_t* __restrict__ sad,
+                                                           float* __restrict__ uRight, float* __restrict__ depth,
+                                                           int32_t* __restrict__ nStereo) {
+  __shared__ int hist[256];
+  __shared__ int sel[3];  // hi bin, remaining k, total
+  const int tid = threadIdx.x;
+  hist[tid] = 0;
+  if (tid == 0) sel[2] = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int i = tid; i < N; i += 256) {
+    const int s = sad[i];
+    if (s >= 0) { atomicAdd(&hist[s >> 8], 1); mine++; }
+  }
+  if (mine) atomicAdd(&sel[2], mine);
+  __syncthreads();
+  const int total = sel[2];
+  if (total == 0) { if (tid == 0) *nStereo = 0; return; }
+  if (tid == 0) {
+    int k = total / 2, b = 0;
+    while (k >= hist[b]) { k -= hist[b]; b++; }
+    sel[0] = b; sel[1] = k;
+  }
+  __syncthreads();
+  const int hi = sel[0];
+  __syncthreads();
+  hist[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < N; i += 256) {
+    const int s = sad[i];
+    if (s >= 0 && (s >> 8) == hi) atomicAdd(&hist[s & 255], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int k = sel[1], b = 0;
+    while (k >= hist[b]) { k -= hist[b]; b++; }
+    sel[0] = (hi << 8) | b;
+    sel[1] = 0;
+  }
+  __syncthreads();
+  const float median = (float)sel[0];
+  const float thDist = __fmul_rn(1.5f * 1.4f, median);
+  int kept = 0;
+  for (int i = tid; i < N; i += 256) {
+    const int s = sad[i];
+    if (s < 0) continue;
+    if ((float)s < thDist) kept++;
+    else { uRight[i] = -1.0f; depth[i] = -1.0f; }
+  }
+  if (kept) atomicAdd(&sel[1], kept);
+  __syncthreads();
+  if (tid == 0) *nStereo = sel[1];
+}
+
+void launch_stereo(hipStream_t s, const StereoArgs& a, int32_t* d_nStereo) {
+  if (a.N <= 0) return;
+  hipLaunchKernelGGL(k_stereo_match, dim3((a.N + 3) / 4), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_stereo_median_cut, dim3(1), dim3(256), 0, s, a.N, a.sad, a.uRight, a.depth, d_nStereo);
+}
+
+}  // namespace orbfe

@@ -1,0 +1,84 @@
+// kernels.h -- launch wrappers of the hand-written gfx950 kernels (one .hip file per stage).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "orb_params.h"
+
+namespace orbfe {
+
+// A pyramid level of a batch of frames in HBM: frame f, row y starts at
+// base + f*frameStride + y*pitch.  Row-major u8, pitch is a multiple of 64 for owned levels.
+struct LevelView {
+  const uint8_t* base;
+  size_t frameStride;
+  int pitch;
+  int w, h;
+};
+struct LevelViewMut {
+  uint8_t* base;
+  size_t frameStride;
+  int pitch;
+  int w, h;
+};
+
+struct PyramidViews {
+  LevelView lv[kMaxLevels];
+  int nlevels;
+};
+
+// Candidate corner as the FAST grid stage emits it (src/ORBextractor.cc:884-893):
+// xy = x | y<<16 relative to (minBorderX, minBorderY), score = cv::FAST response.
+struct Candidate {
+  uint32_t xy;
+  uint32_t score;
+};
+
+// Keypoint selected by the octree, level coordinates (already + minBorder, :909-916).
+struct LevelKp {
+  uint16_t x, y;
+  uint32_t score;
+};
+
+// ---- pyramid (ComputePyramid, :1203-1234) ----
+void launch_resize(hipStream_t s, LevelView src, LevelViewMut dst, const int32_t* d_xofs,
+                   const int16_t* d_alpha, const int32_t* d_yofs, const int16_t* d_beta,
+                   int nFrames);
+void launch_copy2d(hipStream_t s, LevelView src, LevelViewMut dst, int nFrames);
+
+// ---- FAST grid stage (:846-896) ----
+void launch_fast_cells(hipStream_t s, PyramidViews pyr, const CellDesc* d_cells, int nCells,
+                       int nFrames, int iniTh, int minTh, Candidate* d_slots, int slotsPerFrame,
+                       uint16_t* d_cellCount);
+// ordered compaction of the per-cell slots of each (frame, level) into d_cand
+void launch_gather_candidates(hipStream_t s, const CellDesc* d_cells, const LevelGeom* d_lv,
+                              int nlevels, int nFrames, const Candidate* d_slots,
+                              int slotsPerFrame, const uint16_t* d_cellCount, int cellsPerFrame,
+                              Candidate* d_cand, int32_t* d_candCount, int32_t* d_cellPrefix);
+
+// ---- blur (GaussianBlur 7x7 sigma 2 reflect-101, :1169-1175) ----
+void launch_blur7(hipStream_t s, LevelView src, LevelViewMut dst, int nFrames);
+
+// ---- orientation + descriptor + final keypoint record (:78-152, :905-916, :1187-1195) ----
+struct OrientDescArgs {
+  PyramidViews pyr;   // unblurred levels (IC_Angle)
+  PyramidViews blur;  // blurred levels (rBRIEF)
+  int kpStart[kMaxLevels];
+  int kpCap[kMaxLevels];
+  float scale[kMaxLevels];
+  float kpSize[kMaxLevels];
+  int nlevels;
+  int kpSlotsPerFrame;   // totalKpCap
+  int outCapacity;       // caller's per-frame capacity
+};
+void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d_levelKp,
+                        const int32_t* d_levelCount, const uint32_t* d_pattern,
+                        const int32_t* d_umax, int nFrames, void* d_kpOut, uint8_t* d_descOut,
+                        int32_t* d_nOut);
+
+// ---- matching ----
+void launch_hamming_pairs(hipStream_t s, const uint8_t* a, const uint8_t* b, int n, int32_t* out);
+void launch_hamming_matrix(hipStream_t s, const uint8_t* d1, int n1, const uint8_t* d2, int n2,
+                           int32_t* out);
+
+}  // namespace orbfe

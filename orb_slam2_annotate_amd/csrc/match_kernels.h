@@ -1,0 +1,51 @@
+// match_kernels.h -- argument blocks of the matching kernels (k_match.hip).
+#pragma once
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace orbfe {
+
+struct NodePair {  // one vocabulary node present in both FeatureVectors
+  int32_t off1, cnt1, off2, cnt2;
+};
+
+struct BowArgs {
+  const NodePair* pairs;
+  const uint8_t* desc1; const uint8_t* hasMp1; const float* angle1; const uint32_t* indices1;
+  const uint8_t* desc2; const uint8_t* hasMp2 /* NULL for the KF-Frame form */; const float* angle2;
+  const uint32_t* indices2;
+  float nnratio;
+  int strictLow;   // 0: SearchByBoW(KF,F) accepts best <= TH_LOW; 1: (KF,KF) best < TH_LOW
+  int32_t* match;  // KF-Frame: indexed by frame feature; KF-KF: indexed by KF1 feature
+  int8_t* bin;     // rotation-histogram bin of the accepted match, same indexing
+};
+
+struct TriQuery { uint32_t idx1; int32_t off2, cnt2; };
+
+struct TriArgs {
+  const TriQuery* queries; int nQueries;
+  const uint8_t* desc1; const float* x1; const float* y1; const float* angle1; const uint8_t* stereo1;
+  const uint8_t* desc2; const uint8_t* hasMp2; const float* x2; const float* y2; const float* angle2;
+  const int32_t* octave2; const uint8_t* stereo2; const uint32_t* indices2;
+  const float* F12; float ex, ey;
+  const float* scaleFactors2; const float* levelSigma2_2;
+  int onlyStereo;
+  int32_t* match; int8_t* bin;
+};
+
+struct StereoArgs {
+  const float* kpL; const uint8_t* descL; int N;   // 7 floats per keypoint (cv::KeyPoint layout)
+  const float* kpR; const uint8_t* descR; int Nr;
+  PyramidViews pyrL, pyrR; int frameL, frameR;
+  float scale[kMaxLevels], invScale[kMaxLevels];
+  float mbf, maxD;
+  float* uRight; float* depth; int32_t* sad;
+};
+
+void launch_search_by_bow(hipStream_t s, const BowArgs& a, int nPairs, int maxCnt2);
+void launch_search_triangulation(hipStream_t s, const TriArgs& a);
+void launch_rot_prune(hipStream_t s, int32_t* match, const int8_t* bin, int n, int checkOri, int32_t* nMatches);
+void launch_stereo(hipStream_t s, const StereoArgs& a, int32_t* d_nStereo);
+
+}  // namespace orbfe

@@ -1,0 +1,352 @@
+// matcher.hip -- C-ABI entry points of the Hamming matchers and the stereo matcher
+// (include/orbfe.h, "Matcher").  Stateless and re-entrant: every thread owns a private
+// device arena + stream per device (the reference constructs stack-local ORBmatcher objects
+// on three threads concurrently, src/LocalMapping.cc:261, src/LoopClosing.cc:294).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/orbfe.h"
+#include "kernels.h"
+#include "match_kernels.h"
+
+using namespace orbfe;
+
+static thread_local std::string g_merr = "";
+extern "C" const char* orbfe_last_error(void);  // extractor.hip owns the generic one
+static int mfail(int code, const std::string& msg);
+
+namespace {
+
+struct Arena {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  uint8_t* base = nullptr;
+  size_t cap = 0, used = 0;
+  ~Arena() {
+    if (device >= 0) {
+      (void)hipSetDevice(device);
+      if (base) (void)hipFree(base);
+      if (stream) (void)hipStreamDestroy(stream);
+    }
+  }
+};
+thread_local std::map<int, Arena> t_arenas;
+
+// Reserve `bytes` up front (sum of all buffers of a call), then carve.
+hipError_t arena_begin(int device, size_t bytes, Arena** out) {
+  hipError_t err = hipSetDevice(device);
+  if (err != hipSuccess) return err;
+  Arena& a = t_arenas[device];
+  if (a.device < 0) {
+    a.device = device;
+    err = hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking);
+    if (err != hipSuccess) { a.device = -1; return err; }
+  }
+  if (bytes > a.cap) {
+    if (a.base) (void)hipFree(a.base);
+    a.base = nullptr;
+    a.cap = 0;
+    size_t want = bytes + bytes / 2 + (1u << 20);
+    err = hipMalloc((void**)&a.base, want);
+    if (err != hipSuccess) return err;
+    a.cap = want;
+  }
+  a.used = 0;
+  *out = &a;
+  return hipSuccess;
+}
+template <typename T>
+T* carve(Arena* a, size_t n) {
+  size_t off = (a->used + 255) & ~(size_t)255;
+  a->used = off + n * sizeof(T);
+  return reinterpret_cast<T*>(a->base + off);
+}
+inline size_t pad(size_t bytes) { return ((bytes + 255) & ~(size_t)255) + 256; }
+
+template <typename T>
+hipError_t up(Arena* a, T** d, const T* h, size_t n) {
+  *d = carve<T>(a, n ? n : 1);
+  if (n == 0) return hipSuccess;
+  return hipMemcpyAsync(*d, h, n * sizeof(T), hipMemcpyHostToDevice, a->stream);
+}
+
+// merge-walk of the two ascending node-id lists (the std::map iteration + lower_bound of
+// src/ORBmatcher.cc:211-300)
+void shared_nodes(const orbfe_featvec* f1, const orbfe_featvec* f2, std::vector<NodePair>* out) {
+  int a = 0, b = 0;
+  while (a < f1->n_nodes && b < f2->n_nodes) {
+    const uint32_t ia = f1->node_ids[a], ib = f2->node_ids[b];
+    if (ia == ib) {
+      out->push_back(NodePair{f1->offsets[a], f1->offsets[a + 1] - f1->offsets[a], f2->offsets[b],
+                              f2->offsets[b + 1] - f2->offsets[b]});
+      a++;
+      b++;
+    } else if (ia < ib) a++;
+    else b++;
+  }
+}
+
+bool featvec_ok(const orbfe_featvec* f, int n) {
+  if (!f || f->n_nodes < 0) return false;
+  if (f->n_nodes == 0) return true;
+  if (!f->node_ids || !f->offsets || !f->indices) return false;
+  if (f->offsets[0] != 0) return false;
+  for (int i = 0; i < f->n_nodes; i++) {
+    if (f->offsets[i + 1] < f->offsets[i]) return false;
+    if (i > 0 && f->node_ids[i] <= f->node_ids[i - 1]) return false;
+  }
+  const int tot = f->offsets[f->n_nodes];
+  for (int i = 0; i < tot; i++)
+    if (f->indices[i] >= (uint32_t)n) return false;
+  return true;
+}
+
+}  // namespace
+
+static int mfail(int code, const std::string& msg) {
+  // route through the shared thread-local error text
+  extern int orbfe_set_error_(int, const char*);
+  return orbfe_set_error_(code, msg.c_str());
+}
+#define MHIP(expr)                                                                       \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) return mfail(ORBFE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+extern "C" int orbfe_descriptor_distance(int device, const uint8_t* a, const uint8_t* b, int n, int32_t* out) {
+  if (n < 0 || (n > 0 && (!a || !b || !out))) return mfail(ORBFE_ERR_INVALID, "descriptor_distance: bad argument");
+  if (n == 0) return ORBFE_OK;
+  Arena* ar;
+  MHIP(arena_begin(device, 2 * pad((size_t)n * 32) + pad((size_t)n * 4), &ar));
+  uint8_t *da, *db;
+  MHIP(up(ar, &da, a, (size_t)n * 32));
+  MHIP(up(ar, &db, b, (size_t)n * 32));
+  int32_t* dout = carve<int32_t>(ar, n);
+  launch_hamming_pairs(ar->stream, da, db, n, dout);
+  MHIP(hipGetLastError());
+  MHIP(hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, ar->stream));
+  MHIP(hipStreamSynchronize(ar->stream));
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_hamming_matrix(int device, const uint8_t* d1, int n1, const uint8_t* d2, int n2, int32_t* out) {
+  if (n1 < 0 || n2 < 0 || ((n1 > 0 && n2 > 0) && (!d1 || !d2 || !out)))
+    return mfail(ORBFE_ERR_INVALID, "hamming_matrix: bad argument");
+  if (n1 == 0 || n2 == 0) return ORBFE_OK;
+  Arena* ar;
+  MHIP(arena_begin(device, pad((size_t)n1 * 32) + pad((size_t)n2 * 32) + pad((size_t)n1 * n2 * 4), &ar));
+  uint8_t *da, *db;
+  MHIP(up(ar, &da, d1, (size_t)n1 * 32));
+  MHIP(up(ar, &db, d2, (size_t)n2 * 32));
+  int32_t* dout = carve<int32_t>(ar, (size_t)n1 * n2);
+  launch_hamming_matrix(ar->stream, da, n1, db, n2, dout);
+  MHIP(hipGetLastError());
+  MHIP(hipMemcpyAsync(out, dout, (size_t)n1 * n2 * 4, hipMemcpyDeviceToHost, ar->stream));
+  MHIP(hipStreamSynchronize(ar->stream));
+  return ORBFE_OK;
+}
+
+static int bow_common(int device, const uint8_t* desc1, const uint8_t* has_mp1, const float* angle1, int n1,
+                      const orbfe_featvec* fv1, const uint8_t* desc2, const uint8_t* has_mp2, const float* angle2,
+                      int n2, const orbfe_featvec* fv2, float nnratio, int check_ori, int kfkf, int32_t* match) {
+  if (n1 < 0 || n2 < 0 || !match) return mfail(ORBFE_ERR_INVALID, "search_by_bow: bad argument");
+  const int nOut = kfkf ? n1 : n2;
+  for (int i = 0; i < nOut; i++) match[i] = -1;
+  if (n1 == 0 || n2 == 0) return 0;
+  if (!desc1 || !has_mp1 || !angle1 || !desc2 || !angle2 || (kfkf && !has_mp2))
+    return mfail(ORBFE_ERR_INVALID, "search_by_bow: NULL input");
+  if (!featvec_ok(fv1, n1) || !featvec_ok(fv2, n2)) return mfail(ORBFE_ERR_INVALID, "search_by_bow: malformed FeatureVector");
+  std::vector<NodePair> pairs;
+  shared_nodes(fv1, fv2, &pairs);
+  if (pairs.empty()) return 0;
+  int maxCnt2 = 0;
+  for (const NodePair& p : pairs) maxCnt2 = p.cnt2 > maxCnt2 ? p.cnt2 : maxCnt2;
+  if (maxCnt2 > 65535) return mfail(ORBFE_ERR_INVALID, "search_by_bow: more than 65535 features in one node");
+  const size_t t1 = fv1->offsets[fv1->n_nodes], t2 = fv2->offsets[fv2->n_nodes];
+  Arena* ar;
+  MHIP(arena_begin(device, pad(pairs.size() * sizeof(NodePair)) + pad((size_t)n1 * 32) + pad((size_t)n2 * 32) + 2 * pad(n1) +
+                               2 * pad(n2) + 2 * pad((size_t)n1 * 4) + 2 * pad((size_t)n2 * 4) + pad(t1 * 4) + pad(t2 * 4) + 4096, &ar));
+  BowArgs a = {};
+  NodePair* dp;
+  MHIP(up(ar, &dp, pairs.data(), pairs.size()));
+  uint8_t *dd1, *dd2, *dm1, *dm2 = nullptr;
+  float *da1, *da2;
+  uint32_t *di1, *di2;
+  MHIP(up(ar, &dd1, desc1, (size_t)n1 * 32));
+  MHIP(up(ar, &dd2, desc2, (size_t)n2 * 32));
+  MHIP(up(ar, &dm1, has_mp1, (size_t)n1));
+  if (kfkf) MHIP(up(ar, &dm2, has_mp2, (size_t)n2));
+  MHIP(up(ar, &da1, angle1, (size_t)n1));
+  MHIP(up(ar, &da2, angle2, (size_t)n2));
+  MHIP(up(ar, &di1, fv1->indices, t1));
+  MHIP(up(ar, &di2, fv2->indices, t2));
+  int32_t* dmatch = carve<int32_t>(ar, nOut);
+  int8_t* dbin = carve<int8_t>(ar, nOut);
+  int32_t* dcount = carve<int32_t>(ar, 1);
+  MHIP(hipMemsetAsync(dmatch, 0xff, (size_t)nOut * 4, ar->stream));
+  MHIP(hipMemsetAsync(dbin, 0, (size_t)nOut, ar->stream));
+  a.pairs = dp; a.desc1 = dd1; a.hasMp1 = dm1; a.angle1 = da1; a.indices1 = di1;
+  a.desc2 = dd2; a.hasMp2 = dm2; a.angle2 = da2; a.indices2 = di2;
+  a.nnratio = nnratio; a.strictLow = kfkf; a.match = dmatch; a.bin = dbin;
+  launch_search_by_bow(ar->stream, a, (int)pairs.size(), maxCnt2);
+  launch_rot_prune(ar->stream, dmatch, dbin, nOut, check_ori, dcount);
+  MHIP(hipGetLastError());
+  int32_t cnt = 0;
+  MHIP(hipMemcpyAsync(match, dmatch, (size_t)nOut * 4, hipMemcpyDeviceToHost, ar->stream));
+  MHIP(hipMemcpyAsync(&cnt, dcount, 4, hipMemcpyDeviceToHost, ar->stream));
+  MHIP(hipStreamSynchronize(ar->stream));
+  return cnt;
+}
+
+extern "C" int orbfe_search_by_bow(int device, const uint8_t* desc1, const uint8_t* has_mp1, const float* angle1,
+                                   int n1, const orbfe_featvec* fv1, const uint8_t* desc2, const float* angle2,
+                                   int n2, const orbfe_featvec* fv2, float nnratio, int check_orientation,
+                                   int32_t* match_f) {
+  return bow_common(device, desc1, has_mp1, angle1, n1, fv1, desc2, nullptr, angle2, n2, fv2, nnratio,
+                    check_orientation, 0, match_f);
+}
+extern "C" int orbfe_search_by_bow_kf(int device, const uint8_t* desc1, const uint8_t* has_mp1, const float* angle1,
+                                      int n1, const orbfe_featvec* fv1, const uint8_t* desc2,
+                                      const uint8_t* has_mp2, const float* angle2, int n2,
+                                      const orbfe_featvec* fv2, float nnratio, int check_orientation,
+                                      int32_t* match12) {
+  return bow_common(device, desc1, has_mp1, angle1, n1, fv1, desc2, has_mp2, angle2, n2, fv2, nnratio,
+                    check_orientation, 1, match12);
+}
+
+extern "C" int orbfe_search_for_triangulation(int device, const uint8_t* desc1, const uint8_t* has_mp1,
+                                              const float* x1, const float* y1, const float* angle1,
+                                              const uint8_t* stereo1, int n1, const orbfe_featvec* fv1,
+                                              const uint8_t* desc2, const uint8_t* has_mp2, const float* x2,
+                                              const float* y2, const float* angle2, const int32_t* octave2,
+                                              const uint8_t* stereo2, int n2, const orbfe_featvec* fv2,
+                                              const float* F12, float ex, float ey, const float* scale_factors2,
+                                              const float* level_sigma2_2, int n_levels2, int only_stereo,
+                                              int check_orientation, int32_t* match12) {
+  if (n1 < 0 || n2 < 0 || !match12) return mfail(ORBFE_ERR_INVALID, "search_for_triangulation: bad argument");
+  for (int i = 0; i < n1; i++) match12[i] = -1;
+  if (n1 == 0 || n2 == 0) return 0;
+  if (!desc1 || !has_mp1 || !x1 || !y1 || !angle1 || !stereo1 || !desc2 || !has_mp2 || !x2 || !y2 || !angle2 ||
+      !octave2 || !stereo2 || !F12 || !scale_factors2 || !level_sigma2_2 || n_levels2 <= 0 || n_levels2 > ORBFE_MAX_LEVELS)
+    return mfail(ORBFE_ERR_INVALID, "search_for_triangulation: NULL input");
+  if (!featvec_ok(fv1, n1) || !featvec_ok(fv2, n2)) return mfail(ORBFE_ERR_INVALID, "search_for_triangulation: malformed FeatureVector");
+  for (int i = 0; i < n2; i++)
+    if (octave2[i] < 0 || octave2[i] >= n_levels2) return mfail(ORBFE_ERR_INVALID, "search_for_triangulation: octave out of range");
+  std::vector<NodePair> pairs;
+  shared_nodes(fv1, fv2, &pairs);
+  std::vector<TriQuery> queries;
+  for (const NodePair& p : pairs) {
+    if (p.cnt2 > 65535) return mfail(ORBFE_ERR_INVALID, "search_for_triangulation: more than 65535 features in one node");
+    for (int i = 0; i < p.cnt1; i++) {
+      const uint32_t idx1 = fv1->indices[p.off1 + i];
+      if (has_mp1[idx1]) continue;                    // :800-803
+      if (only_stereo && !stereo1[idx1]) continue;    // :807-809
+      queries.push_back(TriQuery{idx1, p.off2, p.cnt2});
+    }
+  }
+  if (queries.empty()) return 0;
+  const size_t t2 = fv2->offsets[fv2->n_nodes];
+  Arena* ar;
+  MHIP(arena_begin(device, pad(queries.size() * sizeof(TriQuery)) + pad((size_t)n1 * 32) + pad((size_t)n2 * 32) +
+                               4 * pad((size_t)n1 * 4) + 6 * pad((size_t)n2 * 4) + 2 * pad(n1) + 2 * pad(n2) + pad(t2 * 4) + 8192, &ar));
+  TriArgs a = {};
+  TriQuery* dq;
+  MHIP(up(ar, &dq, queries.data(), queries.size()));
+  uint8_t *dd1, *dd2, *ds1, *ds2, *dm2;
+  float *dx1, *dy1, *da1, *dx2, *dy2, *da2, *dF, *dsf, *dsg;
+  int32_t* doc2;
+  uint32_t* di2;
+  MHIP(up(ar, &dd1, desc1, (size_t)n1 * 32));
+  MHIP(up(ar, &dd2, desc2, (size_t)n2 * 32));
+  MHIP(up(ar, &ds1, stereo1, (size_t)n1));
+  MHIP(up(ar, &ds2, stereo2, (size_t)n2));
+  MHIP(up(ar, &dm2, has_mp2, (size_t)n2));
+  MHIP(up(ar, &dx1, x1, (size_t)n1));
+  MHIP(up(ar, &dy1, y1, (size_t)n1));
+  MHIP(up(ar, &da1, angle1, (size_t)n1));
+  MHIP(up(ar, &dx2, x2, (size_t)n2));
+  MHIP(up(ar, &dy2, y2, (size_t)n2));
+  MHIP(up(ar, &da2, angle2, (size_t)n2));
+  MHIP(up(ar, &doc2, octave2, (size_t)n2));
+  MHIP(up(ar, &di2, fv2->indices, t2));
+  MHIP(up(ar, &dF, F12, (size_t)9));
+  MHIP(up(ar, &dsf, scale_factors2, (size_t)n_levels2));
+  MHIP(up(ar, &dsg, level_sigma2_2, (size_t)n_levels2));
+  int32_t* dmatch = carve<int32_t>(ar, n1);
+  int8_t* dbin = carve<int8_t>(ar, n1);
+  int32_t* dcount = carve<int32_t>(ar, 1);
+  MHIP(hipMemsetAsync(dmatch, 0xff, (size_t)n1 * 4, ar->stream));
+  MHIP(hipMemsetAsync(dbin, 0, (size_t)n1, ar->stream));
+  a.queries = dq; a.nQueries = (int)queries.size();
+  a.desc1 = dd1; a.x1 = dx1; a.y1 = dy1; a.angle1 = da1; a.stereo1 = ds1;
+  a.desc2 = dd2; a.hasMp2 = dm2; a.x2 = dx2; a.y2 = dy2; a.angle2 = da2; a.octave2 = doc2; a.stereo2 = ds2;
+  a.indices2 = di2; a.F12 = dF; a.ex = ex; a.ey = ey; a.scaleFactors2 = dsf; a.levelSigma2_2 = dsg;
+  a.onlyStereo = only_stereo; a.match = dmatch; a.bin = dbin;
+  launch_search_triangulation(ar->stream, a);
+  launch_rot_prune(ar->stream, dmatch, dbin, n1, check_orientation, dcount);
+  MHIP(hipGetLastError());
+  int32_t cnt = 0;
+  MHIP(hipMemcpyAsync(match12, dmatch, (size_t)n1 * 4, hipMemcpyDeviceToHost, ar->stream));
+  MHIP(hipMemcpyAsync(&cnt, dcount, 4, hipMemcpyDeviceToHost, ar->stream));
+  MHIP(hipStreamSynchronize(ar->stream));
+  return cnt;
+}
+
+// implemented in extractor.hip (needs the handle internals)
+extern "C" int orbfe_stereo_views_(orbfe_extractor* e, int frame, PyramidViews* pv, float* scale, float* invScale,
+                                   int* nlevels, int* device);
+
+extern "C" int orbfe_compute_stereo_matches(orbfe_extractor* left, int frameL, orbfe_extractor* right, int frameR,
+                                            const orbfe_keypoint* kpL, const uint8_t* descL, int N,
+                                            const orbfe_keypoint* kpR, const uint8_t* descR, int Nr, float mbf,
+                                            float mb, float* uRight, float* depth) {
+  if (!left || !right || N < 0 || Nr < 0 || (N > 0 && (!kpL || !descL || !uRight || !depth)) ||
+      (Nr > 0 && (!kpR || !descR)))
+    return mfail(ORBFE_ERR_INVALID, "compute_stereo_matches: bad argument");
+  for (int i = 0; i < N; i++) { uRight[i] = -1.0f; depth[i] = -1.0f; }
+  if (N == 0 || Nr == 0) return 0;
+  if (Nr >= (1 << 20)) return mfail(ORBFE_ERR_INVALID, "compute_stereo_matches: too many right keypoints");
+  StereoArgs a = {};
+  int nlL = 0, nlR = 0, devL = 0, devR = 0;
+  float scR[kMaxLevels], iscR[kMaxLevels];
+  int rc;
+  if ((rc = orbfe_stereo_views_(left, frameL, &a.pyrL, a.scale, a.invScale, &nlL, &devL))) return rc;
+  if ((rc = orbfe_stereo_views_(right, frameR, &a.pyrR, scR, iscR, &nlR, &devR))) return rc;
+  if (nlL != nlR || devL != devR) return mfail(ORBFE_ERR_INVALID, "compute_stereo_matches: extractors differ");
+  for (int l = 0; l < nlL; l++)
+    if (a.pyrL.lv[l].w != a.pyrR.lv[l].w || a.pyrL.lv[l].h != a.pyrR.lv[l].h)
+      return mfail(ORBFE_ERR_INVALID, "compute_stereo_matches: left/right pyramids differ in size");
+  for (int i = 0; i < N; i++)
+    if (kpL[i].octave < 0 || kpL[i].octave >= nlL) return mfail(ORBFE_ERR_INVALID, "compute_stereo_matches: octave out of range");
+  for (int i = 0; i < Nr; i++)
+    if (kpR[i].octave < 0 || kpR[i].octave >= nlL) return mfail(ORBFE_ERR_INVALID, "compute_stereo_matches: octave out of range");
+  Arena* ar;
+  MHIP(arena_begin(devL, pad((size_t)N * 60) + pad((size_t)Nr * 60) + 3 * pad((size_t)N * 4) + 4096, &ar));
+  float *dkl, *dkr;
+  uint8_t *ddl, *ddr;
+  MHIP(up(ar, &dkl, reinterpret_cast<const float*>(kpL), (size_t)N * 7));
+  MHIP(up(ar, &dkr, reinterpret_cast<const float*>(kpR), (size_t)Nr * 7));
+  MHIP(up(ar, &ddl, descL, (size_t)N * 32));
+  MHIP(up(ar, &ddr, descR, (size_t)Nr * 32));
+  a.kpL = dkl; a.descL = ddl; a.N = N; a.kpR = dkr; a.descR = ddr; a.Nr = Nr;
+  a.frameL = frameL; a.frameR = frameR;
+  a.mbf = mbf;
+  a.maxD = mbf / mb;  // minZ = mb, maxD = mbf/minZ (:542-544)
+  a.uRight = carve<float>(ar, N);
+  a.depth = carve<float>(ar, N);
+  a.sad = carve<int32_t>(ar, N);
+  int32_t* dcount = carve<int32_t>(ar, 1);
+  launch_stereo(ar->stream, a, dcount);
+  MHIP(hipGetLastError());
+  int32_t cnt = 0;
+  MHIP(hipMemcpyAsync(uRight, a.uRight, (size_t)N * 4, hipMemcpyDeviceToHost, ar->stream));
+  MHIP(hipMemcpyAsync(depth, a.depth, (size_t)N * 4, hipMemcpyDeviceToHost, ar->stream));
+  MHIP(hipMemcpyAsync(&cnt, dcount, 4, hipMemcpyDeviceToHost, ar->stream));
+  MHIP(hipStreamSynchronize(ar->stream));
+  return cnt;
+}

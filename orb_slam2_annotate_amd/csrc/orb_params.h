@@ -1,0 +1,64 @@
+// orb_params.h -- host-side constant tables of the extractor and the per-resolution geometry.
+// Restates ORBextractor::ORBextractor (src/ORBextractor.cc:415-486), the level sizes of
+// ComputePyramid (:1207-1208) and the FAST grid of ComputeKeyPointsOctTree (:823-869).
+#pragma once
+#include <stdint.h>
+#include <vector>
+
+#include "orb_spec.h"
+
+namespace orbfe {
+
+constexpr int kMaxLevels = 16;
+
+struct ExtractorTables {
+  int nfeatures = 0;
+  double scaleFactor = 0;  // the reference member is double (include/ORBextractor.h:100)
+  float scaleFactorArg = 0;
+  int nlevels = 0, iniThFAST = 0, minThFAST = 0;
+  float scale[kMaxLevels] = {}, invScale[kMaxLevels] = {};
+  float sigma2[kMaxLevels] = {}, invSigma2[kMaxLevels] = {};
+  int quota[kMaxLevels] = {};  // mnFeaturesPerLevel
+  int umax[16] = {};
+  void init(int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh);
+};
+
+// One FAST grid cell = one cv::FAST call of the reference (:874); (x0,y0,w,h) is the cell's
+// DETECTION rectangle in level coordinates (sub-image minus its 3-px rim).
+struct CellDesc {
+  int16_t level;
+  int16_t x0, y0, w, h;
+  int16_t pad;
+  int32_t slotBase;  // first candidate slot of this cell inside the per-frame slot array
+};
+
+struct LevelGeom {
+  int w, h, pitch;
+  uint32_t off;  // byte offset of the level inside a per-frame pyramid buffer
+  int nCols, nRows, wCell, hCell;
+  int cellStart, nCells;
+  int slotStart, slotCount;  // candidate slots (worst case) of this level
+  int quota;                 // mnFeaturesPerLevel[level]
+  int nIni;                  // root nodes of DistributeOctTree (:570)
+  int kpStart, kpCap;        // per-level keypoint slots inside a per-frame keypoint array
+};
+
+struct ResizeTables {  // cv::resize INTER_LINEAR fixed-point coefficients (level l-1 -> l)
+  std::vector<int32_t> xofs, yofs;
+  std::vector<int16_t> alpha, beta;  // 2 per output column / row
+};
+
+struct FrameGeom {
+  int W = 0, H = 0, nlevels = 0;
+  LevelGeom lv[kMaxLevels] = {};
+  std::vector<CellDesc> cells;
+  ResizeTables rz[kMaxLevels];
+  uint32_t pyrBytes = 0;   // bytes of levels 1..n-1 (+ level 0 when owned) per frame
+  int totalSlots = 0;      // candidate slots per frame
+  int totalKpCap = 0;      // keypoint slots per frame
+  void build(const ExtractorTables& t, int W, int H);
+};
+
+void build_resize_tables(int sw, int sh, int dw, int dh, ResizeTables* out);
+
+}  // namespace orbfe

@@ -1,0 +1,168 @@
+"""Python mirror of ``ORB_SLAM2::ORBextractor`` (reference: include/ORBextractor.h:46-114)
+on top of the C-ABI of liborbfe.so.  Same constructor arguments, same getters, ``__call__``
+in place of ``operator()``, ``mvImagePyramid`` as a lazily copied property."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import KP_DTYPE, check, ptr
+
+
+class ORBextractor:
+    HARRIS_SCORE = 0  # include/ORBextractor.h:50 (unused by the reference as well)
+    FAST_SCORE = 1
+
+    def __init__(self, nfeatures: int, scaleFactor: float, nlevels: int, iniThFAST: int, minThFAST: int,
+                 device: int = 0):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        check(self._L.orbfe_extractor_create(int(nfeatures), float(scaleFactor), int(nlevels), int(iniThFAST),
+                                             int(minThFAST), int(device), C.byref(h)))
+        self._h = h
+        self.device = device
+        self.nfeatures = int(nfeatures)
+        self._last_shape = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.orbfe_extractor_destroy(h)
+            self._h = None
+
+    # ---- getters, include/ORBextractor.h:66-87 ----
+    def GetLevels(self) -> int:
+        return self._L.orbfe_extractor_get_levels(self._h)
+
+    def GetScaleFactor(self) -> float:
+        return float(self._L.orbfe_extractor_get_scale_factor(self._h))
+
+    def _vec(self, name, dtype=np.float32, n=None):
+        out = np.zeros(n or self.GetLevels(), dtype=dtype)
+        check(getattr(self._L, name)(self._h, ptr(out)))
+        return out
+
+    def GetScaleFactors(self):
+        return self._vec("orbfe_extractor_get_scale_factors")
+
+    def GetInverseScaleFactors(self):
+        return self._vec("orbfe_extractor_get_inverse_scale_factors")
+
+    def GetScaleSigmaSquares(self):
+        return self._vec("orbfe_extractor_get_scale_sigma_squares")
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._vec("orbfe_extractor_get_inverse_scale_sigma_squares")
+
+    def features_per_level(self):
+        return self._vec("orbfe_extractor_get_features_per_level", np.int32)
+
+    def umax(self):
+        return self._vec("orbfe_extractor_get_umax", np.int32, 16)
+
+    def max_keypoints(self) -> int:
+        return self._L.orbfe_extractor_max_keypoints(self._h)
+
+    def level_size(self, width, height, level):
+        w, h = C.c_int(), C.c_int()
+        check(self._L.orbfe_extractor_level_size(self._h, width, height, level, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    # ---- operator(), src/ORBextractor.cc:1119-1197 ----
+    def __call__(self, image: np.ndarray, mask=None, capacity: int | None = None):
+        """Returns (keypoints[KP_DTYPE], descriptors[N,32] uint8).  `mask` is ignored, as in
+        the reference.  An empty image returns empty outputs silently."""
+        if image is None or image.size == 0:
+            return np.zeros(0, dtype=KP_DTYPE), np.zeros((0, 32), dtype=np.uint8)
+        if image.dtype != np.uint8 or image.ndim != 2:
+            raise AssertionError("image.type() == CV_8UC1")  # the reference asserts (:1126)
+        if image.strides[1] != 1:
+            image = np.ascontiguousarray(image)
+        H, W = image.shape
+        cap = capacity or self.max_keypoints()
+        kps = np.zeros(cap, dtype=KP_DTYPE)
+        desc = np.zeros((cap, 32), dtype=np.uint8)
+        n = C.c_int(0)
+        check(self._L.orbfe_extract(self._h, ptr(image), W, H, image.strides[0], ptr(kps), ptr(desc), cap,
+                                    C.byref(n)))
+        self._last_shape = (1, H, W)
+        return kps[: n.value].copy(), desc[: n.value].copy()
+
+    def extract_batch(self, images: np.ndarray, capacity: int | None = None):
+        """images: [B,H,W] uint8 (host).  Returns list of (keypoints, descriptors) per frame."""
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        B, H, W = images.shape
+        cap = capacity or self.max_keypoints()
+        kps = np.zeros((B, cap), dtype=KP_DTYPE)
+        desc = np.zeros((B, cap, 32), dtype=np.uint8)
+        n = np.zeros(B, dtype=np.int32)
+        check(self._L.orbfe_extract_batch(self._h, ptr(images), B, W, H, W, W * H, ptr(kps), ptr(desc), cap,
+                                          ptr(n)))
+        self._last_shape = (B, H, W)
+        return [(kps[f, : n[f]].copy(), desc[f, : n[f]].copy()) for f in range(B)]
+
+    def extract_batch_device(self, d_images: int, n_frames: int, width: int, height: int, stride: int,
+                             frame_stride: int, d_keypoints: int, d_descriptors: int, capacity: int,
+                             d_n_out: int):
+        """All pointers are raw DEVICE addresses (e.g. torch tensor .data_ptr())."""
+        check(self._L.orbfe_extract_batch_device(self._h, C.c_void_p(d_images), n_frames, width, height, stride,
+                                                 frame_stride, C.c_void_p(d_keypoints),
+                                                 C.c_void_p(d_descriptors), capacity, C.c_void_p(d_n_out)))
+        self._last_shape = (n_frames, height, width)
+
+    # ---- mvImagePyramid, include/ORBextractor.h:86 ----
+    def pyramid_level(self, level: int, frame: int = 0) -> np.ndarray:
+        if self._last_shape is None:
+            raise RuntimeError("no extract call yet")
+        _, H, W = self._last_shape
+        w, h = self.level_size(W, H, level)
+        out = np.zeros((h, w), dtype=np.uint8)
+        check(self._L.orbfe_extractor_get_pyramid_level(self._h, frame, level, ptr(out), w))
+        return out
+
+    @property
+    def mvImagePyramid(self):
+        return [self.pyramid_level(l) for l in range(self.GetLevels())]
+
+    # ---- diagnostics ----
+    def debug_blurred_level(self, level: int, frame: int = 0) -> np.ndarray:
+        _, H, W = self._last_shape
+        w, h = self.level_size(W, H, level)
+        out = np.zeros((h, w), dtype=np.uint8)
+        check(self._L.orbfe_extractor_debug_blurred_level(self._h, frame, level, ptr(out), w))
+        return out
+
+    def debug_candidates(self, level: int, frame: int = 0):
+        _, H, W = self._last_shape
+        w, h = self.level_size(W, H, level)
+        cap = w * h // 4 + 16
+        xs = np.zeros(cap, np.float32); ys = np.zeros(cap, np.float32); rs = np.zeros(cap, np.float32)
+        n = check(self._L.orbfe_extractor_debug_candidates(self._h, frame, level, ptr(xs), ptr(ys), ptr(rs), cap))
+        return xs[:n].copy(), ys[:n].copy(), rs[:n].copy()
+
+    def profile(self, enable: bool):
+        check(self._L.orbfe_extractor_profile(self._h, int(bool(enable))))
+
+    def profile_get(self):
+        ms = np.zeros(len(_lib.STAGES), dtype=np.float64)
+        cnt = np.zeros(len(_lib.STAGES), dtype=np.int64)
+        check(self._L.orbfe_extractor_profile_get(self._h, ptr(ms), ptr(cnt)))
+        return {s: (float(ms[i]), int(cnt[i])) for i, s in enumerate(_lib.STAGES)}
+
+
+def resize_linear(src: np.ndarray, dw: int, dh: int, device: int = 0) -> np.ndarray:
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    sh, sw = src.shape
+    dst = np.zeros((dh, dw), dtype=np.uint8)
+    check(_lib.load().orbfe_resize_linear(device, ptr(src), sw, sh, sw, ptr(dst), dw, dh, dw))
+    return dst
+
+
+def gaussian_blur7(src: np.ndarray, device: int = 0) -> np.ndarray:
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    h, w = src.shape
+    dst = np.zeros_like(src)
+    check(_lib.load().orbfe_gaussian_blur7(device, ptr(src), w, h, w, ptr(dst), w))
+    return dst

@@ -1,0 +1,145 @@
+"""GPU parity tests of the Hamming matchers and the stereo matcher against the CPU oracle."""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from orb_slam2_annotate_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import orb_slam2_annotate_amd as m
+    return m
+
+
+def _nodes(desc, seed, n_nodes=100):
+    """Synthetic 2-level k=10 vocabulary stand-in (the real ORBvoc.txt is absent):
+    node = index of the nearest of 100 seeded 256-bit centroids."""
+    rng = np.random.default_rng(seed)
+    cent = rng.integers(0, 256, size=(n_nodes, 32), dtype=np.uint8)
+    x = np.unpackbits(desc, axis=1).astype(np.int16)
+    c = np.unpackbits(cent, axis=1).astype(np.int16)
+    d = (x[:, None, :] != c[None, :, :]).sum(axis=2)
+    return d.argmin(axis=1).astype(np.uint32) * 7 + 3  # sparse, non-contiguous node ids
+
+
+def _two_frames(amd, seed, w=640, h=480, nf=1000):
+    fr = synth.render_sequence(seed, 2, w, h, step=3.0)
+    e = amd.ORBextractor(nf, 1.2, 8, 20, 7)
+    (k1, d1), (k2, d2) = e.extract_batch(np.stack(fr))
+    return k1, d1, k2, d2
+
+
+def test_descriptor_distance(amd):
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, size=(1000, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, size=(1000, 32), dtype=np.uint8)
+    got = amd.ORBmatcher.DescriptorDistance(a, b)
+    ref = np.unpackbits(a ^ b, axis=1).sum(axis=1)
+    assert np.array_equal(got, ref)
+    assert amd.ORBmatcher.DescriptorDistance(a[0], a[0]) == 0
+    assert amd.ORBmatcher.DescriptorDistance(a[0], ~a[0]) == 256
+    m = amd.ORBmatcher.HammingMatrix(a[:37], b[:129])
+    assert np.array_equal(m, np.unpackbits(a[:37, None, :] ^ b[None, :129, :], axis=2).sum(axis=2))
+
+
+@pytest.mark.parametrize("seed,nnratio,ori", [(1, 0.7, True), (2, 0.75, True), (3, 0.6, False)])
+def test_search_by_bow_frame(amd, seed, nnratio, ori):
+    k1, d1, k2, d2 = _two_frames(amd, seed)
+    rng = np.random.default_rng(seed)
+    has1 = (rng.random(len(k1)) < 0.7).astype(np.uint8)
+    n1, n2 = _nodes(d1, 11), _nodes(d2, 11)
+    ref_n, ref = orc.search_by_bow(d1, has1, k1["angle"], orc.FeatVec(n1), d2, k2["angle"], orc.FeatVec(n2), nnratio, ori)
+    m = amd.ORBmatcher(nnratio, ori)
+    fv1, fv2 = amd.FeatureVector.from_node_of_feature(n1), amd.FeatureVector.from_node_of_feature(n2)
+    got_n, got = m.SearchByBoW(d1, has1, k1["angle"], fv1, d2, k2["angle"], fv2)
+    assert ref_n == got_n and np.array_equal(ref, got)
+    assert ref_n > 20
+
+
+@pytest.mark.parametrize("seed", [4, 5])
+def test_search_by_bow_kf(amd, seed):
+    k1, d1, k2, d2 = _two_frames(amd, seed)
+    rng = np.random.default_rng(seed)
+    has1 = (rng.random(len(k1)) < 0.6).astype(np.uint8)
+    has2 = (rng.random(len(k2)) < 0.6).astype(np.uint8)
+    n1, n2 = _nodes(d1, 12, 40), _nodes(d2, 12, 40)
+    ref_n, ref = orc.search_by_bow_kf(d1, has1, k1["angle"], orc.FeatVec(n1), d2, has2, k2["angle"], orc.FeatVec(n2), 0.75, True)
+    m = amd.ORBmatcher(0.75, True)
+    got_n, got = m.SearchByBoW(d1, has1, k1["angle"], amd.FeatureVector.from_node_of_feature(n1), d2, k2["angle"],
+                               amd.FeatureVector.from_node_of_feature(n2), has_mp2=has2)
+    assert ref_n == got_n and np.array_equal(ref, got)
+    assert ref_n > 5
+
+
+@pytest.mark.parametrize("seed,only_stereo", [(6, False), (7, True), (8, False)])
+def test_search_for_triangulation(amd, seed, only_stereo):
+    k1, d1, k2, d2 = _two_frames(amd, seed)
+    rng = np.random.default_rng(seed)
+    has1 = (rng.random(len(k1)) < 0.4).astype(np.uint8)
+    has2 = (rng.random(len(k2)) < 0.4).astype(np.uint8)
+    st1 = (rng.random(len(k1)) < 0.5).astype(np.uint8)
+    st2 = (rng.random(len(k2)) < 0.5).astype(np.uint8)
+    n1, n2 = _nodes(d1, 13, 60), _nodes(d2, 13, 60)
+    # pure x-translation between the views (3 px per frame): F = [t]_x with t=(1,0,0)
+    F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], dtype=np.float32) * 0.01
+    ex, ey = 5000.0, 240.0
+    o = orc.Oracle()
+    sf, sg = o.scale_factors(), o.level_sigma2()
+    ref_n, ref = orc.search_for_triangulation(d1, has1, k1["x"], k1["y"], k1["angle"], st1, orc.FeatVec(n1), d2, has2,
+                                              k2["x"], k2["y"], k2["angle"], k2["octave"], st2, orc.FeatVec(n2), F12,
+                                              ex, ey, sf, sg, only_stereo, seed != 8)
+    m = amd.ORBmatcher(0.6, seed != 8)
+    got_n, pairs = m.SearchForTriangulation(d1, has1, k1["x"], k1["y"], k1["angle"], st1,
+                                            amd.FeatureVector.from_node_of_feature(n1), d2, has2, k2["x"], k2["y"],
+                                            k2["angle"], k2["octave"], st2, amd.FeatureVector.from_node_of_feature(n2),
+                                            F12, ex, ey, sf, sg, only_stereo)
+    idx = np.nonzero(ref >= 0)[0]
+    assert ref_n == got_n
+    assert np.array_equal(pairs, np.stack([idx, ref[idx]], axis=1))
+    assert ref_n > 5
+
+
+def test_bow_edge_cases(amd):
+    m = amd.ORBmatcher(0.7, True)
+    d = np.zeros((0, 32), np.uint8)
+    fv = amd.FeatureVector.from_node_of_feature(np.zeros(0, np.uint32))
+    n, out = m.SearchByBoW(d, np.zeros(0, np.uint8), np.zeros(0, np.float32), fv, d, np.zeros(0, np.float32), fv)
+    assert n == 0 and len(out) == 0
+    # identical descriptors everywhere: ties, ratio test rejects everything (best == second)
+    d = np.zeros((50, 32), np.uint8)
+    nodes = np.zeros(50, np.uint32)
+    fvo = orc.FeatVec(nodes)
+    ang = np.linspace(0, 359, 50).astype(np.float32)
+    rn, r = orc.search_by_bow(d, np.ones(50, np.uint8), ang, fvo, d, ang, fvo, 0.7, True)
+    gn, g = m.SearchByBoW(d, np.ones(50, np.uint8), ang, amd.FeatureVector.from_node_of_feature(nodes), d, ang,
+                          amd.FeatureVector.from_node_of_feature(nodes))
+    assert rn == gn and np.array_equal(r, g)
+    # disjoint node sets: nothing to match
+    gn, g = m.SearchByBoW(d, np.ones(50, np.uint8), ang, amd.FeatureVector.from_node_of_feature(nodes), d, ang,
+                          amd.FeatureVector.from_node_of_feature(nodes + 1))
+    assert gn == 0 and (g == -1).all()
+
+
+@pytest.mark.parametrize("seed,shape,nf,bf,fx", [(1, (1241, 376), 2000, 386.1448, 718.856),
+                                                   (2, (752, 480), 1200, 47.90639384423901, 435.2046959714599)])
+def test_compute_stereo_matches(amd, seed, shape, nf, bf, fx):
+    w, h = shape
+    left, right = synth.render_stereo(seed, w, h)
+    eL = amd.ORBextractor(nf, 1.2, 8, 20, 7)
+    eR = amd.ORBextractor(nf, 1.2, 8, 20, 7)
+    kL, dL = eL(left)
+    kR, dR = eR(right)
+    o = orc.Oracle(nf, 1.2, 8, 20, 7)
+    krL, drL, pL = o.extract(left, want_pyramid=True)
+    krR, drR, pR = o.extract(right, want_pyramid=True)
+    assert np.array_equal(krL, kL) and np.array_equal(krR, kR)
+    mbf = np.float32(bf)
+    mb = np.float32(mbf / np.float32(fx))
+    u_ref, d_ref = o.stereo(w, h, krL, drL, krR, drR, pL, pR, float(mbf), float(mb))
+    u, d = amd.ComputeStereoMatches(eL, eR, kL, dL, kR, dR, float(mbf), float(mb))
+    assert np.array_equal(u_ref, u)
+    assert np.array_equal(d_ref, d)
+    assert (u >= 0).sum() > 100
