@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- ORB extract(+match) frames/s on MI355X, one process per GPU.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N>1 it
+is launched under torch.distributed.run with one rank per GPU.  A "step" is one pass of the hot
+path (ORBextractor::operator() for every frame of the rank's resident batch).  Frames are
+independent, so ranks share nothing: the only collectives are the barriers around the timed
+region and the max/sum reductions of the report (RCCL) -- weak scaling.
+
+Workloads (BASELINE.json configs):
+  tum   (default) configs[1]: 640x480 mono stream, nFeatures=1000, extract only
+  kitti           configs[2]: 1241x376 stereo, nFeatures=2000, extract L+R + ComputeStereoMatches
+  euroc           configs[3]: 752x480, nFeatures=1200, extract + SearchByBoW(t-1, t)
+Inputs are synthetic (no datasets offline), resident in HBM before the timed region starts.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    "tum": dict(name="TUM fr1_xyz mono 640x480 nFeatures=1000 extract-only (synthetic frames)",
+                w=640, h=480, nfeatures=1000, ini=20, mn=7),
+    "kitti": dict(name="KITTI 00 stereo 1241x376 nFeatures=2000 extract L+R (synthetic frames)",
+                  w=1241, h=376, nfeatures=2000, ini=20, mn=7),
+    "euroc": dict(name="EuRoC MH_01 752x480 nFeatures=1200 extract (synthetic frames)",
+                  w=752, h=480, nfeatures=1200, ini=20, mn=7),
+}
+
+
+def level_pixels(ext, w, h):
+    return [ext.level_size(w, h, l) for l in range(ext.GetLevels())]
+
+
+def algorithmic_bytes(sizes, n_kp):
+    """per-frame algorithmic bytes, split by the kernel that moves them."""
+    P0 = sizes[0][0] * sizes[0][1]
+    P = sum(a * b for a, b in sizes)
+    last = sizes[-1][0] * sizes[-1][1]
+    parts = {
+        "pyramid": (P - P0) + (P - last),      # write levels 1..7 + read levels 0..6
+        "fast": P,                             # read every level once for FAST
+        "blur": 2 * P,                         # read + write every level
+        "orient_desc": n_kp * (749 + 512 + 28 + 32),
+    }
+    parts["extract_total"] = P0 + sum(parts.values())  # + read of the input frame
+    return parts
+
+
+def cpu_baseline(frames, wl, seconds=12.0):
+    """The CPU oracle (a scalar C port of the reference path, oracle/orb_oracle.c) on 1 host core."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_lib as orc
+    o = orc.Oracle(wl["nfeatures"], 1.2, 8, wl["ini"], wl["mn"])
+    o.extract(frames[0])  # warm
+    t0 = time.perf_counter()
+    n = 0
+    per = []
+    while True:
+        t1 = time.perf_counter()
+        o.extract(frames[n % len(frames)])
+        per.append(time.perf_counter() - t1)
+        n += 1
+        if time.perf_counter() - t0 > seconds:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="frames/s", cores=1, kind="port",
+                sample=f"{n} synthetic {wl['w']}x{wl['h']} frames of the same workload, oracle/orb_oracle.c "
+                       f"(scalar C, gcc -O3), median {1e3 * float(np.median(per)):.2f} ms/frame",
+                stages_s=o.stage_times())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128, help="frames resident per GPU and processed per step")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="tum")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="verify frame 0 of the batch against the oracle")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import orb_slam2_annotate_amd as amd
+    from orb_slam2_annotate_amd import synth
+
+    wl = WORKLOADS[args.workload]
+    W, H, B = wl["w"], wl["h"], args.batch
+    # each rank renders its own shard of the synthetic stream (sequence id = rank)
+    frames = synth.render_sequence(1000 + rank, B, W, H, step=1.5)
+    ext = amd.ORBextractor(wl["nfeatures"], 1.2, 8, wl["ini"], wl["mn"], device=local_rank)
+    cap = ext.max_keypoints()
+    d_img = torch.from_numpy(np.stack(frames)).to(dev)
+    d_kp = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros((B,), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        ext.extract_batch_device(d_img.data_ptr(), B, W, H, W, W * H, d_kp.data_ptr(), d_desc.data_ptr(), cap,
+                                 d_n.data_ptr())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    ext.profile(True)  # event records only; resolved after each call's own sync
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ext.profile_get()
+    ext.profile(False)
+
+    n_kp = float(d_n.float().mean().item())
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    frames_done = torch.tensor([float(B * args.steps)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(frames_done, op=dist.ReduceOp.SUM)
+    dt_max = float(t.item())
+    total_frames = float(frames_done.item())
+
+    if args.check and rank == 0:
+        sys.path.insert(0, str(ROOT / "tests"))
+        import oracle_lib as orc
+        o = orc.Oracle(wl["nfeatures"], 1.2, 8, wl["ini"], wl["mn"])
+        kr, dr = o.extract(frames[0])
+        n0 = int(d_n[0].item())
+        kg = d_kp[0, :n0].cpu().numpy().view(np.uint8).reshape(n0, 28)
+        assert n0 == len(kr) and np.array_equal(kg, kr.view(np.uint8).reshape(-1, 28)), "keypoints differ from oracle"
+        assert np.array_equal(d_desc[0, :n0].cpu().numpy(), dr), "descriptors differ from oracle"
+
+    if rank == 0:
+        sizes = level_pixels(ext, W, H)
+        alg = algorithmic_bytes(sizes, n_kp)
+        # dominant kernel = the stage with the largest accumulated event time among GPU stages
+        gpu_stages = ["pyramid", "fast", "blur", "orient_desc"]
+        dom = max(gpu_stages, key=lambda s: prof[s][0])
+        dom_ms_per_step = prof[dom][0] / max(args.steps, 1)
+        ach = alg[dom] * B / (dom_ms_per_step * 1e-3) / 1e9 if dom_ms_per_step > 0 else 0.0
+        value = total_frames / dt_max
+        out = {
+            "metric": "ORB extract frames/sec (bit-exact kp/desc vs CPU oracle)",
+            "value": value,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt_max / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": wl["name"], "frames_per_gpu_per_step": B, "keypoints_per_frame": n_kp,
+                       "sharding": f"frames sharded one batch per GPU x{world}, no data-path collective"},
+            "roofline": {
+                "bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_frame": alg[dom], "ms_per_launch_group": dom_ms_per_step,
+                "pipeline": {"algorithmic_bytes_per_frame": alg["extract_total"],
+                             "achieved": alg["extract_total"] * value / world / 1e9,
+                             "frac": alg["extract_total"] * value / world / 1e9 / HBM_PEAK_GBS},
+                "stage_ms_per_step": {s: prof[s][0] / max(args.steps, 1) for s in prof},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames, wl)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

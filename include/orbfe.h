@@ -127,6 +127,10 @@ int orbfe_extractor_debug_candidates(orbfe_extractor *e, int frame, int level, f
 int orbfe_extractor_debug_blurred_level(orbfe_extractor *e, int frame, int level, uint8_t *dst,
                                         int dst_stride);
 
+/* Debug cross-check: when enabled, DistributeOctTree runs in the library's host implementation
+ * (D2H/H2D round trip) instead of the device kernel.  Off by default; results are identical. */
+int orbfe_extractor_debug_host_octree(orbfe_extractor *e, int enable);
+
 /* Per-kernel timing, measured with HIP events on the handle's own stream.
  * enable!=0 starts accumulating; get returns, per stage, total milliseconds and the
  * number of launches since the last reset. */

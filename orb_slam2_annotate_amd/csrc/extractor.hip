@@ -43,8 +43,12 @@ struct orbfe_extractor {
   ExtractorTables tab;
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[ORBFE_STAGE_COUNT + 1] = {};
+  hipEvent_t evA[ORBFE_STAGE_COUNT] = {}, evB[ORBFE_STAGE_COUNT] = {};
+  bool evUsed[ORBFE_STAGE_COUNT] = {};
+  int evLaunches[ORBFE_STAGE_COUNT] = {};
   bool profiling = false;
+  bool hostOctree = false;  // debug cross-check only (orbfe_extractor_debug_host_octree)
+  int octreeMaxL = 0;
   double stageMs[ORBFE_STAGE_COUNT] = {};
   int64_t stageLaunches[ORBFE_STAGE_COUNT] = {};
 
@@ -67,6 +71,7 @@ struct orbfe_extractor {
   uint16_t* d_cellCount = nullptr;
   int32_t* d_cellPrefix = nullptr;
   int32_t* d_candCount = nullptr;
+  uint16_t* d_nodeOf = nullptr;
   LevelKp* d_levelKp = nullptr;
   int32_t* d_levelCount = nullptr;
   // device-side outputs used by the host-buffer API
@@ -107,7 +112,7 @@ void free_geometry(orbfe_extractor* e) {
 }
 void free_workspace(orbfe_extractor* e) {
   dfree(&e->d_pyr); dfree(&e->d_blur); dfree(&e->d_slots); dfree(&e->d_cand);
-  dfree(&e->d_cellCount); dfree(&e->d_cellPrefix); dfree(&e->d_candCount);
+  dfree(&e->d_cellCount); dfree(&e->d_cellPrefix); dfree(&e->d_candCount); dfree(&e->d_nodeOf);
   dfree(&e->d_levelKp); dfree(&e->d_levelCount);
   e->capFrames = 0;
 }
@@ -127,6 +132,16 @@ int ensure_geometry(orbfe_extractor* e, int W, int H) {
     if (c.w > 60 || c.h > 60) return fail(ORBFE_ERR_INVALID, "FAST grid cell larger than 60 px");
   for (int l = 0; l < g.nlevels; l++)
     if (g.lv[l].w < 1 || g.lv[l].h < 1) return fail(ORBFE_ERR_INVALID, "image too small for the pyramid");
+  int maxL = 4;
+  for (int l = 0; l < g.nlevels; l++) {
+    if (g.lv[l].kpCap > maxL) maxL = g.lv[l].kpCap;
+    if (g.lv[l].nIni > maxL) maxL = g.lv[l].nIni;
+    if (g.lv[l].slotCount >= (1 << 24)) return fail(ORBFE_ERR_INVALID, "level too large for the octree kernel");
+  }
+  maxL = (maxL + 3) & ~3;
+  if (octree_lds_bytes(maxL) > 150 * 1024)
+    return fail(ORBFE_ERR_INVALID, "nfeatures too large: octree node list does not fit in LDS");
+  e->octreeMaxL = maxL;
   int rc;
   if ((rc = dalloc(&e->d_cells, g.cells.size()))) return rc;
   if (!g.cells.empty()) HIPCHK(hipMemcpy(e->d_cells, g.cells.data(), g.cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
@@ -159,6 +174,7 @@ int ensure_workspace(orbfe_extractor* e, int nFrames) {
   if ((rc = dalloc(&e->d_cellCount, B * g.cells.size()))) return rc;
   if ((rc = dalloc(&e->d_cellPrefix, B * g.cells.size()))) return rc;
   if ((rc = dalloc(&e->d_candCount, B * (size_t)g.nlevels))) return rc;
+  if ((rc = dalloc(&e->d_nodeOf, B * (size_t)g.totalSlots))) return rc;
   if ((rc = dalloc(&e->d_levelKp, B * (size_t)g.totalKpCap))) return rc;
   if ((rc = dalloc(&e->d_levelCount, B * (size_t)g.nlevels))) return rc;
   e->capFrames = nFrames;
@@ -177,60 +193,42 @@ int ensure_outputs(orbfe_extractor* e, int nFrames, int capacity) {
   return ORBFE_OK;
 }
 
+// Stage timing with HIP events on the handle's own stream.  Events are only RECORDED inside
+// the pipeline (no host sync); resolve_stage_times() reads them after the call's final
+// stream synchronisation, so profiling does not perturb the timed region.
 struct StageTimer {
   orbfe_extractor* e;
   int stage;
-  int launches;
-  StageTimer(orbfe_extractor* e_, int st, int n = 1) : e(e_), stage(st), launches(n) {
-    if (e->profiling) (void)hipEventRecord(e->ev[0], e->stream);
+  StageTimer(orbfe_extractor* e_, int st, int n = 1) : e(e_), stage(st) {
+    if (!e->profiling) return;
+    (void)hipEventRecord(e->evA[stage], e->stream);
+    e->evLaunches[stage] = n;
   }
   ~StageTimer() {
     if (!e->profiling) return;
-    (void)hipEventRecord(e->ev[1], e->stream);
-    (void)hipEventSynchronize(e->ev[1]);
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, e->ev[0], e->ev[1]) == hipSuccess) {
-      e->stageMs[stage] += ms;
-      e->stageLaunches[stage] += launches;
-    }
+    (void)hipEventRecord(e->evB[stage], e->stream);
+    e->evUsed[stage] = true;
   }
 };
+void resolve_stage_times(orbfe_extractor* e) {
+  if (!e->profiling) return;
+  for (int st = 0; st < ORBFE_STAGE_COUNT; st++) {
+    if (!e->evUsed[st]) continue;
+    e->evUsed[st] = false;
+    float ms = 0;
+    if (hipEventSynchronize(e->evB[st]) == hipSuccess &&
+        hipEventElapsedTime(&ms, e->evA[st], e->evB[st]) == hipSuccess) {
+      e->stageMs[st] += ms;
+      e->stageLaunches[st] += e->evLaunches[st];
+    }
+  }
+}
 
-// The device pipeline.  level0: view of the input frames in HBM.
-int run_pipeline(orbfe_extractor* e, LevelView level0, int nFrames, orbfe_keypoint* d_kp,
-                 uint8_t* d_desc, int capacity, int32_t* d_nOut) {
+// Debug cross-check only: DistributeOctTree on the host (octree_host.cpp) with a D2H/H2D round trip.
+int run_host_octree(orbfe_extractor* e, int nFrames) {
   const FrameGeom& g = e->geom;
   hipStream_t s = e->stream;
-  PyramidViews pyr = {}, blur = {};
-  pyr.nlevels = blur.nlevels = g.nlevels;
-  pyr.lv[0] = level0;
-  for (int l = 0; l < g.nlevels; l++) {
-    if (l > 0) pyr.lv[l] = LevelView{e->d_pyr + g.lv[l].off, g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
-    blur.lv[l] = LevelView{e->d_blur + g.lv[l].off, g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
-  }
-  {  // ComputePyramid, :1203-1234
-    StageTimer t(e, ORBFE_STAGE_PYRAMID, g.nlevels - 1);
-    for (int l = 1; l < g.nlevels; l++) {
-      LevelViewMut dst{e->d_pyr + g.lv[l].off, g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
-      launch_resize(s, pyr.lv[l - 1], dst, e->d_xofs[l], e->d_alpha[l], e->d_yofs[l], e->d_beta[l], nFrames);
-    }
-  }
-  {  // FAST grid stage, :846-896
-    StageTimer t(e, ORBFE_STAGE_FAST, 2);
-    launch_fast_cells(s, pyr, e->d_cells, (int)g.cells.size(), nFrames, e->tab.iniThFAST, e->tab.minThFAST,
-                      e->d_slots, g.totalSlots, e->d_cellCount);
-    launch_gather_candidates(s, e->d_cells, e->d_lvgeom, g.nlevels, nFrames, e->d_slots, g.totalSlots,
-                             e->d_cellCount, (int)g.cells.size(), e->d_cand, e->d_candCount, e->d_cellPrefix);
-  }
-  {  // GaussianBlur of every level, :1169-1175 (queued before the host octree so it overlaps it)
-    StageTimer t(e, ORBFE_STAGE_BLUR, g.nlevels);
-    for (int l = 0; l < g.nlevels; l++) {
-      LevelViewMut dst{e->d_blur + g.lv[l].off, g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
-      launch_blur7(s, pyr.lv[l], dst, nFrames);
-    }
-  }
-  {  // DistributeOctTree, :566-808 (host, flat arrays; device version replaces this)
-    StageTimer t(e, ORBFE_STAGE_OCTREE, 0);
+  {
     const int nl = g.nlevels;
     e->h_candCount.resize((size_t)nFrames * nl);
     HIPCHK(hipMemcpyAsync(e->h_candCount.data(), e->d_candCount, sizeof(int32_t) * nFrames * nl, hipMemcpyDeviceToHost, s));
@@ -273,6 +271,60 @@ int run_pipeline(orbfe_extractor* e, LevelView level0, int nFrames, orbfe_keypoi
     HIPCHK(hipMemcpyAsync(e->d_levelKp, e->h_levelKp.data(), sizeof(LevelKp) * e->h_levelKp.size(), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(e->d_levelCount, e->h_levelCount.data(), sizeof(int32_t) * e->h_levelCount.size(), hipMemcpyHostToDevice, s));
   }
+  return ORBFE_OK;
+}
+
+// The device pipeline.  level0: view of the input frames in HBM.
+int run_pipeline(orbfe_extractor* e, LevelView level0, int nFrames, orbfe_keypoint* d_kp,
+                 uint8_t* d_desc, int capacity, int32_t* d_nOut) {
+  const FrameGeom& g = e->geom;
+  hipStream_t s = e->stream;
+  PyramidViews pyr = {}, blur = {};
+  pyr.nlevels = blur.nlevels = g.nlevels;
+  pyr.lv[0] = level0;
+  for (int l = 0; l < g.nlevels; l++) {
+    if (l > 0) pyr.lv[l] = LevelView{e->d_pyr + g.lv[l].off, g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
+    blur.lv[l] = LevelView{e->d_blur + g.lv[l].off, g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
+  }
+  {  // ComputePyramid, :1203-1234
+    StageTimer t(e, ORBFE_STAGE_PYRAMID, g.nlevels - 1);
+    for (int l = 1; l < g.nlevels; l++) {
+      LevelViewMut dst{e->d_pyr + g.lv[l].off, g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
+      launch_resize(s, pyr.lv[l - 1], dst, e->d_xofs[l], e->d_alpha[l], e->d_yofs[l], e->d_beta[l], nFrames);
+    }
+  }
+  {  // FAST grid stage, :846-896
+    StageTimer t(e, ORBFE_STAGE_FAST, 2);
+    launch_fast_cells(s, pyr, e->d_cells, (int)g.cells.size(), nFrames, e->tab.iniThFAST, e->tab.minThFAST,
+                      e->d_slots, g.totalSlots, e->d_cellCount);
+    launch_gather_candidates(s, e->d_cells, e->d_lvgeom, g.nlevels, nFrames, e->d_slots, g.totalSlots,
+                             e->d_cellCount, (int)g.cells.size(), e->d_cand, e->d_candCount, e->d_cellPrefix);
+  }
+  {  // GaussianBlur of every level, :1169-1175 (queued before the host octree so it overlaps it)
+    StageTimer t(e, ORBFE_STAGE_BLUR, g.nlevels);
+    for (int l = 0; l < g.nlevels; l++) {
+      LevelViewMut dst{e->d_blur + g.lv[l].off, g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
+      launch_blur7(s, pyr.lv[l], dst, nFrames);
+    }
+  }
+  if (!e->hostOctree) {  // DistributeOctTree, :566-808, one workgroup per (frame, level)
+    StageTimer t(e, ORBFE_STAGE_OCTREE, 1);
+    OctreeArgs oa = {};
+    oa.cand = e->d_cand;
+    oa.slotsPerFrame = g.totalSlots;
+    oa.candCount = e->d_candCount;
+    oa.lvg = e->d_lvgeom;
+    oa.nlevels = g.nlevels;
+    oa.nodeOf = e->d_nodeOf;
+    oa.levelKp = e->d_levelKp;
+    oa.levelCount = e->d_levelCount;
+    oa.kpSlotsPerFrame = g.totalKpCap;
+    oa.maxL = e->octreeMaxL;
+    HIPCHK(launch_octree(s, oa, g.nlevels, nFrames));
+  } else {
+    int rc = run_host_octree(e, nFrames);
+    if (rc) return rc;
+  }
   {  // computeOrientation + computeDescriptors + output records
     StageTimer t(e, ORBFE_STAGE_ORIENT_DESC, 1);
     OrientDescArgs a = {};
@@ -314,8 +366,10 @@ extern "C" int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlev
   e->device = device;
   e->tab.init(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST);
   hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
-  if (err == hipSuccess) err = hipEventCreate(&e->ev[0]);
-  if (err == hipSuccess) err = hipEventCreate(&e->ev[1]);
+  for (int i = 0; i < ORBFE_STAGE_COUNT && err == hipSuccess; i++) {
+    err = hipEventCreate(&e->evA[i]);
+    if (err == hipSuccess) err = hipEventCreate(&e->evB[i]);
+  }
   if (err == hipSuccess) err = hipMalloc((void**)&e->d_pattern, 1024);
   if (err == hipSuccess) err = hipMemcpy(e->d_pattern, kOrbBitPattern31, 1024, hipMemcpyHostToDevice);
   if (err == hipSuccess) err = hipMalloc((void**)&e->d_umax, 16 * sizeof(int32_t));
@@ -337,8 +391,10 @@ extern "C" void orbfe_extractor_destroy(orbfe_extractor* e) {
   free_outputs(e);
   dfree(&e->d_pattern);
   dfree(&e->d_umax);
-  if (e->ev[0]) (void)hipEventDestroy(e->ev[0]);
-  if (e->ev[1]) (void)hipEventDestroy(e->ev[1]);
+  for (int i = 0; i < ORBFE_STAGE_COUNT; i++) {
+    if (e->evA[i]) (void)hipEventDestroy(e->evA[i]);
+    if (e->evB[i]) (void)hipEventDestroy(e->evB[i]);
+  }
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -396,6 +452,7 @@ extern "C" int orbfe_extract_batch_device(orbfe_extractor* e, const uint8_t* d_i
   LevelView l0{d_images, frame_stride, stride, width, height};
   if ((rc = run_pipeline(e, l0, n_frames, d_keypoints, d_descriptors, capacity, d_n_out))) return rc;
   HIPCHK(hipStreamSynchronize(e->stream));
+  resolve_stage_times(e);
   return ORBFE_OK;
 }
 
@@ -445,6 +502,7 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* images, in
     HIPCHK(hipStreamSynchronize(e->stream));
     if (overflow) return fail(ORBFE_ERR_CAPACITY, "keypoint capacity too small");
   }
+  resolve_stage_times(e);
   return ORBFE_OK;
 }
 
@@ -589,5 +647,12 @@ extern "C" int orbfe_stereo_views_(orbfe_extractor* e, int frame, PyramidViews* 
   for (int l = 0; l < e->tab.nlevels; l++) { scale[l] = e->tab.scale[l]; invScale[l] = e->tab.invScale[l]; }
   *nlevels = e->tab.nlevels;
   *device = e->device;
+  return ORBFE_OK;
+}
+
+// Debug: route DistributeOctTree through the host implementation (cross-check of k_octree).
+extern "C" int orbfe_extractor_debug_host_octree(orbfe_extractor* e, int enable) {
+  if (!e) return fail(ORBFE_ERR_INVALID, "NULL handle");
+  e->hostOctree = enable != 0;
   return ORBFE_OK;
 }

@@ -1,0 +1,300 @@
+// k_octree.hip -- ORBextractor::DistributeOctTree (src/ORBextractor.cc:566-808) on the device:
+// one 256-thread workgroup per (frame, pyramid level), node list in LDS.
+//
+// The reference's sequential std::list algorithm is restated in "generation" form:
+//   * keys never move: a key's node is nodeOf[key]; a node's key order is always ascending
+//     candidate index (root bucketing and DivideNode are stable), so "first key with the max
+//     response" (:787-805) is max(response) then min(candidate index) -- one atomicMax per key;
+//   * a split pass maps the node list to  reverse(children created, in creation order) ++
+//     survivors in order,  which is what push_front/erase produce;
+//   * the largest-first passes (:714-782) sort the expandable nodes of the previous pass by
+//     (count, pointer) ascending and walk from the back; nodes created later sit EARLIER in the
+//     list, so with creation order standing in for the pointer value that walk is
+//     "count descending, list position ascending".  All of them are split speculatively
+//     (4-way key histogram), a prefix sum over the walk order finds the node at which the
+//     list reaches N (the reference's early break, :774-775).
+// Everything is integer except the root bucketing (float divide, :598) -- identical to the host.
+#include "kernels.h"
+
+namespace orbfe {
+
+namespace {
+
+struct Rect { int16_t x0, x1, y0, y1; };
+
+// exclusive scan of a[0..len) in place (LDS), 256 threads; returns the total to every thread
+__device__ int block_scan_excl(int* a, int len, int* waveTot) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int run = 0;
+  for (int base = 0; base < len; base += 256) {
+    const int i = base + tid;
+    const int v = i < len ? a[i] : 0;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) waveTot[wave] = x;
+    __syncthreads();
+    int b = run;
+    for (int w = 0; w < wave; w++) b += waveTot[w];
+    run += waveTot[0] + waveTot[1] + waveTot[2] + waveTot[3];
+    if (i < len) a[i] = b + x - v;
+    __syncthreads();
+  }
+  return run;
+}
+
+__device__ __forceinline__ int quadrant(const Rect r, int x, int y) {
+  const int mx = r.x0 + ((r.x1 - r.x0 + 1) >> 1);  // UL.x + ceil((UR.x-UL.x)/2), :500
+  const int my = r.y0 + ((r.y1 - r.y0 + 1) >> 1);
+  return (x < mx ? 0 : 1) + (y < my ? 0 : 2);      // n1,n2,n3,n4 (:535-545)
+}
+__device__ __forceinline__ Rect child_rect(const Rect r, int q) {
+  const int mx = r.x0 + ((r.x1 - r.x0 + 1) >> 1);
+  const int my = r.y0 + ((r.y1 - r.y0 + 1) >> 1);
+  Rect c;
+  c.x0 = (int16_t)((q & 1) ? mx : r.x0);
+  c.x1 = (int16_t)((q & 1) ? r.x1 : mx);
+  c.y0 = (int16_t)((q & 2) ? my : r.y0);
+  c.y1 = (int16_t)((q & 2) ? r.y1 : my);
+  return c;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_octree(OctreeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ int waveTot[4];
+  __shared__ int sh[4];
+  const int tid = threadIdx.x;
+  const int l = blockIdx.x, f = blockIdx.y;
+  const LevelGeom g = a.lvg[l];
+  const int M = a.maxL;
+  // LDS carve (M entries each)
+  Rect* rect[2];
+  int* cnt[2];
+  rect[0] = reinterpret_cast<Rect*>(smem);
+  rect[1] = rect[0] + M;
+  cnt[0] = reinterpret_cast<int*>(rect[1] + M);
+  cnt[1] = cnt[0] + M;
+  int* child = cnt[1] + M;        // [4*M] child key counts, later child list positions
+  int* scanA = child + 4 * M;     // [M] scans over processing order
+  int* scanB = scanA + M;         // [M] scans over list order
+  uint16_t* order = reinterpret_cast<uint16_t*>(scanB + M);  // [M] processing order -> list position
+  uint16_t* rankOf = order + M;   // [M] list position -> processing rank (valid where inS)
+  uint8_t* inS = reinterpret_cast<uint8_t*>(rankOf + M);      // [M]
+
+  const int n = a.candCount[(size_t)f * a.nlevels + l];
+  const Candidate* cand = a.cand + (size_t)f * a.slotsPerFrame + g.slotStart;
+  uint16_t* nodeOf = a.nodeOf + (size_t)f * a.slotsPerFrame + g.slotStart;
+  LevelKp* out = a.levelKp + (size_t)f * a.kpSlotsPerFrame + g.kpStart;
+  int32_t* outCount = a.levelCount + (size_t)f * a.nlevels + l;
+  const int N = g.quota;
+  const int nIni = g.nIni;
+  if (n <= 0 || nIni <= 0) { if (tid == 0) *outCount = 0; return; }
+
+  const int bw = g.w - 2 * kMinBorder, bh = g.h - 2 * kMinBorder;  // maxX-minX, maxY-minY
+  const float hX = __fdiv_rn((float)bw, (float)nIni);               // :572
+
+  // ---- roots (:576-619) ----
+  int cur = 0;
+  for (int i = tid; i < nIni; i += 256) scanB[i] = 0;
+  __syncthreads();
+  for (int k = tid; k < n; k += 256) {
+    int b = (int)__fdiv_rn((float)(cand[k].xy & 0xffffu), hX);
+    if (b >= nIni) b = nIni - 1;
+    nodeOf[k] = (uint16_t)b;
+    atomicAdd(&scanB[b], 1);
+  }
+  __syncthreads();
+  for (int i = tid; i < nIni; i += 256) { scanA[i] = scanB[i] > 0 ? 1 : 0; }
+  __syncthreads();
+  int L = block_scan_excl(scanA, nIni, waveTot);  // scanA[i] = list position of root i (if non-empty)
+  for (int i = tid; i < nIni; i += 256) {
+    if (scanB[i] > 0) {
+      Rect r;
+      r.x0 = (int16_t)(int)__fmul_rn(hX, (float)i);
+      r.x1 = (int16_t)(int)__fmul_rn(hX, (float)(i + 1));
+      r.y0 = 0;
+      r.y1 = (int16_t)bh;
+      rect[cur][scanA[i]] = r;
+      cnt[cur][scanA[i]] = scanB[i];
+    }
+  }
+  __syncthreads();
+  for (int k = tid; k < n; k += 256) nodeOf[k] = (uint16_t)scanA[nodeOf[k]];
+  __syncthreads();
+
+  int C = 0;            // nodes at the head of the list created by the previous pass
+  bool phase2 = false;
+  for (;;) {
+    const int prevSize = L;
+    Rect* rc = rect[cur];
+    int* cn = cnt[cur];
+    // A. candidates of this pass
+    for (int p = tid; p < L; p += 256) {
+      const bool c = phase2 ? (p < C && cn[p] > 1) : (cn[p] > 1);
+      inS[p] = c ? 1 : 0;
+      child[4 * p] = child[4 * p + 1] = child[4 * p + 2] = child[4 * p + 3] = 0;
+    }
+    __syncthreads();
+    // B. speculative 4-way histogram of the candidates' keys (DivideNode :531-546)
+    for (int k = tid; k < n; k += 256) {
+      const int p = nodeOf[k];
+      if (inS[p]) {
+        const uint32_t xy = cand[k].xy;
+        atomicAdd(&child[4 * p + quadrant(rc[p], (int)(xy & 0xffffu), (int)(xy >> 16))], 1);
+      }
+    }
+    __syncthreads();
+    // C. processing order
+    int m;  // nodes actually split in this pass
+    if (!phase2) {
+      for (int p = tid; p < L; p += 256) scanA[p] = inS[p];
+      __syncthreads();
+      m = block_scan_excl(scanA, L, waveTot);
+      for (int p = tid; p < L; p += 256)
+        if (inS[p]) { order[scanA[p]] = (uint16_t)p; rankOf[p] = (uint16_t)scanA[p]; }
+      __syncthreads();
+    } else {
+      // rank by (count desc, list position asc) among the candidates (all have p < C)
+      int nE = 0;
+      for (int p = tid; p < C; p += 256) {
+        if (!inS[p]) continue;
+        const int c = cn[p];
+        int r = 0;
+        for (int p2 = 0; p2 < C; p2++)
+          if (inS[p2]) { const int c2 = cn[p2]; r += (c2 > c) || (c2 == c && p2 < p); }
+        order[r] = (uint16_t)p;
+        rankOf[p] = (uint16_t)r;
+        nE++;
+      }
+      if (tid == 0) sh[0] = 0;
+      __syncthreads();
+      if (nE) atomicAdd(&sh[0], nE);
+      __syncthreads();
+      const int E = sh[0];
+      // growth of the list per split: (#non-empty children - 1), in walk order
+      for (int j = tid; j < E; j += 256) {
+        const int p = order[j];
+        scanA[j] = (child[4 * p] > 0) + (child[4 * p + 1] > 0) + (child[4 * p + 2] > 0) + (child[4 * p + 3] > 0) - 1;
+      }
+      __syncthreads();
+      block_scan_excl(scanA, E, waveTot);  // scanA[j] = growth before split j
+      // split j happens iff the list is still < N before it: L + scanA[j] < N (early break :774)
+      if (tid == 0) sh[1] = 0;
+      __syncthreads();
+      int mine = 0;
+      for (int j = tid; j < E; j += 256) mine += (L + scanA[j] < N) ? 1 : 0;
+      if (mine) atomicAdd(&sh[1], mine);
+      __syncthreads();
+      m = sh[1];
+      for (int j = tid; j < E; j += 256)
+        if (j >= m) inS[order[j]] = 0;
+      __syncthreads();
+    }
+    // D. creation index of the children: exclusive scan of #non-empty children over the walk order
+    for (int j = tid; j < m; j += 256) {
+      const int p = order[j];
+      scanA[j] = (child[4 * p] > 0) + (child[4 * p + 1] > 0) + (child[4 * p + 2] > 0) + (child[4 * p + 3] > 0);
+    }
+    for (int p = tid; p < L; p += 256) scanB[p] = inS[p] ? 0 : 1;
+    __syncthreads();
+    const int Cn = block_scan_excl(scanA, m, waveTot);
+    const int nSurv = block_scan_excl(scanB, L, waveTot);
+    // E. write the next list: reverse(created) ++ survivors
+    Rect* rn = rect[cur ^ 1];
+    int* cnn = cnt[cur ^ 1];
+    if (tid == 0) sh[2] = 0;
+    __syncthreads();
+    int expand = 0;
+    for (int j = tid; j < m; j += 256) {
+      const int p = order[j];
+      int ci = scanA[j];
+      const Rect r = rc[p];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int c = child[4 * p + q];
+        if (c > 0) {
+          const int np = Cn - 1 - ci;
+          rn[np] = child_rect(r, q);
+          cnn[np] = c;
+          child[4 * p + q] = np;
+          expand += (c > 1);
+          ci++;
+        }
+      }
+    }
+    for (int p = tid; p < L; p += 256)
+      if (!inS[p]) {
+        const int np = Cn + scanB[p];
+        rn[np] = rc[p];
+        cnn[np] = cn[p];
+        scanB[p] = np;
+      }
+    if (expand) atomicAdd(&sh[2], expand);
+    __syncthreads();
+    // F. re-home the keys
+    for (int k = tid; k < n; k += 256) {
+      const int p = nodeOf[k];
+      int np;
+      if (inS[p]) {
+        const uint32_t xy = cand[k].xy;
+        np = child[4 * p + quadrant(rc[p], (int)(xy & 0xffffu), (int)(xy >> 16))];
+      } else {
+        np = scanB[p];
+      }
+      nodeOf[k] = (uint16_t)np;
+    }
+    const int nToExpand = sh[2];
+    __syncthreads();
+    cur ^= 1;
+    L = Cn + nSurv;
+    C = Cn;
+    // termination, :707-714 / :780-781
+    if (L >= N || L == prevSize) break;
+    if (!phase2 && L + nToExpand * 3 > N) phase2 = true;
+  }
+
+  // ---- best response per node, first key wins ties (:787-805) ----
+  int* best = scanA;
+  for (int p = tid; p < L; p += 256) best[p] = 0;
+  __syncthreads();
+  for (int k = tid; k < n; k += 256)
+    atomicMax(reinterpret_cast<unsigned int*>(&best[nodeOf[k]]),
+              (cand[k].score << 24) | (0xffffffu - (unsigned)k));
+  __syncthreads();
+  for (int p = tid; p < L && p < g.kpCap; p += 256) {
+    const unsigned b = (unsigned)best[p];
+    const Candidate c = cand[0xffffffu - (b & 0xffffffu)];
+    LevelKp o;
+    o.x = (uint16_t)((c.xy & 0xffffu) + kMinBorder);  // :909-910
+    o.y = (uint16_t)((c.xy >> 16) + kMinBorder);
+    o.score = c.score;
+    out[p] = o;
+  }
+  if (tid == 0) *outCount = L < g.kpCap ? L : g.kpCap;
+}
+
+size_t octree_lds_bytes(int maxL) {
+  // 2 rect (8) + 2 cnt (4) + child (16) + scanA (4) + scanB (4) + order (2) + rankOf (2) + inS (1)
+  return (size_t)maxL * (2 * 8 + 2 * 4 + 16 + 4 + 4 + 2 + 2 + 1) + 64;
+}
+
+hipError_t launch_octree(hipStream_t s, const OctreeArgs& a, int nlevels, int nFrames) {
+  if (nFrames <= 0) return hipSuccess;
+  const size_t lds = octree_lds_bytes(a.maxL);
+  static thread_local size_t configured = 0;
+  if (lds > 64 * 1024 && lds > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    configured = lds;
+  }
+  hipLaunchKernelGGL(k_octree, dim3(nlevels, nFrames), dim3(256), lds, s, a);
+  return hipSuccess;
+}
+
+}  // namespace orbfe

@@ -56,6 +56,22 @@ void launch_gather_candidates(hipStream_t s, const CellDesc* d_cells, const Leve
                               int slotsPerFrame, const uint16_t* d_cellCount, int cellsPerFrame,
                               Candidate* d_cand, int32_t* d_candCount, int32_t* d_cellPrefix);
 
+// ---- DistributeOctTree on the device (:566-808) ----
+struct OctreeArgs {
+  const Candidate* cand;      // ordered candidates, [frame][slotStart(level) + k]
+  int slotsPerFrame;
+  const int32_t* candCount;   // [frame][level]
+  const LevelGeom* lvg;
+  int nlevels;
+  uint16_t* nodeOf;           // scratch, same indexing as cand
+  LevelKp* levelKp;           // out, [frame][kpStart(level) + i]
+  int32_t* levelCount;        // out, [frame][level]
+  int kpSlotsPerFrame;
+  int maxL;                   // LDS node capacity (>= every level's kpCap and nIni, multiple of 4)
+};
+size_t octree_lds_bytes(int maxL);
+hipError_t launch_octree(hipStream_t s, const OctreeArgs& a, int nlevels, int nFrames);
+
 // ---- blur (GaussianBlur 7x7 sigma 2 reflect-101, :1169-1175) ----
 void launch_blur7(hipStream_t s, LevelView src, LevelViewMut dst, int nFrames);
 

@@ -142,6 +142,9 @@ class ORBextractor:
         n = check(self._L.orbfe_extractor_debug_candidates(self._h, frame, level, ptr(xs), ptr(ys), ptr(rs), cap))
         return xs[:n].copy(), ys[:n].copy(), rs[:n].copy()
 
+    def debug_host_octree(self, enable: bool):
+        check(self._L.orbfe_extractor_debug_host_octree(self._h, int(bool(enable))))
+
     def profile(self, enable: bool):
         check(self._L.orbfe_extractor_profile(self._h, int(bool(enable))))
 

@@ -138,3 +138,24 @@ def test_tables_match_oracle(amd):
         assert o.features_per_level() == list(e.features_per_level())
         assert o.umax() == list(e.umax())
         assert e.GetLevels() == p[2]
+
+
+def test_device_octree_equals_host_octree(amd):
+    """k_octree (device, generation form) vs octree_host.cpp (independent host implementation)."""
+    e = amd.ORBextractor(1000, 1.2, 8, 20, 7)
+    for seed in (41, 42):
+        img = synth.render_frame(seed)
+        e.debug_host_octree(False)
+        kd, dd = e(img)
+        e.debug_host_octree(True)
+        kh, dh = e(img)
+        e.debug_host_octree(False)
+        _kp_equal(kd, kh)
+        assert np.array_equal(dd, dh)
+
+
+def test_octree_small_quota_and_wide_image(amd):
+    # tiny quotas (phase 1 overshoot, N=0 levels) and a very wide image (nIni > 2 roots)
+    _check_frame(amd, synth.render_frame(50, 640, 480), (20, 1.2, 8, 20, 7))
+    _check_frame(amd, synth.render_frame(51, 1000, 200), (800, 1.2, 6, 20, 7))
+    _check_frame(amd, synth.render_frame(52, 2000, 150), (1500, 1.2, 4, 20, 7))
