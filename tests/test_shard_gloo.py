@@ -1,0 +1,75 @@
+"""Host logic of the multi-GPU path on CPU: sharding plans, and the barrier/reduction protocol of
+bench.py with torch.distributed (gloo, world_size 2)."""
+import os
+import socket
+
+import pytest
+
+from orb_slam2_annotate_amd import shard
+
+
+def test_sequence_sharding_covers_everything_once():
+    for world in (1, 2, 4, 8):
+        for mode in ("sequence", "round_robin"):
+            plan = shard.shard_sequences(shard.KITTI_00_07, world, mode)
+            assert len(plan) == world
+            seen = {}
+            for r in range(world):
+                for s, b, e in plan[r]:
+                    assert 0 <= b < e <= shard.KITTI_00_07[s]
+                    for f in (b, e - 1):
+                        assert (s, f) not in seen
+                    seen.setdefault(s, []).append((b, e))
+            for s, n in enumerate(shard.KITTI_00_07):
+                iv = sorted(seen[s])
+                assert iv[0][0] == 0 and iv[-1][1] == n
+                assert all(iv[i][1] == iv[i + 1][0] for i in range(len(iv) - 1))
+    # one-per-GPU is bounded by the longest sequence; round robin is balanced
+    p8 = shard.shard_sequences(shard.KITTI_00_07, 8, "sequence")
+    assert max(shard.frames_of(p) for p in p8) == 4661
+    rr = shard.shard_sequences(shard.KITTI_00_07, 8, "round_robin")
+    counts = [shard.frames_of(p) for p in rr]
+    assert max(counts) - min(counts) <= 1 and sum(counts) == sum(shard.KITTI_00_07)
+    assert shard.shard_sequences([], 3) == [[], [], []]
+    with pytest.raises(ValueError):
+        shard.shard_sequences([1], 0)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan = shard.shard_sequences(shard.KITTI_00_07, world, "sequence")[rank]
+    frames = shard.frames_of(plan)
+    dist.barrier()
+    elapsed = 1.0 + rank  # pretend the ranks took different times
+    dist.barrier()
+    t, n = shard.aggregate(elapsed, frames, dist)
+    q.put((rank, t, n))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_barrier_and_reductions():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, t, n in res:
+        assert t == 2.0  # max over ranks
+        assert n == float(sum(shard.KITTI_00_07))  # every frame counted exactly once
