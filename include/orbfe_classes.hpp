@@ -1,0 +1,191 @@
+// orbfe_classes.hpp -- header-only C++ host layer over the C-ABI (orbfe.h), OpenCV-free.
+//
+// Mirrors the reference's operator/plugin interface for the hot path with the same names,
+// argument meaning and error behaviour:
+//   ORB_SLAM2::ORBextractor  include/ORBextractor.h:46-114   (reference paths)
+//   ORB_SLAM2::ORBmatcher    include/ORBmatcher.h:38-118     (DescriptorDistance, SearchByBoW x2,
+//                                                            SearchForTriangulation)
+//   Frame::ComputeStereoMatches  src/Frame.cc:512-686
+// cv::KeyPoint / cv::Mat are replaced by layout-compatible PODs so that tests and tools build
+// without OpenCV; include/ORBextractor.h and include/ORBmatcher.h of this repo wrap these
+// classes once more with the exact cv:: signatures when OpenCV is available.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "orbfe.h"
+
+namespace orbfe_cpp {
+
+struct KeyPoint {  // == cv::KeyPoint, 28 bytes
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+};
+static_assert(sizeof(KeyPoint) == sizeof(orbfe_keypoint), "layout");
+
+struct Image {  // minimal stand-in for a CV_8UC1 cv::Mat
+  int cols = 0, rows = 0;
+  std::vector<uint8_t> data;
+  const uint8_t* ptr(int y) const { return data.data() + (size_t)y * cols; }
+};
+
+inline void check(int rc, const char* what) {
+  if (rc < 0) throw std::runtime_error(std::string(what) + ": " + orbfe_last_error());
+}
+
+class ORBextractor {
+ public:
+  enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+
+  ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device = 0) {
+    check(orbfe_extractor_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device, &h_), "ORBextractor");
+  }
+  ~ORBextractor() { orbfe_extractor_destroy(h_); }
+  ORBextractor(const ORBextractor&) = delete;
+  ORBextractor& operator=(const ORBextractor&) = delete;
+
+  // operator()(InputArray image, InputArray mask /*ignored*/, vector<KeyPoint>&, OutputArray descriptors)
+  // Empty image: returns silently leaving the outputs untouched (src/ORBextractor.cc:1122-1123);
+  // zero keypoints: descriptors released (:1145-1146).
+  void operator()(const uint8_t* image, int width, int height, int stride, std::vector<KeyPoint>& keypoints,
+                  std::vector<uint8_t>& descriptors) {
+    if (!image || width <= 0 || height <= 0) return;
+    const int cap = orbfe_extractor_max_keypoints(h_);
+    keypoints.resize(cap);
+    descriptors.resize((size_t)cap * 32);
+    int n = 0;
+    check(orbfe_extract(h_, image, width, height, stride, reinterpret_cast<orbfe_keypoint*>(keypoints.data()),
+                        descriptors.data(), cap, &n), "ORBextractor::operator()");
+    keypoints.resize(n);
+    descriptors.resize((size_t)n * 32);
+    w_ = width;
+    h0_ = height;
+    pyramidValid_ = false;
+  }
+
+  int GetLevels() { return orbfe_extractor_get_levels(h_); }
+  float GetScaleFactor() { return orbfe_extractor_get_scale_factor(h_); }
+  std::vector<float> GetScaleFactors() { return vec(orbfe_extractor_get_scale_factors); }
+  std::vector<float> GetInverseScaleFactors() { return vec(orbfe_extractor_get_inverse_scale_factors); }
+  std::vector<float> GetScaleSigmaSquares() { return vec(orbfe_extractor_get_scale_sigma_squares); }
+  std::vector<float> GetInverseScaleSigmaSquares() { return vec(orbfe_extractor_get_inverse_scale_sigma_squares); }
+
+  // The reference exposes `std::vector<cv::Mat> mvImagePyramid` (include/ORBextractor.h:86) that
+  // Frame::ComputeStereoMatches reads.  Here the pyramid stays in HBM; this accessor copies it to
+  // the host on first use after an extraction (the device stereo matcher never needs it).
+  const std::vector<Image>& mvImagePyramid() {
+    if (!pyramidValid_) {
+      const int nl = GetLevels();
+      pyr_.assign(nl, Image());
+      for (int l = 0; l < nl && w_ > 0; l++) {
+        Image& im = pyr_[l];
+        check(orbfe_extractor_level_size(h_, w_, h0_, l, &im.cols, &im.rows), "level_size");
+        im.data.resize((size_t)im.cols * im.rows);
+        check(orbfe_extractor_get_pyramid_level(h_, 0, l, im.data.data(), im.cols), "get_pyramid_level");
+      }
+      pyramidValid_ = true;
+    }
+    return pyr_;
+  }
+
+  orbfe_extractor* handle() { return h_; }
+
+ private:
+  template <typename F>
+  std::vector<float> vec(F f) {
+    std::vector<float> v(GetLevels());
+    check(f(h_, v.data()), "getter");
+    return v;
+  }
+  orbfe_extractor* h_ = nullptr;
+  int w_ = 0, h0_ = 0;
+  bool pyramidValid_ = false;
+  std::vector<Image> pyr_;
+};
+
+// DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned>>) -> CSR view for the C-ABI
+struct FeatureVectorCSR {
+  std::vector<uint32_t> node_ids, indices;
+  std::vector<int32_t> offsets;
+  orbfe_featvec c{};
+  template <typename Map>
+  explicit FeatureVectorCSR(const Map& fv) {
+    offsets.push_back(0);
+    for (const auto& kv : fv) {
+      node_ids.push_back((uint32_t)kv.first);
+      for (unsigned i : kv.second) indices.push_back(i);
+      offsets.push_back((int32_t)indices.size());
+    }
+    c.n_nodes = (int32_t)node_ids.size();
+    c.node_ids = node_ids.data();
+    c.offsets = offsets.data();
+    c.indices = indices.data();
+  }
+};
+
+class ORBmatcher {
+ public:
+  static const int TH_LOW = 50;
+  static const int TH_HIGH = 100;
+  static const int HISTO_LENGTH = 30;
+
+  ORBmatcher(float nnratio = 0.6f, bool checkOri = true, int device = 0)
+      : mfNNratio(nnratio), mbCheckOrientation(checkOri), device_(device) {}
+
+  // static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b)
+  static int DescriptorDistance(const uint8_t* a, const uint8_t* b, int device = 0) {
+    int32_t d = 0;
+    check(orbfe_descriptor_distance(device, a, b, 1, &d), "DescriptorDistance");
+    return d;
+  }
+
+  // int SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches):
+  // matchF[j] = KF feature whose MapPoint goes to frame feature j (or -1).
+  int SearchByBoW(const uint8_t* descKF, const uint8_t* hasMapPointKF, const float* angleKF, int nKF,
+                  const FeatureVectorCSR& fvKF, const uint8_t* descF, const float* angleF, int nF,
+                  const FeatureVectorCSR& fvF, std::vector<int32_t>& matchF) {
+    matchF.assign(nF, -1);
+    int rc = orbfe_search_by_bow(device_, descKF, hasMapPointKF, angleKF, nKF, &fvKF.c, descF, angleF, nF, &fvF.c,
+                                 mfNNratio, mbCheckOrientation, matchF.data());
+    check(rc, "SearchByBoW");
+    return rc;
+  }
+  // int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12)
+  int SearchByBoW(const uint8_t* desc1, const uint8_t* hasMp1, const float* angle1, int n1,
+                  const FeatureVectorCSR& fv1, const uint8_t* desc2, const uint8_t* hasMp2, const float* angle2,
+                  int n2, const FeatureVectorCSR& fv2, std::vector<int32_t>& match12) {
+    match12.assign(n1, -1);
+    int rc = orbfe_search_by_bow_kf(device_, desc1, hasMp1, angle1, n1, &fv1.c, desc2, hasMp2, angle2, n2, &fv2.c,
+                                    mfNNratio, mbCheckOrientation, match12.data());
+    check(rc, "SearchByBoW(KF,KF)");
+    return rc;
+  }
+
+  float mfNNratio;
+  bool mbCheckOrientation;
+
+ private:
+  int device_;
+};
+
+// void Frame::ComputeStereoMatches(): fills mvuRight / mvDepth
+inline int ComputeStereoMatches(ORBextractor& left, ORBextractor& right, const std::vector<KeyPoint>& kL,
+                                const std::vector<uint8_t>& dL, const std::vector<KeyPoint>& kR,
+                                const std::vector<uint8_t>& dR, float mbf, float mb, std::vector<float>& mvuRight,
+                                std::vector<float>& mvDepth) {
+  mvuRight.assign(kL.size(), -1.0f);
+  mvDepth.assign(kL.size(), -1.0f);
+  int rc = orbfe_compute_stereo_matches(left.handle(), 0, right.handle(), 0,
+                                        reinterpret_cast<const orbfe_keypoint*>(kL.data()), dL.data(), (int)kL.size(),
+                                        reinterpret_cast<const orbfe_keypoint*>(kR.data()), dR.data(), (int)kR.size(),
+                                        mbf, mb, mvuRight.data(), mvDepth.data());
+  check(rc, "ComputeStereoMatches");
+  return rc;
+}
+
+}  // namespace orbfe_cpp
