@@ -1,52 +1,119 @@
 // k_blur.hip -- cv::GaussianBlur(7x7, sigma=2, BORDER_REFLECT_101) on a u8 level
 // (the `workingMat` of src/ORBextractor.cc:1169-1175), OpenCV's bit-exact fixed-point path:
-// separable kernel [18,34,48,56,48,34,18]/256, horizontal pass exact in 8.8, vertical pass
-// in 16.16, one rounding (x + 2^15) >> 16.  HBM-bound stencil: each 256-thread workgroup
-// stages a (64+6)x(16+6) tile in LDS (one read of every source byte plus the 3-px halo),
-// keeps the horizontal sums in LDS and writes 64x16 outputs as 32-bit coalesced stores.
+// separable kernel [18,34,48,56,48,34,18]/256, first pass exact in 8.8, second pass in 16.16,
+// one rounding (x + 2^15) >> 16.  Both passes are exact integer sums, so their order is free:
+//   1. a 64x32 output tile stages (32+6) x (64+8) source bytes in LDS as aligned dwords
+//      (reflect-101 resolved while loading);
+//   2. VERTICAL pass, packed 16-bit: a thread takes 4 adjacent columns of one row, two pixels
+//      per VALU lane-op (v_pk_add_u16 / v_pk_mad_u16), result kept in LDS as natural-order u16;
+//   3. HORIZONTAL pass on u16 pairs with v_dot2_u32_u16 (two taps per instruction, 32-bit
+//      accumulate), rounding, one 32-bit coalesced store per 4 pixels.
+// HBM-bound by design: every source byte is read once per tile (+ halo), every output once.
 #include "kernels.h"
 
 namespace orbfe {
 
 namespace {
-constexpr int kBW = 64, kBH = 16, kInPitch = 72;
+constexpr int kBW = 64, kBH = 32;
+constexpr int kTDW = (kBW + 8) / 4;  // 18 tile dwords per row: columns bx-4 .. bx+67
+constexpr int kTH = kBH + 6;         // rows by-3 .. by+34
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ uint32_t as_u(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t dot2(uint32_t a, uint32_t k, uint32_t c) {
+  return __builtin_amdgcn_udot2(as_u2(a), as_u2(k), c, false);
+}
 __device__ __forceinline__ int reflect101c(int i, int n) {
   if (i < 0) i = -i;
   if (i >= n) i = 2 * n - 2 - i;
   return i < 0 ? 0 : (i >= n ? n - 1 : i);  // clamp only matters for never-used tile cells
 }
+constexpr uint32_t pk(uint32_t lo, uint32_t hi) { return lo | (hi << 16); }
 }  // namespace
 
 __global__ __launch_bounds__(256) void k_blur7(LevelView src, LevelViewMut dst) {
-  __shared__ uint8_t tin[(kBH + 6) * kInPitch];
-  __shared__ uint16_t hb[(kBH + 6) * kBW];
+  __shared__ uint32_t tin[kTH * kTDW];             // source bytes
+  __shared__ uint2 vbuf[kBH * kTDW];               // vertical sums, 4 u16 per entry
   const int tid = threadIdx.x;
   const int bx = blockIdx.x * kBW, by = blockIdx.y * kBH, f = blockIdx.z;
   const uint8_t* S = src.base + (size_t)f * src.frameStride;
-  for (int i = tid; i < (kBH + 6) * (kBW + 6); i += 256) {
-    const int ty = i / (kBW + 6), tx = i - ty * (kBW + 6);
-    const int sx = reflect101c(bx - 3 + tx, src.w), sy = reflect101c(by - 3 + ty, src.h);
-    tin[ty * kInPitch + tx] = S[(size_t)sy * src.pitch + sx];
+  const bool aligned = (src.pitch & 3) == 0;
+  // ---- 1. stage ----
+  for (int i = tid; i < kTH * kTDW; i += 256) {
+    const int ty = i / kTDW, tj = i - ty * kTDW;
+    const int sy = reflect101c(by - 3 + ty, src.h);
+    const int c = bx - 4 + 4 * tj;
+    const uint8_t* row = S + (size_t)sy * src.pitch;
+    uint32_t v;
+    if (aligned && c >= 0 && c + 3 < src.w) {
+      const uintptr_t ad = reinterpret_cast<uintptr_t>(row + c);
+      const uint32_t a = (uint32_t)(ad & 3);
+      const uint32_t* p = reinterpret_cast<const uint32_t*>(ad - a);
+      const uint32_t lo = p[0];
+      const uint32_t hi = a ? p[1] : 0u;  // stays inside the row: c+3 < w <= pitch
+      v = __builtin_amdgcn_alignbyte(hi, lo, a);
+    } else {
+      v = (uint32_t)row[reflect101c(c, src.w)] | ((uint32_t)row[reflect101c(c + 1, src.w)] << 8) |
+          ((uint32_t)row[reflect101c(c + 2, src.w)] << 16) | ((uint32_t)row[reflect101c(c + 3, src.w)] << 24);
+    }
+    tin[i] = v;
   }
   __syncthreads();
-  for (int i = tid; i < (kBH + 6) * kBW; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    const uint8_t* t = &tin[r * kInPitch + c];
-    hb[i] = (uint16_t)(18 * (t[0] + t[6]) + 34 * (t[1] + t[5]) + 48 * (t[2] + t[4]) + 56 * t[3]);
-  }
-  __syncthreads();
-  const int row = tid >> 4, cg = (tid & 15) * 4;
-  const int y = by + row, x = bx + cg;
-  if (y >= dst.h || x >= dst.w) return;
-  uint32_t packed = 0;
+  // ---- 2. vertical pass: 8.8 sums of 4 adjacent columns, packed two pixels per lane-op ----
+  for (int i = tid; i < kBH * kTDW; i += 256) {
+    uint32_t r[7];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const uint16_t* h = &hb[row * kBW + cg + k];
-    const uint32_t acc = 18u * ((uint32_t)h[0] + h[6 * kBW]) + 34u * ((uint32_t)h[kBW] + h[5 * kBW]) +
-                         48u * ((uint32_t)h[2 * kBW] + h[4 * kBW]) + 56u * (uint32_t)h[3 * kBW];
-    packed |= ((acc + (1u << 15)) >> 16) << (8 * k);
+    for (int j = 0; j < 7; j++) r[j] = tin[i + j * kTDW];
+    u16x2 acc[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {  // s=0: bytes 0,2; s=1: bytes 1,3
+      u16x2 t[7];
+#pragma unroll
+      for (int j = 0; j < 7; j++)
+        t[j] = as_u2(s == 0 ? (r[j] & 0x00ff00ffu) : __builtin_amdgcn_perm(r[j], r[j], 0x0c030c01u));
+      const u16x2 k18 = {18, 18}, k34 = {34, 34}, k48 = {48, 48}, k56 = {56, 56};
+      u16x2 a = (t[0] + t[6]) * k18;
+      a = (t[1] + t[5]) * k34 + a;
+      a = (t[2] + t[4]) * k48 + a;
+      acc[s] = t[3] * k56 + a;
+    }
+    const uint32_t A = as_u(acc[0]), B = as_u(acc[1]);  // A = (v0,v2), B = (v1,v3)
+    uint2 o;
+    o.x = __builtin_amdgcn_perm(B, A, 0x05040100u);     // (v0, v1)
+    o.y = __builtin_amdgcn_perm(B, A, 0x07060302u);     // (v2, v3)
+    vbuf[i] = o;
   }
-  *reinterpret_cast<uint32_t*>(dst.base + (size_t)f * dst.frameStride + (size_t)y * dst.pitch + x) = packed;
+  __syncthreads();
+  // ---- 3. horizontal pass on u16 pairs: out[x] = (sum_i K[i] * v[x+4+i-3] + 2^15) >> 16 ----
+  for (int i = tid; i < kBH * (kBW / 4); i += 256) {
+    const int row = i >> 4, gx = i & 15;
+    const int y = by + row, x = bx + 4 * gx;
+    if (y >= dst.h || x >= dst.w) continue;
+    const uint2* vp = &vbuf[row * kTDW + gx];
+    const uint2 e0 = vp[0], e1 = vp[1], e2 = vp[2];
+    // d_k = (v'[2k], v'[2k+1]) with v' indexed from tile column 4*gx
+    const uint32_t d0 = e0.x, d1 = e0.y, d2 = e1.x, d3 = e1.y, d4 = e2.x, d5 = e2.y;
+    const uint32_t R = 1u << 15;
+    uint32_t o0 = dot2(d0, pk(0, 18), R);   // taps v'1..v'7
+    o0 = dot2(d1, pk(34, 48), o0);
+    o0 = dot2(d2, pk(56, 48), o0);
+    o0 = dot2(d3, pk(34, 18), o0);
+    uint32_t o1 = dot2(d1, pk(18, 34), R);  // taps v'2..v'8
+    o1 = dot2(d2, pk(48, 56), o1);
+    o1 = dot2(d3, pk(48, 34), o1);
+    o1 = dot2(d4, pk(18, 0), o1);
+    uint32_t o2 = dot2(d1, pk(0, 18), R);   // taps v'3..v'9
+    o2 = dot2(d2, pk(34, 48), o2);
+    o2 = dot2(d3, pk(56, 48), o2);
+    o2 = dot2(d4, pk(34, 18), o2);
+    uint32_t o3 = dot2(d2, pk(18, 34), R);  // taps v'4..v'10
+    o3 = dot2(d3, pk(48, 56), o3);
+    o3 = dot2(d4, pk(48, 34), o3);
+    o3 = dot2(d5, pk(18, 0), o3);
+    const uint32_t packed = (o0 >> 16) | ((o1 >> 16) << 8) | ((o2 >> 16) << 16) | ((o3 >> 16) << 24);
+    *reinterpret_cast<uint32_t*>(dst.base + (size_t)f * dst.frameStride + (size_t)y * dst.pitch + x) = packed;
+  }
 }
 
 void launch_blur7(hipStream_t s, LevelView src, LevelViewMut dst, int nFrames) {

@@ -2,9 +2,8 @@
 // as ONE fused kernel: one 256-thread workgroup per (frame, grid cell) = per cv::FAST call
 // of the reference.  The cell's pixels plus the 3-px ring halo are staged in LDS once
 // (coalesced row reads from HBM/L2), then
-//   A. every pixel gets the 9-of-16 contiguous-arc test at the LOWER threshold; corners are
-//      appended to an LDS work queue (dense, so phase B has no idle lanes),
-//   B. queue entries get the exact cv::FAST score (cornerScore<16>, S-1),
+//   A/B. every pixel gets the exact cv::FAST response (cornerScore<16>, S-1) in packed 16-bit
+//      arithmetic, two pixels per VALU lane-op; a pixel is a corner at threshold t iff S > t,
 //   C. 3x3 strict non-max suppression restricted to the cell's detection rectangle
 //      (the reference's NMS never sees across a cell boundary),
 //   D. per-cell threshold fallback (:874-882): corners >= iniThFAST if any survive NMS,
@@ -17,169 +16,234 @@
 namespace orbfe {
 
 namespace {
-constexpr int kMaxCell = 60;             // cell side bound: wCell = ceil(width/nCols) < 60
-constexpr int kTilePitch = 72;           // >= kMaxCell + 6
+constexpr int kMaxCell = 60;    // cell side bound: wCell = ceil(width/nCols) < 60
+constexpr int kPitchDw = 24;    // LDS row pitch in dwords (96 B): 4 rows x 8 groups hit 32 distinct banks
 constexpr int kTileRows = kMaxCell + 6;
-constexpr int kScorePitch = 64;          // >= kMaxCell + 2
 constexpr int kScoreRows = kMaxCell + 2;
+constexpr int kMaxIter = 4;     // ceil(15 groups * 60 rows / 256 threads)
 
-// Bresenham circle of radius 3, the order cv::FAST uses (any rotation gives the same result).
-__device__ constexpr int kRingDx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
-__device__ constexpr int kRingDy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
-__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ s16x2 as_s2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ uint32_t as_u(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ s16x2 pmin(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
 
-// S = max over the 16 arcs of 9 contiguous ring pixels of min(v - x) resp. min(x - v).
-// cv::FAST's response is S-1; the pixel is a corner at threshold t iff S > t.
-__device__ __forceinline__ int fast_S(const uint8_t* c) {
-  const int v = c[0];
-  int d[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) d[k] = v - (int)c[kRingDx[k] + kRingDy[k] * kTilePitch];
-  int lo1[16], hi1[16], lo2[16], hi2[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) { lo1[k] = imin(d[k], d[(k + 1) & 15]); hi1[k] = imax(d[k], d[(k + 1) & 15]); }
-#pragma unroll
-  for (int k = 0; k < 16; k++) { lo2[k] = imin(lo1[k], lo1[(k + 2) & 15]); hi2[k] = imax(hi1[k], hi1[(k + 2) & 15]); }
-#pragma unroll
-  for (int k = 0; k < 16; k++) { lo1[k] = imin(lo2[k], lo2[(k + 4) & 15]); hi1[k] = imax(hi2[k], hi2[(k + 4) & 15]); }
-  int sd = -256, sb = 256;
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    sd = imax(sd, imin(lo1[k], d[(k + 8) & 15]));
-    sb = imin(sb, imax(hi1[k], d[(k + 8) & 15]));
-  }
-  return imax(sd, -sb);
-}
+// Bresenham circle of radius 3 in cv::FAST's order.
+constexpr int kRingDx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+constexpr int kRingDy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
 
-// 9 contiguous set bits in a cyclic 16-bit mask?
-__device__ __forceinline__ bool has_arc9(uint32_t m16) {
-  uint32_t m = m16 | (m16 << 16);
-  uint32_t r = m & (m >> 1);
-  r &= r >> 2;
-  r &= r >> 4;
-  r &= m >> 8;
-  return (r & 0xffffu) != 0;
-}
+// v_perm_b32 selector that builds the packed u16 pair (byte[o], byte[o+2]) of the 8 bytes {hi,lo}
+constexpr uint32_t sel2(int o) { return (uint32_t)o | 0x0c00u | ((uint32_t)(o + 2) << 16) | 0x0c000000u; }
 }  // namespace
 
+// 32-bit 3-input forms for the per-pixel exact score (one pixel per lane)
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+
+// One workgroup per (frame, grid cell).  The tile lives in LDS with the cell's first pixel at
+// byte column 4, so a group of 4 horizontally adjacent pixels reads aligned dwords.
+//   A. cheap necessary test, packed 16-bit, 4 pixels per thread: a 9-of-16 arc always covers two
+//      ADJACENT cardinal ring points (0,4,8,12), so a corner needs (c0|c8)&(c4|c12) in one
+//      polarity.  ~19 % of pixels pass; they are pushed to an LDS work queue.
+//   B. exact cv::FAST response S-1 for the queued pixels, one pixel per lane (dense lanes).
+//   C. cell-local 3x3 strict NMS + threshold classes, packed, 4 pixels per thread.
+//   D. per-cell 20->7 fallback and ordered emission.
 __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
                                                     const CellDesc* __restrict__ cells,
                                                     int nCells, int iniTh, int minTh,
                                                     Candidate* __restrict__ slots,
                                                     int slotsPerFrame,
                                                     uint16_t* __restrict__ cellCount) {
-  __shared__ __attribute__((aligned(16))) uint8_t tile[kTileRows * kTilePitch];  // reused as class map
-  __shared__ __attribute__((aligned(16))) uint8_t score[kScoreRows * kScorePitch];
+  __shared__ uint32_t tile[kTileRows * kPitchDw];    // pixels: origin (x0-4, y0-3)
+  __shared__ uint32_t score[kScoreRows * kPitchDw];  // FAST responses: origin (x0-4, y0-1)
   __shared__ uint16_t queue[kMaxCell * kMaxCell];
-  __shared__ int qn, nHigh;
   __shared__ int waveTot[4];
+  __shared__ int qn;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cellId = blockIdx.x, f = blockIdx.y;
   const CellDesc cd = cells[cellId];
   const LevelView lv = pyr.lv[cd.level];
   const int cw = cd.w, ch = cd.h, x0 = cd.x0, y0 = cd.y0;
-  const int tlo = imin(iniTh, minTh);
+  const int tlo = iniTh < minTh ? iniTh : minTh;
+  const int ngx = (cw + 3) >> 2;          // 4-pixel groups per row
+  const int ngroups = ngx * ch;
+  const int tdw = ngx + 2;                // tile dwords per row
+  // exact i / ngx and i / tdw for i < 4096 by multiply-shift (divisors <= 17)
+  const uint32_t invG = 65536u / (uint32_t)ngx + 1u, invT = 65536u / (uint32_t)tdw + 1u;
 
-  if (tid == 0) { qn = 0; nHigh = 0; }
-  // stage pixels [x0-3, x0+cw+2] x [y0-3, y0+ch+2] (always inside the level: x0 >= 19)
+  if (tid == 0) qn = 0;
+  // ---- stage the tile: rows y0-3 .. y0+ch+2, bytes x0-4 .. x0+4*ngx+3 (inside the level) ----
   {
-    const uint8_t* img = lv.base + (size_t)f * lv.frameStride + (size_t)(y0 - 3) * lv.pitch + (x0 - 3);
-    const int tw = cw + 6, th = ch + 6;
-    for (int ty = wave; ty < th; ty += 4) {
-      const uint8_t* row = img + (size_t)ty * lv.pitch;
-      for (int tx = lane; tx < tw; tx += 64) tile[ty * kTilePitch + tx] = row[tx];
+    const uint8_t* img = lv.base + (size_t)f * lv.frameStride + (size_t)(y0 - 3) * lv.pitch + (x0 - 4);
+    const int th = ch + 6;
+    const uintptr_t addr0 = reinterpret_cast<uintptr_t>(img);
+    if ((lv.pitch & 3) == 0) {
+      const int a = (int)(addr0 & 3);     // same misalignment for every row
+      const uint8_t* al = img - a;
+      for (int i = tid; i < th * tdw; i += 256) {
+        const int ty = (int)(((uint32_t)i * invT) >> 16), tx = i - ty * tdw;
+        const uint32_t* row = reinterpret_cast<const uint32_t*>(al + (size_t)ty * lv.pitch);
+        const uint32_t lo = row[tx];
+        const uint32_t hi = a ? row[tx + 1] : 0u;
+        tile[ty * kPitchDw + tx] = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)a);
+      }
+    } else {  // caller-owned level 0 with an odd stride: byte loads
+      for (int i = tid; i < th * tdw; i += 256) {
+        const int ty = (int)(((uint32_t)i * invT) >> 16), tx = i - ty * tdw;
+        const uint8_t* p = img + (size_t)ty * lv.pitch + 4 * tx;
+        tile[ty * kPitchDw + tx] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+      }
     }
-    for (int i = tid; i < kScoreRows * kScorePitch / 4; i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
+    for (int i = tid; i < (ch + 2) * kPitchDw; i += 256) score[i] = 0;
   }
   __syncthreads();
 
-  const int npix = cw * ch;
-  const int stepY = 256 / cw, stepX = 256 - stepY * cw;
-  const int py0 = tid / cw, px0 = tid - py0 * cw;
-
-  // ---- A: arc test at the lower threshold ----
+  // ---- A: cardinal-pair test at the lower threshold ----
   {
-    int px = px0, py = py0;
-    for (int p = tid; p < npix; p += 256) {
-      const uint8_t* c = &tile[(py + 3) * kTilePitch + px + 3];
-      const int v = c[0];
-      uint32_t dark = 0, bright = 0;
+    const s16x2 T = {(short)tlo, (short)tlo};
+    for (int g = tid; g < ngroups; g += 256) {
+      const int gy = (int)(((uint32_t)g * invG) >> 16), gx = g - gy * ngx;
+      const uint32_t* mid = &tile[(gy + 3) * kPitchDw + gx];
+      const uint32_t up = tile[gy * kPitchDw + gx + 1], dn = tile[(gy + 6) * kPitchDw + gx + 1];
+      const uint32_t m0 = mid[0], m1 = mid[1], m2 = mid[2];
+      uint32_t pass = 0;
 #pragma unroll
-      for (int k = 0; k < 16; k++) {
-        const int x = c[kRingDx[k] + kRingDy[k] * kTilePitch];
-        dark |= (uint32_t)(x < v - tlo) << k;
-        bright |= (uint32_t)(x > v + tlo) << k;
+      for (int st = 0; st < 2; st++) {  // stream 0: pixels (0,2); stream 1: pixels (1,3)
+        const s16x2 c = as_s2(__builtin_amdgcn_perm(m1, m0, sel2(4 + st)));
+        const s16x2 dS = c - as_s2(__builtin_amdgcn_perm(dn, dn, sel2(st)));      // ring 0  (0,+3)
+        const s16x2 dE = c - as_s2(__builtin_amdgcn_perm(m2, m1, sel2(3 + st)));  // ring 4  (+3,0)
+        const s16x2 dN = c - as_s2(__builtin_amdgcn_perm(up, up, sel2(st)));      // ring 8  (0,-3)
+        const s16x2 dW = c - as_s2(__builtin_amdgcn_perm(m1, m0, sel2(1 + st)));  // ring 12 (-3,0)
+        // sign bit set <=> darker than v-t (d > t) / brighter than v+t (d < -t)
+        const uint32_t dk = (as_u(T - dS) | as_u(T - dN)) & (as_u(T - dE) | as_u(T - dW));
+        const uint32_t br = (as_u(dS + T) | as_u(dN + T)) & (as_u(dE + T) | as_u(dW + T));
+        const uint32_t p = dk | br;
+        pass |= (((p >> 15) & 1u) | ((p >> 29) & 4u)) << st;
       }
-      if (has_arc9(dark) || has_arc9(bright)) {
-        const int q = atomicAdd(&qn, 1);
-        queue[q] = (uint16_t)((py << 8) | px);
+      const int valid = cw - 4 * gx;
+      if (valid < 4) pass &= (1u << valid) - 1u;
+      if (pass) {
+        int q = atomicAdd(&qn, __popc(pass));
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (pass & (1u << j)) queue[q++] = (uint16_t)((gy << 8) | (4 * gx + j));
       }
-      px += stepX; py += stepY;
-      if (px >= cw) { px -= cw; py++; }
     }
   }
   __syncthreads();
-  // ---- B: exact score of the queued corners ----
+
+  // ---- B: exact response of the queued pixels (cornerScore<16>: S-1, corner iff S > t) ----
   {
+    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
+    uint8_t* sbytes = reinterpret_cast<uint8_t*>(score);
     const int n = qn;
     for (int q = tid; q < n; q += 256) {
       const int e = queue[q], px = e & 255, py = e >> 8;
-      const int S = fast_S(&tile[(py + 3) * kTilePitch + px + 3]);
-      score[(py + 1) * kScorePitch + px + 1] = (uint8_t)(S - 1);
-    }
-  }
-  __syncthreads();
-  // ---- C: cell-local 3x3 NMS, classify against both thresholds ----
-  uint8_t* cls = tile;  // the pixel tile is dead from here on
-  {
-    int px = px0, py = py0, high = 0;
-    for (int p = tid; p < npix; p += 256) {
-      const uint8_t* s = &score[(py + 1) * kScorePitch + px + 1];
-      const int v = s[0];
-      int c = 0;
-      if (v > 0) {
-        const bool keep = v > s[-1] && v > s[1] && v > s[-kScorePitch - 1] && v > s[-kScorePitch] &&
-                          v > s[-kScorePitch + 1] && v > s[kScorePitch - 1] && v > s[kScorePitch] &&
-                          v > s[kScorePitch + 1];
-        if (keep) c = (v >= minTh ? 1 : 0) | (v >= iniTh ? 2 : 0);
+      const uint8_t* c = tb + (py + 3) * (kPitchDw * 4) + 4 + px;
+      const int v = c[0];
+      int d[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) d[k] = v - (int)c[kRingDx[k] + kRingDy[k] * (kPitchDw * 4)];
+      int lo3[16], hi3[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+        hi3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
       }
-      cls[p] = (uint8_t)c;
-      high += (c >> 1);
-      px += stepX; py += stepY;
-      if (px >= cw) { px -= cw; py++; }
+      int lo9[16], hi9[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        lo9[k] = min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
+        hi9[k] = max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
+      }
+      int sd = max3i(lo9[0], lo9[1], lo9[2]), sb = min3i(hi9[0], hi9[1], hi9[2]);
+#pragma unroll
+      for (int k = 3; k < 15; k += 2) { sd = max3i(sd, lo9[k], lo9[k + 1]); sb = min3i(sb, hi9[k], hi9[k + 1]); }
+      sd = max(sd, lo9[15]);
+      sb = min(sb, hi9[15]);
+      const int S = max(sd, -sb);
+      if (S > tlo) sbytes[(py + 1) * (kPitchDw * 4) + 4 + px] = (uint8_t)(S - 1);
     }
-    if (high) atomicAdd(&nHigh, high);
   }
   __syncthreads();
-  // ---- D: ordered emission (raster order inside the cell, :884-893) ----
-  const int want = nHigh > 0 ? 2 : 1;
+
+  // ---- C: cell-local 3x3 strict NMS + both threshold classes ----
+  uint32_t selLo[kMaxIter], selHi[kMaxIter];
+  int anyHigh = 0;
+  const s16x2 tIni = {(short)iniTh, (short)iniTh}, tMin = {(short)minTh, (short)minTh};
+#pragma unroll
+  for (int it = 0; it < kMaxIter; it++) {
+    selLo[it] = selHi[it] = 0;
+    const int g = tid + 256 * it;
+    if (g < ngroups) {
+      const int gy = (int)(((uint32_t)g * invG) >> 16), gx = g - gy * ngx;
+      const uint32_t* row1 = &score[(gy + 1) * kPitchDw + gx];
+      if (row1[1] != 0) {
+        uint32_t q[3][3];
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) {
+          const uint32_t* row = &score[(gy + dy) * kPitchDw + gx];
+          q[dy][0] = row[0]; q[dy][1] = row[1]; q[dy][2] = row[2];
+        }
+        s16x2 p35[3], p46[3], p57[3], p68[3];
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) {
+          p35[dy] = as_s2(__builtin_amdgcn_perm(q[dy][1], q[dy][0], sel2(3)));
+          p46[dy] = as_s2(__builtin_amdgcn_perm(q[dy][1], q[dy][0], sel2(4)));
+          p57[dy] = as_s2(__builtin_amdgcn_perm(q[dy][1], q[dy][0], sel2(5)));
+          p68[dy] = as_s2(__builtin_amdgcn_perm(q[dy][2], q[dy][1], sel2(2)));
+        }
+        const s16x2 cA = p46[1], cB = p57[1];  // pixels (0,2) and (1,3)
+        s16x2 nA = pmax(pmax(p35[0], p46[0]), pmax(p57[0], p35[1]));
+        nA = pmax(nA, pmax(pmax(p57[1], p35[2]), pmax(p46[2], p57[2])));
+        s16x2 nB = pmax(pmax(p46[0], p57[0]), pmax(p68[0], p46[1]));
+        nB = pmax(nB, pmax(pmax(p68[1], p46[2]), pmax(p57[2], p68[2])));
+        // keep where centre > every neighbour; classes: >= minTh (lo), >= iniTh (hi)
+        const uint32_t kA = as_u((nA - cA) >> 15), kB = as_u((nB - cB) >> 15);  // 0xffff where kept
+        const uint32_t loA = kA & ~as_u((cA - tMin) >> 15), loB = kB & ~as_u((cB - tMin) >> 15);
+        const uint32_t hiA = kA & ~as_u((cA - tIni) >> 15), hiB = kB & ~as_u((cB - tIni) >> 15);
+        selLo[it] = (loA & 1u) | ((loB & 1u) << 1) | ((loA >> 14) & 4u) | ((loB >> 13) & 8u);
+        selHi[it] = (hiA & 1u) | ((hiB & 1u) << 1) | ((hiA >> 14) & 4u) | ((hiB >> 13) & 8u);
+        anyHigh |= (int)selHi[it];
+      }
+    }
+  }
+  // per-cell threshold fallback (:874-882): corners >= iniThFAST if any survived NMS, else >= minThFAST
+  const int useHigh = __syncthreads_or(anyHigh);
+
+  // ---- D: ordered emission: groups in raster order, pixels of a group left to right ----
   Candidate* out = slots + (size_t)f * slotsPerFrame + cd.slotBase;
   int run = 0;  // identical in every thread
-  {
-    int px = px0, py = py0;
-    for (int pbase = 0; pbase < npix; pbase += 256) {
-      const int p = pbase + tid;
-      const bool sel = p < npix && (cls[p] & want);
-      const unsigned long long bal = __ballot(sel);
-      const int inWave = __popcll(bal & ((1ull << lane) - 1ull));
-      if (lane == 0) waveTot[wave] = __popcll(bal);
-      __syncthreads();
-      int base = run;
-      for (int w = 0; w < wave; w++) base += waveTot[w];
-      run += waveTot[0] + waveTot[1] + waveTot[2] + waveTot[3];
-      if (sel) {
-        Candidate c;
-        c.xy = (uint32_t)(x0 + px - kMinBorder) | ((uint32_t)(y0 + py - kMinBorder) << 16);
-        c.score = score[(py + 1) * kScorePitch + px + 1];
-        out[base + inWave] = c;
-      }
-      __syncthreads();
-      px += stepX; py += stepY;
-      if (px >= cw) { px -= cw; py++; }
+#pragma unroll
+  for (int it = 0; it < kMaxIter; it++) {
+    if (256 * it >= ngroups) break;
+    const uint32_t sel = useHigh ? selHi[it] : selLo[it];
+    const int c = __popc(sel);  // 0..2: NMS keeps no two adjacent pixels
+    const unsigned long long b0 = __ballot(c & 1), b1 = __ballot(c & 2);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int inWave = __popcll(b0 & lt) + 2 * __popcll(b1 & lt);
+    if (lane == 0) waveTot[wave] = __popcll(b0) + 2 * __popcll(b1);
+    __syncthreads();
+    int base = run;
+    for (int w = 0; w < wave; w++) base += waveTot[w];
+    run += waveTot[0] + waveTot[1] + waveTot[2] + waveTot[3];
+    if (sel) {
+      const int g = tid + 256 * it;
+      const int gy = (int)(((uint32_t)g * invG) >> 16), gx = g - gy * ngx;
+      const uint32_t sc = score[(gy + 1) * kPitchDw + gx + 1];
+      int o = base + inWave;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (sel & (1u << j)) {
+          Candidate cnd;
+          cnd.xy = (uint32_t)(x0 + 4 * gx + j - kMinBorder) | ((uint32_t)(y0 + gy - kMinBorder) << 16);
+          cnd.score = (sc >> (8 * j)) & 0xffu;
+          out[o++] = cnd;
+        }
     }
+    __syncthreads();
   }
   if (tid == 0) cellCount[(size_t)f * nCells + cellId] = (uint16_t)run;
 }
