@@ -7,11 +7,96 @@
 
 namespace orbfe {
 
+namespace {
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+constexpr int kRowsPerThread = 8;
+
+// horizontal interpolation of one source row for the thread's 4 output columns:
+// 8 source bytes starting at column `sxb` (two or three aligned dword loads), then per column
+// one v_perm_b32 (bytes S[sx], S[sx+1] as a u16 pair) and one v_dot2_u32_u16 with (a0, a1).
+struct HRow { int h[4]; };
+__device__ __forceinline__ HRow hrow(const uint8_t* rowp, uint32_t mis, const uint32_t (&sel)[4],
+                                     const uint32_t (&al)[4]) {
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(rowp);  // 4-byte aligned
+  const uint32_t d0 = p[0], d1 = p[1];
+  const uint32_t d2 = mis ? p[2] : 0u;
+  const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, mis);
+  const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, mis);
+  HRow r;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    r.h[k] = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(hi, lo, sel[k])),
+                                         __builtin_bit_cast(u16x2, al[k]), 0u, false) >> 4;
+  return r;
+}
+}  // namespace
+
+// Each thread produces 4 adjacent output columns x 8 output rows, walking down the source rows
+// so that every horizontally interpolated source row is computed once and reused by the two
+// output rows that blend it.  Requires pitch % 4 == 0 (owned levels always; caller-owned level 0
+// falls back to k_resize_generic otherwise) and scale <= 2 (the 4 columns' taps span <= 8 bytes).
 __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelViewMut dst,
                                                 const int32_t* __restrict__ xofs,
                                                 const int16_t* __restrict__ alpha,
                                                 const int32_t* __restrict__ yofs,
                                                 const int16_t* __restrict__ beta) {
+  const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+  const int dyBase = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kRowsPerThread;  // wave-uniform
+  const int f = blockIdx.z;
+  if (dx0 >= dst.w || dyBase >= dst.h) return;
+  // per-thread column setup
+  int sx[4];
+  uint32_t al[4], sel[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int dx = dx0 + k < dst.w ? dx0 + k : dst.w - 1;
+    sx[k] = xofs[dx];
+    al[k] = (uint32_t)(uint16_t)alpha[2 * dx] | ((uint32_t)(uint16_t)alpha[2 * dx + 1] << 16);
+  }
+  int sxb = sx[0];
+  if (sxb > src.w - 8) sxb = src.w - 8;  // keep the 8-byte window inside the row
+  if (sxb < 0) sxb = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t o = (uint32_t)(sx[k] - sxb);
+    const uint32_t o1 = o + 1 < 8 ? o + 1 : o;  // tap sx+1 beyond the window only when its weight is 0
+    sel[k] = o | 0x0c00u | (o1 << 16) | 0x0c000000u;
+  }
+  const uint8_t* S = src.base + (size_t)f * src.frameStride + sxb;
+  const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(S) & 3);
+  S -= mis;
+  uint8_t* D = dst.base + (size_t)f * dst.frameStride + dx0;
+
+  int idxA = -1, idxB = -1;
+  HRow A = {}, B = {};
+  for (int r = 0; r < kRowsPerThread; r++) {
+    const int dy = dyBase + r;
+    if (dy >= dst.h) break;
+    const int sy = yofs[dy];
+    const int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
+    const int r0 = sy < 0 ? 0 : (sy >= src.h ? src.h - 1 : sy);
+    const int r1 = sy + 1 < 0 ? 0 : (sy + 1 >= src.h ? src.h - 1 : sy + 1);
+    // (A,B) <- rows (r0,r1), reusing what the previous output row already interpolated
+    if (r0 == idxB) { A = B; idxA = idxB; }
+    else if (r0 != idxA) { A = hrow(S + (size_t)r0 * src.pitch, mis, sel, al); idxA = r0; }
+    if (r1 == idxA) { B = A; idxB = idxA; }
+    else if (r1 != idxB) { B = hrow(S + (size_t)r1 * src.pitch, mis, sel, al); idxB = r1; }
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int v = (((b0 * A.h[k]) >> 16) + ((b1 * B.h[k]) >> 16) + 2) >> 2;
+      packed |= (uint32_t)(v & 0xff) << (8 * k);
+    }
+    *reinterpret_cast<uint32_t*>(D + (size_t)dy * dst.pitch) = packed;  // pitch % 64 == 0: aligned, in-row
+  }
+}
+
+// Generic path (any pitch/alignment/scale): 4 output pixels per thread, byte loads.
+__global__ __launch_bounds__(256) void k_resize_generic(LevelView src, LevelViewMut dst,
+                                                        const int32_t* __restrict__ xofs,
+                                                        const int16_t* __restrict__ alpha,
+                                                        const int32_t* __restrict__ yofs,
+                                                        const int16_t* __restrict__ beta) {
   const int gx = blockIdx.x * 64 + threadIdx.x;  // group of 4 output columns
   const int dy = blockIdx.y * 4 + threadIdx.y;
   const int f = blockIdx.z;
@@ -45,9 +130,14 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelViewMut dst,
 void launch_resize(hipStream_t s, LevelView src, LevelViewMut dst, const int32_t* d_xofs,
                    const int16_t* d_alpha, const int32_t* d_yofs, const int16_t* d_beta,
                    int nFrames) {
-  dim3 block(64, 4);
-  dim3 grid((dst.w + 255) / 256, (dst.h + 3) / 4, nFrames);
-  hipLaunchKernelGGL(k_resize, grid, block, 0, s, src, dst, d_xofs, d_alpha, d_yofs, d_beta);
+  const bool fast = (src.pitch & 3) == 0 && src.w >= 8 && (long long)src.w <= 2LL * dst.w;
+  if (fast) {
+    dim3 grid((dst.w + 255) / 256, (dst.h + 4 * kRowsPerThread - 1) / (4 * kRowsPerThread), nFrames);
+    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, src, dst, d_xofs, d_alpha, d_yofs, d_beta);
+  } else {
+    dim3 grid((dst.w + 255) / 256, (dst.h + 3) / 4, nFrames);
+    hipLaunchKernelGGL(k_resize_generic, grid, dim3(64, 4), 0, s, src, dst, d_xofs, d_alpha, d_yofs, d_beta);
+  }
 }
 
 // level 0 = copy of the caller's image (the copyMakeBorder of :1231 without the dead border)
