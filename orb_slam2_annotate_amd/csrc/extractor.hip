@@ -55,7 +55,8 @@ struct orbfe_extractor {
   FrameGeom geom;
   int capFrames = 0;  // frames the workspace is sized for
   // constant device tables
-  uint32_t* d_pattern = nullptr;
+  float4* d_patternF = nullptr;
+  uint4* d_momentTab = nullptr;
   int32_t* d_umax = nullptr;
   CellDesc* d_cells = nullptr;
   LevelGeom* d_lvgeom = nullptr;
@@ -339,7 +340,7 @@ int run_pipeline(orbfe_extractor* e, LevelView level0, int nFrames, orbfe_keypoi
       a.scale[l] = e->tab.scale[l];
       a.kpSize[l] = (float)(int)(kPatchSize * e->tab.scale[l]);  // :905
     }
-    launch_orient_desc(s, a, e->d_levelKp, e->d_levelCount, e->d_pattern, e->d_umax, nFrames, d_kp, d_desc, d_nOut);
+    launch_orient_desc(s, a, e->d_levelKp, e->d_levelCount, e->d_patternF, e->d_momentTab, e->d_umax, nFrames, d_kp, d_desc, d_nOut);
   }
   HIPCHK(hipGetLastError());
   e->lastPyr = pyr;
@@ -370,8 +371,14 @@ extern "C" int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlev
     err = hipEventCreate(&e->evA[i]);
     if (err == hipSuccess) err = hipEventCreate(&e->evB[i]);
   }
-  if (err == hipSuccess) err = hipMalloc((void**)&e->d_pattern, 1024);
-  if (err == hipSuccess) err = hipMemcpy(e->d_pattern, kOrbBitPattern31, 1024, hipMemcpyHostToDevice);
+  float patF[1024];
+  for (int i = 0; i < 1024; i++) patF[i] = (float)kOrbBitPattern31[i];
+  uint8_t momTab[1024];
+  build_moment_table(momTab);
+  if (err == hipSuccess) err = hipMalloc((void**)&e->d_patternF, sizeof(patF));
+  if (err == hipSuccess) err = hipMemcpy(e->d_patternF, patF, sizeof(patF), hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMalloc((void**)&e->d_momentTab, sizeof(momTab));
+  if (err == hipSuccess) err = hipMemcpy(e->d_momentTab, momTab, sizeof(momTab), hipMemcpyHostToDevice);
   if (err == hipSuccess) err = hipMalloc((void**)&e->d_umax, 16 * sizeof(int32_t));
   if (err == hipSuccess) err = hipMemcpy(e->d_umax, e->tab.umax, 16 * sizeof(int32_t), hipMemcpyHostToDevice);
   if (err != hipSuccess) {
@@ -389,7 +396,8 @@ extern "C" void orbfe_extractor_destroy(orbfe_extractor* e) {
   free_geometry(e);
   free_workspace(e);
   free_outputs(e);
-  dfree(&e->d_pattern);
+  dfree(&e->d_patternF);
+  dfree(&e->d_momentTab);
   dfree(&e->d_umax);
   for (int i = 0; i < ORBFE_STAGE_COUNT; i++) {
     if (e->evA[i]) (void)hipEventDestroy(e->evA[i]);

@@ -1,108 +1,209 @@
 // k_desc.hip -- per-keypoint tail of ORBextractor::operator(): IC_Angle orientation
 // (src/ORBextractor.cc:78-106) on the UNBLURRED level, the 256-bit steered BRIEF descriptor
 // (:111-152) on the BLURRED level, and the final cv::KeyPoint record (:905-916,:1187-1195).
-// One 64-lane wavefront per keypoint: the 749-pixel disc moments are lane-strided integer
-// sums reduced with DPP shuffles (exact, order-free); the 256 binary tests map to
-// 4 x 64 lanes and a wave ballot IS the 8 descriptor bytes (bit k of byte i = test 8i+k).
-// Gathers hit L2 (a 37x37 neighbourhood per keypoint); output is 28+32 B per keypoint.
+//
+// A 256-thread workgroup owns 64 keypoint slots and runs three phases:
+//   1. moments, one wavefront per keypoint: lane = (disc row, left/right half); each lane loads
+//      its 16 pixels as aligned dwords and folds them with v_dot4_u32_u8 against per-row weight
+//      bytes ((dx+16) inside the disc, 0 outside) and mask bytes -> m10 = sum(w*I) - 16*sum(I),
+//      m01 = dy*sum(I); integer, order-free, DPP reduction across the 62 lanes;
+//   2. one THREAD per keypoint: cv::fastAtan2 and the double-precision sincos_spec, so the
+//      transcendental part is not replicated across 64 lanes;
+//   3. descriptors, one wavefront per keypoint: lane l evaluates tests l, l+64, l+128, l+192
+//      (rotation in packed fp32 mul/add, no FMA); a wave ballot IS 8 descriptor bytes.
 #include "kernels.h"
 
 namespace orbfe {
 
+namespace {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int kKpPerBlock = 64;
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+}  // namespace
+
 __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
                                                      const LevelKp* __restrict__ levelKp,
                                                      const int32_t* __restrict__ levelCount,
-                                                     const uint32_t* __restrict__ pattern,
+                                                     const float4* __restrict__ patternF,
+                                                     const uint4* __restrict__ momentTab,
                                                      const int32_t* __restrict__ umax,
                                                      float* __restrict__ kpOut,
                                                      uint8_t* __restrict__ descOut,
                                                      int32_t* __restrict__ nOut) {
-  const int lane = threadIdx.x & 63;
-  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int f = blockIdx.y;
-  if (slot >= a.kpSlotsPerFrame) return;
-  const int32_t* cnt = levelCount + (size_t)f * a.nlevels;
-  int l = 0, base = 0;
-  for (int k = 0; k < a.nlevels; k++) {
-    if (slot >= a.kpStart[k]) l = k;
-  }
-  for (int k = 0; k < l; k++) base += cnt[k];
-  if (slot == 0 && lane == 0) {
-    int tot = 0;
-    for (int k = 0; k < a.nlevels; k++) tot += cnt[k];
-    nOut[f] = tot;
-  }
-  const int i = slot - a.kpStart[l];
-  if (i >= cnt[l]) return;
-  const int outIdx = base + i;
-  if (outIdx >= a.outCapacity) return;  // host reports ORBFE_ERR_CAPACITY from nOut
-  const LevelKp kp = levelKp[(size_t)f * a.kpSlotsPerFrame + slot];
-  const int x = kp.x, y = kp.y;
+  __shared__ int s_m10[kKpPerBlock], s_m01[kKpPerBlock];
+  __shared__ int s_x[kKpPerBlock], s_y[kKpPerBlock], s_level[kKpPerBlock], s_out[kKpPerBlock];
+  __shared__ unsigned s_score[kKpPerBlock];
+  __shared__ float s_angle[kKpPerBlock], s_cos[kKpPerBlock], s_sin[kKpPerBlock];
 
-  // ---- IC_Angle ----
-  const LevelView lv = a.pyr.lv[l];
-  const uint8_t* c = lv.base + (size_t)f * lv.frameStride + (size_t)y * lv.pitch + x;
-  int m10 = 0, m01 = 0;
-  for (int idx = lane; idx < 31 * 31; idx += 64) {
-    const int r = idx / 31;
-    const int dy = r - 15, dx = idx - r * 31 - 15;
-    const int ady = dy < 0 ? -dy : dy, adx = dx < 0 ? -dx : dx;
-    if (adx <= umax[ady]) {
-      const int I = c[dy * lv.pitch + dx];
-      m10 += dx * I;
-      m01 += dy * I;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int f = blockIdx.y;
+  const int slot0 = blockIdx.x * kKpPerBlock;
+  const int32_t* cnt = levelCount + (size_t)f * a.nlevels;
+
+  // ---- slot -> (level, index, output row); thread t < 64 resolves slot0 + t ----
+  if (tid < kKpPerBlock) {
+    const int slot = slot0 + tid;
+    int out = -1, l = 0;
+    if (slot < a.kpSlotsPerFrame) {
+      int base = 0;
+      for (int k = 0; k < a.nlevels; k++) {
+        if (slot >= a.kpStart[k]) { l = k; }
+      }
+      for (int k = 0; k < l; k++) base += cnt[k];
+      const int i = slot - a.kpStart[l];
+      if (i < cnt[l] && base + i < a.outCapacity) {
+        out = base + i;
+        const LevelKp kp = levelKp[(size_t)f * a.kpSlotsPerFrame + slot];
+        s_x[tid] = kp.x;
+        s_y[tid] = kp.y;
+        s_score[tid] = kp.score;
+      }
+    }
+    s_level[tid] = l;
+    s_out[tid] = out;
+    if (slot == 0) {
+      int tot = 0;
+      for (int k = 0; k < a.nlevels; k++) tot += cnt[k];
+      nOut[f] = tot;  // the host reports ORBFE_ERR_CAPACITY when this exceeds the capacity
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    m10 += __shfl_xor(m10, o, 64);
-    m01 += __shfl_xor(m01, o, 64);
-  }
-  const float angle = fast_atan2((float)m01, (float)m10);
+  __syncthreads();
 
-  // ---- steered BRIEF ----
-  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-  float ca, sb;
-  sincos_spec(__fmul_rn(angle, factorPI), &ca, &sb);
-  const LevelView bl = a.blur.lv[l];
-  const uint8_t* cb = bl.base + (size_t)f * bl.frameStride + (size_t)y * bl.pitch + x;
-  unsigned long long* dout = reinterpret_cast<unsigned long long*>(
-      descOut + ((size_t)f * a.outCapacity + outIdx) * 32);
+  // ---- 1. intensity-centroid moments over the 749-pixel disc ----
+  {
+    const int row = lane >> 1, half = lane & 1;  // rows 0..30 <-> dy = -15..15 (lanes 62,63 idle)
+    const int dy = row - 15;
+    const int ady = dy < 0 ? -dy : dy;
+    const bool active = row < 31;
+    uint4 wt = make_uint4(0, 0, 0, 0), mk = make_uint4(0, 0, 0, 0);
+    if (active) {
+      const int d = umax[ady];
+      wt = momentTab[(d * 2 + half) * 2];
+      mk = momentTab[(d * 2 + half) * 2 + 1];
+    }
+    for (int j = wave; j < kKpPerBlock; j += 4) {
+      if (s_out[j] < 0) continue;  // wave-uniform
+      const LevelView lv = a.pyr.lv[s_level[j]];
+      int sW = 0, sI = 0;
+      if (active) {
+        const uint8_t* p = lv.base + (size_t)f * lv.frameStride + (size_t)(s_y[j] + dy) * lv.pitch +
+                           (s_x[j] + (half ? 1 : -15));
+        uint32_t q0, q1, q2, q3;
+        if ((lv.pitch & 3) == 0) {
+          const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3);
+          const uint32_t* al = reinterpret_cast<const uint32_t*>(p - mis);
+          const uint32_t d0 = al[0], d1 = al[1], d2 = al[2], d3 = al[3];
+          const uint32_t d4 = mis ? al[4] : 0u;
+          q0 = __builtin_amdgcn_alignbyte(d1, d0, mis);
+          q1 = __builtin_amdgcn_alignbyte(d2, d1, mis);
+          q2 = __builtin_amdgcn_alignbyte(d3, d2, mis);
+          q3 = __builtin_amdgcn_alignbyte(d4, d3, mis);
+        } else {
+          uint32_t q[4];
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const uint32_t p = pattern[lane + 64 * j];  // (x0,y0,x1,y1) as int8
-    const float x0 = (float)(int8_t)(p & 0xff), y0 = (float)(int8_t)((p >> 8) & 0xff);
-    const float x1 = (float)(int8_t)((p >> 16) & 0xff), y1 = (float)(int8_t)(p >> 24);
-    const int r0 = cv_round(__fadd_rn(__fmul_rn(x0, sb), __fmul_rn(y0, ca)));
-    const int c0 = cv_round(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sb)));
-    const int r1 = cv_round(__fadd_rn(__fmul_rn(x1, sb), __fmul_rn(y1, ca)));
-    const int c1 = cv_round(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sb)));
-    const int t0 = cb[r0 * bl.pitch + c0];
-    const int t1 = cb[r1 * bl.pitch + c1];
-    const unsigned long long bits = __ballot(t0 < t1);
-    if (lane == 0) dout[j] = bits;
+          for (int k = 0; k < 4; k++)
+            q[k] = (uint32_t)p[4 * k] | ((uint32_t)p[4 * k + 1] << 8) | ((uint32_t)p[4 * k + 2] << 16) | ((uint32_t)p[4 * k + 3] << 24);
+          q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+        }
+        unsigned w = __builtin_amdgcn_udot4(q0, wt.x, 0u, false);
+        w = __builtin_amdgcn_udot4(q1, wt.y, w, false);
+        w = __builtin_amdgcn_udot4(q2, wt.z, w, false);
+        w = __builtin_amdgcn_udot4(q3, wt.w, w, false);
+        unsigned s = __builtin_amdgcn_udot4(q0, mk.x, 0u, false);
+        s = __builtin_amdgcn_udot4(q1, mk.y, s, false);
+        s = __builtin_amdgcn_udot4(q2, mk.z, s, false);
+        s = __builtin_amdgcn_udot4(q3, mk.w, s, false);
+        sW = (int)w - 16 * (int)s;  // sum(dx * I)
+        sI = dy * (int)s;           // sum(dy * I)
+      }
+      const int m10 = wave_sum(sW), m01 = wave_sum(sI);
+      if (lane == 0) { s_m10[j] = m10; s_m01[j] = m01; }
+    }
   }
-  if (lane == 0) {
-    float* o = kpOut + ((size_t)f * a.outCapacity + outIdx) * 7;
-    const float sc = a.scale[l];
-    o[0] = __fmul_rn((float)x, sc);
-    o[1] = __fmul_rn((float)y, sc);
-    o[2] = a.kpSize[l];
-    o[3] = angle;
-    o[4] = (float)kp.score;
-    reinterpret_cast<int32_t*>(o)[5] = l;
-    reinterpret_cast<int32_t*>(o)[6] = -1;
+  __syncthreads();
+
+  // ---- 2. angle and rotation, one thread per keypoint ----
+  if (tid < kKpPerBlock && s_out[tid] >= 0) {
+    const float angle = fast_atan2((float)s_m01[tid], (float)s_m10[tid]);
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    float ca, sb;
+    sincos_spec(__fmul_rn(angle, factorPI), &ca, &sb);
+    s_angle[tid] = angle;
+    s_cos[tid] = ca;
+    s_sin[tid] = sb;
+  }
+  __syncthreads();
+
+  // ---- 3. steered BRIEF + output record ----
+  {
+    float4 P[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) P[j] = patternF[lane + 64 * j];  // (x0,y0,x1,y1) of test lane+64j
+    for (int j = wave; j < kKpPerBlock; j += 4) {
+      const int outIdx = s_out[j];
+      if (outIdx < 0) continue;  // wave-uniform
+      const int l = s_level[j];
+      const LevelView bl = a.blur.lv[l];
+      const int x = s_x[j], y = s_y[j];
+      const float ca = s_cos[j], sb = s_sin[j];
+      const uint8_t* cb = bl.base + (size_t)f * bl.frameStride + (size_t)y * bl.pitch + x;
+      unsigned long long* dout = reinterpret_cast<unsigned long long*>(
+          descOut + ((size_t)f * a.outCapacity + outIdx) * 32);
+      const f32x2 ba = {sb, ca}, ab = {ca, sb};
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const f32x2 p0 = {P[t].x, P[t].y}, p1 = {P[t].z, P[t].w};
+        const f32x2 r0 = p0 * ba, c0 = p0 * ab, r1 = p1 * ba, c1 = p1 * ab;  // (x*b, y*a), (x*a, y*b)
+        const int rr0 = cv_round(__fadd_rn(r0.x, r0.y)), cc0 = cv_round(__fsub_rn(c0.x, c0.y));
+        const int rr1 = cv_round(__fadd_rn(r1.x, r1.y)), cc1 = cv_round(__fsub_rn(c1.x, c1.y));
+        const int t0 = cb[rr0 * bl.pitch + cc0];
+        const int t1 = cb[rr1 * bl.pitch + cc1];
+        const unsigned long long bits = __ballot(t0 < t1);
+        if (lane == 0) dout[t] = bits;
+      }
+      if (lane == 0) {
+        float* o = kpOut + ((size_t)f * a.outCapacity + outIdx) * 7;
+        const float sc = a.scale[l];
+        o[0] = __fmul_rn((float)x, sc);
+        o[1] = __fmul_rn((float)y, sc);
+        o[2] = a.kpSize[l];
+        o[3] = s_angle[j];
+        o[4] = (float)s_score[j];
+        reinterpret_cast<int32_t*>(o)[5] = l;
+        reinterpret_cast<int32_t*>(o)[6] = -1;
+      }
+    }
   }
 }
 
 void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d_levelKp,
-                        const int32_t* d_levelCount, const uint32_t* d_pattern,
+                        const int32_t* d_levelCount, const float4* d_patternF, const uint4* d_momentTab,
                         const int32_t* d_umax, int nFrames, void* d_kpOut, uint8_t* d_descOut,
                         int32_t* d_nOut) {
   if (nFrames <= 0 || a.kpSlotsPerFrame <= 0) return;
-  dim3 grid((a.kpSlotsPerFrame + 3) / 4, nFrames);
-  hipLaunchKernelGGL(k_orient_desc, grid, dim3(256), 0, s, a, d_levelKp, d_levelCount, d_pattern,
-                     d_umax, (float*)d_kpOut, d_descOut, d_nOut);
+  dim3 grid((a.kpSlotsPerFrame + kKpPerBlock - 1) / kKpPerBlock, nFrames);
+  hipLaunchKernelGGL(k_orient_desc, grid, dim3(256), 0, s, a, d_levelKp, d_levelCount, d_patternF,
+                     d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut);
+}
+
+// Weight/mask bytes of a 16-pixel half row of the orientation disc, for every half-width d:
+// entry ((d*2 + half)*2 + kind): kind 0 = weights (dx + 16 inside the disc, else 0), kind 1 = mask.
+// half 0 covers dx = -15..0, half 1 covers dx = +1..+16 (dx = 16 is padding).
+void build_moment_table(uint8_t* tab /* 16*2*2*16 bytes */) {
+  for (int d = 0; d < 16; d++)
+    for (int half = 0; half < 2; half++)
+      for (int i = 0; i < 16; i++) {
+        const int dx = half ? i + 1 : i - 15;
+        const int adx = dx < 0 ? -dx : dx;
+        const bool in = adx <= d && adx <= 15;
+        tab[((d * 2 + half) * 2 + 0) * 16 + i] = (uint8_t)(in ? dx + 16 : 0);
+        tab[((d * 2 + half) * 2 + 1) * 16 + i] = (uint8_t)(in ? 1 : 0);
+      }
 }
 
 }  // namespace orbfe

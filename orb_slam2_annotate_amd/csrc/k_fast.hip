@@ -26,7 +26,6 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ s16x2 as_s2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
 __device__ __forceinline__ uint32_t as_u(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
-__device__ __forceinline__ s16x2 pmin(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
 
 // Bresenham circle of radius 3 in cv::FAST's order.
@@ -295,12 +294,14 @@ __global__ __launch_bounds__(256) void k_gather_candidates(const CellDesc* __res
     __syncthreads();
   }
   if (tid == 0) candCount[(size_t)f * nlevels + l] = run;
+  // one thread per cell: most cells hold a handful of candidates, so the copies run in parallel
+  // instead of a latency-bound walk over the cells
   const Candidate* sl = slots + (size_t)f * slotsPerFrame;
   Candidate* out = cand + (size_t)f * slotsPerFrame + g.slotStart;
-  for (int c = wave; c < g.nCells; c += 4) {
+  for (int c = tid; c < g.nCells; c += 256) {
     const int n = cnt[c], b = pre[c];
     const Candidate* src = sl + cells[g.cellStart + c].slotBase;
-    for (int i = lane; i < n; i += 64) out[b + i] = src[i];
+    for (int i = 0; i < n; i++) out[b + i] = src[i];
   }
 }
 

@@ -88,9 +88,10 @@ struct OrientDescArgs {
   int outCapacity;       // caller's per-frame capacity
 };
 void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d_levelKp,
-                        const int32_t* d_levelCount, const uint32_t* d_pattern,
+                        const int32_t* d_levelCount, const float4* d_patternF, const uint4* d_momentTab,
                         const int32_t* d_umax, int nFrames, void* d_kpOut, uint8_t* d_descOut,
                         int32_t* d_nOut);
+void build_moment_table(uint8_t* tab /* 1024 bytes */);
 
 // ---- matching ----
 void launch_hamming_pairs(hipStream_t s, const uint8_t* a, const uint8_t* b, int n, int32_t* out);
