@@ -106,6 +106,15 @@ int orbfe_extract_batch_device(orbfe_extractor *e, const uint8_t *d_images, int 
                                orbfe_keypoint *d_keypoints, uint8_t *d_descriptors, int capacity,
                                int32_t *d_n_out);
 
+/* Asynchronous form: enqueues the whole batch on the handle's stream and returns; results are
+ * valid after orbfe_extractor_synchronize (calls on one handle execute in order, so a caller may
+ * keep several batches in flight as long as each uses its own output buffers). */
+int orbfe_extract_batch_device_async(orbfe_extractor *e, const uint8_t *d_images, int n_frames,
+                                     int width, int height, int stride, size_t frame_stride,
+                                     orbfe_keypoint *d_keypoints, uint8_t *d_descriptors,
+                                     int capacity, int32_t *d_n_out);
+int orbfe_extractor_synchronize(orbfe_extractor *e);
+
 /* Replaces reads of the public member `mvImagePyramid[level]` (include/ORBextractor.h:86;
  * read by Frame::ComputeStereoMatches, src/Frame.cc:519,609,621,626): copies level `level`
  * of frame `frame` of the LAST extract call into `dst` (host, dst_stride bytes per row).
@@ -131,9 +140,10 @@ int orbfe_extractor_debug_blurred_level(orbfe_extractor *e, int frame, int level
  * (D2H/H2D round trip) instead of the device kernel.  Off by default; results are identical. */
 int orbfe_extractor_debug_host_octree(orbfe_extractor *e, int enable);
 
-/* Per-kernel timing, measured with HIP events on the handle's own stream.
- * enable!=0 starts accumulating; get returns, per stage, total milliseconds and the
- * number of launches since the last reset. */
+/* Per-kernel timing, measured with HIP events on the handle's own stream (events are recorded
+ * inside the calls and read back at the next synchronisation, so timing does not stall the
+ * pipeline).  stage_mask: bit i enables ORBFE_STAGE_i, -1 = all, 0 = off; setting it resets the
+ * accumulators.  get returns, per stage, total milliseconds and launches since the last reset. */
 enum {
   ORBFE_STAGE_H2D = 0,
   ORBFE_STAGE_PYRAMID,
@@ -144,7 +154,7 @@ enum {
   ORBFE_STAGE_D2H,
   ORBFE_STAGE_COUNT
 };
-int orbfe_extractor_profile(orbfe_extractor *e, int enable);
+int orbfe_extractor_profile(orbfe_extractor *e, int stage_mask);
 int orbfe_extractor_profile_get(orbfe_extractor *e, double *ms_out /*[ORBFE_STAGE_COUNT]*/,
                                 int64_t *launches_out /*[ORBFE_STAGE_COUNT]*/);
 const char *orbfe_stage_name(int stage);

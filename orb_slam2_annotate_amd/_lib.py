@@ -39,7 +39,7 @@ EXPORTS = [
     "orbfe_extractor_get_inverse_scale_factors", "orbfe_extractor_get_scale_sigma_squares",
     "orbfe_extractor_get_inverse_scale_sigma_squares", "orbfe_extractor_get_features_per_level",
     "orbfe_extractor_get_umax", "orbfe_extractor_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
-    "orbfe_extract_batch_device", "orbfe_extractor_level_size", "orbfe_extractor_get_pyramid_level",
+    "orbfe_extract_batch_device", "orbfe_extract_batch_device_async", "orbfe_extractor_synchronize", "orbfe_extractor_level_size", "orbfe_extractor_get_pyramid_level",
     "orbfe_extractor_pyramid_level_device", "orbfe_extractor_debug_candidates",
     "orbfe_extractor_debug_blurred_level", "orbfe_extractor_debug_host_octree", "orbfe_extractor_profile", "orbfe_extractor_profile_get",
     "orbfe_stage_name", "orbfe_resize_linear", "orbfe_gaussian_blur7", "orbfe_descriptor_distance",
@@ -76,6 +76,8 @@ def load():
     L.orbfe_extract.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, vp]
     L.orbfe_extract_batch.argtypes = [vp, vp, ci, ci, ci, ci, cs, vp, vp, ci, vp]
     L.orbfe_extract_batch_device.argtypes = [vp, vp, ci, ci, ci, ci, cs, vp, vp, ci, vp]
+    L.orbfe_extract_batch_device_async.argtypes = [vp, vp, ci, ci, ci, ci, cs, vp, vp, ci, vp]
+    L.orbfe_extractor_synchronize.argtypes = [vp]
     L.orbfe_extractor_level_size.argtypes = [vp, ci, ci, ci, vp, vp]
     L.orbfe_extractor_get_pyramid_level.argtypes = [vp, ci, ci, vp, ci]
     L.orbfe_extractor_pyramid_level_device.argtypes = [vp, ci, ci, vp, vp, vp, vp]

@@ -43,10 +43,13 @@ struct orbfe_extractor {
   ExtractorTables tab;
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t evA[ORBFE_STAGE_COUNT] = {}, evB[ORBFE_STAGE_COUNT] = {};
-  bool evUsed[ORBFE_STAGE_COUNT] = {};
-  int evLaunches[ORBFE_STAGE_COUNT] = {};
-  bool profiling = false;
+  // stage timing: a ring of event pairs per stage so that asynchronous calls can stay in flight
+  static constexpr int kEvRing = 16;
+  hipEvent_t evA[kEvRing][ORBFE_STAGE_COUNT] = {}, evB[kEvRing][ORBFE_STAGE_COUNT] = {};
+  bool evUsed[kEvRing][ORBFE_STAGE_COUNT] = {};
+  int evLaunches[kEvRing][ORBFE_STAGE_COUNT] = {};
+  int evSlot = 0;
+  unsigned stageMask = 0;
   bool hostOctree = false;  // debug cross-check only (orbfe_extractor_debug_host_octree)
   int octreeMaxL = 0;
   double stageMs[ORBFE_STAGE_COUNT] = {};
@@ -200,29 +203,38 @@ int ensure_outputs(orbfe_extractor* e, int nFrames, int capacity) {
 struct StageTimer {
   orbfe_extractor* e;
   int stage;
-  StageTimer(orbfe_extractor* e_, int st, int n = 1) : e(e_), stage(st) {
-    if (!e->profiling) return;
-    (void)hipEventRecord(e->evA[stage], e->stream);
-    e->evLaunches[stage] = n;
+  bool on;
+  StageTimer(orbfe_extractor* e_, int st, int n = 1) : e(e_), stage(st), on((e_->stageMask >> st) & 1u) {
+    if (!on) return;
+    (void)hipEventRecord(e->evA[e->evSlot][stage], e->stream);
+    e->evLaunches[e->evSlot][stage] = n;
   }
   ~StageTimer() {
-    if (!e->profiling) return;
-    (void)hipEventRecord(e->evB[stage], e->stream);
-    e->evUsed[stage] = true;
+    if (!on) return;
+    (void)hipEventRecord(e->evB[e->evSlot][stage], e->stream);
+    e->evUsed[e->evSlot][stage] = true;
   }
 };
-void resolve_stage_times(orbfe_extractor* e) {
-  if (!e->profiling) return;
+void resolve_slot(orbfe_extractor* e, int slot) {
   for (int st = 0; st < ORBFE_STAGE_COUNT; st++) {
-    if (!e->evUsed[st]) continue;
-    e->evUsed[st] = false;
+    if (!e->evUsed[slot][st]) continue;
+    e->evUsed[slot][st] = false;
     float ms = 0;
-    if (hipEventSynchronize(e->evB[st]) == hipSuccess &&
-        hipEventElapsedTime(&ms, e->evA[st], e->evB[st]) == hipSuccess) {
+    if (hipEventSynchronize(e->evB[slot][st]) == hipSuccess &&
+        hipEventElapsedTime(&ms, e->evA[slot][st], e->evB[slot][st]) == hipSuccess) {
       e->stageMs[st] += ms;
-      e->stageLaunches[st] += e->evLaunches[st];
+      e->stageLaunches[st] += e->evLaunches[slot][st];
     }
   }
+}
+void resolve_stage_times(orbfe_extractor* e) {
+  for (int slot = 0; slot < orbfe_extractor::kEvRing; slot++) resolve_slot(e, slot);
+}
+// advance to the next ring slot before a call records into it (waits for a 16-calls-old one)
+void next_event_slot(orbfe_extractor* e) {
+  if (!e->stageMask) return;
+  e->evSlot = (e->evSlot + 1) % orbfe_extractor::kEvRing;
+  resolve_slot(e, e->evSlot);
 }
 
 // Debug cross-check only: DistributeOctTree on the host (octree_host.cpp) with a D2H/H2D round trip.
@@ -367,10 +379,11 @@ extern "C" int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlev
   e->device = device;
   e->tab.init(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST);
   hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
-  for (int i = 0; i < ORBFE_STAGE_COUNT && err == hipSuccess; i++) {
-    err = hipEventCreate(&e->evA[i]);
-    if (err == hipSuccess) err = hipEventCreate(&e->evB[i]);
-  }
+  for (int r = 0; r < orbfe_extractor::kEvRing; r++)
+    for (int i = 0; i < ORBFE_STAGE_COUNT && err == hipSuccess; i++) {
+      err = hipEventCreate(&e->evA[r][i]);
+      if (err == hipSuccess) err = hipEventCreate(&e->evB[r][i]);
+    }
   float patF[1024];
   for (int i = 0; i < 1024; i++) patF[i] = (float)kOrbBitPattern31[i];
   uint8_t momTab[1024];
@@ -399,10 +412,11 @@ extern "C" void orbfe_extractor_destroy(orbfe_extractor* e) {
   dfree(&e->d_patternF);
   dfree(&e->d_momentTab);
   dfree(&e->d_umax);
-  for (int i = 0; i < ORBFE_STAGE_COUNT; i++) {
-    if (e->evA[i]) (void)hipEventDestroy(e->evA[i]);
-    if (e->evB[i]) (void)hipEventDestroy(e->evB[i]);
-  }
+  for (int r = 0; r < orbfe_extractor::kEvRing; r++)
+    for (int i = 0; i < ORBFE_STAGE_COUNT; i++) {
+      if (e->evA[r][i]) (void)hipEventDestroy(e->evA[r][i]);
+      if (e->evB[r][i]) (void)hipEventDestroy(e->evB[r][i]);
+    }
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -444,10 +458,10 @@ extern "C" int orbfe_extractor_level_size(const orbfe_extractor* e, int width, i
   return ORBFE_OK;
 }
 
-extern "C" int orbfe_extract_batch_device(orbfe_extractor* e, const uint8_t* d_images, int n_frames,
-                                          int width, int height, int stride, size_t frame_stride,
-                                          orbfe_keypoint* d_keypoints, uint8_t* d_descriptors,
-                                          int capacity, int32_t* d_n_out) {
+extern "C" int orbfe_extract_batch_device_async(orbfe_extractor* e, const uint8_t* d_images, int n_frames,
+                                                int width, int height, int stride, size_t frame_stride,
+                                                orbfe_keypoint* d_keypoints, uint8_t* d_descriptors,
+                                                int capacity, int32_t* d_n_out) {
   if (!e || !d_keypoints || !d_descriptors || !d_n_out || capacity <= 0 || n_frames < 0)
     return fail(ORBFE_ERR_INVALID, "extract_batch_device: bad argument");
   if (n_frames == 0) return ORBFE_OK;
@@ -455,13 +469,31 @@ extern "C" int orbfe_extract_batch_device(orbfe_extractor* e, const uint8_t* d_i
     return fail(ORBFE_ERR_INVALID, "extract_batch_device: bad image");
   HIPCHK(hipSetDevice(e->device));
   int rc;
+  if (e->geom.W != width || e->geom.H != height || n_frames > e->capFrames)
+    HIPCHK(hipStreamSynchronize(e->stream));  // the workspace is about to be re-allocated
   if ((rc = ensure_geometry(e, width, height))) return rc;
   if ((rc = ensure_workspace(e, n_frames))) return rc;
+  next_event_slot(e);
   LevelView l0{d_images, frame_stride, stride, width, height};
-  if ((rc = run_pipeline(e, l0, n_frames, d_keypoints, d_descriptors, capacity, d_n_out))) return rc;
+  return run_pipeline(e, l0, n_frames, d_keypoints, d_descriptors, capacity, d_n_out);
+}
+
+extern "C" int orbfe_extractor_synchronize(orbfe_extractor* e) {
+  if (!e) return fail(ORBFE_ERR_INVALID, "NULL handle");
+  HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->stream));
   resolve_stage_times(e);
   return ORBFE_OK;
+}
+
+extern "C" int orbfe_extract_batch_device(orbfe_extractor* e, const uint8_t* d_images, int n_frames,
+                                          int width, int height, int stride, size_t frame_stride,
+                                          orbfe_keypoint* d_keypoints, uint8_t* d_descriptors,
+                                          int capacity, int32_t* d_n_out) {
+  int rc = orbfe_extract_batch_device_async(e, d_images, n_frames, width, height, stride, frame_stride,
+                                            d_keypoints, d_descriptors, capacity, d_n_out);
+  if (rc) return rc;
+  return orbfe_extractor_synchronize(e);
 }
 
 extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* images, int n_frames, int width,
@@ -480,6 +512,7 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* images, in
   if ((rc = ensure_workspace(e, n_frames))) return rc;
   if ((rc = ensure_outputs(e, n_frames, capacity))) return rc;
   const FrameGeom& g = e->geom;
+  next_event_slot(e);
   {
     StageTimer t(e, ORBFE_STAGE_H2D, 0);
     // level 0 lives at the head of the per-frame pyramid slab (pitch-aligned copy)
@@ -574,9 +607,12 @@ extern "C" int orbfe_extractor_debug_candidates(orbfe_extractor* e, int frame, i
   return n;
 }
 
-extern "C" int orbfe_extractor_profile(orbfe_extractor* e, int enable) {
+extern "C" int orbfe_extractor_profile(orbfe_extractor* e, int stage_mask) {
   if (!e) return fail(ORBFE_ERR_INVALID, "NULL handle");
-  e->profiling = enable != 0;
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  resolve_stage_times(e);
+  e->stageMask = stage_mask < 0 ? 0xffffffffu : (unsigned)stage_mask;
   for (int i = 0; i < ORBFE_STAGE_COUNT; i++) { e->stageMs[i] = 0; e->stageLaunches[i] = 0; }
   return ORBFE_OK;
 }

@@ -86,43 +86,54 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
       wt = momentTab[(d * 2 + half) * 2];
       mk = momentTab[(d * 2 + half) * 2 + 1];
     }
-    for (int j = wave; j < kKpPerBlock; j += 4) {
-      if (s_out[j] < 0) continue;  // wave-uniform
-      const LevelView lv = a.pyr.lv[s_level[j]];
-      int sW = 0, sI = 0;
-      if (active) {
-        const uint8_t* p = lv.base + (size_t)f * lv.frameStride + (size_t)(s_y[j] + dy) * lv.pitch +
-                           (s_x[j] + (half ? 1 : -15));
-        uint32_t q0, q1, q2, q3;
-        if ((lv.pitch & 3) == 0) {
-          const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3);
-          const uint32_t* al = reinterpret_cast<const uint32_t*>(p - mis);
-          const uint32_t d0 = al[0], d1 = al[1], d2 = al[2], d3 = al[3];
-          const uint32_t d4 = mis ? al[4] : 0u;
-          q0 = __builtin_amdgcn_alignbyte(d1, d0, mis);
-          q1 = __builtin_amdgcn_alignbyte(d2, d1, mis);
-          q2 = __builtin_amdgcn_alignbyte(d3, d2, mis);
-          q3 = __builtin_amdgcn_alignbyte(d4, d3, mis);
-        } else {
-          uint32_t q[4];
+    // 16 keypoints per wave, 4 at a time: the 4 x 5 row loads are issued back to back so one
+    // memory latency covers four keypoints (the kernel is latency-bound, not VALU-bound)
+    for (int j0 = wave * 16; j0 < wave * 16 + 16; j0 += 4) {
+      uint32_t dw[4][5];
+      uint32_t mis[4];
 #pragma unroll
-          for (int k = 0; k < 4; k++)
-            q[k] = (uint32_t)p[4 * k] | ((uint32_t)p[4 * k + 1] << 8) | ((uint32_t)p[4 * k + 2] << 16) | ((uint32_t)p[4 * k + 3] << 24);
-          q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+      for (int u = 0; u < 4; u++) {
+        const int j = j0 + u;
+        mis[u] = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) dw[u][k] = 0;
+        if (s_out[j] >= 0 && active) {
+          const LevelView lv = a.pyr.lv[s_level[j]];
+          const uint8_t* p = lv.base + (size_t)f * lv.frameStride + (size_t)(s_y[j] + dy) * lv.pitch +
+                             (s_x[j] + (half ? 1 : -15));
+          if ((lv.pitch & 3) == 0) {
+            mis[u] = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3);
+            const uint32_t* al = reinterpret_cast<const uint32_t*>(p - mis[u]);
+            dw[u][0] = al[0]; dw[u][1] = al[1]; dw[u][2] = al[2]; dw[u][3] = al[3];
+            dw[u][4] = mis[u] ? al[4] : 0u;
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+              dw[u][k] = (uint32_t)p[4 * k] | ((uint32_t)p[4 * k + 1] << 8) | ((uint32_t)p[4 * k + 2] << 16) | ((uint32_t)p[4 * k + 3] << 24);
+          }
         }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int j = j0 + u;
+        if (s_out[j] < 0) continue;  // wave-uniform
+        const uint32_t q0 = __builtin_amdgcn_alignbyte(dw[u][1], dw[u][0], mis[u]);
+        const uint32_t q1 = __builtin_amdgcn_alignbyte(dw[u][2], dw[u][1], mis[u]);
+        const uint32_t q2 = __builtin_amdgcn_alignbyte(dw[u][3], dw[u][2], mis[u]);
+        const uint32_t q3 = __builtin_amdgcn_alignbyte(dw[u][4], dw[u][3], mis[u]);
         unsigned w = __builtin_amdgcn_udot4(q0, wt.x, 0u, false);
         w = __builtin_amdgcn_udot4(q1, wt.y, w, false);
         w = __builtin_amdgcn_udot4(q2, wt.z, w, false);
         w = __builtin_amdgcn_udot4(q3, wt.w, w, false);
-        unsigned s = __builtin_amdgcn_udot4(q0, mk.x, 0u, false);
-        s = __builtin_amdgcn_udot4(q1, mk.y, s, false);
-        s = __builtin_amdgcn_udot4(q2, mk.z, s, false);
-        s = __builtin_amdgcn_udot4(q3, mk.w, s, false);
-        sW = (int)w - 16 * (int)s;  // sum(dx * I)
-        sI = dy * (int)s;           // sum(dy * I)
+        unsigned sm = __builtin_amdgcn_udot4(q0, mk.x, 0u, false);
+        sm = __builtin_amdgcn_udot4(q1, mk.y, sm, false);
+        sm = __builtin_amdgcn_udot4(q2, mk.z, sm, false);
+        sm = __builtin_amdgcn_udot4(q3, mk.w, sm, false);
+        const int sW = (int)w - 16 * (int)sm;  // sum(dx * I); inactive lanes have zero weights
+        const int sI = dy * (int)sm;           // sum(dy * I)
+        const int m10 = wave_sum(sW), m01 = wave_sum(sI);
+        if (lane == 0) { s_m10[j] = m10; s_m01[j] = m01; }
       }
-      const int m10 = wave_sum(sW), m01 = wave_sum(sI);
-      if (lane == 0) { s_m10[j] = m10; s_m01[j] = m01; }
     }
   }
   __syncthreads();
@@ -144,38 +155,53 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
     float4 P[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) P[j] = patternF[lane + 64 * j];  // (x0,y0,x1,y1) of test lane+64j
-    for (int j = wave; j < kKpPerBlock; j += 4) {
-      const int outIdx = s_out[j];
-      if (outIdx < 0) continue;  // wave-uniform
-      const int l = s_level[j];
-      const LevelView bl = a.blur.lv[l];
-      const int x = s_x[j], y = s_y[j];
-      const float ca = s_cos[j], sb = s_sin[j];
-      const uint8_t* cb = bl.base + (size_t)f * bl.frameStride + (size_t)y * bl.pitch + x;
-      unsigned long long* dout = reinterpret_cast<unsigned long long*>(
-          descOut + ((size_t)f * a.outCapacity + outIdx) * 32);
-      const f32x2 ba = {sb, ca}, ab = {ca, sb};
+    // two keypoints per iteration: their 16 sample loads are in flight together
+    for (int j0 = wave * 16; j0 < wave * 16 + 16; j0 += 2) {
+      int t0v[2][4], t1v[2][4];
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const f32x2 p0 = {P[t].x, P[t].y}, p1 = {P[t].z, P[t].w};
-        const f32x2 r0 = p0 * ba, c0 = p0 * ab, r1 = p1 * ba, c1 = p1 * ab;  // (x*b, y*a), (x*a, y*b)
-        const int rr0 = cv_round(__fadd_rn(r0.x, r0.y)), cc0 = cv_round(__fsub_rn(c0.x, c0.y));
-        const int rr1 = cv_round(__fadd_rn(r1.x, r1.y)), cc1 = cv_round(__fsub_rn(c1.x, c1.y));
-        const int t0 = cb[rr0 * bl.pitch + cc0];
-        const int t1 = cb[rr1 * bl.pitch + cc1];
-        const unsigned long long bits = __ballot(t0 < t1);
-        if (lane == 0) dout[t] = bits;
+      for (int u = 0; u < 2; u++) {
+        const int j = j0 + u;
+#pragma unroll
+        for (int t = 0; t < 4; t++) { t0v[u][t] = 0; t1v[u][t] = 0; }
+        if (s_out[j] < 0) continue;  // wave-uniform
+        const LevelView bl = a.blur.lv[s_level[j]];
+        const float ca = s_cos[j], sb = s_sin[j];
+        const uint8_t* cb = bl.base + (size_t)f * bl.frameStride + (size_t)s_y[j] * bl.pitch + s_x[j];
+        const f32x2 ba = {sb, ca}, ab = {ca, sb};
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const f32x2 p0 = {P[t].x, P[t].y}, p1 = {P[t].z, P[t].w};
+          const f32x2 r0 = p0 * ba, c0 = p0 * ab, r1 = p1 * ba, c1 = p1 * ab;  // (x*b, y*a), (x*a, y*b)
+          const int rr0 = cv_round(__fadd_rn(r0.x, r0.y)), cc0 = cv_round(__fsub_rn(c0.x, c0.y));
+          const int rr1 = cv_round(__fadd_rn(r1.x, r1.y)), cc1 = cv_round(__fsub_rn(c1.x, c1.y));
+          t0v[u][t] = cb[rr0 * bl.pitch + cc0];
+          t1v[u][t] = cb[rr1 * bl.pitch + cc1];
+        }
       }
-      if (lane == 0) {
-        float* o = kpOut + ((size_t)f * a.outCapacity + outIdx) * 7;
-        const float sc = a.scale[l];
-        o[0] = __fmul_rn((float)x, sc);
-        o[1] = __fmul_rn((float)y, sc);
-        o[2] = a.kpSize[l];
-        o[3] = s_angle[j];
-        o[4] = (float)s_score[j];
-        reinterpret_cast<int32_t*>(o)[5] = l;
-        reinterpret_cast<int32_t*>(o)[6] = -1;
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int j = j0 + u;
+        const int outIdx = s_out[j];
+        if (outIdx < 0) continue;  // wave-uniform
+        unsigned long long* dout = reinterpret_cast<unsigned long long*>(
+            descOut + ((size_t)f * a.outCapacity + outIdx) * 32);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const unsigned long long bits = __ballot(t0v[u][t] < t1v[u][t]);
+          if (lane == 0) dout[t] = bits;
+        }
+        if (lane == 0) {
+          const int l = s_level[j];
+          float* o = kpOut + ((size_t)f * a.outCapacity + outIdx) * 7;
+          const float sc = a.scale[l];
+          o[0] = __fmul_rn((float)s_x[j], sc);
+          o[1] = __fmul_rn((float)s_y[j], sc);
+          o[2] = a.kpSize[l];
+          o[3] = s_angle[j];
+          o[4] = (float)s_score[j];
+          reinterpret_cast<int32_t*>(o)[5] = l;
+          reinterpret_cast<int32_t*>(o)[6] = -1;
+        }
       }
     }
   }

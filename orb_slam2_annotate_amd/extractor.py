@@ -105,12 +105,16 @@ class ORBextractor:
 
     def extract_batch_device(self, d_images: int, n_frames: int, width: int, height: int, stride: int,
                              frame_stride: int, d_keypoints: int, d_descriptors: int, capacity: int,
-                             d_n_out: int):
-        """All pointers are raw DEVICE addresses (e.g. torch tensor .data_ptr())."""
-        check(self._L.orbfe_extract_batch_device(self._h, C.c_void_p(d_images), n_frames, width, height, stride,
-                                                 frame_stride, C.c_void_p(d_keypoints),
-                                                 C.c_void_p(d_descriptors), capacity, C.c_void_p(d_n_out)))
+                             d_n_out: int, wait: bool = True):
+        """All pointers are raw DEVICE addresses (e.g. torch tensor .data_ptr()).  wait=False only
+        enqueues the batch on the handle's stream; call synchronize() before reading results."""
+        fn = self._L.orbfe_extract_batch_device if wait else self._L.orbfe_extract_batch_device_async
+        check(fn(self._h, C.c_void_p(d_images), n_frames, width, height, stride, frame_stride,
+                 C.c_void_p(d_keypoints), C.c_void_p(d_descriptors), capacity, C.c_void_p(d_n_out)))
         self._last_shape = (n_frames, height, width)
+
+    def synchronize(self):
+        check(self._L.orbfe_extractor_synchronize(self._h))
 
     # ---- mvImagePyramid, include/ORBextractor.h:86 ----
     def pyramid_level(self, level: int, frame: int = 0) -> np.ndarray:
@@ -145,8 +149,15 @@ class ORBextractor:
     def debug_host_octree(self, enable: bool):
         check(self._L.orbfe_extractor_debug_host_octree(self._h, int(bool(enable))))
 
-    def profile(self, enable: bool):
-        check(self._L.orbfe_extractor_profile(self._h, int(bool(enable))))
+    def profile(self, stages=True):
+        """stages: True/False, or an iterable of stage names from _lib.STAGES."""
+        if stages is True:
+            mask = -1
+        elif not stages:
+            mask = 0
+        else:
+            mask = sum(1 << _lib.STAGES.index(s) for s in stages)
+        check(self._L.orbfe_extractor_profile(self._h, mask))
 
     def profile_get(self):
         ms = np.zeros(len(_lib.STAGES), dtype=np.float64)
