@@ -140,6 +140,12 @@ int orbfe_extractor_debug_blurred_level(orbfe_extractor *e, int frame, int level
  * (D2H/H2D round trip) instead of the device kernel.  Off by default; results are identical. */
 int orbfe_extractor_debug_host_octree(orbfe_extractor *e, int enable);
 
+/* A call's frames are split into n consecutive sub-batches that run concurrently on n HIP
+ * streams with private workspace slices (1..4, default 2 or $ORBFE_STREAMS); results do not
+ * depend on n.  Stage timing covers the kernels of sub-batch 0 (frames_out reports how many
+ * frames those launches processed). */
+int orbfe_extractor_set_streams(orbfe_extractor *e, int n);
+
 /* Per-kernel timing, measured with HIP events on the handle's own stream (events are recorded
  * inside the calls and read back at the next synchronisation, so timing does not stall the
  * pipeline).  stage_mask: bit i enables ORBFE_STAGE_i, -1 = all, 0 = off; setting it resets the
@@ -156,7 +162,8 @@ enum {
 };
 int orbfe_extractor_profile(orbfe_extractor *e, int stage_mask);
 int orbfe_extractor_profile_get(orbfe_extractor *e, double *ms_out /*[ORBFE_STAGE_COUNT]*/,
-                                int64_t *launches_out /*[ORBFE_STAGE_COUNT]*/);
+                                int64_t *launches_out /*[ORBFE_STAGE_COUNT]*/,
+                                double *frames_out /*[ORBFE_STAGE_COUNT], may be NULL*/);
 const char *orbfe_stage_name(int stage);
 
 /* Standalone primitives on host buffers (tests of the individual kernels). */

@@ -41,7 +41,7 @@ EXPORTS = [
     "orbfe_extractor_get_umax", "orbfe_extractor_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
     "orbfe_extract_batch_device", "orbfe_extract_batch_device_async", "orbfe_extractor_synchronize", "orbfe_extractor_level_size", "orbfe_extractor_get_pyramid_level",
     "orbfe_extractor_pyramid_level_device", "orbfe_extractor_debug_candidates",
-    "orbfe_extractor_debug_blurred_level", "orbfe_extractor_debug_host_octree", "orbfe_extractor_profile", "orbfe_extractor_profile_get",
+    "orbfe_extractor_debug_blurred_level", "orbfe_extractor_debug_host_octree", "orbfe_extractor_set_streams", "orbfe_extractor_profile", "orbfe_extractor_profile_get",
     "orbfe_stage_name", "orbfe_resize_linear", "orbfe_gaussian_blur7", "orbfe_descriptor_distance",
     "orbfe_hamming_matrix", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",
     "orbfe_search_for_triangulation", "orbfe_compute_stereo_matches",
@@ -85,7 +85,8 @@ def load():
     L.orbfe_extractor_debug_blurred_level.argtypes = [vp, ci, ci, vp, ci]
     L.orbfe_extractor_profile.argtypes = [vp, ci]
     L.orbfe_extractor_debug_host_octree.argtypes = [vp, ci]
-    L.orbfe_extractor_profile_get.argtypes = [vp, vp, vp]
+    L.orbfe_extractor_profile_get.argtypes = [vp, vp, vp, vp]
+    L.orbfe_extractor_set_streams.argtypes = [vp, ci]
     L.orbfe_stage_name.argtypes = [ci]
     L.orbfe_resize_linear.argtypes = [ci, vp, ci, ci, ci, vp, ci, ci, ci]
     L.orbfe_gaussian_blur7.argtypes = [ci, vp, ci, ci, ci, vp, ci]

@@ -4,6 +4,7 @@
 
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -42,12 +43,18 @@ static_assert(sizeof(orbfe_keypoint) == 28, "cv::KeyPoint layout");
 struct orbfe_extractor {
   ExtractorTables tab;
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;              // stream 0: owns the timing events and the copies
+  static constexpr int kMaxStreams = 4;
+  hipStream_t extra[kMaxStreams - 1] = {};   // sub-batch streams 1..3
+  int nStreams = 1;                          // >1: sub-batches of one call run concurrently
+  int lastSplitFrames = -1, lastSplitStreams = -1;
+  double stageFrames[ORBFE_STAGE_COUNT] = {};
   // stage timing: a ring of event pairs per stage so that asynchronous calls can stay in flight
   static constexpr int kEvRing = 16;
   hipEvent_t evA[kEvRing][ORBFE_STAGE_COUNT] = {}, evB[kEvRing][ORBFE_STAGE_COUNT] = {};
   bool evUsed[kEvRing][ORBFE_STAGE_COUNT] = {};
   int evLaunches[kEvRing][ORBFE_STAGE_COUNT] = {};
+  int evFrames[kEvRing][ORBFE_STAGE_COUNT] = {};
   int evSlot = 0;
   unsigned stageMask = 0;
   bool hostOctree = false;  // debug cross-check only (orbfe_extractor_debug_host_octree)
@@ -204,10 +211,12 @@ struct StageTimer {
   orbfe_extractor* e;
   int stage;
   bool on;
-  StageTimer(orbfe_extractor* e_, int st, int n = 1) : e(e_), stage(st), on((e_->stageMask >> st) & 1u) {
+  StageTimer(orbfe_extractor* e_, int st, int n = 1, int frames = 0, bool timed = true)
+      : e(e_), stage(st), on(timed && ((e_->stageMask >> st) & 1u)) {
     if (!on) return;
     (void)hipEventRecord(e->evA[e->evSlot][stage], e->stream);
     e->evLaunches[e->evSlot][stage] = n;
+    e->evFrames[e->evSlot][stage] = frames;
   }
   ~StageTimer() {
     if (!on) return;
@@ -224,6 +233,7 @@ void resolve_slot(orbfe_extractor* e, int slot) {
         hipEventElapsedTime(&ms, e->evA[slot][st], e->evB[slot][st]) == hipSuccess) {
       e->stageMs[st] += ms;
       e->stageLaunches[st] += e->evLaunches[slot][st];
+      e->stageFrames[st] += e->evFrames[slot][st];
     }
   }
 }
@@ -287,59 +297,74 @@ int run_host_octree(orbfe_extractor* e, int nFrames) {
   return ORBFE_OK;
 }
 
-// The device pipeline.  level0: view of the input frames in HBM.
-int run_pipeline(orbfe_extractor* e, LevelView level0, int nFrames, orbfe_keypoint* d_kp,
-                 uint8_t* d_desc, int capacity, int32_t* d_nOut) {
+// The device pipeline for frames [f0, f0+nFrames) of a call, enqueued on stream `s`.
+// level0: view of the call's input frames in HBM (frame 0 of the call).
+int run_chunk(orbfe_extractor* e, hipStream_t s, bool timed, LevelView level0, int f0, int nFrames,
+              orbfe_keypoint* d_kp, uint8_t* d_desc, int capacity, int32_t* d_nOut, PyramidViews* pyrOut,
+              PyramidViews* blurOut) {
   const FrameGeom& g = e->geom;
-  hipStream_t s = e->stream;
-  PyramidViews pyr = {}, blur = {};
-  pyr.nlevels = blur.nlevels = g.nlevels;
-  pyr.lv[0] = level0;
+  const size_t F = (size_t)f0;
+  const int nCells = (int)g.cells.size();
+  PyramidViews pyr = {}, blur = {}, pyr0 = {}, blur0 = {};
+  pyr.nlevels = blur.nlevels = pyr0.nlevels = blur0.nlevels = g.nlevels;
+  pyr0.lv[0] = level0;
   for (int l = 0; l < g.nlevels; l++) {
-    if (l > 0) pyr.lv[l] = LevelView{e->d_pyr + g.lv[l].off, g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
-    blur.lv[l] = LevelView{e->d_blur + g.lv[l].off, g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
+    if (l > 0) pyr0.lv[l] = LevelView{e->d_pyr + g.lv[l].off, g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
+    blur0.lv[l] = LevelView{e->d_blur + g.lv[l].off, g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
+    pyr.lv[l] = pyr0.lv[l];
+    pyr.lv[l].base += F * pyr0.lv[l].frameStride;
+    blur.lv[l] = blur0.lv[l];
+    blur.lv[l].base += F * blur0.lv[l].frameStride;
   }
+  if (pyrOut) { *pyrOut = pyr0; *blurOut = blur0; }
+  Candidate* slots = e->d_slots + F * g.totalSlots;
+  Candidate* cand = e->d_cand + F * g.totalSlots;
+  uint16_t* cellCount = e->d_cellCount + F * nCells;
+  int32_t* cellPrefix = e->d_cellPrefix + F * nCells;
+  int32_t* candCount = e->d_candCount + F * g.nlevels;
+  LevelKp* levelKp = e->d_levelKp + F * g.totalKpCap;
+  int32_t* levelCount = e->d_levelCount + F * g.nlevels;
   {  // ComputePyramid, :1203-1234
-    StageTimer t(e, ORBFE_STAGE_PYRAMID, g.nlevels - 1);
+    StageTimer t(e, ORBFE_STAGE_PYRAMID, g.nlevels - 1, nFrames, timed);
     for (int l = 1; l < g.nlevels; l++) {
-      LevelViewMut dst{e->d_pyr + g.lv[l].off, g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
+      LevelViewMut dst{const_cast<uint8_t*>(pyr.lv[l].base), g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
       launch_resize(s, pyr.lv[l - 1], dst, e->d_xofs[l], e->d_alpha[l], e->d_yofs[l], e->d_beta[l], nFrames);
     }
   }
   {  // FAST grid stage, :846-896
-    StageTimer t(e, ORBFE_STAGE_FAST, 2);
-    launch_fast_cells(s, pyr, e->d_cells, (int)g.cells.size(), nFrames, e->tab.iniThFAST, e->tab.minThFAST,
-                      e->d_slots, g.totalSlots, e->d_cellCount);
-    launch_gather_candidates(s, e->d_cells, e->d_lvgeom, g.nlevels, nFrames, e->d_slots, g.totalSlots,
-                             e->d_cellCount, (int)g.cells.size(), e->d_cand, e->d_candCount, e->d_cellPrefix);
+    StageTimer t(e, ORBFE_STAGE_FAST, 2, nFrames, timed);
+    launch_fast_cells(s, pyr, e->d_cells, nCells, nFrames, e->tab.iniThFAST, e->tab.minThFAST, slots,
+                      g.totalSlots, cellCount);
+    launch_gather_candidates(s, e->d_cells, e->d_lvgeom, g.nlevels, nFrames, slots, g.totalSlots, cellCount,
+                             nCells, cand, candCount, cellPrefix);
   }
-  {  // GaussianBlur of every level, :1169-1175 (queued before the host octree so it overlaps it)
-    StageTimer t(e, ORBFE_STAGE_BLUR, g.nlevels);
+  {  // GaussianBlur of every level, :1169-1175
+    StageTimer t(e, ORBFE_STAGE_BLUR, g.nlevels, nFrames, timed);
     for (int l = 0; l < g.nlevels; l++) {
-      LevelViewMut dst{e->d_blur + g.lv[l].off, g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
+      LevelViewMut dst{const_cast<uint8_t*>(blur.lv[l].base), g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
       launch_blur7(s, pyr.lv[l], dst, nFrames);
     }
   }
   if (!e->hostOctree) {  // DistributeOctTree, :566-808, one workgroup per (frame, level)
-    StageTimer t(e, ORBFE_STAGE_OCTREE, 1);
+    StageTimer t(e, ORBFE_STAGE_OCTREE, 1, nFrames, timed);
     OctreeArgs oa = {};
-    oa.cand = e->d_cand;
+    oa.cand = cand;
     oa.slotsPerFrame = g.totalSlots;
-    oa.candCount = e->d_candCount;
+    oa.candCount = candCount;
     oa.lvg = e->d_lvgeom;
     oa.nlevels = g.nlevels;
-    oa.nodeOf = e->d_nodeOf;
-    oa.levelKp = e->d_levelKp;
-    oa.levelCount = e->d_levelCount;
+    oa.nodeOf = e->d_nodeOf + F * g.totalSlots;
+    oa.levelKp = levelKp;
+    oa.levelCount = levelCount;
     oa.kpSlotsPerFrame = g.totalKpCap;
     oa.maxL = e->octreeMaxL;
     HIPCHK(launch_octree(s, oa, g.nlevels, nFrames));
   } else {
-    int rc = run_host_octree(e, nFrames);
+    int rc = run_host_octree(e, nFrames);  // single-stream debug path: f0 == 0
     if (rc) return rc;
   }
   {  // computeOrientation + computeDescriptors + output records
-    StageTimer t(e, ORBFE_STAGE_ORIENT_DESC, 1);
+    StageTimer t(e, ORBFE_STAGE_ORIENT_DESC, 1, nFrames, timed);
     OrientDescArgs a = {};
     a.pyr = pyr;
     a.blur = blur;
@@ -352,13 +377,48 @@ int run_pipeline(orbfe_extractor* e, LevelView level0, int nFrames, orbfe_keypoi
       a.scale[l] = e->tab.scale[l];
       a.kpSize[l] = (float)(int)(kPatchSize * e->tab.scale[l]);  // :905
     }
-    launch_orient_desc(s, a, e->d_levelKp, e->d_levelCount, e->d_patternF, e->d_momentTab, e->d_umax, nFrames, d_kp, d_desc, d_nOut);
+    launch_orient_desc(s, a, levelKp, levelCount, e->d_patternF, e->d_momentTab, e->d_umax, nFrames,
+                       d_kp + F * capacity, d_desc + F * (size_t)capacity * 32, d_nOut + F);
   }
   HIPCHK(hipGetLastError());
-  e->lastPyr = pyr;
-  e->lastBlur = blur;
+  return ORBFE_OK;
+}
+
+// One call = up to nStreams sub-batches of consecutive frames, each on its own HIP stream with
+// its own slice of the workspace: the VALU-bound kernels (FAST, blur) of one sub-batch overlap the
+// gather/latency-bound ones (orientation+descriptor, octree, resize) of the other.
+int run_pipeline(orbfe_extractor* e, LevelView level0, int nFrames, orbfe_keypoint* d_kp,
+                 uint8_t* d_desc, int capacity, int32_t* d_nOut) {
+  int S = e->hostOctree ? 1 : e->nStreams;
+  if (S > nFrames) S = nFrames;
+  if (S < 1) S = 1;
+  if (e->lastSplitFrames != nFrames || e->lastSplitStreams != S) {
+    // a different split maps frames to different streams: drain everything first
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < orbfe_extractor::kMaxStreams - 1; i++)
+      if (e->extra[i]) HIPCHK(hipStreamSynchronize(e->extra[i]));
+    e->lastSplitFrames = nFrames;
+    e->lastSplitStreams = S;
+  }
+  const int per = (nFrames + S - 1) / S;
+  for (int i = 0; i < S; i++) {
+    const int f0 = i * per;
+    const int n = f0 + per <= nFrames ? per : nFrames - f0;
+    if (n <= 0) break;
+    hipStream_t s = i == 0 ? e->stream : e->extra[i - 1];
+    int rc = run_chunk(e, s, i == 0, level0, f0, n, d_kp, d_desc, capacity, d_nOut, i == 0 ? &e->lastPyr : nullptr,
+                       i == 0 ? &e->lastBlur : nullptr);
+    if (rc) return rc;
+  }
   e->lastFrames = nFrames;
   e->haveLast = true;
+  return ORBFE_OK;
+}
+
+int sync_all(orbfe_extractor* e) {
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (int i = 0; i < orbfe_extractor::kMaxStreams - 1; i++)
+    if (e->extra[i]) HIPCHK(hipStreamSynchronize(e->extra[i]));
   return ORBFE_OK;
 }
 
@@ -379,6 +439,12 @@ extern "C" int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlev
   e->device = device;
   e->tab.init(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST);
   hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  for (int i = 0; i < orbfe_extractor::kMaxStreams - 1 && err == hipSuccess; i++)
+    err = hipStreamCreateWithFlags(&e->extra[i], hipStreamNonBlocking);
+  if (const char* env = getenv("ORBFE_STREAMS")) {
+    int v = atoi(env);
+    if (v >= 1 && v <= orbfe_extractor::kMaxStreams) e->nStreams = v;
+  }
   for (int r = 0; r < orbfe_extractor::kEvRing; r++)
     for (int i = 0; i < ORBFE_STAGE_COUNT && err == hipSuccess; i++) {
       err = hipEventCreate(&e->evA[r][i]);
@@ -406,6 +472,8 @@ extern "C" void orbfe_extractor_destroy(orbfe_extractor* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  for (int i = 0; i < orbfe_extractor::kMaxStreams - 1; i++)
+    if (e->extra[i]) { (void)hipStreamSynchronize(e->extra[i]); (void)hipStreamDestroy(e->extra[i]); }
   free_geometry(e);
   free_workspace(e);
   free_outputs(e);
@@ -469,8 +537,10 @@ extern "C" int orbfe_extract_batch_device_async(orbfe_extractor* e, const uint8_
     return fail(ORBFE_ERR_INVALID, "extract_batch_device: bad image");
   HIPCHK(hipSetDevice(e->device));
   int rc;
-  if (e->geom.W != width || e->geom.H != height || n_frames > e->capFrames)
-    HIPCHK(hipStreamSynchronize(e->stream));  // the workspace is about to be re-allocated
+  if (e->geom.W != width || e->geom.H != height || n_frames > e->capFrames) {
+    int rcs = sync_all(e);  // the workspace is about to be re-allocated
+    if (rcs) return rcs;
+  }
   if ((rc = ensure_geometry(e, width, height))) return rc;
   if ((rc = ensure_workspace(e, n_frames))) return rc;
   next_event_slot(e);
@@ -481,7 +551,8 @@ extern "C" int orbfe_extract_batch_device_async(orbfe_extractor* e, const uint8_
 extern "C" int orbfe_extractor_synchronize(orbfe_extractor* e) {
   if (!e) return fail(ORBFE_ERR_INVALID, "NULL handle");
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  int rc = sync_all(e);
+  if (rc) return rc;
   resolve_stage_times(e);
   return ORBFE_OK;
 }
@@ -508,6 +579,7 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* images, in
     return fail(ORBFE_ERR_INVALID, "extract_batch: bad output buffers");
   HIPCHK(hipSetDevice(e->device));
   int rc;
+  if ((rc = sync_all(e))) return rc;  // an earlier asynchronous call may still use the workspace
   if ((rc = ensure_geometry(e, width, height))) return rc;
   if ((rc = ensure_workspace(e, n_frames))) return rc;
   if ((rc = ensure_outputs(e, n_frames, capacity))) return rc;
@@ -521,8 +593,10 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* images, in
                               images + (size_t)f * frame_stride, stride, width, height,
                               hipMemcpyHostToDevice, e->stream));
   }
+  HIPCHK(hipStreamSynchronize(e->stream));  // the sub-batch streams read the uploaded frames
   LevelView l0{e->d_pyr + g.lv[0].off, g.pyrBytes, g.lv[0].pitch, width, height};
   if ((rc = run_pipeline(e, l0, n_frames, e->d_kpOut, e->d_descOut, capacity, e->d_nOut))) return rc;
+  if ((rc = sync_all(e))) return rc;
   {
     StageTimer t(e, ORBFE_STAGE_D2H, 0);
     std::vector<int32_t> cnt(n_frames);
@@ -561,6 +635,7 @@ static int copy_level_out(orbfe_extractor* e, const PyramidViews& pv, int frame,
   const LevelView& v = pv.lv[level];
   if (dst_stride < v.w) return fail(ORBFE_ERR_INVALID, "dst_stride too small");
   HIPCHK(hipSetDevice(e->device));
+  { int rcs = sync_all(e); if (rcs) return rcs; }
   HIPCHK(hipMemcpy2DAsync(dst, dst_stride, v.base + (size_t)frame * v.frameStride, v.pitch, v.w, v.h,
                           hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -593,6 +668,7 @@ extern "C" int orbfe_extractor_debug_candidates(orbfe_extractor* e, int frame, i
   if (!e->haveLast || frame < 0 || frame >= e->lastFrames || level < 0 || level >= e->geom.nlevels)
     return fail(ORBFE_ERR_INVALID, "frame/level out of range");
   HIPCHK(hipSetDevice(e->device));
+  { int rcs = sync_all(e); if (rcs) return rcs; }
   int32_t n = 0;
   HIPCHK(hipMemcpy(&n, e->d_candCount + (size_t)frame * e->geom.nlevels + level, 4, hipMemcpyDeviceToHost));
   std::vector<Candidate> c((size_t)(n > 0 ? n : 1));
@@ -610,15 +686,20 @@ extern "C" int orbfe_extractor_debug_candidates(orbfe_extractor* e, int frame, i
 extern "C" int orbfe_extractor_profile(orbfe_extractor* e, int stage_mask) {
   if (!e) return fail(ORBFE_ERR_INVALID, "NULL handle");
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  { int rcs = sync_all(e); if (rcs) return rcs; }
   resolve_stage_times(e);
   e->stageMask = stage_mask < 0 ? 0xffffffffu : (unsigned)stage_mask;
-  for (int i = 0; i < ORBFE_STAGE_COUNT; i++) { e->stageMs[i] = 0; e->stageLaunches[i] = 0; }
+  for (int i = 0; i < ORBFE_STAGE_COUNT; i++) { e->stageMs[i] = 0; e->stageLaunches[i] = 0; e->stageFrames[i] = 0; }
   return ORBFE_OK;
 }
-extern "C" int orbfe_extractor_profile_get(orbfe_extractor* e, double* ms_out, int64_t* launches_out) {
+extern "C" int orbfe_extractor_profile_get(orbfe_extractor* e, double* ms_out, int64_t* launches_out,
+                                           double* frames_out) {
   if (!e || !ms_out || !launches_out) return fail(ORBFE_ERR_INVALID, "NULL argument");
-  for (int i = 0; i < ORBFE_STAGE_COUNT; i++) { ms_out[i] = e->stageMs[i]; launches_out[i] = e->stageLaunches[i]; }
+  for (int i = 0; i < ORBFE_STAGE_COUNT; i++) {
+    ms_out[i] = e->stageMs[i];
+    launches_out[i] = e->stageLaunches[i];
+    if (frames_out) frames_out[i] = e->stageFrames[i];
+  }
   return ORBFE_OK;
 }
 extern "C" const char* orbfe_stage_name(int stage) {
@@ -686,7 +767,7 @@ extern "C" int orbfe_stereo_views_(orbfe_extractor* e, int frame, PyramidViews* 
   if (!e->haveLast) return fail(ORBFE_ERR_INVALID, "compute_stereo_matches: extractor has no pyramid yet");
   if (frame < 0 || frame >= e->lastFrames) return fail(ORBFE_ERR_INVALID, "compute_stereo_matches: frame out of range");
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  { int rcs = sync_all(e); if (rcs) return rcs; }
   *pv = e->lastPyr;
   for (int l = 0; l < e->tab.nlevels; l++) { scale[l] = e->tab.scale[l]; invScale[l] = e->tab.invScale[l]; }
   *nlevels = e->tab.nlevels;
@@ -698,5 +779,15 @@ extern "C" int orbfe_stereo_views_(orbfe_extractor* e, int frame, PyramidViews* 
 extern "C" int orbfe_extractor_debug_host_octree(orbfe_extractor* e, int enable) {
   if (!e) return fail(ORBFE_ERR_INVALID, "NULL handle");
   e->hostOctree = enable != 0;
+  return ORBFE_OK;
+}
+
+// Number of sub-batch streams one call is split over (1..4; default 1, or $ORBFE_STREAMS).
+extern "C" int orbfe_extractor_set_streams(orbfe_extractor* e, int n) {
+  if (!e || n < 1 || n > orbfe_extractor::kMaxStreams) return fail(ORBFE_ERR_INVALID, "set_streams: 1..4");
+  HIPCHK(hipSetDevice(e->device));
+  int rc = sync_all(e);
+  if (rc) return rc;
+  e->nStreams = n;
   return ORBFE_OK;
 }

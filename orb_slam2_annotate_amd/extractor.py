@@ -160,10 +160,15 @@ class ORBextractor:
         check(self._L.orbfe_extractor_profile(self._h, mask))
 
     def profile_get(self):
+        """{stage: (total ms, launches, frames processed by the timed launches)}"""
         ms = np.zeros(len(_lib.STAGES), dtype=np.float64)
         cnt = np.zeros(len(_lib.STAGES), dtype=np.int64)
-        check(self._L.orbfe_extractor_profile_get(self._h, ptr(ms), ptr(cnt)))
-        return {s: (float(ms[i]), int(cnt[i])) for i, s in enumerate(_lib.STAGES)}
+        fr = np.zeros(len(_lib.STAGES), dtype=np.float64)
+        check(self._L.orbfe_extractor_profile_get(self._h, ptr(ms), ptr(cnt), ptr(fr)))
+        return {s: (float(ms[i]), int(cnt[i]), float(fr[i])) for i, s in enumerate(_lib.STAGES)}
+
+    def set_streams(self, n: int):
+        check(self._L.orbfe_extractor_set_streams(self._h, int(n)))
 
 
 def resize_linear(src: np.ndarray, dw: int, dh: int, device: int = 0) -> np.ndarray:

@@ -159,3 +159,23 @@ def test_octree_small_quota_and_wide_image(amd):
     _check_frame(amd, synth.render_frame(50, 640, 480), (20, 1.2, 8, 20, 7))
     _check_frame(amd, synth.render_frame(51, 1000, 200), (800, 1.2, 6, 20, 7))
     _check_frame(amd, synth.render_frame(52, 2000, 150), (1500, 1.2, 4, 20, 7))
+
+
+def test_streams_and_async_give_identical_results(amd):
+    """Sub-batch streams (1..4) and the asynchronous entry point must not change a single byte."""
+    import ctypes as C
+    imgs = np.stack([synth.render_frame(60 + i, 320, 240) for i in range(7)])
+    o = orc.Oracle(400, 1.2, 8, 20, 7)
+    ref = [o.extract(im) for im in imgs]
+    for n in (1, 2, 3, 4):
+        e = amd.ORBextractor(400, 1.2, 8, 20, 7)
+        e.set_streams(n)
+        for _ in range(2):  # second call reuses the workspace slices
+            res = e.extract_batch(imgs)
+            for f in range(len(imgs)):
+                _kp_equal(ref[f][0], res[f][0])
+                assert np.array_equal(ref[f][1], res[f][1])
+        # batch size change with streams in flight
+        res = e.extract_batch(imgs[:3])
+        for f in range(3):
+            _kp_equal(ref[f][0], res[f][0])
