@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
   __shared__ uint32_t tile[kTileRows * kPitchDw];    // pixels: origin (x0-4, y0-3)
   __shared__ uint32_t score[kScoreRows * kPitchDw];  // FAST responses: origin (x0-4, y0-1)
   __shared__ uint16_t queue[kMaxCell * kMaxCell];
-  __shared__ int waveTot[4];
+  __shared__ int waveTot[2][4];  // double-buffered: one barrier per emission round
   __shared__ int qn;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -99,32 +99,51 @@ __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
   }
   __syncthreads();
 
+#if defined(FAST_ABLATE) && FAST_ABLATE == 1
+  if (tid == 0) cellCount[(size_t)f * nCells + cellId] = (uint16_t)(tile[5] & 1);
+  return;
+#endif
   // ---- A: cardinal-pair test at the lower threshold ----
   {
     const s16x2 T = {(short)tlo, (short)tlo};
-    for (int g = tid; g < ngroups; g += 256) {
-      const int gy = (int)(((uint32_t)g * invG) >> 16), gx = g - gy * ngx;
-      const uint32_t* mid = &tile[(gy + 3) * kPitchDw + gx];
-      const uint32_t up = tile[gy * kPitchDw + gx + 1], dn = tile[(gy + 6) * kPitchDw + gx + 1];
-      const uint32_t m0 = mid[0], m1 = mid[1], m2 = mid[2];
+    const int lane = tid & 63;
+    for (int g0 = 0; g0 < ngroups; g0 += 256) {  // block-uniform trip count (wave-wide ballots inside)
+      const int g = g0 + tid;
       uint32_t pass = 0;
+      int gy = 0, gx = 0;
+      if (g < ngroups) {
+        gy = (int)(((uint32_t)g * invG) >> 16);
+        gx = g - gy * ngx;
+        const uint32_t* mid = &tile[(gy + 3) * kPitchDw + gx];
+        const uint32_t up = tile[gy * kPitchDw + gx + 1], dn = tile[(gy + 6) * kPitchDw + gx + 1];
+        const uint32_t m0 = mid[0], m1 = mid[1], m2 = mid[2];
 #pragma unroll
-      for (int st = 0; st < 2; st++) {  // stream 0: pixels (0,2); stream 1: pixels (1,3)
-        const s16x2 c = as_s2(__builtin_amdgcn_perm(m1, m0, sel2(4 + st)));
-        const s16x2 dS = c - as_s2(__builtin_amdgcn_perm(dn, dn, sel2(st)));      // ring 0  (0,+3)
-        const s16x2 dE = c - as_s2(__builtin_amdgcn_perm(m2, m1, sel2(3 + st)));  // ring 4  (+3,0)
-        const s16x2 dN = c - as_s2(__builtin_amdgcn_perm(up, up, sel2(st)));      // ring 8  (0,-3)
-        const s16x2 dW = c - as_s2(__builtin_amdgcn_perm(m1, m0, sel2(1 + st)));  // ring 12 (-3,0)
-        // sign bit set <=> darker than v-t (d > t) / brighter than v+t (d < -t)
-        const uint32_t dk = (as_u(T - dS) | as_u(T - dN)) & (as_u(T - dE) | as_u(T - dW));
-        const uint32_t br = (as_u(dS + T) | as_u(dN + T)) & (as_u(dE + T) | as_u(dW + T));
-        const uint32_t p = dk | br;
-        pass |= (((p >> 15) & 1u) | ((p >> 29) & 4u)) << st;
+        for (int st = 0; st < 2; st++) {  // stream 0: pixels (0,2); stream 1: pixels (1,3)
+          const s16x2 c = as_s2(__builtin_amdgcn_perm(m1, m0, sel2(4 + st)));
+          const s16x2 dS = c - as_s2(__builtin_amdgcn_perm(dn, dn, sel2(st)));      // ring 0  (0,+3)
+          const s16x2 dE = c - as_s2(__builtin_amdgcn_perm(m2, m1, sel2(3 + st)));  // ring 4  (+3,0)
+          const s16x2 dN = c - as_s2(__builtin_amdgcn_perm(up, up, sel2(st)));      // ring 8  (0,-3)
+          const s16x2 dW = c - as_s2(__builtin_amdgcn_perm(m1, m0, sel2(1 + st)));  // ring 12 (-3,0)
+          // sign bit set <=> darker than v-t (d > t) / brighter than v+t (d < -t)
+          const uint32_t dk = (as_u(T - dS) | as_u(T - dN)) & (as_u(T - dE) | as_u(T - dW));
+          const uint32_t br = (as_u(dS + T) | as_u(dN + T)) & (as_u(dE + T) | as_u(dW + T));
+          const uint32_t p = dk | br;
+          pass |= (((p >> 15) & 1u) | ((p >> 29) & 4u)) << st;
+        }
+        const int valid = cw - 4 * gx;
+        if (valid < 4) pass &= (1u << valid) - 1u;
       }
-      const int valid = cw - 4 * gx;
-      if (valid < 4) pass &= (1u << valid) - 1u;
-      if (pass) {
-        int q = atomicAdd(&qn, __popc(pass));
+      // wave-aggregated push: one LDS atomic per wave instead of one per thread
+      const int c = __popc(pass);  // 0..4
+      const unsigned long long b0 = __ballot(c & 1), b1 = __ballot(c & 2), b2 = __ballot(c & 4);
+      if ((b0 | b1 | b2) != 0ull) {
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const int before = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
+        const int total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&qn, total);
+        base = __shfl(base, 0, 64);
+        int q = base + before;
 #pragma unroll
         for (int j = 0; j < 4; j++)
           if (pass & (1u << j)) queue[q++] = (uint16_t)((gy << 8) | (4 * gx + j));
@@ -133,6 +152,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
   }
   __syncthreads();
 
+#if defined(FAST_ABLATE) && FAST_ABLATE == 2
+  if (tid == 0) cellCount[(size_t)f * nCells + cellId] = (uint16_t)(qn & 1);
+  return;
+#endif
   // ---- B: exact response of the queued pixels (cornerScore<16>: S-1, corner iff S > t) ----
   {
     const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
@@ -168,6 +191,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
   }
   __syncthreads();
 
+#if defined(FAST_ABLATE) && FAST_ABLATE == 3
+  if (tid == 0) cellCount[(size_t)f * nCells + cellId] = (uint16_t)(score[30] & 1);
+  return;
+#endif
   // ---- C: cell-local 3x3 strict NMS + both threshold classes ----
   uint32_t selLo[kMaxIter], selHi[kMaxIter];
   int anyHigh = 0;
@@ -212,6 +239,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
   // per-cell threshold fallback (:874-882): corners >= iniThFAST if any survived NMS, else >= minThFAST
   const int useHigh = __syncthreads_or(anyHigh);
 
+#if defined(FAST_ABLATE) && FAST_ABLATE == 4
+  if (tid == 0) cellCount[(size_t)f * nCells + cellId] = (uint16_t)(useHigh & 1);
+  return;
+#endif
   // ---- D: ordered emission: groups in raster order, pixels of a group left to right ----
   Candidate* out = slots + (size_t)f * slotsPerFrame + cd.slotBase;
   int run = 0;  // identical in every thread
@@ -223,11 +254,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
     const unsigned long long b0 = __ballot(c & 1), b1 = __ballot(c & 2);
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int inWave = __popcll(b0 & lt) + 2 * __popcll(b1 & lt);
-    if (lane == 0) waveTot[wave] = __popcll(b0) + 2 * __popcll(b1);
+    int* wt = waveTot[it & 1];
+    if (lane == 0) wt[wave] = __popcll(b0) + 2 * __popcll(b1);
     __syncthreads();
     int base = run;
-    for (int w = 0; w < wave; w++) base += waveTot[w];
-    run += waveTot[0] + waveTot[1] + waveTot[2] + waveTot[3];
+    for (int w = 0; w < wave; w++) base += wt[w];
+    run += wt[0] + wt[1] + wt[2] + wt[3];
     if (sel) {
       const int g = tid + 256 * it;
       const int gy = (int)(((uint32_t)g * invG) >> 16), gx = g - gy * ngx;
@@ -242,7 +274,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
           out[o++] = cnd;
         }
     }
-    __syncthreads();
   }
   if (tid == 0) cellCount[(size_t)f * nCells + cellId] = (uint16_t)run;
 }
