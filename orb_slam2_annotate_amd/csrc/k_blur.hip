@@ -32,11 +32,21 @@ __device__ __forceinline__ int reflect101c(int i, int n) {
 constexpr uint32_t pk(uint32_t lo, uint32_t hi) { return lo | (hi << 16); }
 }  // namespace
 
-__global__ __launch_bounds__(256) void k_blur7(LevelView src, LevelViewMut dst) {
+__global__ __launch_bounds__(256) void k_blur7(LevelView src, LevelViewMut dst, int tilesX, int tilesY,
+                                               int nFrames) {
   __shared__ uint32_t tin[kTH * kTDW];             // source bytes
   __shared__ uint2 vbuf[kBH * kTDW];               // vertical sums, 4 u16 per entry
   const int tid = threadIdx.x;
-  const int bx = blockIdx.x * kBW, by = blockIdx.y * kBH, f = blockIdx.z;
+  // XCD-aware work mapping (speed only): block b -> work item (b % 8) * chunk + b / 8, so the
+  // tiles one XCD's L2 sees are a contiguous raster run and share their halo rows there
+  const unsigned chunk = gridDim.x >> 3;
+  const unsigned work = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+  const unsigned perFrame = (unsigned)tilesX * (unsigned)tilesY;
+  if (work >= perFrame * (unsigned)nFrames) return;
+  const int f = (int)(work / perFrame);
+  const unsigned rem = work - (unsigned)f * perFrame;
+  const int tyI = (int)(rem / (unsigned)tilesX);
+  const int bx = (int)(rem - (unsigned)tyI * (unsigned)tilesX) * kBW, by = tyI * kBH;
   const uint8_t* S = src.base + (size_t)f * src.frameStride;
   const bool aligned = (src.pitch & 3) == 0;
   // ---- 1. stage ----
@@ -118,8 +128,9 @@ __global__ __launch_bounds__(256) void k_blur7(LevelView src, LevelViewMut dst) 
 
 void launch_blur7(hipStream_t s, LevelView src, LevelViewMut dst, int nFrames) {
   if (dst.w <= 0 || dst.h <= 0 || nFrames <= 0) return;
-  dim3 grid((dst.w + kBW - 1) / kBW, (dst.h + kBH - 1) / kBH, nFrames);
-  hipLaunchKernelGGL(k_blur7, grid, dim3(256), 0, s, src, dst);
+  const int tilesX = (dst.w + kBW - 1) / kBW, tilesY = (dst.h + kBH - 1) / kBH;
+  const unsigned total = (unsigned)tilesX * (unsigned)tilesY * (unsigned)nFrames;
+  hipLaunchKernelGGL(k_blur7, dim3((total + 7u) / 8u * 8u), dim3(256), 0, s, src, dst, tilesX, tilesY, nFrames);
 }
 
 }  // namespace orbfe

@@ -104,8 +104,12 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
           if ((lv.pitch & 3) == 0) {
             mis[u] = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3);
             const uint32_t* al = reinterpret_cast<const uint32_t*>(p - mis[u]);
+#if defined(DESC_ABLATE) && (DESC_ABLATE & 2)
+            dw[u][0] = mis[u] + (uint32_t)(uintptr_t)al; dw[u][1] = dw[u][0] * 3; dw[u][2] = dw[u][0] * 5; dw[u][3] = dw[u][0] * 7;
+#else
             dw[u][0] = al[0]; dw[u][1] = al[1]; dw[u][2] = al[2]; dw[u][3] = al[3];
             dw[u][4] = mis[u] ? al[4] : 0u;
+#endif
           } else {
 #pragma unroll
             for (int k = 0; k < 4; k++)
@@ -174,8 +178,12 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
           const f32x2 r0 = p0 * ba, c0 = p0 * ab, r1 = p1 * ba, c1 = p1 * ab;  // (x*b, y*a), (x*a, y*b)
           const int rr0 = cv_round(__fadd_rn(r0.x, r0.y)), cc0 = cv_round(__fsub_rn(c0.x, c0.y));
           const int rr1 = cv_round(__fadd_rn(r1.x, r1.y)), cc1 = cv_round(__fsub_rn(c1.x, c1.y));
+#if defined(DESC_ABLATE) && (DESC_ABLATE & 1)
+          t0v[u][t] = rr0 + cc0; t1v[u][t] = rr1 + cc1 + (int)cb[0];
+#else
           t0v[u][t] = cb[rr0 * bl.pitch + cc0];
           t1v[u][t] = cb[rr1 * bl.pitch + cc1];
+#endif
         }
       }
 #pragma unroll

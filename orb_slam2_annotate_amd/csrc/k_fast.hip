@@ -50,7 +50,7 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b)
 //   D. per-cell 20->7 fallback and ordered emission.
 __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
                                                     const CellDesc* __restrict__ cells,
-                                                    int nCells, int iniTh, int minTh,
+                                                    int nCells, int nFrames, int iniTh, int minTh,
                                                     Candidate* __restrict__ slots,
                                                     int slotsPerFrame,
                                                     uint16_t* __restrict__ cellCount) {
@@ -61,7 +61,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
   __shared__ int qn;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cellId = blockIdx.x, f = blockIdx.y;
+  // XCD-aware work mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, so
+  // block b takes work item (b % 8) * chunk + b / 8 -- every XCD walks a contiguous run of
+  // (frame, cell) items and neighbouring cells, which share halo rows, meet in the same L2.
+  const unsigned chunk = gridDim.x >> 3;
+  const unsigned work = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+  if (work >= (unsigned)nCells * (unsigned)nFrames) return;
+  const int f = (int)(work / (unsigned)nCells);
+  const int cellId = (int)(work - (unsigned)f * (unsigned)nCells);
   const CellDesc cd = cells[cellId];
   const LevelView lv = pyr.lv[cd.level];
   const int cw = cd.w, ch = cd.h, x0 = cd.x0, y0 = cd.y0;
@@ -284,7 +291,8 @@ void launch_fast_cells(hipStream_t s, PyramidViews pyr, const CellDesc* d_cells,
   if (nCells <= 0 || nFrames <= 0) return;
   iniTh = iniTh < 0 ? 0 : (iniTh > 255 ? 255 : iniTh);  // cv::FAST clamps the threshold
   minTh = minTh < 0 ? 0 : (minTh > 255 ? 255 : minTh);
-  hipLaunchKernelGGL(k_fast_cells, dim3(nCells, nFrames), dim3(256), 0, s, pyr, d_cells, nCells,
+  const unsigned total = (unsigned)nCells * (unsigned)nFrames;
+  hipLaunchKernelGGL(k_fast_cells, dim3((total + 7u) / 8u * 8u), dim3(256), 0, s, pyr, d_cells, nCells, nFrames,
                      iniTh, minTh, d_slots, slotsPerFrame, d_cellCount);
 }
 
