@@ -58,6 +58,33 @@ def algorithmic_bytes(sizes, n_kp):
     return parts
 
 
+STAGE_KERNELS = {  # kernels (and launches per step) behind each timed stage
+    "pyramid": [("k_resize", 7)], "fast": [("k_fast_cells", 1), ("k_gather_candidates", 1)],
+    "octree": [("k_octree", 1)], "blur": [("k_blur7", 8)], "orient_desc": [("k_orient_desc", 1)],
+}
+
+
+def pmc_traffic(stage, workload, batch):
+    """HBM bytes per step of the stage's kernels from the committed rocprofv3 --pmc summary
+    (profiles/*_traffic.json, produced by tools/collect_traffic.py); None when no summary matches."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("*_traffic.json")):
+        try:
+            t = json.loads(f.read_text())
+        except Exception:
+            continue
+        if t.get("workload") == workload and t.get("batch") == batch:
+            best = t
+    if best is None:
+        return None
+    tot = 0.0
+    for k, n in STAGE_KERNELS[stage]:
+        if k not in best["kernels"]:
+            return None
+        tot += best["kernels"][k]["traffic_bytes_per_launch"] * n
+    return tot
+
+
 def cpu_baseline(frames, wl, seconds=12.0):
     """The CPU oracle (a scalar C port of the reference path, oracle/orb_oracle.c) on 1 host core."""
     sys.path.insert(0, str(ROOT / "tests"))
@@ -201,7 +228,8 @@ def main():
                        "sharding": f"frames sharded one batch per GPU x{world}, no data-path collective"},
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args.workload, B),
+                "algorithmic_bytes_per_launch_group": alg[dom] * prof[dom][2] / max(args.steps, 1),
                 "algorithmic_bytes_per_frame": alg[dom], "ms_per_launch_group": dom_ms_per_step,
                 "frames_per_launch": prof[dom][2] / max(args.steps, 1),
                 "pipeline": {"algorithmic_bytes_per_frame": alg["extract_total"],
