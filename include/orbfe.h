@@ -238,6 +238,17 @@ int orbfe_compute_stereo_matches(orbfe_extractor *left, int frameL, orbfe_extrac
                                  int N, const orbfe_keypoint *kpR, const uint8_t *descR, int Nr,
                                  float mbf, float mb, float *uRight, float *depth);
 
+/* The same for a device-resident batch: the handle's LAST orbfe_extract_batch_device(_async) call
+ * processed frames L0,R0,L1,R1,... (pair p = frames 2p, 2p+1, both images through ONE handle);
+ * d_keypoints / d_descriptors / d_n are that call's outputs (same capacity).  Writes mvuRight and
+ * mvDepth of pair p at [p*capacity + i] (i < capacity; -1 beyond the left frame's keypoints) and
+ * the number of surviving stereo matches at d_n_stereo[p].  Enqueued on the handle's stream after
+ * the extraction; wait with orbfe_extractor_synchronize. */
+int orbfe_stereo_match_batch_device(orbfe_extractor *e, int n_pairs, const orbfe_keypoint *d_keypoints,
+                                    const uint8_t *d_descriptors, const int32_t *d_n, int capacity,
+                                    float mbf, float mb, float *d_uRight, float *d_depth,
+                                    int32_t *d_n_stereo);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,10 +44,34 @@ EXPORTS = [
     "orbfe_extractor_debug_blurred_level", "orbfe_extractor_debug_host_octree", "orbfe_extractor_set_streams", "orbfe_extractor_profile", "orbfe_extractor_profile_get",
     "orbfe_stage_name", "orbfe_resize_linear", "orbfe_gaussian_blur7", "orbfe_descriptor_distance",
     "orbfe_hamming_matrix", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",
-    "orbfe_search_for_triangulation", "orbfe_compute_stereo_matches",
+    "orbfe_search_for_triangulation", "orbfe_compute_stereo_matches", "orbfe_stereo_match_batch_device",
 ]
 
 _lib = None
+
+
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP/HSA
+    runtimes in one process cannot both own the GPU, so when torch is installed but not imported
+    yet, its runtime is loaded first and liborbfe.so binds to it by SONAME -- `import torch` then
+    works in either order.  No torch module is imported here; without torch this is a no-op."""
+    import importlib.util
+    import os
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    hip = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(hip):
+        try:
+            C.CDLL(hip, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # fall back to the system runtime
 
 
 def load():
@@ -58,6 +82,7 @@ def load():
     if not LIB_PATH.exists():
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(str(LIB_PATH))
     L.orbfe_last_error.restype = C.c_char_p
     L.orbfe_stage_name.restype = C.c_char_p
@@ -98,6 +123,7 @@ def load():
     L.orbfe_search_for_triangulation.argtypes = [ci, vp, vp, vp, vp, vp, vp, ci, fvp, vp, vp, vp, vp, vp, vp, vp,
                                                  ci, fvp, vp, cf, cf, vp, vp, ci, ci, ci, vp]
     L.orbfe_compute_stereo_matches.argtypes = [vp, ci, vp, ci, vp, vp, ci, vp, vp, ci, cf, cf, vp, vp]
+    L.orbfe_stereo_match_batch_device.argtypes = [vp, ci, vp, vp, vp, ci, cf, cf, vp, vp, vp]
     _lib = L
     return L
 

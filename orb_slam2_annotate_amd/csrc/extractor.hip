@@ -12,6 +12,7 @@
 
 #include "../../include/orbfe.h"
 #include "kernels.h"
+#include "match_kernels.h"
 #include "octree_host.h"
 #include "orb_params.h"
 #include "orb_pattern.inc"
@@ -83,6 +84,8 @@ struct orbfe_extractor {
   int32_t* d_cellPrefix = nullptr;
   int32_t* d_candCount = nullptr;
   uint16_t* d_nodeOf = nullptr;
+  int32_t* d_stereoSad = nullptr;  // scratch of the batched stereo matcher
+  size_t stereoSadCap = 0;
   LevelKp* d_levelKp = nullptr;
   int32_t* d_levelCount = nullptr;
   // device-side outputs used by the host-buffer API
@@ -478,6 +481,7 @@ extern "C" void orbfe_extractor_destroy(orbfe_extractor* e) {
   free_workspace(e);
   free_outputs(e);
   dfree(&e->d_patternF);
+  dfree(&e->d_stereoSad);
   dfree(&e->d_momentTab);
   dfree(&e->d_umax);
   for (int r = 0; r < orbfe_extractor::kEvRing; r++)
@@ -790,4 +794,44 @@ extern "C" int orbfe_extractor_set_streams(orbfe_extractor* e, int n) {
   if (rc) return rc;
   e->nStreams = n;
   return ORBFE_OK;
+}
+
+// Frame::ComputeStereoMatches for every stereo pair of a device-resident batch (see orbfe.h).
+extern "C" int orbfe_stereo_match_batch_device(orbfe_extractor* e, int n_pairs, const orbfe_keypoint* d_keypoints,
+                                               const uint8_t* d_descriptors, const int32_t* d_n, int capacity,
+                                               float mbf, float mb, float* d_uRight, float* d_depth,
+                                               int32_t* d_n_stereo) {
+  if (!e || n_pairs < 0 || capacity <= 0 || !d_keypoints || !d_descriptors || !d_n || !d_uRight || !d_depth ||
+      !d_n_stereo)
+    return fail(ORBFE_ERR_INVALID, "stereo_match_batch_device: bad argument");
+  if (n_pairs == 0) return ORBFE_OK;
+  if (!e->haveLast || e->lastFrames < 2 * n_pairs)
+    return fail(ORBFE_ERR_INVALID, "stereo_match_batch_device: the last extract call holds fewer than 2*n_pairs frames");
+  if (capacity >= (1 << 20)) return fail(ORBFE_ERR_INVALID, "stereo_match_batch_device: capacity too large");
+  HIPCHK(hipSetDevice(e->device));
+  if (e->nStreams > 1) { int rc = sync_all(e); if (rc) return rc; }  // all sub-batches must have landed
+  const size_t need = (size_t)n_pairs * capacity;
+  if (need > e->stereoSadCap) {
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int rc = dalloc(&e->d_stereoSad, need);
+    if (rc) return rc;
+    e->stereoSadCap = need;
+  }
+  StereoArgs a = {};
+  a.pyrL = e->lastPyr;
+  a.pyrR = e->lastPyr;
+  for (int l = 0; l < e->tab.nlevels; l++) { a.scale[l] = e->tab.scale[l]; a.invScale[l] = e->tab.invScale[l]; }
+  a.mbf = mbf;
+  a.maxD = mbf / mb;  // minZ = mb, maxD = mbf/minZ (src/Frame.cc:542-544)
+  StereoBatch b = {};
+  b.kp = reinterpret_cast<const float*>(d_keypoints);
+  b.desc = d_descriptors;
+  b.n = d_n;
+  b.capacity = capacity;
+  b.uRight = d_uRight;
+  b.depth = d_depth;
+  b.sad = e->d_stereoSad;
+  launch_stereo_batch(e->stream, a, b, n_pairs, d_n_stereo);
+  HIPCHK(hipGetLastError());
+  return ORBFE_OK;  // asynchronous on the handle's stream: orbfe_extractor_synchronize() to wait
 }

@@ -245,10 +245,7 @@ void launch_rot_prune(hipStream_t s, int32_t* match, const int8_t* bin, int n, i
 // ---------------------------------------------------------------------------------------
 // Frame::ComputeStereoMatches (src/Frame.cc:512-686)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (iL >= a.N) return;
+__device__ __forceinline__ void stereo_one(const StereoArgs& a, int iL, int lane) {
   const float* kl = a.kpL + (size_t)iL * 7;
   const float uL = kl[0], vL = kl[1];
   const int levelL = reinterpret_cast<const int32_t*>(kl)[5];
@@ -348,11 +345,44 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (iL >= a.N) return;
+  stereo_one(a, iL, lane);
+}
+
+// Batched, device-resident form: pair p = frames (2p, 2p+1) of one extractor batch; the
+// keypoint counts are read from device memory (d_n of orbfe_extract_batch_device).
+__global__ __launch_bounds__(256) void k_stereo_match_batch(StereoArgs a, StereoBatch b) {
+  const int lane = threadIdx.x & 63;
+  const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int p = blockIdx.y;
+  int N = b.n[2 * p], Nr = b.n[2 * p + 1];
+  if (N > b.capacity) N = b.capacity;
+  if (Nr > b.capacity) Nr = b.capacity;
+  if (iL >= b.capacity) return;
+  const size_t oL = (size_t)(2 * p) * b.capacity, oR = (size_t)(2 * p + 1) * b.capacity, oO = (size_t)p * b.capacity;
+  if (iL >= N) {  // slots past the left frame's keypoints: defined "no stereo" outputs
+    if (lane == 0) { b.uRight[oO + iL] = -1.0f; b.depth[oO + iL] = -1.0f; b.sad[oO + iL] = -1; }
+    return;
+  }
+  a.kpL = b.kp + oL * 7; a.descL = b.desc + oL * 32; a.N = N;
+  a.kpR = b.kp + oR * 7; a.descR = b.desc + oR * 32; a.Nr = Nr;
+  a.frameL = 2 * p; a.frameR = 2 * p + 1;
+  a.uRight = b.uRight + oO; a.depth = b.depth + oO; a.sad = b.sad + oO;
+  stereo_one(a, iL, lane);
+}
+
 // Median cut (:672-685): drop matches whose SAD >= 1.5*1.4*median, median = sorted[size/2].
-// SAD <= 121*510 < 65536 -> two-level 8+8 bit radix select in one workgroup.
+// SAD <= 121*510 < 65536 -> two-level 8+8 bit radix select in one workgroup (one per pair).
 __global__ __launch_bounds__(256) void k_stereo_median_cut(int N, const int32_t* __restrict__ sad,
                                                            float* __restrict__ uRight, float* __restrict__ depth,
-                                                           int32_t* __restrict__ nStereo) {
+                                                           int32_t* __restrict__ nStereo, int pairStride) {
+  sad += (size_t)blockIdx.x * pairStride;
+  uRight += (size_t)blockIdx.x * pairStride;
+  depth += (size_t)blockIdx.x * pairStride;
+  nStereo += blockIdx.x;
   __shared__ int hist[256];
   __shared__ int sel[3];  // hi bin, remaining k, total
   const int tid = threadIdx.x;
@@ -407,7 +437,14 @@ __global__ __launch_bounds__(256) void k_stereo_median_cut(int N, const int32_t*
 void launch_stereo(hipStream_t s, const StereoArgs& a, int32_t* d_nStereo) {
   if (a.N <= 0) return;
   hipLaunchKernelGGL(k_stereo_match, dim3((a.N + 3) / 4), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_stereo_median_cut, dim3(1), dim3(256), 0, s, a.N, a.sad, a.uRight, a.depth, d_nStereo);
+  hipLaunchKernelGGL(k_stereo_median_cut, dim3(1), dim3(256), 0, s, a.N, a.sad, a.uRight, a.depth, d_nStereo, 0);
+}
+
+void launch_stereo_batch(hipStream_t s, const StereoArgs& a, const StereoBatch& b, int nPairs, int32_t* d_nStereo) {
+  if (nPairs <= 0 || b.capacity <= 0) return;
+  hipLaunchKernelGGL(k_stereo_match_batch, dim3((b.capacity + 3) / 4, nPairs), dim3(256), 0, s, a, b);
+  hipLaunchKernelGGL(k_stereo_median_cut, dim3(nPairs), dim3(256), 0, s, b.capacity, b.sad, b.uRight, b.depth,
+                     d_nStereo, b.capacity);
 }
 
 }  // namespace orbfe

@@ -43,9 +43,15 @@ struct StereoArgs {
   float* uRight; float* depth; int32_t* sad;
 };
 
+struct StereoBatch {  // frames 2p / 2p+1 of an extractor batch are the left / right image of pair p
+  const float* kp; const uint8_t* desc; const int32_t* n; int capacity;
+  float* uRight; float* depth; int32_t* sad;   // [nPairs * capacity]
+};
+
 void launch_search_by_bow(hipStream_t s, const BowArgs& a, int nPairs, int maxCnt2);
 void launch_search_triangulation(hipStream_t s, const TriArgs& a);
 void launch_rot_prune(hipStream_t s, int32_t* match, const int8_t* bin, int n, int checkOri, int32_t* nMatches);
 void launch_stereo(hipStream_t s, const StereoArgs& a, int32_t* d_nStereo);
+void launch_stereo_batch(hipStream_t s, const StereoArgs& a, const StereoBatch& b, int nPairs, int32_t* d_nStereo);
 
 }  // namespace orbfe

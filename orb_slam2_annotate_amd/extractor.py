@@ -113,6 +113,13 @@ class ORBextractor:
                  C.c_void_p(d_keypoints), C.c_void_p(d_descriptors), capacity, C.c_void_p(d_n_out)))
         self._last_shape = (n_frames, height, width)
 
+    def stereo_match_batch_device(self, n_pairs: int, d_keypoints: int, d_descriptors: int, d_n: int, capacity: int,
+                                  mbf: float, mb: float, d_uRight: int, d_depth: int, d_n_stereo: int):
+        """Frame::ComputeStereoMatches for pairs (2p, 2p+1) of the last device batch; device addresses."""
+        check(self._L.orbfe_stereo_match_batch_device(self._h, n_pairs, C.c_void_p(d_keypoints), C.c_void_p(d_descriptors),
+                                                      C.c_void_p(d_n), capacity, float(mbf), float(mb),
+                                                      C.c_void_p(d_uRight), C.c_void_p(d_depth), C.c_void_p(d_n_stereo)))
+
     def synchronize(self):
         check(self._L.orbfe_extractor_synchronize(self._h))
 

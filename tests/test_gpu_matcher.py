@@ -143,3 +143,44 @@ def test_compute_stereo_matches(amd, seed, shape, nf, bf, fx):
     assert np.array_equal(u_ref, u)
     assert np.array_equal(d_ref, d)
     assert (u >= 0).sum() > 100
+
+
+def test_stereo_batch_device_resident(amd):
+    """orbfe_stereo_match_batch_device: pairs (2p, 2p+1) of one device batch, everything in HBM."""
+    torch = pytest.importorskip("torch")
+    w, h, nf = 640, 240, 800
+    pairs = [synth.render_stereo(20 + p, w, h, n_shapes=300, max_disp=48) for p in range(3)]
+    imgs = np.stack([im for pr in pairs for im in pr])  # L0,R0,L1,R1,L2,R2
+    e = amd.ORBextractor(nf, 1.2, 8, 20, 7)
+    cap = e.max_keypoints()
+    dev = torch.device("cuda", 0)
+    d_img = torch.from_numpy(imgs).to(dev)
+    B = len(imgs)
+    d_kp = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros((B,), dtype=torch.int32, device=dev)
+    d_u = torch.zeros((B // 2, cap), dtype=torch.float32, device=dev)
+    d_d = torch.zeros((B // 2, cap), dtype=torch.float32, device=dev)
+    d_ns = torch.zeros((B // 2,), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    mbf = np.float32(120.0)
+    mb = np.float32(mbf / np.float32(400.0))
+    for streams in (1, 2):
+        e.set_streams(streams)
+        e.extract_batch_device(d_img.data_ptr(), B, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(), cap,
+                               d_n.data_ptr(), wait=False)
+        e.stereo_match_batch_device(B // 2, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, float(mbf),
+                                    float(mb), d_u.data_ptr(), d_d.data_ptr(), d_ns.data_ptr())
+        e.synchronize()
+        o = orc.Oracle(nf, 1.2, 8, 20, 7)
+        n = d_n.cpu().numpy()
+        for p in range(B // 2):
+            kL, dL, pL = o.extract(imgs[2 * p], want_pyramid=True)
+            kR, dR, pR = o.extract(imgs[2 * p + 1], want_pyramid=True)
+            assert n[2 * p] == len(kL) and n[2 * p + 1] == len(kR)
+            u_ref, d_ref = o.stereo(w, h, kL, dL, kR, dR, pL, pR, float(mbf), float(mb))
+            u = d_u[p].cpu().numpy()
+            d = d_d[p].cpu().numpy()
+            assert np.array_equal(u[: len(kL)], u_ref) and np.array_equal(d[: len(kL)], d_ref)
+            assert (u[len(kL):] == -1).all()
+            assert int(d_ns[p].item()) == int((u_ref >= 0).sum()) > 30
