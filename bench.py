@@ -32,8 +32,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 WORKLOADS = {
     "tum": dict(name="TUM fr1_xyz mono 640x480 nFeatures=1000 extract-only (synthetic frames)",
                 w=640, h=480, nfeatures=1000, ini=20, mn=7),
-    "kitti": dict(name="KITTI 00 stereo 1241x376 nFeatures=2000 extract L+R (synthetic frames)",
-                  w=1241, h=376, nfeatures=2000, ini=20, mn=7),
+    "kitti": dict(name="KITTI 00 stereo 1241x376 nFeatures=2000 extract L+R + ComputeStereoMatches "
+                       "(synthetic stereo pairs; frames/s counts stereo frames)",
+                  w=1241, h=376, nfeatures=2000, ini=20, mn=7, stereo=True, bf=386.1448, fx=718.856),
     "euroc": dict(name="EuRoC MH_01 752x480 nFeatures=1200 extract (synthetic frames)",
                   w=752, h=480, nfeatures=1200, ini=20, mn=7),
 }
@@ -141,20 +142,37 @@ def main():
     wl = WORKLOADS[args.workload]
     W, H, B = wl["w"], wl["h"], args.batch
     # each rank renders its own shard of the synthetic stream (sequence id = rank)
-    frames = synth.render_sequence(1000 + rank, B, W, H, step=1.5)
+    stereo = bool(wl.get("stereo"))
+    if stereo:  # B stereo frames = 2B images, ordered L0,R0,L1,R1,... through one extractor handle
+        pairs = [synth.render_stereo(5000 + 1000 * rank + i, W, H) for i in range(B)]
+        frames = [im for pr in pairs for im in pr]
+    else:
+        frames = synth.render_sequence(1000 + rank, B, W, H, step=1.5)
+    NI = len(frames)  # images resident per GPU
     ext = amd.ORBextractor(wl["nfeatures"], 1.2, 8, wl["ini"], wl["mn"], device=local_rank)
     if args.streams:
         ext.set_streams(args.streams)
     cap = ext.max_keypoints()
     d_img = torch.from_numpy(np.stack(frames)).to(dev)
-    d_kp = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
-    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
-    d_n = torch.zeros((B,), dtype=torch.int32, device=dev)
+    d_kp = torch.zeros((NI, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((NI, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros((NI,), dtype=torch.int32, device=dev)
+    if stereo:
+        mbf = np.float32(wl["bf"])
+        mb = np.float32(mbf / np.float32(wl["fx"]))  # src/Frame.cc:114
+        d_u = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+        d_dep = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+        d_ns = torch.zeros((B,), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
     def step(wait=False):
-        ext.extract_batch_device(d_img.data_ptr(), B, W, H, W, W * H, d_kp.data_ptr(), d_desc.data_ptr(), cap,
-                                 d_n.data_ptr(), wait=wait)
+        ext.extract_batch_device(d_img.data_ptr(), NI, W, H, W, W * H, d_kp.data_ptr(), d_desc.data_ptr(), cap,
+                                 d_n.data_ptr(), wait=wait and not stereo)
+        if stereo:
+            ext.stereo_match_batch_device(B, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, float(mbf),
+                                          float(mb), d_u.data_ptr(), d_dep.data_ptr(), d_ns.data_ptr())
+            if wait:
+                ext.synchronize()
 
     def barrier():
         ext.synchronize()
@@ -195,12 +213,18 @@ def main():
         sys.path.insert(0, str(ROOT / "tests"))
         import oracle_lib as orc
         o = orc.Oracle(wl["nfeatures"], 1.2, 8, wl["ini"], wl["mn"])
-        for fi in sorted({0, B // 2, B - 1}):  # first, middle (second sub-batch) and last frame
+        for fi in sorted({0, NI // 2, NI - 1}):  # first, middle (second sub-batch) and last image
             kr, dr = o.extract(frames[fi])
             n0 = int(d_n[fi].item())
             kg = d_kp[fi, :n0].cpu().numpy().view(np.uint8).reshape(n0, 28)
             assert n0 == len(kr) and np.array_equal(kg, kr.view(np.uint8).reshape(-1, 28)), "keypoints differ from oracle"
             assert np.array_equal(d_desc[fi, :n0].cpu().numpy(), dr), "descriptors differ from oracle"
+        if stereo:
+            kL, dL, pL = o.extract(frames[0], want_pyramid=True)
+            kR, dR, pR = o.extract(frames[1], want_pyramid=True)
+            u_ref, dep_ref = o.stereo(W, H, kL, dL, kR, dR, pL, pR, float(mbf), float(mb))
+            assert np.array_equal(d_u[0, :len(kL)].cpu().numpy(), u_ref), "mvuRight differs from oracle"
+            assert np.array_equal(d_dep[0, :len(kL)].cpu().numpy(), dep_ref), "mvDepth differs from oracle"
 
     if rank == 0:
         sizes = level_pixels(ext, W, H)
@@ -210,6 +234,7 @@ def main():
         # the timed launches are those of sub-batch 0 of every call (prof[dom][2] frames in total)
         dom_ms_per_step = prof[dom][0] / max(args.steps, 1)
         ach = alg[dom] * prof[dom][2] / (prof[dom][0] * 1e-3) / 1e9 if prof[dom][0] > 0 else 0.0
+        imgs_per_frame = NI / B
         value = total_frames / dt_max
         out = {
             "metric": "ORB extract frames/sec (bit-exact kp/desc vs CPU oracle)",
@@ -224,7 +249,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": wl["name"], "frames_per_gpu_per_step": B, "keypoints_per_frame": n_kp,
+            "config": {"workload": wl["name"], "frames_per_gpu_per_step": B, "images_per_gpu_per_step": NI,
+                       "keypoints_per_frame": n_kp,
                        "sharding": f"frames sharded one batch per GPU x{world}, no data-path collective"},
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -232,14 +258,16 @@ def main():
                 "algorithmic_bytes_per_launch_group": alg[dom] * prof[dom][2] / max(args.steps, 1),
                 "algorithmic_bytes_per_frame": alg[dom], "ms_per_launch_group": dom_ms_per_step,
                 "frames_per_launch": prof[dom][2] / max(args.steps, 1),
-                "pipeline": {"algorithmic_bytes_per_frame": alg["extract_total"],
-                             "achieved": alg["extract_total"] * value / world / 1e9,
-                             "frac": alg["extract_total"] * value / world / 1e9 / HBM_PEAK_GBS},
+                "pipeline": {"algorithmic_bytes_per_image": alg["extract_total"],
+                             "achieved": alg["extract_total"] * imgs_per_frame * value / world / 1e9,
+                             "frac": alg["extract_total"] * imgs_per_frame * value / world / 1e9 / HBM_PEAK_GBS},
                 "stage_ms_per_step_warmup": {s_: warm[s_][0] / n_warm for s_ in gpu_stages},
             },
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, wl)
+            if stereo:
+                out["cpu_baseline"]["note"] = "extraction only (per image); stereo matching not included"
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -179,3 +179,20 @@ def test_streams_and_async_give_identical_results(amd):
         res = e.extract_batch(imgs[:3])
         for f in range(3):
             _kp_equal(ref[f][0], res[f][0])
+
+
+def test_large_and_tiny_images(amd):
+    # full-HD frame with a large quota (octree node list in LDS ~1.1k nodes), and images so small
+    # that the upper pyramid levels have no FAST grid at all
+    assert _check_frame(amd, synth.render_frame(70, 1920, 1080, n_shapes=2500), (5000, 1.2, 8, 20, 7)) > 3000
+    _check_frame(amd, synth.render_frame(71, 96, 80, n_shapes=30), (200, 1.2, 8, 20, 7))
+    _check_frame(amd, synth.render_frame(72, 66, 64, n_shapes=20), (100, 1.2, 8, 20, 7))
+    _check_frame(amd, synth.adversarial("noise", 100, 72, seed=9), (500, 1.2, 8, 20, 7))
+
+
+def test_noise_fullsize_stresses_cell_capacity(amd):
+    # pure noise: corners everywhere, work queues and per-cell slot ranges near their bounds
+    _check_frame(amd, synth.adversarial("noise", 640, 480, seed=3), (1000, 1.2, 8, 7, 7))
+    img = np.zeros((480, 640), np.uint8)
+    img[::2, ::2] = 255  # isolated bright pixels on a 2-px lattice: maximal NMS-survivor density
+    _check_frame(amd, img, (1000, 1.2, 8, 20, 7))
