@@ -20,13 +20,11 @@ constexpr int kMaxCell = 60;    // cell side bound: wCell = ceil(width/nCols) < 
 constexpr int kPitchDw = 24;    // LDS row pitch in dwords (96 B): 4 rows x 8 groups hit 32 distinct banks
 constexpr int kTileRows = kMaxCell + 6;
 constexpr int kScoreRows = kMaxCell + 2;
-constexpr int kMaxIter = 4;     // ceil(15 groups * 60 rows / 256 threads)
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ s16x2 as_s2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
 __device__ __forceinline__ uint32_t as_u(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
-__device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
 
 // Bresenham circle of radius 3 in cv::FAST's order.
 constexpr int kRingDx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
@@ -44,10 +42,11 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b)
 // byte column 4, so a group of 4 horizontally adjacent pixels reads aligned dwords.
 //   A. cheap necessary test, packed 16-bit, 4 pixels per thread: a 9-of-16 arc always covers two
 //      ADJACENT cardinal ring points (0,4,8,12), so a corner needs (c0|c8)&(c4|c12) in one
-//      polarity.  ~19 % of pixels pass; they are pushed to an LDS work queue.
-//   B. exact cv::FAST response S-1 for the queued pixels, one pixel per lane (dense lanes).
-//   C. cell-local 3x3 strict NMS + threshold classes, packed, 4 pixels per thread.
-//   D. per-cell 20->7 fallback and ordered emission.
+//      polarity.  ~19 % of pixels pass; they are appended to an LDS work list IN RASTER ORDER
+//      (ballot prefix inside a wave, wave totals through LDS).
+//   B. exact cv::FAST response S-1 for the listed pixels, one pixel per lane (dense lanes).
+//   C. cell-local 3x3 strict NMS of the corners (one lane per corner) + threshold classes.
+//   D. per-cell 20->7 fallback, then ordered compaction of the survivors = emission order.
 __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
                                                     const CellDesc* __restrict__ cells,
                                                     int nCells, int nFrames, int iniTh, int minTh,
@@ -56,9 +55,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
                                                     uint16_t* __restrict__ cellCount) {
   __shared__ uint32_t tile[kTileRows * kPitchDw];    // pixels: origin (x0-4, y0-3)
   __shared__ uint32_t score[kScoreRows * kPitchDw];  // FAST responses: origin (x0-4, y0-1)
-  __shared__ uint16_t queue[kMaxCell * kMaxCell];
-  __shared__ int waveTot[2][4];  // double-buffered: one barrier per emission round
-  __shared__ int qn;
+  __shared__ uint16_t queue[kMaxCell * kMaxCell];    // work list: py<<8 | px, bits 14/15 = NMS classes
+  __shared__ int waveTot[2][4];                      // double-buffered wave totals of the scans
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware work mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, so
@@ -78,8 +76,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
   const int tdw = ngx + 2;                // tile dwords per row
   // exact i / ngx and i / tdw for i < 4096 by multiply-shift (divisors <= 17)
   const uint32_t invG = 65536u / (uint32_t)ngx + 1u, invT = 65536u / (uint32_t)tdw + 1u;
+  const unsigned long long ltMask = (1ull << lane) - 1ull;
+  constexpr int P = kPitchDw * 4;         // LDS row pitch in bytes
 
-  if (tid == 0) qn = 0;
   // ---- stage the tile: rows y0-3 .. y0+ch+2, bytes x0-4 .. x0+4*ngx+3 (inside the level) ----
   {
     const uint8_t* img = lv.base + (size_t)f * lv.frameStride + (size_t)(y0 - 3) * lv.pitch + (x0 - 4);
@@ -106,15 +105,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
   }
   __syncthreads();
 
-#if defined(FAST_ABLATE) && FAST_ABLATE == 1
-  if (tid == 0) cellCount[(size_t)f * nCells + cellId] = (uint16_t)(tile[5] & 1);
-  return;
-#endif
-  // ---- A: cardinal-pair test at the lower threshold ----
+  // ---- A: cardinal-pair test at the lower threshold; ordered work list ----
+  int nq = 0;  // identical in every thread
   {
     const s16x2 T = {(short)tlo, (short)tlo};
-    const int lane = tid & 63;
-    for (int g0 = 0; g0 < ngroups; g0 += 256) {  // block-uniform trip count (wave-wide ballots inside)
+    int it = 0;
+    for (int g0 = 0; g0 < ngroups; g0 += 256, it++) {  // block-uniform trip count
       const int g = g0 + tid;
       uint32_t pass = 0;
       int gy = 0, gx = 0;
@@ -140,41 +136,33 @@ __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
         const int valid = cw - 4 * gx;
         if (valid < 4) pass &= (1u << valid) - 1u;
       }
-      // wave-aggregated push: one LDS atomic per wave instead of one per thread
       const int c = __popc(pass);  // 0..4
       const unsigned long long b0 = __ballot(c & 1), b1 = __ballot(c & 2), b2 = __ballot(c & 4);
-      if ((b0 | b1 | b2) != 0ull) {
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        const int before = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
-        const int total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&qn, total);
-        base = __shfl(base, 0, 64);
-        int q = base + before;
+      const int before = __popcll(b0 & ltMask) + 2 * __popcll(b1 & ltMask) + 4 * __popcll(b2 & ltMask);
+      int* wt = waveTot[it & 1];
+      if (lane == 0) wt[wave] = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+      __syncthreads();
+      int q = nq + before;
+      for (int w = 0; w < wave; w++) q += wt[w];
+      nq += wt[0] + wt[1] + wt[2] + wt[3];
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (pass & (1u << j)) queue[q++] = (uint16_t)((gy << 8) | (4 * gx + j));
-      }
+      for (int j = 0; j < 4; j++)
+        if (pass & (1u << j)) queue[q++] = (uint16_t)((gy << 8) | (4 * gx + j));
     }
   }
   __syncthreads();
 
-#if defined(FAST_ABLATE) && FAST_ABLATE == 2
-  if (tid == 0) cellCount[(size_t)f * nCells + cellId] = (uint16_t)(qn & 1);
-  return;
-#endif
-  // ---- B: exact response of the queued pixels (cornerScore<16>: S-1, corner iff S > t) ----
+  // ---- B: exact response of the listed pixels (cornerScore<16>: S-1, corner iff S > t) ----
   {
     const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
     uint8_t* sbytes = reinterpret_cast<uint8_t*>(score);
-    const int n = qn;
-    for (int q = tid; q < n; q += 256) {
+    for (int q = tid; q < nq; q += 256) {
       const int e = queue[q], px = e & 255, py = e >> 8;
-      const uint8_t* c = tb + (py + 3) * (kPitchDw * 4) + 4 + px;
+      const uint8_t* c = tb + (py + 3) * P + 4 + px;
       const int v = c[0];
       int d[16];
 #pragma unroll
-      for (int k = 0; k < 16; k++) d[k] = v - (int)c[kRingDx[k] + kRingDy[k] * (kPitchDw * 4)];
+      for (int k = 0; k < 16; k++) d[k] = v - (int)c[kRingDx[k] + kRingDy[k] * P];
       int lo3[16], hi3[16];
 #pragma unroll
       for (int k = 0; k < 16; k++) {
@@ -193,93 +181,51 @@ __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
       sd = max(sd, lo9[15]);
       sb = min(sb, hi9[15]);
       const int S = max(sd, -sb);
-      if (S > tlo) sbytes[(py + 1) * (kPitchDw * 4) + 4 + px] = (uint8_t)(S - 1);
+      if (S > tlo) sbytes[(py + 1) * P + 4 + px] = (uint8_t)(S - 1);
+      else queue[q] = 0xffffu;  // not a corner: drop from the list
     }
   }
   __syncthreads();
 
-#if defined(FAST_ABLATE) && FAST_ABLATE == 3
-  if (tid == 0) cellCount[(size_t)f * nCells + cellId] = (uint16_t)(score[30] & 1);
-  return;
-#endif
-  // ---- C: cell-local 3x3 strict NMS + both threshold classes ----
-  uint32_t selLo[kMaxIter], selHi[kMaxIter];
+  // ---- C: cell-local 3x3 strict NMS, one lane per corner; classes in bits 14 (>= minThFAST)
+  //      and 15 (>= iniThFAST) of the list entry ----
+  const uint8_t* sbytes = reinterpret_cast<const uint8_t*>(score);
   int anyHigh = 0;
-  const s16x2 tIni = {(short)iniTh, (short)iniTh}, tMin = {(short)minTh, (short)minTh};
-#pragma unroll
-  for (int it = 0; it < kMaxIter; it++) {
-    selLo[it] = selHi[it] = 0;
-    const int g = tid + 256 * it;
-    if (g < ngroups) {
-      const int gy = (int)(((uint32_t)g * invG) >> 16), gx = g - gy * ngx;
-      const uint32_t* row1 = &score[(gy + 1) * kPitchDw + gx];
-      if (row1[1] != 0) {
-        uint32_t q[3][3];
-#pragma unroll
-        for (int dy = 0; dy < 3; dy++) {
-          const uint32_t* row = &score[(gy + dy) * kPitchDw + gx];
-          q[dy][0] = row[0]; q[dy][1] = row[1]; q[dy][2] = row[2];
-        }
-        s16x2 p35[3], p46[3], p57[3], p68[3];
-#pragma unroll
-        for (int dy = 0; dy < 3; dy++) {
-          p35[dy] = as_s2(__builtin_amdgcn_perm(q[dy][1], q[dy][0], sel2(3)));
-          p46[dy] = as_s2(__builtin_amdgcn_perm(q[dy][1], q[dy][0], sel2(4)));
-          p57[dy] = as_s2(__builtin_amdgcn_perm(q[dy][1], q[dy][0], sel2(5)));
-          p68[dy] = as_s2(__builtin_amdgcn_perm(q[dy][2], q[dy][1], sel2(2)));
-        }
-        const s16x2 cA = p46[1], cB = p57[1];  // pixels (0,2) and (1,3)
-        s16x2 nA = pmax(pmax(p35[0], p46[0]), pmax(p57[0], p35[1]));
-        nA = pmax(nA, pmax(pmax(p57[1], p35[2]), pmax(p46[2], p57[2])));
-        s16x2 nB = pmax(pmax(p46[0], p57[0]), pmax(p68[0], p46[1]));
-        nB = pmax(nB, pmax(pmax(p68[1], p46[2]), pmax(p57[2], p68[2])));
-        // keep where centre > every neighbour; classes: >= minTh (lo), >= iniTh (hi)
-        const uint32_t kA = as_u((nA - cA) >> 15), kB = as_u((nB - cB) >> 15);  // 0xffff where kept
-        const uint32_t loA = kA & ~as_u((cA - tMin) >> 15), loB = kB & ~as_u((cB - tMin) >> 15);
-        const uint32_t hiA = kA & ~as_u((cA - tIni) >> 15), hiB = kB & ~as_u((cB - tIni) >> 15);
-        selLo[it] = (loA & 1u) | ((loB & 1u) << 1) | ((loA >> 14) & 4u) | ((loB >> 13) & 8u);
-        selHi[it] = (hiA & 1u) | ((hiB & 1u) << 1) | ((hiA >> 14) & 4u) | ((hiB >> 13) & 8u);
-        anyHigh |= (int)selHi[it];
-      }
-    }
+  for (int q = tid; q < nq; q += 256) {
+    const int e = queue[q];
+    if (e == 0xffff) continue;
+    const uint8_t* c = sbytes + ((e >> 8) + 1) * P + 4 + (e & 255);
+    const int v = c[0];
+    const int nb = max3i(max3i(c[-P - 1], c[-P], c[-P + 1]), max3i(c[-1], c[1], c[P - 1]), max(c[P], c[P + 1]));
+    int flags = 0;
+    if (v > nb) flags = ((v >= minTh) << 14) | ((v >= iniTh) << 15);
+    queue[q] = (uint16_t)(flags ? (e | flags) : 0xffff);
+    anyHigh |= flags >> 15;
   }
   // per-cell threshold fallback (:874-882): corners >= iniThFAST if any survived NMS, else >= minThFAST
   const int useHigh = __syncthreads_or(anyHigh);
 
-#if defined(FAST_ABLATE) && FAST_ABLATE == 4
-  if (tid == 0) cellCount[(size_t)f * nCells + cellId] = (uint16_t)(useHigh & 1);
-  return;
-#endif
-  // ---- D: ordered emission: groups in raster order, pixels of a group left to right ----
+  // ---- D: ordered compaction of the survivors (the list is in raster order, :884-893) ----
   Candidate* out = slots + (size_t)f * slotsPerFrame + cd.slotBase;
-  int run = 0;  // identical in every thread
-#pragma unroll
-  for (int it = 0; it < kMaxIter; it++) {
-    if (256 * it >= ngroups) break;
-    const uint32_t sel = useHigh ? selHi[it] : selLo[it];
-    const int c = __popc(sel);  // 0..2: NMS keeps no two adjacent pixels
-    const unsigned long long b0 = __ballot(c & 1), b1 = __ballot(c & 2);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const int inWave = __popcll(b0 & lt) + 2 * __popcll(b1 & lt);
-    int* wt = waveTot[it & 1];
-    if (lane == 0) wt[wave] = __popcll(b0) + 2 * __popcll(b1);
+  const int bit = useHigh ? 0x8000 : 0x4000;
+  int run = 0, it2 = 0;  // identical in every thread
+  for (int q0 = 0; q0 < nq; q0 += 256, it2++) {
+    const int q = q0 + tid;
+    const int e = q < nq ? queue[q] : 0xffff;
+    const bool sel = e != 0xffff && (e & bit);
+    const unsigned long long bal = __ballot(sel);
+    int* wt = waveTot[it2 & 1];
+    if (lane == 0) wt[wave] = __popcll(bal);
     __syncthreads();
-    int base = run;
-    for (int w = 0; w < wave; w++) base += wt[w];
+    int o = run + __popcll(bal & ltMask);
+    for (int w = 0; w < wave; w++) o += wt[w];
     run += wt[0] + wt[1] + wt[2] + wt[3];
     if (sel) {
-      const int g = tid + 256 * it;
-      const int gy = (int)(((uint32_t)g * invG) >> 16), gx = g - gy * ngx;
-      const uint32_t sc = score[(gy + 1) * kPitchDw + gx + 1];
-      int o = base + inWave;
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-        if (sel & (1u << j)) {
-          Candidate cnd;
-          cnd.xy = (uint32_t)(x0 + 4 * gx + j - kMinBorder) | ((uint32_t)(y0 + gy - kMinBorder) << 16);
-          cnd.score = (sc >> (8 * j)) & 0xffu;
-          out[o++] = cnd;
-        }
+      const int px = e & 255, py = (e >> 8) & 63;
+      Candidate cnd;
+      cnd.xy = (uint32_t)(x0 + px - kMinBorder) | ((uint32_t)(y0 + py - kMinBorder) << 16);
+      cnd.score = sbytes[(py + 1) * P + 4 + px];
+      out[o] = cnd;
     }
   }
   if (tid == 0) cellCount[(size_t)f * nCells + cellId] = (uint16_t)run;

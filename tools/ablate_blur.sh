@@ -1,0 +1,7 @@
+#!/bin/bash
+cd "$(dirname "$0")/../orb_slam2_annotate_amd/csrc"
+for a in 1 2 0; do
+  rm -f build/k_blur.o
+  if [ "$a" = "0" ]; then make -j8 >/dev/null 2>&1; else make -j8 CXXFLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DBLUR_ABLATE=$a" >/dev/null 2>&1; fi
+  (cd ../.. && python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ablate=$a', 'blur_ms', d['roofline']['stage_ms_per_step_warmup']['blur'])")
+done
