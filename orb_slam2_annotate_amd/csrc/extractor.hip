@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -84,8 +85,11 @@ struct orbfe_extractor {
   int32_t* d_cellPrefix = nullptr;
   int32_t* d_candCount = nullptr;
   uint16_t* d_nodeOf = nullptr;
+  float* d_scaleTab = nullptr;     // mvScaleFactor[16] + mvInvScaleFactor[16]
   int32_t* d_stereoSad = nullptr;  // scratch of the batched stereo matcher
-  size_t stereoSadCap = 0;
+  int32_t* d_stereoRowStart = nullptr;
+  int32_t* d_stereoSorted = nullptr;
+  size_t stereoSadCap = 0, stereoRowCap = 0;
   LevelKp* d_levelKp = nullptr;
   int32_t* d_levelCount = nullptr;
   // device-side outputs used by the host-buffer API
@@ -459,6 +463,10 @@ extern "C" int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlev
   build_moment_table(momTab);
   if (err == hipSuccess) err = hipMalloc((void**)&e->d_patternF, sizeof(patF));
   if (err == hipSuccess) err = hipMemcpy(e->d_patternF, patF, sizeof(patF), hipMemcpyHostToDevice);
+  float scTab[2 * kMaxLevels] = {};
+  for (int i = 0; i < e->tab.nlevels; i++) { scTab[i] = e->tab.scale[i]; scTab[kMaxLevels + i] = e->tab.invScale[i]; }
+  if (err == hipSuccess) err = hipMalloc((void**)&e->d_scaleTab, sizeof(scTab));
+  if (err == hipSuccess) err = hipMemcpy(e->d_scaleTab, scTab, sizeof(scTab), hipMemcpyHostToDevice);
   if (err == hipSuccess) err = hipMalloc((void**)&e->d_momentTab, sizeof(momTab));
   if (err == hipSuccess) err = hipMemcpy(e->d_momentTab, momTab, sizeof(momTab), hipMemcpyHostToDevice);
   if (err == hipSuccess) err = hipMalloc((void**)&e->d_umax, 16 * sizeof(int32_t));
@@ -482,6 +490,9 @@ extern "C" void orbfe_extractor_destroy(orbfe_extractor* e) {
   free_outputs(e);
   dfree(&e->d_patternF);
   dfree(&e->d_stereoSad);
+  dfree(&e->d_scaleTab);
+  dfree(&e->d_stereoRowStart);
+  dfree(&e->d_stereoSorted);
   dfree(&e->d_momentTab);
   dfree(&e->d_umax);
   for (int r = 0; r < orbfe_extractor::kEvRing; r++)
@@ -767,7 +778,7 @@ extern "C" int orbfe_gaussian_blur7(int device, const uint8_t* src, int w, int h
 
 // internal (matcher.hip): pyramid views + scale tables of the last extract call
 extern "C" int orbfe_stereo_views_(orbfe_extractor* e, int frame, PyramidViews* pv, float* scale, float* invScale,
-                                   int* nlevels, int* device) {
+                                   int* nlevels, int* device, const float** d_scaleTab) {
   if (!e->haveLast) return fail(ORBFE_ERR_INVALID, "compute_stereo_matches: extractor has no pyramid yet");
   if (frame < 0 || frame >= e->lastFrames) return fail(ORBFE_ERR_INVALID, "compute_stereo_matches: frame out of range");
   HIPCHK(hipSetDevice(e->device));
@@ -776,6 +787,7 @@ extern "C" int orbfe_stereo_views_(orbfe_extractor* e, int frame, PyramidViews* 
   for (int l = 0; l < e->tab.nlevels; l++) { scale[l] = e->tab.scale[l]; invScale[l] = e->tab.invScale[l]; }
   *nlevels = e->tab.nlevels;
   *device = e->device;
+  *d_scaleTab = e->d_scaleTab;
   return ORBFE_OK;
 }
 
@@ -811,18 +823,29 @@ extern "C" int orbfe_stereo_match_batch_device(orbfe_extractor* e, int n_pairs, 
   HIPCHK(hipSetDevice(e->device));
   if (e->nStreams > 1) { int rc = sync_all(e); if (rc) return rc; }  // all sub-batches must have landed
   const size_t need = (size_t)n_pairs * capacity;
-  if (need > e->stereoSadCap) {
+  const int rows = e->lastPyr.lv[0].h;
+  const size_t needRows = (size_t)n_pairs * (rows + 1);
+  if (need > e->stereoSadCap || needRows > e->stereoRowCap) {
     HIPCHK(hipStreamSynchronize(e->stream));
     int rc = dalloc(&e->d_stereoSad, need);
+    if (!rc) rc = dalloc(&e->d_stereoSorted, need);
+    if (!rc) rc = dalloc(&e->d_stereoRowStart, needRows);
     if (rc) return rc;
     e->stereoSadCap = need;
+    e->stereoRowCap = needRows;
   }
   StereoArgs a = {};
   a.pyrL = e->lastPyr;
   a.pyrR = e->lastPyr;
-  for (int l = 0; l < e->tab.nlevels; l++) { a.scale[l] = e->tab.scale[l]; a.invScale[l] = e->tab.invScale[l]; }
+  a.scaleTab = e->d_scaleTab;
   a.mbf = mbf;
   a.maxD = mbf / mb;  // minZ = mb, maxD = mbf/minZ (src/Frame.cc:542-544)
+  if (rows + 1 <= 8192) {  // row index of the right keypoints (k_stereo_bucket)
+    a.rowStart = e->d_stereoRowStart;
+    a.sortedIdx = e->d_stereoSorted;
+    a.rows = rows;
+    a.bandR = (int)std::ceil(2.0f * e->tab.scale[e->tab.nlevels - 1]) + 2;
+  }
   StereoBatch b = {};
   b.kp = reinterpret_cast<const float*>(d_keypoints);
   b.desc = d_descriptors;

@@ -245,31 +245,53 @@ void launch_rot_prune(hipStream_t s, int32_t* match, const int8_t* bin, int n, i
 // ---------------------------------------------------------------------------------------
 // Frame::ComputeStereoMatches (src/Frame.cc:512-686)
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void stereo_one(const StereoArgs& a, int iL, int lane) {
-  const float* kl = a.kpL + (size_t)iL * 7;
+struct StereoPair {  // per-pair operands (kept apart from the kernel argument so that stays read-only)
+  const float* kpL; const uint8_t* descL; int N;
+  const float* kpR; const uint8_t* descR; int Nr;
+  int frameL, frameR;
+  float* uRight; float* depth; int32_t* sad;
+  const int32_t* rowStart; const int32_t* sortedIdx;
+};
+
+__device__ __forceinline__ void stereo_one(const StereoArgs& a, const StereoPair& pp, int iL, int lane) {
+  const float* kl = pp.kpL + (size_t)iL * 7;
   const float uL = kl[0], vL = kl[1];
-  const int levelL = reinterpret_cast<const int32_t*>(kl)[5];
-  if (lane == 0) { a.uRight[iL] = -1.0f; a.depth[iL] = -1.0f; a.sad[iL] = -1; }
+  // the left keypoint is wave-uniform: make its level a scalar so the per-level tables of the
+  // kernel argument are read with scalar loads (a vector index would spill the struct to scratch)
+  const int levelL = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int32_t*>(kl)[5]);
+  if (lane == 0) { pp.uRight[iL] = -1.0f; pp.depth[iL] = -1.0f; pp.sad[iL] = -1; }
   const int row = (int)vL;
   const float minU = __fsub_rn(uL, a.maxD), maxU = uL;  // minD = 0
   if (maxU < 0) return;
-  const Desc dL = load_desc(a.descL, iL);
+  const Desc dL = load_desc(pp.descL, iL);
   // candidates: right keypoints whose row band [floor(y-r), ceil(y+r)], r = 2*scale[octave],
   // contains `row` (:522-539), octave within +-1 (:579), uR in [minU, maxU] (:584);
   // best = strictly smaller distance, i.e. first minimum in ascending iR (:589-593)
   uint32_t best = 0xffffffffu;  // dist << 20 | iR
-  for (int iR = lane; iR < a.Nr; iR += 64) {
-    const float* kr = a.kpR + (size_t)iR * 7;
+  // right keypoints are bucketed by floor(y) (k_stereo_bucket): only the rows that can hold a
+  // band covering `row` are scanned; ties still resolve to the smallest original index iR
+  int pBeg = 0, pEnd = pp.Nr;
+  if (pp.rowStart) {
+    int lo = row - a.bandR, hi = row + a.bandR;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > a.rows - 1 ? a.rows - 1 : hi;
+    if (lo > hi) return;
+    pBeg = pp.rowStart[lo];
+    pEnd = pp.rowStart[hi + 1];
+  }
+  for (int p = pBeg + lane; p < pEnd; p += 64) {
+    const int iR = pp.rowStart ? pp.sortedIdx[p] : p;
+    const float* kr = pp.kpR + (size_t)iR * 7;
     const int octR = reinterpret_cast<const int32_t*>(kr)[5];
     const float yR = kr[1];
-    const float r = __fmul_rn(2.0f, a.scale[octR]);
+    const float r = __fmul_rn(2.0f, a.scaleTab[octR]);
     const int maxr = (int)ceilf(__fadd_rn(yR, r));
     const int minr = (int)floorf(__fsub_rn(yR, r));
     if (row < minr || row > maxr) continue;
     if (octR < levelL - 1 || octR > levelL + 1) continue;
     const float uR = kr[0];
     if (!(uR >= minU && uR <= maxU)) continue;
-    const uint32_t dist = (uint32_t)hdist(dL, load_desc(a.descR, iR));
+    const uint32_t dist = (uint32_t)hdist(dL, load_desc(pp.descR, iR));
     if (dist >= 100u) continue;  // bestDist starts at TH_HIGH, strict <
     const uint32_t key = (dist << 20) | (uint32_t)iR;
     best = key < best ? key : best;
@@ -279,8 +301,8 @@ __device__ __forceinline__ void stereo_one(const StereoArgs& a, int iL, int lane
   const int bestDist = (int)(best >> 20), bestIdxR = (int)(best & 0xfffffu);
   if (bestDist >= 75) return;  // thOrbDist = (TH_HIGH+TH_LOW)/2, :517,598
   // ---- SAD refinement on the left keypoint's pyramid level (:600-638) ----
-  const float uR0 = a.kpR[(size_t)bestIdxR * 7];
-  const float sf = a.invScale[levelL];
+  const float uR0 = pp.kpR[(size_t)bestIdxR * 7];
+  const float sf = a.scaleTab[kMaxLevels + levelL];
   const float scaleduL = roundf(__fmul_rn(uL, sf));
   const float scaledvL = roundf(__fmul_rn(vL, sf));
   const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
@@ -289,8 +311,8 @@ __device__ __forceinline__ void stereo_one(const StereoArgs& a, int iL, int lane
   const float endu = scaleduR0 + 5 + 5 + 1;
   if (iniu < 0 || endu >= (float)R.w) return;
   const int cy = (int)scaledvL, cxL = (int)scaleduL, cxR0 = (int)scaleduR0;
-  const uint8_t* IL = L.base + (size_t)a.frameL * L.frameStride;
-  const uint8_t* IR = R.base + (size_t)a.frameR * R.frameStride;
+  const uint8_t* IL = L.base + (size_t)pp.frameL * L.frameStride;
+  const uint8_t* IR = R.base + (size_t)pp.frameR * R.frameStride;
   const int cL = IL[(size_t)cy * L.pitch + cxL];
   // lanes own patch pixels p = lane, lane+64 of the 11x11 window
   int pl[2], py[2], px[2];
@@ -330,7 +352,7 @@ __device__ __forceinline__ void stereo_one(const StereoArgs& a, int iL, int lane
   const float deltaR = __fdiv_rn(__fsub_rn(d1, d3),
                                  __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2))));
   if (deltaR < -1 || deltaR > 1) return;
-  float bestuR = __fmul_rn(a.scale[levelL], __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));
+  float bestuR = __fmul_rn(a.scaleTab[levelL], __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));
   float disparity = __fsub_rn(uL, bestuR);
   if (disparity >= 0 && disparity < a.maxD) {
     if (disparity <= 0) {
@@ -338,10 +360,58 @@ __device__ __forceinline__ void stereo_one(const StereoArgs& a, int iL, int lane
       bestuR = (float)__dsub_rn((double)uL, 0.01);
     }
     if (lane == 0) {
-      a.depth[iL] = __fdiv_rn(a.mbf, disparity);
-      a.uRight[iL] = bestuR;
-      a.sad[iL] = bestSad;
+      pp.depth[iL] = __fdiv_rn(a.mbf, disparity);
+      pp.uRight[iL] = bestuR;
+      pp.sad[iL] = bestSad;
     }
+  }
+}
+
+// Counting sort of the right keypoints by image row floor(y): rowStart[r] .. rowStart[r+1] index
+// sortedIdx (the flat equivalent of vRowIndices, src/Frame.cc:519-539, before band expansion).
+// One workgroup per stereo pair; rows <= 8191.
+__global__ __launch_bounds__(256) void k_stereo_bucket(const float* __restrict__ kpBase, const int32_t* __restrict__ nArr,
+                                                       int nFixed, int capacity, int rows,
+                                                       int32_t* __restrict__ rowStartBase,
+                                                       int32_t* __restrict__ sortedBase) {
+  extern __shared__ int cnt[];  // rows + 1
+  __shared__ int waveTot[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = blockIdx.x;
+  const float* kpR = nArr ? kpBase + (size_t)(2 * p + 1) * capacity * 7 : kpBase;
+  int Nr = nArr ? nArr[2 * p + 1] : nFixed;
+  if (Nr > capacity) Nr = capacity;
+  int32_t* rowStart = rowStartBase + (size_t)p * (rows + 1);
+  int32_t* sorted = sortedBase + (size_t)p * capacity;
+  for (int i = tid; i <= rows; i += 256) cnt[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < Nr; i += 256) {
+    int b = (int)floorf(kpR[(size_t)i * 7 + 1]);
+    b = b < 0 ? 0 : (b > rows - 1 ? rows - 1 : b);
+    atomicAdd(&cnt[b], 1);
+  }
+  __syncthreads();
+  int run = 0;
+  for (int base = 0; base <= rows; base += 256) {  // exclusive scan over the rows
+    const int i = base + tid;
+    const int v = i <= rows ? cnt[i] : 0;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) waveTot[wave] = x;
+    __syncthreads();
+    int b = run;
+    for (int w = 0; w < wave; w++) b += waveTot[w];
+    run += waveTot[0] + waveTot[1] + waveTot[2] + waveTot[3];
+    if (i <= rows) { cnt[i] = b + x - v; rowStart[i] = b + x - v; }
+    __syncthreads();
+  }
+  for (int i = tid; i < Nr; i += 256) {
+    int b = (int)floorf(kpR[(size_t)i * 7 + 1]);
+    b = b < 0 ? 0 : (b > rows - 1 ? rows - 1 : b);
+    sorted[atomicAdd(&cnt[b], 1)] = i;
   }
 }
 
@@ -349,12 +419,14 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a) {
   const int lane = threadIdx.x & 63;
   const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (iL >= a.N) return;
-  stereo_one(a, iL, lane);
+  StereoPair pp = {a.kpL, a.descL, a.N, a.kpR, a.descR, a.Nr, a.frameL, a.frameR, a.uRight, a.depth, a.sad,
+                   a.rowStart, a.sortedIdx};
+  stereo_one(a, pp, iL, lane);
 }
 
 // Batched, device-resident form: pair p = frames (2p, 2p+1) of one extractor batch; the
 // keypoint counts are read from device memory (d_n of orbfe_extract_batch_device).
-__global__ __launch_bounds__(256) void k_stereo_match_batch(StereoArgs a, StereoBatch b) {
+__global__ __launch_bounds__(256) void k_stereo_match_batch(const StereoArgs a, const StereoBatch b) {
   const int lane = threadIdx.x & 63;
   const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int p = blockIdx.y;
@@ -367,11 +439,14 @@ __global__ __launch_bounds__(256) void k_stereo_match_batch(StereoArgs a, Stereo
     if (lane == 0) { b.uRight[oO + iL] = -1.0f; b.depth[oO + iL] = -1.0f; b.sad[oO + iL] = -1; }
     return;
   }
-  a.kpL = b.kp + oL * 7; a.descL = b.desc + oL * 32; a.N = N;
-  a.kpR = b.kp + oR * 7; a.descR = b.desc + oR * 32; a.Nr = Nr;
-  a.frameL = 2 * p; a.frameR = 2 * p + 1;
-  a.uRight = b.uRight + oO; a.depth = b.depth + oO; a.sad = b.sad + oO;
-  stereo_one(a, iL, lane);
+  StereoPair pp;
+  pp.kpL = b.kp + oL * 7; pp.descL = b.desc + oL * 32; pp.N = N;
+  pp.kpR = b.kp + oR * 7; pp.descR = b.desc + oR * 32; pp.Nr = Nr;
+  pp.frameL = 2 * p; pp.frameR = 2 * p + 1;
+  pp.uRight = b.uRight + oO; pp.depth = b.depth + oO; pp.sad = b.sad + oO;
+  pp.rowStart = a.rowStart ? a.rowStart + (size_t)p * (a.rows + 1) : nullptr;
+  pp.sortedIdx = a.rowStart ? a.sortedIdx + (size_t)p * b.capacity : nullptr;
+  stereo_one(a, pp, iL, lane);
 }
 
 // Median cut (:672-685): drop matches whose SAD >= 1.5*1.4*median, median = sorted[size/2].
@@ -436,12 +511,19 @@ __global__ __launch_bounds__(256) void k_stereo_median_cut(int N, const int32_t*
 
 void launch_stereo(hipStream_t s, const StereoArgs& a, int32_t* d_nStereo) {
   if (a.N <= 0) return;
+  if (a.rowStart)
+    hipLaunchKernelGGL(k_stereo_bucket, dim3(1), dim3(256), (size_t)(a.rows + 1) * sizeof(int), s, a.kpR,
+                       (const int32_t*)nullptr, a.Nr, a.Nr, a.rows, const_cast<int32_t*>(a.rowStart),
+                       const_cast<int32_t*>(a.sortedIdx));
   hipLaunchKernelGGL(k_stereo_match, dim3((a.N + 3) / 4), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_stereo_median_cut, dim3(1), dim3(256), 0, s, a.N, a.sad, a.uRight, a.depth, d_nStereo, 0);
 }
 
 void launch_stereo_batch(hipStream_t s, const StereoArgs& a, const StereoBatch& b, int nPairs, int32_t* d_nStereo) {
   if (nPairs <= 0 || b.capacity <= 0) return;
+  if (a.rowStart)
+    hipLaunchKernelGGL(k_stereo_bucket, dim3(nPairs), dim3(256), (size_t)(a.rows + 1) * sizeof(int), s, b.kp, b.n, 0,
+                       b.capacity, a.rows, const_cast<int32_t*>(a.rowStart), const_cast<int32_t*>(a.sortedIdx));
   hipLaunchKernelGGL(k_stereo_match_batch, dim3((b.capacity + 3) / 4, nPairs), dim3(256), 0, s, a, b);
   hipLaunchKernelGGL(k_stereo_median_cut, dim3(nPairs), dim3(256), 0, s, b.capacity, b.sad, b.uRight, b.depth,
                      d_nStereo, b.capacity);

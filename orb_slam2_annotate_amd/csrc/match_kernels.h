@@ -38,9 +38,11 @@ struct StereoArgs {
   const float* kpL; const uint8_t* descL; int N;   // 7 floats per keypoint (cv::KeyPoint layout)
   const float* kpR; const uint8_t* descR; int Nr;
   PyramidViews pyrL, pyrR; int frameL, frameR;
-  float scale[kMaxLevels], invScale[kMaxLevels];
+  const float* scaleTab;  // device: mvScaleFactor[0..15] then mvInvScaleFactor[0..15]
   float mbf, maxD;
   float* uRight; float* depth; int32_t* sad;
+  // optional row index of the right keypoints (NULL -> scan all): rows+1 starts and Nr indices per pair
+  const int32_t* rowStart; const int32_t* sortedIdx; int rows; int bandR;
 };
 
 struct StereoBatch {  // frames 2p / 2p+1 of an extractor batch are the left / right image of pair p

@@ -4,6 +4,7 @@
 // on three threads concurrently, src/LocalMapping.cc:261, src/LoopClosing.cc:294).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <string>
@@ -299,7 +300,7 @@ extern "C" int orbfe_search_for_triangulation(int device, const uint8_t* desc1, 
 
 // implemented in extractor.hip (needs the handle internals)
 extern "C" int orbfe_stereo_views_(orbfe_extractor* e, int frame, PyramidViews* pv, float* scale, float* invScale,
-                                   int* nlevels, int* device);
+                                   int* nlevels, int* device, const float** d_scaleTab);
 
 extern "C" int orbfe_compute_stereo_matches(orbfe_extractor* left, int frameL, orbfe_extractor* right, int frameR,
                                             const orbfe_keypoint* kpL, const uint8_t* descL, int N,
@@ -313,10 +314,11 @@ extern "C" int orbfe_compute_stereo_matches(orbfe_extractor* left, int frameL, o
   if (Nr >= (1 << 20)) return mfail(ORBFE_ERR_INVALID, "compute_stereo_matches: too many right keypoints");
   StereoArgs a = {};
   int nlL = 0, nlR = 0, devL = 0, devR = 0;
-  float scR[kMaxLevels], iscR[kMaxLevels];
+  float scL[kMaxLevels], iscL[kMaxLevels], scR[kMaxLevels], iscR[kMaxLevels];
+  const float* dTabR = nullptr;
   int rc;
-  if ((rc = orbfe_stereo_views_(left, frameL, &a.pyrL, a.scale, a.invScale, &nlL, &devL))) return rc;
-  if ((rc = orbfe_stereo_views_(right, frameR, &a.pyrR, scR, iscR, &nlR, &devR))) return rc;
+  if ((rc = orbfe_stereo_views_(left, frameL, &a.pyrL, scL, iscL, &nlL, &devL, &a.scaleTab))) return rc;
+  if ((rc = orbfe_stereo_views_(right, frameR, &a.pyrR, scR, iscR, &nlR, &devR, &dTabR))) return rc;
   if (nlL != nlR || devL != devR) return mfail(ORBFE_ERR_INVALID, "compute_stereo_matches: extractors differ");
   for (int l = 0; l < nlL; l++)
     if (a.pyrL.lv[l].w != a.pyrR.lv[l].w || a.pyrL.lv[l].h != a.pyrR.lv[l].h)
@@ -326,7 +328,9 @@ extern "C" int orbfe_compute_stereo_matches(orbfe_extractor* left, int frameL, o
   for (int i = 0; i < Nr; i++)
     if (kpR[i].octave < 0 || kpR[i].octave >= nlL) return mfail(ORBFE_ERR_INVALID, "compute_stereo_matches: octave out of range");
   Arena* ar;
-  MHIP(arena_begin(devL, pad((size_t)N * 60) + pad((size_t)Nr * 60) + 3 * pad((size_t)N * 4) + 4096, &ar));
+  const int rows = a.pyrL.lv[0].h;
+  MHIP(arena_begin(devL, pad((size_t)N * 60) + pad((size_t)Nr * 60) + 3 * pad((size_t)N * 4) + pad((size_t)Nr * 4) +
+                             pad((size_t)(rows + 1) * 4) + 4096, &ar));
   float *dkl, *dkr;
   uint8_t *ddl, *ddr;
   MHIP(up(ar, &dkl, reinterpret_cast<const float*>(kpL), (size_t)N * 7));
@@ -340,6 +344,12 @@ extern "C" int orbfe_compute_stereo_matches(orbfe_extractor* left, int frameL, o
   a.uRight = carve<float>(ar, N);
   a.depth = carve<float>(ar, N);
   a.sad = carve<int32_t>(ar, N);
+  if (rows + 1 <= 8192) {  // row index of the right keypoints (k_stereo_bucket)
+    a.rowStart = carve<int32_t>(ar, (size_t)rows + 1);
+    a.sortedIdx = carve<int32_t>(ar, (size_t)Nr);
+    a.rows = rows;
+    a.bandR = (int)std::ceil(2.0f * scL[nlL - 1]) + 2;
+  }
   int32_t* dcount = carve<int32_t>(ar, 1);
   launch_stereo(ar->stream, a, dcount);
   MHIP(hipGetLastError());
