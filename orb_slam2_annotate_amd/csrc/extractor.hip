@@ -323,6 +323,18 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, bool timed, LevelView level0, i
     blur.lv[l] = blur0.lv[l];
     blur.lv[l].base += F * blur0.lv[l].frameStride;
   }
+  if ((level0.pitch & 3) || (level0.frameStride & 3) || (reinterpret_cast<uintptr_t>(level0.base) & 3)) {
+    // caller-owned frames that are not dword-aligned (e.g. a tight 1241-byte stride): one copy into
+    // the handle's own 64-B pitched level-0 slab keeps every later kernel on its aligned fast path
+    LevelView own{e->d_pyr + g.lv[0].off, g.pyrBytes, g.lv[0].pitch, g.lv[0].w, g.lv[0].h};
+    LevelView src = level0;
+    src.base += F * level0.frameStride;
+    LevelViewMut dst{e->d_pyr + g.lv[0].off + F * g.pyrBytes, g.pyrBytes, g.lv[0].pitch, g.lv[0].w, g.lv[0].h};
+    launch_copy2d(s, src, dst, nFrames);
+    pyr0.lv[0] = own;
+    pyr.lv[0] = own;
+    pyr.lv[0].base += F * own.frameStride;
+  }
   if (pyrOut) { *pyrOut = pyr0; *blurOut = blur0; }
   Candidate* slots = e->d_slots + F * g.totalSlots;
   Candidate* cand = e->d_cand + F * g.totalSlots;
