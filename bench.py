@@ -60,8 +60,9 @@ def algorithmic_bytes(sizes, n_kp):
 
 
 STAGE_KERNELS = {  # kernels (and launches per step) behind each timed stage
-    "pyramid": [("k_resize", 7)], "fast": [("k_fast_cells", 1), ("k_gather_candidates", 1)],
-    "octree": [("k_octree", 1)], "blur": [("k_blur7", 8)], "orient_desc": [("k_orient_desc", 1)],
+    "pyramid": [("k_resize", 7)], "fast": [("k_fast_cells", 1)],
+    "octree": [("k_gather_candidates", 1), ("k_octree", 1)], "blur": [("k_blur7", 8)],
+    "orient_desc": [("k_orient_desc", 1)],
 }
 
 
@@ -253,7 +254,7 @@ def main():
                        "keypoints_per_frame": n_kp,
                        "sharding": f"frames sharded one batch per GPU x{world}, no data-path collective"},
             "roofline": {
-                "bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm", "kernel": "+".join(k for k, _ in STAGE_KERNELS[dom]), "stage": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args.workload, B),
                 "algorithmic_bytes_per_launch_group": alg[dom] * prof[dom][2] / max(args.steps, 1),
                 "algorithmic_bytes_per_frame": alg[dom], "ms_per_launch_group": dom_ms_per_step,

@@ -350,22 +350,15 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, bool timed, LevelView level0, i
       launch_resize(s, pyr.lv[l - 1], dst, e->d_xofs[l], e->d_alpha[l], e->d_yofs[l], e->d_beta[l], nFrames);
     }
   }
-  {  // FAST grid stage, :846-896
-    StageTimer t(e, ORBFE_STAGE_FAST, 2, nFrames, timed);
+  {  // FAST grid stage, :846-896 (timed alone: the dominant kernel of the pipeline)
+    StageTimer t(e, ORBFE_STAGE_FAST, 1, nFrames, timed);
     launch_fast_cells(s, pyr, e->d_cells, nCells, nFrames, e->tab.iniThFAST, e->tab.minThFAST, slots,
                       g.totalSlots, cellCount);
+  }
+  if (!e->hostOctree) {  // candidate ordering + DistributeOctTree, :566-808, one workgroup per (frame, level)
+    StageTimer t(e, ORBFE_STAGE_OCTREE, 2, nFrames, timed);
     launch_gather_candidates(s, e->d_cells, e->d_lvgeom, g.nlevels, nFrames, slots, g.totalSlots, cellCount,
                              nCells, cand, candCount, cellPrefix);
-  }
-  {  // GaussianBlur of every level, :1169-1175
-    StageTimer t(e, ORBFE_STAGE_BLUR, g.nlevels, nFrames, timed);
-    for (int l = 0; l < g.nlevels; l++) {
-      LevelViewMut dst{const_cast<uint8_t*>(blur.lv[l].base), g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
-      launch_blur7(s, pyr.lv[l], dst, nFrames);
-    }
-  }
-  if (!e->hostOctree) {  // DistributeOctTree, :566-808, one workgroup per (frame, level)
-    StageTimer t(e, ORBFE_STAGE_OCTREE, 1, nFrames, timed);
     OctreeArgs oa = {};
     oa.cand = cand;
     oa.slotsPerFrame = g.totalSlots;
@@ -379,9 +372,19 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, bool timed, LevelView level0, i
     oa.maxL = e->octreeMaxL;
     HIPCHK(launch_octree(s, oa, g.nlevels, nFrames));
   } else {
+    launch_gather_candidates(s, e->d_cells, e->d_lvgeom, g.nlevels, nFrames, slots, g.totalSlots, cellCount,
+                             nCells, cand, candCount, cellPrefix);
     int rc = run_host_octree(e, nFrames);  // single-stream debug path: f0 == 0
     if (rc) return rc;
   }
+  {  // GaussianBlur of every level, :1169-1175
+    StageTimer t(e, ORBFE_STAGE_BLUR, g.nlevels, nFrames, timed);
+    for (int l = 0; l < g.nlevels; l++) {
+      LevelViewMut dst{const_cast<uint8_t*>(blur.lv[l].base), g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
+      launch_blur7(s, pyr.lv[l], dst, nFrames);
+    }
+  }
+
   {  // computeOrientation + computeDescriptors + output records
     StageTimer t(e, ORBFE_STAGE_ORIENT_DESC, 1, nFrames, timed);
     OrientDescArgs a = {};
