@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="verify frame 0 of the batch against the oracle")
     ap.add_argument("--streams", type=int, default=0, help="sub-batch HIP streams per call (0 = library default)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for 1 rank")
     args = ap.parse_args()
 
     import torch
@@ -128,7 +129,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    use_dist = args.gpus > 1 or world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world)
@@ -178,7 +180,7 @@ def main():
     def barrier():
         ext.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     # warmup: every stage timed (HIP events on the extractor's stream) to find the dominant kernel
@@ -204,7 +206,7 @@ def main():
     n_kp = float(d_n.float().mean().item())
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     frames_done = torch.tensor([float(B * args.steps)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(frames_done, op=dist.ReduceOp.SUM)
     dt_max = float(t.item())
@@ -270,7 +272,7 @@ def main():
             if stereo:
                 out["cpu_baseline"]["note"] = "extraction only (per image); stereo matching not included"
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
