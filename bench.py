@@ -61,7 +61,7 @@ def algorithmic_bytes(sizes, n_kp):
 
 STAGE_KERNELS = {  # kernels (and launches per step) behind each timed stage
     "pyramid": [("k_resize", 7)], "fast": [("k_fast_cells", 1)],
-    "octree": [("k_gather_candidates", 1), ("k_octree", 1)], "blur": [("k_blur7", 8)],
+    "octree": [("k_gather_candidates", 1), ("k_octree", 1)], "blur": [("k_blur7", 1)],
     "orient_desc": [("k_orient_desc", 1)],
 }
 

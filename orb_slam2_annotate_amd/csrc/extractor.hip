@@ -377,12 +377,12 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, bool timed, LevelView level0, i
     int rc = run_host_octree(e, nFrames);  // single-stream debug path: f0 == 0
     if (rc) return rc;
   }
-  {  // GaussianBlur of every level, :1169-1175
-    StageTimer t(e, ORBFE_STAGE_BLUR, g.nlevels, nFrames, timed);
-    for (int l = 0; l < g.nlevels; l++) {
-      LevelViewMut dst{const_cast<uint8_t*>(blur.lv[l].base), g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
-      launch_blur7(s, pyr.lv[l], dst, nFrames);
-    }
+  {  // GaussianBlur of every level, :1169-1175 -- the levels are independent: one launch
+    StageTimer t(e, ORBFE_STAGE_BLUR, 1, nFrames, timed);
+    LevelViewMut dsts[kMaxLevels];
+    for (int l = 0; l < g.nlevels; l++)
+      dsts[l] = LevelViewMut{const_cast<uint8_t*>(blur.lv[l].base), g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
+    launch_blur7_levels(s, pyr.lv, dsts, g.nlevels, nFrames);
   }
 
   {  // computeOrientation + computeDescriptors + output records

@@ -32,8 +32,17 @@ __device__ __forceinline__ int reflect101c(int i, int n) {
 constexpr uint32_t pk(uint32_t lo, uint32_t hi) { return lo | (hi << 16); }
 }  // namespace
 
-__global__ __launch_bounds__(256) void k_blur7(LevelView src, LevelViewMut dst, int tilesX, int tilesY,
-                                               int nFrames) {
+// All pyramid levels of all frames in ONE launch (the levels are independent): the grid is the
+// concatenation of every level's tiles, tileStart[l] = first work item of level l.
+struct BlurBatch {
+  LevelView src[kMaxLevels];
+  LevelViewMut dst[kMaxLevels];
+  int tilesX[kMaxLevels], tilesY[kMaxLevels];
+  unsigned tileStart[kMaxLevels + 1];  // in units of (tile, frame) work items
+  int nlevels, nFrames;
+};
+
+__global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   __shared__ uint32_t tin[kTH * kTDW];             // source bytes
   __shared__ uint2 vbuf[kBH * kTDW];               // vertical sums, 4 u16 per entry
   const int tid = threadIdx.x;
@@ -41,33 +50,49 @@ __global__ __launch_bounds__(256) void k_blur7(LevelView src, LevelViewMut dst, 
   // tiles one XCD's L2 sees are a contiguous raster run and share their halo rows there
   const unsigned chunk = gridDim.x >> 3;
   const unsigned work = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
-  const unsigned perFrame = (unsigned)tilesX * (unsigned)tilesY;
-  if (work >= perFrame * (unsigned)nFrames) return;
-  const int f = (int)(work / perFrame);
-  const unsigned rem = work - (unsigned)f * perFrame;
+  if (work >= bb.tileStart[bb.nlevels]) return;
+  int l = 0;
+  for (int k = 1; k < bb.nlevels; k++)
+    if (work >= bb.tileStart[k]) l = k;   // block-uniform (scalar) search
+  const LevelView src = bb.src[l];
+  const LevelViewMut dst = bb.dst[l];
+  const int tilesX = bb.tilesX[l];
+  const unsigned perFrame = (unsigned)tilesX * (unsigned)bb.tilesY[l];
+  const unsigned w0 = work - bb.tileStart[l];
+  const int f = (int)(w0 / perFrame);
+  const unsigned rem = w0 - (unsigned)f * perFrame;
   const int tyI = (int)(rem / (unsigned)tilesX);
   const int bx = (int)(rem - (unsigned)tyI * (unsigned)tilesX) * kBW, by = tyI * kBH;
   const uint8_t* S = src.base + (size_t)f * src.frameStride;
-  const bool aligned = (src.pitch & 3) == 0;
+  const bool aligned = (src.pitch & 3) == 0 && (reinterpret_cast<uintptr_t>(S) & 3) == 0;
   // ---- 1. stage ----
-  for (int i = tid; i < kTH * kTDW; i += 256) {
-    const int ty = i / kTDW, tj = i - ty * kTDW;
-    const int sy = reflect101c(by - 3 + ty, src.h);
-    const int c = bx - 4 + 4 * tj;
-    const uint8_t* row = S + (size_t)sy * src.pitch;
-    uint32_t v;
-    if (aligned && c >= 0 && c + 3 < src.w) {
-      const uintptr_t ad = reinterpret_cast<uintptr_t>(row + c);
-      const uint32_t a = (uint32_t)(ad & 3);
-      const uint32_t* p = reinterpret_cast<const uint32_t*>(ad - a);
-      const uint32_t lo = p[0];
-      const uint32_t hi = a ? p[1] : 0u;  // stays inside the row: c+3 < w <= pitch
-      v = __builtin_amdgcn_alignbyte(hi, lo, a);
-    } else {
-      v = (uint32_t)row[reflect101c(c, src.w)] | ((uint32_t)row[reflect101c(c + 1, src.w)] << 8) |
-          ((uint32_t)row[reflect101c(c + 2, src.w)] << 16) | ((uint32_t)row[reflect101c(c + 3, src.w)] << 24);
+  if (aligned && bx >= 4 && bx + kBW + 4 <= src.w && by >= 3 && by + kBH + 3 <= src.h) {
+    // interior tile (block-uniform): no reflection, every dword is an aligned in-row load
+    const uint8_t* T = S + (size_t)(by - 3) * src.pitch + (bx - 4);
+    for (int i = tid; i < kTH * kTDW; i += 256) {
+      const int ty = i / kTDW, tj = i - ty * kTDW;
+      tin[i] = *reinterpret_cast<const uint32_t*>(T + (size_t)ty * src.pitch + 4 * tj);
     }
-    tin[i] = v;
+  } else {
+    for (int i = tid; i < kTH * kTDW; i += 256) {
+      const int ty = i / kTDW, tj = i - ty * kTDW;
+      const int sy = reflect101c(by - 3 + ty, src.h);
+      const int c = bx - 4 + 4 * tj;
+      const uint8_t* row = S + (size_t)sy * src.pitch;
+      uint32_t v;
+      if ((src.pitch & 3) == 0 && c >= 0 && c + 3 < src.w) {
+        const uintptr_t ad = reinterpret_cast<uintptr_t>(row + c);
+        const uint32_t a = (uint32_t)(ad & 3);
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(ad - a);
+        const uint32_t lo = p[0];
+        const uint32_t hi = a ? p[1] : 0u;  // stays inside the row: c+3 < w <= pitch
+        v = __builtin_amdgcn_alignbyte(hi, lo, a);
+      } else {
+        v = (uint32_t)row[reflect101c(c, src.w)] | ((uint32_t)row[reflect101c(c + 1, src.w)] << 8) |
+            ((uint32_t)row[reflect101c(c + 2, src.w)] << 16) | ((uint32_t)row[reflect101c(c + 3, src.w)] << 24);
+      }
+      tin[i] = v;
+    }
   }
   __syncthreads();
   // ---- 2. vertical pass: 8.8 sums of 4 adjacent columns, packed two pixels per lane-op ----
@@ -126,11 +151,28 @@ __global__ __launch_bounds__(256) void k_blur7(LevelView src, LevelViewMut dst, 
   }
 }
 
+void launch_blur7_levels(hipStream_t s, const LevelView* src, const LevelViewMut* dst, int nlevels, int nFrames) {
+  if (nlevels <= 0 || nFrames <= 0) return;
+  BlurBatch bb = {};
+  bb.nlevels = nlevels;
+  bb.nFrames = nFrames;
+  unsigned total = 0;
+  for (int l = 0; l < nlevels; l++) {
+    bb.src[l] = src[l];
+    bb.dst[l] = dst[l];
+    bb.tilesX[l] = (dst[l].w + kBW - 1) / kBW;
+    bb.tilesY[l] = (dst[l].h + kBH - 1) / kBH;
+    bb.tileStart[l] = total;
+    total += (unsigned)bb.tilesX[l] * (unsigned)bb.tilesY[l] * (unsigned)nFrames;
+  }
+  bb.tileStart[nlevels] = total;
+  if (total == 0) return;
+  hipLaunchKernelGGL(k_blur7, dim3((total + 7u) / 8u * 8u), dim3(256), 0, s, bb);
+}
+
 void launch_blur7(hipStream_t s, LevelView src, LevelViewMut dst, int nFrames) {
-  if (dst.w <= 0 || dst.h <= 0 || nFrames <= 0) return;
-  const int tilesX = (dst.w + kBW - 1) / kBW, tilesY = (dst.h + kBH - 1) / kBH;
-  const unsigned total = (unsigned)tilesX * (unsigned)tilesY * (unsigned)nFrames;
-  hipLaunchKernelGGL(k_blur7, dim3((total + 7u) / 8u * 8u), dim3(256), 0, s, src, dst, tilesX, tilesY, nFrames);
+  if (dst.w <= 0 || dst.h <= 0) return;
+  launch_blur7_levels(s, &src, &dst, 1, nFrames);
 }
 
 }  // namespace orbfe

@@ -74,6 +74,7 @@ hipError_t launch_octree(hipStream_t s, const OctreeArgs& a, int nlevels, int nF
 
 // ---- blur (GaussianBlur 7x7 sigma 2 reflect-101, :1169-1175) ----
 void launch_blur7(hipStream_t s, LevelView src, LevelViewMut dst, int nFrames);
+void launch_blur7_levels(hipStream_t s, const LevelView* src, const LevelViewMut* dst, int nlevels, int nFrames);
 
 // ---- orientation + descriptor + final keypoint record (:78-152, :905-916, :1187-1195) ----
 struct OrientDescArgs {
