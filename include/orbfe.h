@@ -249,6 +249,46 @@ int orbfe_stereo_match_batch_device(orbfe_extractor *e, int n_pairs, const orbfe
                                     float mbf, float mb, float *d_uRight, float *d_depth,
                                     int32_t *d_n_stereo);
 
+/* ------------------------------------------------------------------------- */
+/* DBoW2 vocabulary (the step right before SearchByBoW)       */
+/* ------------------------------------------------------------------------- */
+typedef struct orbfe_vocabulary orbfe_vocabulary;
+
+/* TemplatedVocabulary::loadFromTextFile (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1424):
+ * first line "k L scoring weighting", then one node per line "parent is_leaf d0..d31 weight".
+ * Deviation: empty lines are ignored (the reference turns the file's trailing empty line into a
+ * child of the root with an UNINITIALISED descriptor). */
+int orbfe_vocabulary_load_text(const char *path, int device, orbfe_vocabulary **out);
+void orbfe_vocabulary_destroy(orbfe_vocabulary *v);
+int orbfe_vocabulary_info(const orbfe_vocabulary *v, int *k, int *L, int *n_nodes, int *n_words);
+
+/* transform(feature, word_id, weight, nid, levelsup) (:1218-1259) for n host descriptors: the
+ * k-ary descent with FORB::distance.  Features with weight > 0 are the ones transform(features,
+ * BowVector&, FeatureVector&, levelsup) (:1127-1194; called with levelsup = 4 at src/Frame.cc:438)
+ * adds as BowVector.addWeight(word_id, weight) / FeatureVector.addFeature(node_id, i).  Returns
+ * their number, or a negative status. */
+int orbfe_vocabulary_transform(orbfe_vocabulary *v, const uint8_t *descriptors, int n, int levelsup,
+                               uint32_t *word_id, double *weight, uint32_t *node_id);
+
+/* Frame::ComputeBoW for every frame of a device-resident extractor batch: FeatureVector f as CSR at
+ * d_fv_nodes[f*capacity ..] (ascending, d_fv_count[f] of them), d_fv_offsets[f*(capacity+1) ..],
+ * d_fv_indices[f*capacity ..]; optional per-feature word ids / weights (both or neither). */
+int orbfe_vocabulary_featvec_batch_device(orbfe_vocabulary *v, const uint8_t *d_descriptors,
+                                          const int32_t *d_n, int n_frames, int capacity, int levelsup,
+                                          uint32_t *d_fv_nodes, int32_t *d_fv_offsets,
+                                          uint32_t *d_fv_indices, int32_t *d_fv_count, uint32_t *d_word,
+                                          double *d_weight);
+
+/* ComputeBoW + SearchByBoW(KF = frame t-1, F = frame t) for t = 1..n_frames-1 of a device-resident
+ * batch (every KF feature counts as having a MapPoint): d_match[(t-1)*capacity + j] = index of the
+ * frame t-1 feature matched to feature j of frame t, or -1; d_nmatches[t-1] = nmatches. */
+int orbfe_bow_match_consecutive_batch_device(orbfe_vocabulary *v, int n_frames,
+                                             const orbfe_keypoint *d_keypoints,
+                                             const uint8_t *d_descriptors, const int32_t *d_n,
+                                             int capacity, int levelsup, float nnratio,
+                                             int check_orientation, int32_t *d_match,
+                                             int32_t *d_nmatches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,7 @@
 
 #include <float.h>
 #include <limits.h>
+#include <stdio.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1149,4 +1150,110 @@ int orc_compute_stereo_matches(const orc_extractor *e, int W, int H, const orc_k
   free(rowCnt);
   free(vDistIdx);
   return cnt;
+}
+
+/* ------------------------------------------------------------------ */
+/* DBoW2 vocabulary: text loader and transform                         */
+/* Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1424, 1127-1259   */
+/* ------------------------------------------------------------------ */
+orc_vocab *orc_vocab_load_text(const char *path) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return NULL;
+  fseek(f, 0, SEEK_END);
+  long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  char *txt = (char *)malloc((size_t)sz + 1);
+  if (fread(txt, 1, (size_t)sz, f) != (size_t)sz) { fclose(f); free(txt); return NULL; }
+  fclose(f);
+  txt[sz] = 0;
+  orc_vocab *v = (orc_vocab *)calloc(1, sizeof(orc_vocab));
+  char *line = txt, *end;
+  /* header: k L scoring weighting (:1351-1362) */
+  end = strchr(line, '\n');
+  if (end) *end = 0;
+  int n1 = -1, n2 = -1;
+  if (sscanf(line, "%d %d %d %d", &v->k, &v->L, &n1, &n2) != 4 || v->k < 0 || v->k > 20 || v->L < 1 ||
+      v->L > 10 || n1 < 0 || n1 > 5 || n2 < 0 || n2 > 3) { free(txt); free(v); return NULL; }
+  v->scoring = n1;
+  v->weighting = n2;
+  int cap = 1024, n = 1;
+  v->parent = (int32_t *)malloc(sizeof(int32_t) * cap);
+  v->desc = (uint8_t *)calloc((size_t)cap * 32, 1);
+  v->weight = (double *)calloc(cap, sizeof(double));
+  v->word_id = (int32_t *)malloc(sizeof(int32_t) * cap);
+  v->parent[0] = 0;
+  v->word_id[0] = -1;
+  line = end ? end + 1 : txt + sz;
+  while (line < txt + sz) {
+    end = strchr(line, '\n');
+    if (end) *end = 0;
+    char *p = line;
+    while (*p == ' ' || *p == '\t' || *p == '\r') p++;
+    if (*p) { /* non-empty line = one node (:1374-1417) */
+      if (n == cap) {
+        cap *= 2;
+        v->parent = (int32_t *)realloc(v->parent, sizeof(int32_t) * cap);
+        v->desc = (uint8_t *)realloc(v->desc, (size_t)cap * 32);
+        v->weight = (double *)realloc(v->weight, sizeof(double) * cap);
+        v->word_id = (int32_t *)realloc(v->word_id, sizeof(int32_t) * cap);
+      }
+      char *q;
+      long pid = strtol(p, &q, 10);
+      long leaf = strtol(q, &q, 10);
+      for (int i = 0; i < 32; i++) v->desc[(size_t)n * 32 + i] = (uint8_t)strtol(q, &q, 10);
+      v->weight[n] = strtod(q, &q);
+      v->parent[n] = (int32_t)pid;
+      v->word_id[n] = leaf > 0 ? v->n_words++ : -1;
+      n++;
+    }
+    line = end ? end + 1 : txt + sz;
+  }
+  v->n_nodes = n;
+  /* children lists in file order */
+  v->child_off = (int32_t *)calloc((size_t)n + 1, sizeof(int32_t));
+  v->child_idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 1 ? n - 1 : 1));
+  for (int i = 1; i < n; i++) v->child_off[v->parent[i] + 1]++;
+  for (int i = 0; i < n; i++) v->child_off[i + 1] += v->child_off[i];
+  int32_t *cur = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+  memcpy(cur, v->child_off, sizeof(int32_t) * (size_t)n);
+  for (int i = 1; i < n; i++) v->child_idx[cur[v->parent[i]]++] = i;
+  free(cur);
+  free(txt);
+  return v;
+}
+
+void orc_vocab_free(orc_vocab *v) {
+  if (!v) return;
+  free(v->parent); free(v->child_off); free(v->child_idx); free(v->desc); free(v->weight); free(v->word_id);
+  free(v);
+}
+
+int orc_vocab_transform(const orc_vocab *v, const uint8_t *desc, int n, int levelsup, uint32_t *word_id,
+                        double *weight, uint32_t *node_id) {
+  int used = 0;
+  const int nid_level = v->L - levelsup;
+  for (int i = 0; i < n; i++) {
+    word_id[i] = 0; weight[i] = 0; node_id[i] = 0;
+    if (v->child_off[1] == v->child_off[0]) continue; /* empty vocabulary (:1134) */
+    const uint8_t *fd = desc + (size_t)i * 32;
+    int final_id = 0, current_level = 0;
+    uint32_t nid = 0; /* root when nid_level <= 0 (:1228) */
+    do {
+      ++current_level;
+      const int b = v->child_off[final_id], e = v->child_off[final_id + 1];
+      final_id = v->child_idx[b];
+      int best_d = orc_descriptor_distance(fd, v->desc + (size_t)final_id * 32); /* FORB::distance */
+      for (int c = b + 1; c < e; c++) {
+        const int id = v->child_idx[c];
+        const int d = orc_descriptor_distance(fd, v->desc + (size_t)id * 32);
+        if (d < best_d) { best_d = d; final_id = id; }
+      }
+      if (current_level == nid_level) nid = (uint32_t)final_id;
+    } while (v->child_off[final_id + 1] > v->child_off[final_id]);
+    word_id[i] = v->word_id[final_id] >= 0 ? (uint32_t)v->word_id[final_id] : 0u;
+    weight[i] = v->weight[final_id];
+    node_id[i] = nid;
+    if (weight[i] > 0) used++;
+  }
+  return used;
 }

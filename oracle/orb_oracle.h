@@ -135,6 +135,28 @@ int orc_compute_stereo_matches(const orc_extractor *e, int W, int H, const orc_k
                                const uint8_t *pyrR, float mbf, float mb, float *uRight,
                                float *depth);
 
+/* ---- DBoW2 vocabulary (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h) ---- */
+typedef struct orc_vocab {
+  int k, L, scoring, weighting;
+  int n_nodes, n_words;
+  int32_t *parent;     /* [n_nodes] */
+  int32_t *child_off;  /* [n_nodes+1] into child_idx, children in file order */
+  int32_t *child_idx;
+  uint8_t *desc;       /* [n_nodes*32] */
+  double *weight;      /* [n_nodes] */
+  int32_t *word_id;    /* [n_nodes], -1 when the node is not a word */
+} orc_vocab;
+
+/* loadFromTextFile (:1338-1424).  Deviation: an empty (trailing) line is ignored; the reference
+ * turns it into a child of the root with an UNINITIALISED descriptor (UB). */
+orc_vocab *orc_vocab_load_text(const char *path);
+void orc_vocab_free(orc_vocab *v);
+/* transform(feature, word_id, weight, nid, levelsup) (:1218-1259) for n features.
+ * Returns the number of features with weight > 0 (the ones transform(features,...) :1127-1194
+ * adds to the Bow/Feature vectors). */
+int orc_vocab_transform(const orc_vocab *v, const uint8_t *desc, int n, int levelsup,
+                        uint32_t *word_id, double *weight, uint32_t *node_id);
+
 #ifdef __cplusplus
 }
 #endif

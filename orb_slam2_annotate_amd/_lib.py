@@ -44,7 +44,9 @@ EXPORTS = [
     "orbfe_extractor_debug_blurred_level", "orbfe_extractor_debug_host_octree", "orbfe_extractor_set_streams", "orbfe_extractor_profile", "orbfe_extractor_profile_get",
     "orbfe_stage_name", "orbfe_resize_linear", "orbfe_gaussian_blur7", "orbfe_descriptor_distance",
     "orbfe_hamming_matrix", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",
-    "orbfe_search_for_triangulation", "orbfe_compute_stereo_matches", "orbfe_stereo_match_batch_device",
+    "orbfe_search_for_triangulation", "orbfe_compute_stereo_matches", "orbfe_stereo_match_batch_device", "orbfe_vocabulary_load_text", "orbfe_vocabulary_destroy",
+    "orbfe_vocabulary_info", "orbfe_vocabulary_transform", "orbfe_vocabulary_featvec_batch_device",
+    "orbfe_bow_match_consecutive_batch_device",
 ]
 
 _lib = None
@@ -124,6 +126,13 @@ def load():
                                                  ci, fvp, vp, cf, cf, vp, vp, ci, ci, ci, vp]
     L.orbfe_compute_stereo_matches.argtypes = [vp, ci, vp, ci, vp, vp, ci, vp, vp, ci, cf, cf, vp, vp]
     L.orbfe_stereo_match_batch_device.argtypes = [vp, ci, vp, vp, vp, ci, cf, cf, vp, vp, vp]
+    L.orbfe_vocabulary_load_text.argtypes = [C.c_char_p, ci, C.POINTER(C.c_void_p)]
+    L.orbfe_vocabulary_destroy.argtypes = [vp]
+    L.orbfe_vocabulary_destroy.restype = None
+    L.orbfe_vocabulary_info.argtypes = [vp, vp, vp, vp, vp]
+    L.orbfe_vocabulary_transform.argtypes = [vp, vp, ci, ci, vp, vp, vp]
+    L.orbfe_vocabulary_featvec_batch_device.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp]
+    L.orbfe_bow_match_consecutive_batch_device.argtypes = [vp, ci, vp, vp, vp, ci, ci, cf, ci, vp, vp]
     _lib = L
     return L
 

@@ -33,7 +33,7 @@ static int fail(int code, const std::string& msg) {
   } while (0)
 
 extern "C" const char* orbfe_last_error(void) { return g_err.c_str(); }
-int orbfe_set_error_(int code, const char* msg) { return fail(code, msg); }  // used by matcher.hip
+int orbfe_set_error_(int code, const char* msg) { return fail(code, msg); }  // used by matcher.hip, vocabulary.hip
 extern "C" int orbfe_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -85,15 +85,13 @@ void launch_hamming_matrix(hipStream_t s, const uint8_t* d1, int n1, const uint8
 // node.  Queries inside a node are sequential (a frame feature claimed by an earlier query is
 // skipped by later ones, :242-244/:664,691); different nodes never interact.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_search_by_bow(BowArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t claimed[];  // per position in node 2
-  const int lane = threadIdx.x;
-  const NodePair np = a.pairs[blockIdx.x];
+// one shared vocabulary node: the wave scans node-2 for every node-1 feature, in order
+__device__ __forceinline__ void bow_node(const BowArgs& a, const NodePair np, int lane, uint8_t* claimed) {
   for (int i = lane; i < np.cnt2; i += 64) claimed[i] = 0;
   __syncthreads();
   for (int q = 0; q < np.cnt1; q++) {
     const uint32_t idx1 = a.indices1[np.off1 + q];
-    if (!a.hasMp1[idx1]) continue;  // wave-uniform
+    if (a.hasMp1 && !a.hasMp1[idx1]) continue;  // wave-uniform (NULL: every feature has a MapPoint)
     const Desc d1 = load_desc(a.desc1, idx1);
     uint32_t key1 = (256u << 16) | 0xffffu;  // (bestDist1, position) -- first minimum wins
     uint32_t best2 = 256u;
@@ -122,17 +120,59 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowArgs a) {
       if (lane == 0) {
         claimed[pos] = 1;
         const uint32_t idx2 = a.indices2[np.off2 + pos];
+        const int bin = rot_bin(a.angle1[(size_t)idx1 * a.angleStride], a.angle2[(size_t)idx2 * a.angleStride]);
         if (a.strictLow) {  // KF-KF: vpMatches12[idx1] = MapPoint of idx2; histogram holds idx1
           a.match[idx1] = (int32_t)idx2;
-          a.bin[idx1] = (int8_t)rot_bin(a.angle1[idx1], a.angle2[idx2]);
+          a.bin[idx1] = (int8_t)bin;
         } else {            // KF-Frame: vpMapPointMatches[idxF] = MapPoint of idxKF; histogram holds idxF
           a.match[idx2] = (int32_t)idx1;
-          a.bin[idx2] = (int8_t)rot_bin(a.angle1[idx1], a.angle2[idx2]);
+          a.bin[idx2] = (int8_t)bin;
         }
       }
       __syncthreads();  // single-wave block: orders the LDS claim before the next query
     }
   }
+}
+
+__global__ __launch_bounds__(64) void k_search_by_bow(BowArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t claimed[];  // per position in node 2
+  bow_node(a, a.pairs[blockIdx.x], threadIdx.x, claimed);
+}
+
+// Device-resident batch: pair p = SearchByBoW(KF = frame p, F = frame p+1) with the FeatureVectors
+// built by k_vocab_featvec.  Block (i, p) takes the i-th node of frame p and looks the same node
+// id up in frame p+1 (the merge-walk of :211-300 as a binary search over the ascending ids).
+__global__ __launch_bounds__(64) void k_search_by_bow_batch(BowBatch b) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t claimed[];
+  const int lane = threadIdx.x, i = blockIdx.x, p = blockIdx.y;
+  const int n1 = b.fvCount[p], n2 = b.fvCount[p + 1];
+  if (i >= n1) return;
+  const size_t c = (size_t)b.capacity;
+  const uint32_t* nodes1 = b.fvNodes + (size_t)p * c;
+  const uint32_t* nodes2 = b.fvNodes + (size_t)(p + 1) * c;
+  const int32_t* off1 = b.fvOffsets + (size_t)p * (c + 1);
+  const int32_t* off2 = b.fvOffsets + (size_t)(p + 1) * (c + 1);
+  const uint32_t id = nodes1[i];
+  int lo = 0, hi = n2;  // lower_bound
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (nodes2[mid] < id) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= n2 || nodes2[lo] != id) return;
+  BowArgs a = {};
+  a.desc1 = b.desc + (size_t)p * c * 32;
+  a.desc2 = b.desc + (size_t)(p + 1) * c * 32;
+  a.indices1 = b.fvIndices + (size_t)p * c;
+  a.indices2 = b.fvIndices + (size_t)(p + 1) * c;
+  a.angle1 = b.kp + (size_t)p * c * 7 + 3;        // cv::KeyPoint::angle
+  a.angle2 = b.kp + (size_t)(p + 1) * c * 7 + 3;
+  a.angleStride = 7;
+  a.nnratio = b.nnratio;
+  a.strictLow = 0;
+  a.match = b.match + (size_t)p * c;
+  a.bin = b.bin + (size_t)p * c;
+  const NodePair np = {off1[i], off1[i + 1] - off1[i], off2[lo], off2[lo + 1] - off2[lo]};
+  bow_node(a, np, lane, claimed);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -190,7 +230,11 @@ __global__ __launch_bounds__(256) void k_search_triangulation(TriArgs a) {
 // Rotation-consistency pruning shared by the three searches (:303-322, ComputeThreeMaxima
 // :1777-1821): one workgroup histograms the accepted matches, keeps the three dominant bins.
 __global__ __launch_bounds__(256) void k_rot_prune(int32_t* __restrict__ match, const int8_t* __restrict__ bin,
-                                                   int n, int checkOri, int32_t* __restrict__ nMatches) {
+                                                   int n, int checkOri, int32_t* __restrict__ nMatches,
+                                                   int batchStride) {
+  match += (size_t)blockIdx.x * batchStride;  // one workgroup per match array of a batch
+  bin += (size_t)blockIdx.x * batchStride;
+  nMatches += blockIdx.x;
   __shared__ int hist[30];
   __shared__ int keep[3];
   __shared__ int total;
@@ -239,7 +283,14 @@ void launch_search_triangulation(hipStream_t s, const TriArgs& a) {
   hipLaunchKernelGGL(k_search_triangulation, dim3((a.nQueries + 3) / 4), dim3(256), 0, s, a);
 }
 void launch_rot_prune(hipStream_t s, int32_t* match, const int8_t* bin, int n, int checkOri, int32_t* nMatches) {
-  hipLaunchKernelGGL(k_rot_prune, dim3(1), dim3(256), 0, s, match, bin, n, checkOri, nMatches);
+  hipLaunchKernelGGL(k_rot_prune, dim3(1), dim3(256), 0, s, match, bin, n, checkOri, nMatches, 0);
+}
+void launch_search_by_bow_batch(hipStream_t s, const BowBatch& b, int nPairs, int checkOri, int32_t* d_nMatches) {
+  if (nPairs <= 0 || b.capacity <= 0) return;
+  const size_t lds = (size_t)((b.capacity + 15) & ~15);
+  hipLaunchKernelGGL(k_search_by_bow_batch, dim3(b.capacity, nPairs), dim3(64), lds, s, b);
+  hipLaunchKernelGGL(k_rot_prune, dim3(nPairs), dim3(256), 0, s, b.match, b.bin, b.capacity, checkOri, d_nMatches,
+                     b.capacity);
 }
 
 // ---------------------------------------------------------------------------------------

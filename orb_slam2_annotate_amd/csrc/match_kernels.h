@@ -12,9 +12,10 @@ struct NodePair {  // one vocabulary node present in both FeatureVectors
 
 struct BowArgs {
   const NodePair* pairs;
-  const uint8_t* desc1; const uint8_t* hasMp1; const float* angle1; const uint32_t* indices1;
+  const uint8_t* desc1; const uint8_t* hasMp1 /* NULL: all set */; const float* angle1; const uint32_t* indices1;
   const uint8_t* desc2; const uint8_t* hasMp2 /* NULL for the KF-Frame form */; const float* angle2;
   const uint32_t* indices2;
+  int angleStride;  // floats between consecutive angles (1 for plain arrays, 7 inside cv::KeyPoint records)
   float nnratio;
   int strictLow;   // 0: SearchByBoW(KF,F) accepts best <= TH_LOW; 1: (KF,KF) best < TH_LOW
   int32_t* match;  // KF-Frame: indexed by frame feature; KF-KF: indexed by KF1 feature
@@ -50,7 +51,36 @@ struct StereoBatch {  // frames 2p / 2p+1 of an extractor batch are the left / r
   float* uRight; float* depth; int32_t* sad;   // [nPairs * capacity]
 };
 
+// DBoW2 vocabulary tree on the device (vocabulary.hip)
+struct VocabDevice {
+  const uint8_t* desc;      // [nNodes][32]
+  const int32_t* childOff;  // [nNodes+1]
+  const int32_t* childIdx;  // children in file order
+  const int32_t* wordId;    // -1 when the node is not a word
+  const double* weight;
+};
+
+// Batched FeatureVector construction: frame f uses desc[f*capacity ..], n[f] descriptors
+struct FeatVecBatch {
+  const uint8_t* desc; const int32_t* n; int capacity;
+  int sortN;                 // power of two >= capacity
+  uint32_t* word; double* weight;          // optional per-feature outputs [nFrames*capacity]
+  uint32_t* fvNodes;         // [nFrames*capacity] node ids ascending
+  int32_t* fvOffsets;        // [nFrames*(capacity+1)]
+  uint32_t* fvIndices;       // [nFrames*capacity]
+  int32_t* fvCount;          // [nFrames] nodes per frame
+};
+void launch_vocab_featvec(hipStream_t s, const VocabDevice& v, const FeatVecBatch& b, int nFrames, int nidLevel);
+
+struct BowBatch {  // consecutive-frame SearchByBoW over a device-resident batch
+  const float* kp; const uint8_t* desc; int capacity;
+  const uint32_t* fvNodes; const int32_t* fvOffsets; const uint32_t* fvIndices; const int32_t* fvCount;
+  float nnratio;
+  int32_t* match; int8_t* bin;  // [nPairs*capacity], match pre-set to -1
+};
+
 void launch_search_by_bow(hipStream_t s, const BowArgs& a, int nPairs, int maxCnt2);
+void launch_search_by_bow_batch(hipStream_t s, const BowBatch& b, int nPairs, int checkOri, int32_t* d_nMatches);
 void launch_search_triangulation(hipStream_t s, const TriArgs& a);
 void launch_rot_prune(hipStream_t s, int32_t* match, const int8_t* bin, int n, int checkOri, int32_t* nMatches);
 void launch_stereo(hipStream_t s, const StereoArgs& a, int32_t* d_nStereo);

@@ -193,6 +193,7 @@ static int bow_common(int device, const uint8_t* desc1, const uint8_t* has_mp1, 
   MHIP(hipMemsetAsync(dbin, 0, (size_t)nOut, ar->stream));
   a.pairs = dp; a.desc1 = dd1; a.hasMp1 = dm1; a.angle1 = da1; a.indices1 = di1;
   a.desc2 = dd2; a.hasMp2 = dm2; a.angle2 = da2; a.indices2 = di2;
+  a.angleStride = 1;
   a.nnratio = nnratio; a.strictLow = kfkf; a.match = dmatch; a.bin = dbin;
   launch_search_by_bow(ar->stream, a, (int)pairs.size(), maxCnt2);
   launch_rot_prune(ar->stream, dmatch, dbin, nOut, check_ori, dcount);

@@ -1,0 +1,109 @@
+"""Python mirror of ``ORB_SLAM2::ORBVocabulary`` (DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>,
+reference: include/ORBVocabulary.h, Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h) for the calls next to
+the hot path: loadFromTextFile and transform (Frame::ComputeBoW, src/Frame.cc:433-440)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, ptr
+from .matcher import FeatureVector
+
+
+class ORBVocabulary:
+    def __init__(self, device: int = 0):
+        self._L = _lib.load()
+        self._h = None
+        self.device = device
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.orbfe_vocabulary_destroy(self._h)
+            self._h = None
+
+    def loadFromTextFile(self, filename: str) -> bool:
+        h = C.c_void_p()
+        rc = self._L.orbfe_vocabulary_load_text(str(filename).encode(), self.device, C.byref(h))
+        if rc != 0:
+            return False
+        if self._h:
+            self._L.orbfe_vocabulary_destroy(self._h)
+        self._h = h
+        return True
+
+    def info(self):
+        k, L, n, w = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(self._L.orbfe_vocabulary_info(self._h, C.byref(k), C.byref(L), C.byref(n), C.byref(w)))
+        return dict(k=k.value, L=L.value, nodes=n.value, words=w.value)
+
+    def transform_features(self, descriptors, levelsup: int = 4):
+        """Per-feature (word_id, weight, node_id) of transform(feature, ...)."""
+        d = np.ascontiguousarray(descriptors, dtype=np.uint8).reshape(-1, 32)
+        n = len(d)
+        word = np.zeros(max(n, 1), np.uint32)
+        weight = np.zeros(max(n, 1), np.float64)
+        node = np.zeros(max(n, 1), np.uint32)
+        check(self._L.orbfe_vocabulary_transform(self._h, ptr(d), n, levelsup, ptr(word), ptr(weight), ptr(node)))
+        return word[:n], weight[:n], node[:n]
+
+    def transform(self, descriptors, levelsup: int = 4):
+        """transform(features, BowVector&, FeatureVector&, levelsup): returns (bow, featvec) where bow
+        is {word_id: value} (TF-IDF weights summed in feature order, L1-normalised for the L1 scoring
+        the ORB vocabulary uses) and featvec a FeatureVector (CSR)."""
+        word, weight, node = self.transform_features(descriptors, levelsup)
+        bow = {}
+        used = np.nonzero(weight > 0)[0]
+        for i in used:  # BowVector::addWeight in feature order (BowVector.cpp:34-46)
+            bow[int(word[i])] = bow.get(int(word[i]), 0.0) + float(weight[i])
+        norm = sum(abs(x) for _, x in sorted(bow.items()))  # normalize(L1), ascending word order
+        if norm > 0:
+            bow = {k: x / norm for k, x in bow.items()}
+        nodes = node[used]
+        ids, counts = np.unique(nodes, return_counts=True)
+        order = used[np.argsort(nodes, kind="stable")]
+        fv = FeatureVector(ids, np.concatenate([[0], np.cumsum(counts)]), order)
+        return bow, fv
+
+    def featvec_batch_device(self, d_desc, d_n, n_frames, capacity, d_nodes, d_offsets, d_indices, d_count,
+                             levelsup: int = 4, d_word=0, d_weight=0):
+        check(self._L.orbfe_vocabulary_featvec_batch_device(self._h, C.c_void_p(d_desc), C.c_void_p(d_n), n_frames,
+                                                            capacity, levelsup, C.c_void_p(d_nodes),
+                                                            C.c_void_p(d_offsets), C.c_void_p(d_indices),
+                                                            C.c_void_p(d_count), C.c_void_p(d_word or None),
+                                                            C.c_void_p(d_weight or None)))
+
+    def bow_match_consecutive_batch_device(self, n_frames, d_kp, d_desc, d_n, capacity, d_match, d_nmatches,
+                                           nnratio: float = 0.7, check_orientation: bool = True, levelsup: int = 4):
+        check(self._L.orbfe_bow_match_consecutive_batch_device(self._h, n_frames, C.c_void_p(d_kp), C.c_void_p(d_desc),
+                                                               C.c_void_p(d_n), capacity, levelsup, float(nnratio),
+                                                               int(bool(check_orientation)), C.c_void_p(d_match),
+                                                               C.c_void_p(d_nmatches)))
+
+
+def write_synthetic_vocabulary(path, k: int = 10, L: int = 2, seed: int = 0, flip_bits: int = 60):
+    """A seeded k-ary, L-level ORB vocabulary in DBoW2's text format (the real ORBvoc.txt is absent from
+    the reference, .MISSING_LARGE_BLOBS): children are their parent's centroid with `flip_bits` random bits
+    flipped, leaves carry a positive IDF-like weight.  Nodes are written breadth-first like DBoW2 saves them."""
+    rng = np.random.default_rng([0xB0B0, seed])
+    lines = [f"{k} {L} 0 0"]  # scoring L1_NORM, weighting TF_IDF
+    level = [(0, rng.integers(0, 256, 32, dtype=np.uint8))]  # (node id, descriptor); root descriptor unused
+    next_id = 1
+    for depth in range(1, L + 1):
+        nxt = []
+        for pid, pdesc in level:
+            for _ in range(k):
+                bits = np.unpackbits(pdesc)
+                flip = rng.choice(256, size=flip_bits if depth > 1 else 128, replace=False)
+                bits[flip] ^= 1
+                d = np.packbits(bits)
+                leaf = 1 if depth == L else 0
+                w = float(np.round(rng.uniform(0.5, 6.0), 6)) if leaf else 0.0
+                lines.append(f"{pid} {leaf} " + " ".join(str(int(x)) for x in d) + f" {w:.6f}")
+                nxt.append((next_id, d))
+                next_id += 1
+        level = nxt
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return next_id

@@ -255,3 +255,38 @@ def search_for_triangulation(d1, has_mp1, x1, y1, ang1, st1, fv1, d2, has_mp2, x
                                            C.c_float(ey), _p(sf2), _p(sig2), int(only_stereo), int(check_ori),
                                            _p(out))
     return n, out[:n1].copy()
+
+
+class OrcVocab(C.Structure):
+    _fields_ = [("k", C.c_int), ("L", C.c_int), ("scoring", C.c_int), ("weighting", C.c_int),
+                ("n_nodes", C.c_int), ("n_words", C.c_int), ("parent", C.c_void_p), ("child_off", C.c_void_p),
+                ("child_idx", C.c_void_p), ("desc", C.c_void_p), ("weight", C.c_void_p), ("word_id", C.c_void_p)]
+
+
+class Vocabulary:
+    """oracle restatement of DBoW2 loadFromTextFile + transform"""
+
+    def __init__(self, path):
+        L = lib()
+        L.orc_vocab_load_text.restype = C.POINTER(OrcVocab)
+        L.orc_vocab_load_text.argtypes = [C.c_char_p]
+        L.orc_vocab_free.argtypes = [C.POINTER(OrcVocab)]
+        self.v = L.orc_vocab_load_text(str(path).encode())
+        if not self.v:
+            raise RuntimeError("orc_vocab_load_text failed")
+
+    def __del__(self):
+        if getattr(self, "v", None):
+            lib().orc_vocab_free(self.v)
+            self.v = None
+
+    def info(self):
+        c = self.v.contents
+        return dict(k=c.k, L=c.L, nodes=c.n_nodes, words=c.n_words)
+
+    def transform(self, desc, levelsup=4):
+        d = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+        n = len(d)
+        word = np.zeros(max(n, 1), np.uint32); weight = np.zeros(max(n, 1), np.float64); node = np.zeros(max(n, 1), np.uint32)
+        used = lib().orc_vocab_transform(self.v, _p(d), n, int(levelsup), _p(word), _p(weight), _p(node))
+        return used, word[:n], weight[:n], node[:n]
