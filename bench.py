@@ -35,8 +35,9 @@ WORKLOADS = {
     "kitti": dict(name="KITTI 00 stereo 1241x376 nFeatures=2000 extract L+R + ComputeStereoMatches "
                        "(synthetic stereo pairs; frames/s counts stereo frames)",
                   w=1241, h=376, nfeatures=2000, ini=20, mn=7, stereo=True, bf=386.1448, fx=718.856),
-    "euroc": dict(name="EuRoC MH_01 752x480 nFeatures=1200 extract (synthetic frames)",
-                  w=752, h=480, nfeatures=1200, ini=20, mn=7),
+    "euroc": dict(name="EuRoC MH_01 752x480 nFeatures=1200 extract + ComputeBoW + SearchByBoW(t-1,t) "
+                       "(synthetic frames, synthetic k=10 L=2 vocabulary)",
+                  w=752, h=480, nfeatures=1200, ini=20, mn=7, bow=True),
 }
 
 
@@ -166,16 +167,32 @@ def main():
         d_u = torch.zeros((B, cap), dtype=torch.float32, device=dev)
         d_dep = torch.zeros((B, cap), dtype=torch.float32, device=dev)
         d_ns = torch.zeros((B,), dtype=torch.int32, device=dev)
+    bow = bool(wl.get("bow"))
+    if bow:
+        import tempfile
+        from orb_slam2_annotate_amd.vocabulary import write_synthetic_vocabulary
+        vpath = os.path.join(tempfile.gettempdir(), f"orbfe_voc_{os.getpid()}.txt")
+        write_synthetic_vocabulary(vpath, k=10, L=2, seed=1)
+        voc = amd.ORBVocabulary(device=local_rank)
+        assert voc.loadFromTextFile(vpath)
+        os.unlink(vpath)
+        d_match = torch.zeros((NI - 1, cap), dtype=torch.int32, device=dev)
+        d_nm = torch.zeros((NI - 1,), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
     def step(wait=False):
         ext.extract_batch_device(d_img.data_ptr(), NI, W, H, W, W * H, d_kp.data_ptr(), d_desc.data_ptr(), cap,
-                                 d_n.data_ptr(), wait=wait and not stereo)
+                                 d_n.data_ptr(), wait=wait and not stereo and not bow)
         if stereo:
             ext.stereo_match_batch_device(B, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, float(mbf),
                                           float(mb), d_u.data_ptr(), d_dep.data_ptr(), d_ns.data_ptr())
             if wait:
                 ext.synchronize()
+        if bow:
+            ext.synchronize()  # the vocabulary handle runs on its own stream
+            voc.bow_match_consecutive_batch_device(NI, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap,
+                                                   d_match.data_ptr(), d_nm.data_ptr(), nnratio=0.7,
+                                                   check_orientation=True, levelsup=0)
 
     def barrier():
         ext.synchronize()
@@ -228,6 +245,19 @@ def main():
             u_ref, dep_ref = o.stereo(W, H, kL, dL, kR, dR, pL, pR, float(mbf), float(mb))
             assert np.array_equal(d_u[0, :len(kL)].cpu().numpy(), u_ref), "mvuRight differs from oracle"
             assert np.array_equal(d_dep[0, :len(kL)].cpu().numpy(), dep_ref), "mvDepth differs from oracle"
+        if bow:
+            vpath = os.path.join(tempfile.gettempdir(), f"orbfe_voc_chk_{os.getpid()}.txt")
+            write_synthetic_vocabulary(vpath, k=10, L=2, seed=1)
+            vo = orc.Vocabulary(vpath)
+            os.unlink(vpath)
+            k0, de0 = o.extract(frames[0])
+            k1, de1 = o.extract(frames[1])
+            _, _, _, nd0 = vo.transform(de0, 0)
+            _, _, _, nd1 = vo.transform(de1, 0)
+            rn, rm = orc.search_by_bow(de0, np.ones(len(k0), np.uint8), k0["angle"], orc.FeatVec(nd0), de1,
+                                       k1["angle"], orc.FeatVec(nd1), 0.7, True)
+            assert int(d_nm[0].item()) == rn and np.array_equal(d_match[0, :len(k1)].cpu().numpy(), rm), \
+                "SearchByBoW differs from oracle"
 
     if rank == 0:
         sizes = level_pixels(ext, W, H)
