@@ -289,6 +289,27 @@ int orbfe_bow_match_consecutive_batch_device(orbfe_vocabulary *v, int n_frames,
                                              int check_orientation, int32_t *d_match,
                                              int32_t *d_nmatches);
 
+/* ------------------------------------------------------------------------- */
+/* Next to the path                                */
+/* ------------------------------------------------------------------------- */
+
+/* cv::cvtColor(im, im, CV_RGB2GRAY | CV_BGR2GRAY | CV_RGBA2GRAY | CV_BGRA2GRAY) of
+ * Tracking::GrabImage{Stereo,RGBD,Monocular} (src/Tracking.cc:176-262), 8-bit, channels 3 or 4,
+ * rgb_order != 0 for RGB(A) input: (R*4899 + G*9617 + B*1868 + 2^13) >> 14.  Host buffers. */
+int orbfe_cvt_gray(int device, const uint8_t *src, int width, int height, int stride, int channels,
+                   int rgb_order, uint8_t *dst, int dst_stride);
+/* Same on device-resident frames (so colour input never round-trips through the host). */
+int orbfe_cvt_gray_batch_device(int device, const uint8_t *d_src, int n_frames, int width, int height,
+                                int stride, size_t frame_stride, int channels, int rgb_order,
+                                uint8_t *d_dst, int dst_stride, size_t dst_frame_stride);
+
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:269-333) for n_points map points at once:
+ * map point m owns descriptors [offsets[m], offsets[m+1]) (its observations, 32 bytes each);
+ * best_index[m] = index inside that range of the descriptor with the least median Hamming distance
+ * to the others (median = sorted row [(size_t)(0.5*(n-1))]; first minimum wins), -1 if empty. */
+int orbfe_distinctive_descriptors(int device, const uint8_t *descriptors, const int32_t *offsets,
+                                  int n_points, int32_t *best_index);
+
 #ifdef __cplusplus
 }
 #endif

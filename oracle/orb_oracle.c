@@ -1257,3 +1257,34 @@ int orc_vocab_transform(const orc_vocab *v, const uint8_t *desc, int n, int leve
   }
   return used;
 }
+
+/* ------------------------------------------------------------------ */
+/* MapPoint::ComputeDistinctiveDescriptors: src/MapPoint.cc:269-333    */
+/* ------------------------------------------------------------------ */
+static int int_cmp(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
+int orc_distinctive_descriptor(const uint8_t *desc, int n) {
+  if (n <= 0) return -1;
+  int *row = (int *)malloc(sizeof(int) * n);
+  int bestMedian = INT_MAX, bestIdx = 0;
+  for (int i = 0; i < n; i++) {
+    for (int j = 0; j < n; j++) row[j] = i == j ? 0 : orc_descriptor_distance(desc + (size_t)i * 32, desc + (size_t)j * 32);
+    qsort(row, n, sizeof(int), int_cmp);
+    const int median = row[(size_t)(0.5 * (n - 1))];
+    if (median < bestMedian) { bestMedian = median; bestIdx = i; }
+  }
+  free(row);
+  return bestIdx;
+}
+
+/* ------------------------------------------------------------------ */
+/* cv::cvtColor to gray, 8U: src/Tracking.cc:176-262                   */
+/* ------------------------------------------------------------------ */
+void orc_cvt_gray(const uint8_t *src, int w, int h, int sstride, int channels, int rgb_order,
+                  uint8_t *dst, int dstride) {
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      const uint8_t *p = src + (size_t)y * sstride + (size_t)x * channels;
+      const int r = rgb_order ? p[0] : p[2], g = p[1], b = rgb_order ? p[2] : p[0];
+      dst[(size_t)y * dstride + x] = (uint8_t)((r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14);
+    }
+}

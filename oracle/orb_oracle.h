@@ -135,6 +135,15 @@ int orc_compute_stereo_matches(const orc_extractor *e, int W, int H, const orc_k
                                const uint8_t *pyrR, float mbf, float mb, float *uRight,
                                float *depth);
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:269-333): desc = the n observation
+ * descriptors of one map point; returns the index of the descriptor with the least median
+ * distance to the others (median = sorted row [(size_t)(0.5*(n-1))], first minimum wins). */
+int orc_distinctive_descriptor(const uint8_t *desc, int n);
+/* cv::cvtColor(..., CV_RGB2GRAY / CV_BGR2GRAY / CV_RGBA2GRAY / CV_BGRA2GRAY) on 8U (src/Tracking.cc:
+ * 176-262): (R*4899 + G*9617 + B*1868 + 2^13) >> 14 (OpenCV fixed-point coefficients, yuv_shift 14). */
+void orc_cvt_gray(const uint8_t *src, int w, int h, int sstride, int channels, int rgb_order,
+                  uint8_t *dst, int dstride);
+
 /* ---- DBoW2 vocabulary (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h) ---- */
 typedef struct orc_vocab {
   int k, L, scoring, weighting;

@@ -46,7 +46,8 @@ EXPORTS = [
     "orbfe_hamming_matrix", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",
     "orbfe_search_for_triangulation", "orbfe_compute_stereo_matches", "orbfe_stereo_match_batch_device", "orbfe_vocabulary_load_text", "orbfe_vocabulary_destroy",
     "orbfe_vocabulary_info", "orbfe_vocabulary_transform", "orbfe_vocabulary_featvec_batch_device",
-    "orbfe_bow_match_consecutive_batch_device",
+    "orbfe_bow_match_consecutive_batch_device", "orbfe_cvt_gray", "orbfe_cvt_gray_batch_device",
+    "orbfe_distinctive_descriptors",
 ]
 
 _lib = None
@@ -133,6 +134,9 @@ def load():
     L.orbfe_vocabulary_transform.argtypes = [vp, vp, ci, ci, vp, vp, vp]
     L.orbfe_vocabulary_featvec_batch_device.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp]
     L.orbfe_bow_match_consecutive_batch_device.argtypes = [vp, ci, vp, vp, vp, ci, ci, cf, ci, vp, vp]
+    L.orbfe_cvt_gray.argtypes = [ci, vp, ci, ci, ci, ci, ci, vp, ci]
+    L.orbfe_cvt_gray_batch_device.argtypes = [ci, vp, ci, ci, ci, ci, cs, ci, ci, vp, ci, cs]
+    L.orbfe_distinctive_descriptors.argtypes = [ci, vp, vp, ci, vp]
     _lib = L
     return L
 
