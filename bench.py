@@ -67,16 +67,17 @@ STAGE_KERNELS = {  # kernels (and launches per step) behind each timed stage
 }
 
 
-def pmc_traffic(stage, workload, batch):
-    """HBM bytes per step of the stage's kernels from the committed rocprofv3 --pmc summary
-    (profiles/*_traffic.json, produced by tools/collect_traffic.py); None when no summary matches."""
+def pmc_traffic(stage, workload, batch, frames_per_launch):
+    """HBM bytes per launch of the stage's kernels from the committed rocprofv3 --pmc summary
+    (profiles/*_traffic.json, produced by tools/collect_traffic.py, collected at `batch` frames per
+    launch and scaled to the frames one timed launch processes); None when no summary matches."""
     best = None
     for f in sorted((ROOT / "profiles").glob("*_traffic.json")):
         try:
             t = json.loads(f.read_text())
         except Exception:
             continue
-        if t.get("workload") == workload and t.get("batch") == batch:
+        if t.get("workload") == workload:
             best = t
     if best is None:
         return None
@@ -85,7 +86,7 @@ def pmc_traffic(stage, workload, batch):
         if k not in best["kernels"]:
             return None
         tot += best["kernels"][k]["traffic_bytes_per_launch"] * n
-    return tot
+    return tot * frames_per_launch / best["batch"]
 
 
 def cpu_baseline(frames, wl, seconds=12.0):
@@ -116,11 +117,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frames resident per GPU and processed per step")
+    ap.add_argument("--batch", type=int, default=512, help="frames resident per GPU and processed per step")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="tum")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="verify frame 0 of the batch against the oracle")
-    ap.add_argument("--streams", type=int, default=0, help="sub-batch HIP streams per call (0 = library default)")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="sub-batch HIP streams per call in the timed region (1..4): the HBM-bound descriptor "
+                         "kernel of one sub-batch overlaps the VALU-bound FAST/blur kernels of the others")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for 1 rank")
     args = ap.parse_args()
 
@@ -154,8 +157,6 @@ def main():
         frames = synth.render_sequence(1000 + rank, B, W, H, step=1.5)
     NI = len(frames)  # images resident per GPU
     ext = amd.ORBextractor(wl["nfeatures"], 1.2, 8, wl["ini"], wl["mn"], device=local_rank)
-    if args.streams:
-        ext.set_streams(args.streams)
     cap = ext.max_keypoints()
     d_img = torch.from_numpy(np.stack(frames)).to(dev)
     d_kp = torch.zeros((NI, cap, 7), dtype=torch.float32, device=dev)
@@ -200,16 +201,22 @@ def main():
         if use_dist:
             dist.barrier()
 
-    # warmup: every stage timed (HIP events on the extractor's stream) to find the dominant kernel
+    # warmup on ONE stream, every stage timed with HIP events on the extractor's stream: finds the
+    # dominant kernel and gives its exclusive (un-shared) duration
     gpu_stages = ["pyramid", "fast", "octree", "blur", "orient_desc"]
+    ext.set_streams(1)
     ext.profile(True)
     for _ in range(max(args.warmup, 1)):
         step(wait=True)
     warm = ext.profile_get()
     n_warm = max(args.warmup, 1)
     dom = max(gpu_stages, key=lambda s_: warm[s_][0])
-    # timed region: K steps enqueued back to back on the handle's stream (each step = one pass of
-    # ORBextractor::operator() over the resident batch); only the dominant stage keeps its events
+    # timed region: K steps enqueued back to back (each step = one pass of ORBextractor::operator()
+    # over the resident batch, split over `streams` sub-batch streams); only the dominant stage keeps
+    # its events, recorded on sub-batch 0's stream
+    ext.set_streams(max(1, min(4, args.streams)))
+    ext.profile(False)
+    step(wait=True)  # one untimed pass on the new stream split
     ext.profile([dom])
     barrier()
     t0 = time.perf_counter()
@@ -287,14 +294,20 @@ def main():
                        "sharding": f"frames sharded one batch per GPU x{world}, no data-path collective"},
             "roofline": {
                 "bound": "hbm", "kernel": "+".join(k for k, _ in STAGE_KERNELS[dom]), "stage": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args.workload, B),
+                "frac": ach / HBM_PEAK_GBS,
+                "traffic": pmc_traffic(dom, args.workload, B, prof[dom][2] / max(args.steps, 1)),
                 "algorithmic_bytes_per_launch_group": alg[dom] * prof[dom][2] / max(args.steps, 1),
                 "algorithmic_bytes_per_frame": alg[dom], "ms_per_launch_group": dom_ms_per_step,
                 "frames_per_launch": prof[dom][2] / max(args.steps, 1),
                 "pipeline": {"algorithmic_bytes_per_image": alg["extract_total"],
                              "achieved": alg["extract_total"] * imgs_per_frame * value / world / 1e9,
                              "frac": alg["extract_total"] * imgs_per_frame * value / world / 1e9 / HBM_PEAK_GBS},
-                "stage_ms_per_step_warmup": {s_: warm[s_][0] / n_warm for s_ in gpu_stages},
+                "streams": max(1, min(4, args.streams)),
+                "exclusive": {  # the same stage alone on the GPU (single-stream warm-up passes)
+                    "ms_per_launch_group": warm[dom][0] / n_warm, "frames_per_launch": NI,
+                    "achieved": alg[dom] * NI / (warm[dom][0] / n_warm * 1e-3) / 1e9,
+                    "frac": alg[dom] * NI / (warm[dom][0] / n_warm * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "stage_ms_per_step_exclusive": {s_: warm[s_][0] / n_warm for s_ in gpu_stages},
             },
         }
         if world == 1 and not args.no_cpu_baseline:
