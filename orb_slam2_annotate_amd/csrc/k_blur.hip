@@ -2,7 +2,7 @@
 // (the `workingMat` of src/ORBextractor.cc:1169-1175), OpenCV's bit-exact fixed-point path:
 // separable kernel [18,34,48,56,48,34,18]/256, first pass exact in 8.8, second pass in 16.16,
 // one rounding (x + 2^15) >> 16.  Both passes are exact integer sums, so their order is free:
-//   1. a 64x32 output tile stages (32+6) x (64+8) source bytes in LDS as aligned dwords
+//   1. a 64x64 output tile stages (64+6) x (64+8) source bytes in LDS as aligned dwords
 //      (reflect-101 resolved while loading);
 //   2. VERTICAL pass, packed 16-bit: a thread takes 4 adjacent columns of one row, two pixels
 //      per VALU lane-op (v_pk_add_u16 / v_pk_mad_u16), result kept in LDS as natural-order u16;
@@ -14,7 +14,7 @@
 namespace orbfe {
 
 namespace {
-constexpr int kBW = 64, kBH = 32;
+constexpr int kBW = 64, kBH = 64;
 constexpr int kTDW = (kBW + 8) / 4;  // 18 tile dwords per row: columns bx-4 .. bx+67
 constexpr int kTH = kBH + 6;         // rows by-3 .. by+34
 

@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelViewMut dst,
                                                 const int32_t* __restrict__ yofs,
                                                 const int16_t* __restrict__ beta) {
   const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-  const int dyBase = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kRowsPerThread;  // wave-uniform
+  // the row strip is wave-uniform: keep it (and everything derived from it) in scalar registers
+  const int dyBase = __builtin_amdgcn_readfirstlane((blockIdx.y * 4 + (threadIdx.x >> 6)) * kRowsPerThread);
   const int f = blockIdx.z;
   if (dx0 >= dst.w || dyBase >= dst.h) return;
   // per-thread column setup
@@ -67,8 +68,11 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelViewMut dst,
   S -= mis;
   uint8_t* D = dst.base + (size_t)f * dst.frameStride + dx0;
 
-  int idxA = -1, idxB = -1;
-  HRow A = {}, B = {};
+  // two interpolated source rows stay in registers (X, Y); every output row reuses whichever of
+  // them it can (scalar row indices -> scalar branches, no register shuffling)
+  int idxX = -1, idxY = -1;
+  HRow X = {}, Y = {};
+#pragma unroll 1
   for (int r = 0; r < kRowsPerThread; r++) {
     const int dy = dyBase + r;
     if (dy >= dst.h) break;
@@ -76,15 +80,23 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelViewMut dst,
     const int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
     const int r0 = sy < 0 ? 0 : (sy >= src.h ? src.h - 1 : sy);
     const int r1 = sy + 1 < 0 ? 0 : (sy + 1 >= src.h ? src.h - 1 : sy + 1);
-    // (A,B) <- rows (r0,r1), reusing what the previous output row already interpolated
-    if (r0 == idxB) { A = B; idxA = idxB; }
-    else if (r0 != idxA) { A = hrow(S + (size_t)r0 * src.pitch, mis, sel, al); idxA = r0; }
-    if (r1 == idxA) { B = A; idxB = idxA; }
-    else if (r1 != idxB) { B = hrow(S + (size_t)r1 * src.pitch, mis, sel, al); idxB = r1; }
+    bool aIsX;
+    if (r0 == idxY) {
+      if (r1 != idxX && r1 != idxY) { X = hrow(S + (size_t)r1 * src.pitch, mis, sel, al); idxX = r1; }
+      aIsX = false;
+    } else {
+      if (r0 != idxX) { X = hrow(S + (size_t)r0 * src.pitch, mis, sel, al); idxX = r0; }
+      if (r1 != idxX && r1 != idxY) { Y = hrow(S + (size_t)r1 * src.pitch, mis, sel, al); idxY = r1; }
+      aIsX = true;
+    }
+    // (A, B) = rows (r0, r1)
+    const bool bIsX = (r1 == idxX);
     uint32_t packed = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const int v = (((b0 * A.h[k]) >> 16) + ((b1 * B.h[k]) >> 16) + 2) >> 2;
+      const int hA = aIsX ? X.h[k] : Y.h[k];
+      const int hB = bIsX ? X.h[k] : Y.h[k];
+      const int v = (((b0 * hA) >> 16) + ((b1 * hB) >> 16) + 2) >> 2;
       packed |= (uint32_t)(v & 0xff) << (8 * k);
     }
     *reinterpret_cast<uint32_t*>(D + (size_t)dy * dst.pitch) = packed;  // pitch % 64 == 0: aligned, in-row

@@ -1,0 +1,20 @@
+#!/bin/bash
+# VALU instructions per wave and per launch group for every kernel (rocprofv3 --pmc, 1 stream, B=256)
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+rm -rf gpurun_out/pmcq
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmcq -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1 --batch 256 > /dev/null 2>&1
+python3 - <<'PY'
+import csv, glob, collections
+f=glob.glob('gpurun_out/pmcq/*/*counter_collection.csv')[0]
+agg=collections.defaultdict(lambda: collections.defaultdict(float))
+for r in csv.DictReader(open(f)):
+    agg[r['Kernel_Name'].split('(')[0]][r['Counter_Name']]+=float(r['Counter_Value'])
+tot=0
+for k,v in sorted(agg.items()):
+    if 'orbfe' not in k: continue
+    w=v['SQ_WAVES']; steps=5
+    print(k.ljust(30), 'VALU/wave %5.0f'%(v['SQ_INSTS_VALU']/w), 'SALU/wave %5.0f'%(v['SQ_INSTS_SALU']/w), 'VALU M/step %6.1f'%(v['SQ_INSTS_VALU']/steps/1e6))
+    tot+=v['SQ_INSTS_VALU']/steps/1e6
+print('total VALU M wave-instr per 256-frame step: %.1f'%tot)
+PY

@@ -17,6 +17,11 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t seed) {
       if (OP == 2) a[i] = __builtin_amdgcn_perm(a[i], b, 0x0c020c00u + i);
       if (OP == 3) a[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2, a[i]) - __builtin_bit_cast(s2, b));
       if (OP == 4) { int x = (int)a[i], y = (int)b, z = (int)a[(i + 1) & 7]; int m = x < y ? x : y; a[i] = (uint32_t)(m < z ? m : z); }
+      if (OP == 5) a[i] = a[i] * b;
+      if (OP == 6) a[i] = (uint32_t)__mul24((int)a[i], (int)b);
+      if (OP == 7) { unsigned long long t = (unsigned long long)a[i] * b + a[(i + 1) & 7]; a[i] = (uint32_t)(t >> 7); }
+      if (OP == 8) a[i] = __builtin_amdgcn_udot4(a[i], b, a[i], false);
+      if (OP == 9) a[i] = __builtin_amdgcn_alignbyte(a[i], b, a[i] & 3);
       asm volatile("" : "+v"(a[i]));
     }
   }
@@ -48,5 +53,10 @@ int main() {
   run<2>("v_perm_b32");
   run<3>("v_pk_sub_i16");
   run<4>("v_min3_i32");
+  run<5>("v_mul_lo_u32");
+  run<6>("v_mul_i32_i24");
+  run<7>("v_mad_u64_u32");
+  run<8>("v_dot4_u32_u8");
+  run<9>("v_alignbyte");
   return 0;
 }
