@@ -136,6 +136,21 @@ int orbfe_extractor_debug_candidates(orbfe_extractor *e, int frame, int level, f
 int orbfe_extractor_debug_blurred_level(orbfe_extractor *e, int frame, int level, uint8_t *dst,
                                         int dst_stride);
 
+/* Host-logic debug entry points; they run WITHOUT a GPU (CPU tests compare them with the oracle).
+ * debug_octree_host: the library's host DistributeOctTree on flat arrays (candidates relative to
+ * minBorder in emission order -> selected keypoints in list order, level coordinates); returns the count.
+ * debug_geometry: per level 9 ints (w, h, nCols, nRows, wCell, hCell, nCells, quota, nIni) and the FAST
+ * grid cells as 5 int16 (level, x0, y0, w, h: the detection rectangle); returns the cell count.
+ * debug_resize_tables: the cv::resize fixed-point tables (xofs[dw], alpha[2*dw], yofs[dh], beta[2*dh]). */
+int orbfe_debug_octree_host(const uint16_t *xs, const uint16_t *ys, const uint8_t *resp, int n, int minX, int maxX,
+                            int minY, int maxY, int N, uint16_t *out_x, uint16_t *out_y, uint8_t *out_resp,
+                            int cap);
+int orbfe_debug_geometry(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int width,
+                         int height, int32_t *levels9, float *tables4 /* scale, invScale, sigma2, invSigma2 per level; may be NULL */,
+                         int16_t *cells5, int cell_cap);
+int orbfe_debug_resize_tables(int sw, int sh, int dw, int dh, int32_t *xofs, int16_t *alpha, int32_t *yofs,
+                              int16_t *beta);
+
 /* Debug cross-check: when enabled, DistributeOctTree runs in the library's host implementation
  * (D2H/H2D round trip) instead of the device kernel.  Off by default; results are identical. */
 int orbfe_extractor_debug_host_octree(orbfe_extractor *e, int enable);

@@ -41,7 +41,8 @@ EXPORTS = [
     "orbfe_extractor_get_umax", "orbfe_extractor_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
     "orbfe_extract_batch_device", "orbfe_extract_batch_device_async", "orbfe_extractor_synchronize", "orbfe_extractor_level_size", "orbfe_extractor_get_pyramid_level",
     "orbfe_extractor_pyramid_level_device", "orbfe_extractor_debug_candidates",
-    "orbfe_extractor_debug_blurred_level", "orbfe_extractor_debug_host_octree", "orbfe_extractor_set_streams", "orbfe_extractor_profile", "orbfe_extractor_profile_get",
+    "orbfe_extractor_debug_blurred_level", "orbfe_extractor_debug_host_octree", "orbfe_debug_octree_host", "orbfe_debug_geometry",
+    "orbfe_debug_resize_tables", "orbfe_extractor_set_streams", "orbfe_extractor_profile", "orbfe_extractor_profile_get",
     "orbfe_stage_name", "orbfe_resize_linear", "orbfe_gaussian_blur7", "orbfe_descriptor_distance",
     "orbfe_hamming_matrix", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",
     "orbfe_search_for_triangulation", "orbfe_compute_stereo_matches", "orbfe_stereo_match_batch_device", "orbfe_vocabulary_load_text", "orbfe_vocabulary_destroy",
@@ -137,6 +138,9 @@ def load():
     L.orbfe_cvt_gray.argtypes = [ci, vp, ci, ci, ci, ci, ci, vp, ci]
     L.orbfe_cvt_gray_batch_device.argtypes = [ci, vp, ci, ci, ci, ci, cs, ci, ci, vp, ci, cs]
     L.orbfe_distinctive_descriptors.argtypes = [ci, vp, vp, ci, vp]
+    L.orbfe_debug_octree_host.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, ci]
+    L.orbfe_debug_geometry.argtypes = [ci, cf, ci, ci, ci, ci, ci, vp, vp, vp, ci]
+    L.orbfe_debug_resize_tables.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp]
     _lib = L
     return L
 

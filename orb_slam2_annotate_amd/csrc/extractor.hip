@@ -873,3 +873,65 @@ extern "C" int orbfe_stereo_match_batch_device(orbfe_extractor* e, int n_pairs, 
   HIPCHK(hipGetLastError());
   return ORBFE_OK;  // asynchronous on the handle's stream: orbfe_extractor_synchronize() to wait
 }
+
+// ---- host-logic debug entry points (no GPU needed; CPU tests compare them with the oracle) ----
+
+// DistributeOctTree of the library's host implementation (octree_host.cpp) on flat arrays:
+// candidates (x,y relative to minBorder, response) in emission order -> selected (x,y level
+// coordinates, response) in list order.  Returns the count or a negative status.
+extern "C" int orbfe_debug_octree_host(const uint16_t* xs, const uint16_t* ys, const uint8_t* resp, int n, int minX,
+                                       int maxX, int minY, int maxY, int N, uint16_t* out_x, uint16_t* out_y,
+                                       uint8_t* out_resp, int cap) {
+  if (n < 0 || cap < 0 || (n > 0 && (!xs || !ys || !resp)) || (cap > 0 && (!out_x || !out_y || !out_resp)))
+    return fail(ORBFE_ERR_INVALID, "debug_octree_host: bad argument");
+  std::vector<Candidate> cand((size_t)(n > 0 ? n : 1));
+  for (int i = 0; i < n; i++) { cand[i].xy = (uint32_t)xs[i] | ((uint32_t)ys[i] << 16); cand[i].score = resp[i]; }
+  std::vector<LevelKp> out((size_t)(cap > 0 ? cap : 1));
+  const int k = distribute_octree_host(cand.data(), n, minX, maxX, minY, maxY, N, out.data(), cap);
+  for (int i = 0; i < k && i < cap; i++) { out_x[i] = out[i].x; out_y[i] = out[i].y; out_resp[i] = (uint8_t)out[i].score; }
+  return k;
+}
+
+// Geometry tables the pipeline derives on the host for a WxH input: per level (w, h, nCols, nRows,
+// wCell, hCell, nCells, quota, nIni) as 9 ints, and the FAST grid cells as (level, x0, y0, w, h).
+// Returns the number of cells (cells may be NULL to query the count).
+extern "C" int orbfe_debug_geometry(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST,
+                                    int width, int height, int32_t* levels9, float* tables4, int16_t* cells5,
+                                    int cell_cap) {
+  if (width <= 0 || height <= 0 || !levels9 || nlevels < 1 || nlevels > ORBFE_MAX_LEVELS)
+    return fail(ORBFE_ERR_INVALID, "debug_geometry: bad argument");
+  ExtractorTables tab;
+  tab.init(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST);
+  if (tables4)
+    for (int l = 0; l < tab.nlevels; l++) {
+      tables4[l * 4 + 0] = tab.scale[l]; tables4[l * 4 + 1] = tab.invScale[l];
+      tables4[l * 4 + 2] = tab.sigma2[l]; tables4[l * 4 + 3] = tab.invSigma2[l];
+    }
+  FrameGeom g;
+  g.build(tab, width, height);
+  for (int l = 0; l < g.nlevels; l++) {
+    const LevelGeom& v = g.lv[l];
+    const int32_t row[9] = {v.w, v.h, v.nCols, v.nRows, v.wCell, v.hCell, v.nCells, v.quota, v.nIni};
+    for (int k = 0; k < 9; k++) levels9[l * 9 + k] = row[k];
+  }
+  if (cells5)
+    for (int i = 0; i < (int)g.cells.size() && i < cell_cap; i++) {
+      const CellDesc& c = g.cells[i];
+      cells5[i * 5 + 0] = c.level; cells5[i * 5 + 1] = c.x0; cells5[i * 5 + 2] = c.y0; cells5[i * 5 + 3] = c.w; cells5[i * 5 + 4] = c.h;
+    }
+  return (int)g.cells.size();
+}
+
+// cv::resize coefficient tables (xofs, alpha pairs, yofs, beta pairs) the resize kernel uses.
+extern "C" int orbfe_debug_resize_tables(int sw, int sh, int dw, int dh, int32_t* xofs, int16_t* alpha, int32_t* yofs,
+                                         int16_t* beta) {
+  if (sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || !xofs || !alpha || !yofs || !beta)
+    return fail(ORBFE_ERR_INVALID, "debug_resize_tables: bad argument");
+  ResizeTables t;
+  build_resize_tables(sw, sh, dw, dh, &t);
+  std::memcpy(xofs, t.xofs.data(), t.xofs.size() * 4);
+  std::memcpy(alpha, t.alpha.data(), t.alpha.size() * 2);
+  std::memcpy(yofs, t.yofs.data(), t.yofs.size() * 4);
+  std::memcpy(beta, t.beta.data(), t.beta.size() * 2);
+  return ORBFE_OK;
+}
