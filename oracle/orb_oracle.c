@@ -1288,3 +1288,157 @@ void orc_cvt_gray(const uint8_t *src, int w, int h, int sstride, int channels, i
       dst[(size_t)y * dstride + x] = (uint8_t)((r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14);
     }
 }
+
+/* ------------------------------------------------------------------ */
+/* Frame grid: src/Frame.cc:246-267 (AssignFeaturesToGrid), :417-427    */
+/* (PosInGrid), :358-415 (GetFeaturesInArea)                            */
+/* ------------------------------------------------------------------ */
+static int pos_in_grid(const orc_frame *f, float x, float y, int *px, int *py) {
+  const float wInv = (float)ORC_GRID_COLS / (f->mnMaxX - f->mnMinX); /* src/Frame.cc:109-110 */
+  const float hInv = (float)ORC_GRID_ROWS / (f->mnMaxY - f->mnMinY);
+  *px = (int)roundf((x - f->mnMinX) * wInv);
+  *py = (int)roundf((y - f->mnMinY) * hInv);
+  return !(*px < 0 || *px >= ORC_GRID_COLS || *py < 0 || *py >= ORC_GRID_ROWS);
+}
+
+void orc_frame_build_grid(orc_frame *f) {
+  const int nc = ORC_GRID_COLS * ORC_GRID_ROWS;
+  f->cell_off = (int32_t *)calloc((size_t)nc + 1, sizeof(int32_t));
+  f->cell_idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(f->N > 0 ? f->N : 1));
+  int px, py;
+  for (int i = 0; i < f->N; i++)
+    if (pos_in_grid(f, f->x[i], f->y[i], &px, &py)) f->cell_off[px * ORC_GRID_ROWS + py + 1]++;
+  for (int c = 0; c < nc; c++) f->cell_off[c + 1] += f->cell_off[c];
+  int32_t *cur = (int32_t *)malloc(sizeof(int32_t) * (size_t)nc);
+  memcpy(cur, f->cell_off, sizeof(int32_t) * (size_t)nc);
+  for (int i = 0; i < f->N; i++)
+    if (pos_in_grid(f, f->x[i], f->y[i], &px, &py)) f->cell_idx[cur[px * ORC_GRID_ROWS + py]++] = i;
+  free(cur);
+}
+void orc_frame_free_grid(orc_frame *f) { free(f->cell_off); free(f->cell_idx); f->cell_off = NULL; f->cell_idx = NULL; }
+
+int orc_features_in_area(const orc_frame *f, float x, float y, float r, int minLevel, int maxLevel, int32_t *out, int cap) {
+  const float wInv = (float)ORC_GRID_COLS / (f->mnMaxX - f->mnMinX);
+  const float hInv = (float)ORC_GRID_ROWS / (f->mnMaxY - f->mnMinY);
+  int n = 0;
+  int nMinCellX = (int)floorf((x - f->mnMinX - r) * wInv);
+  if (nMinCellX < 0) nMinCellX = 0;
+  if (nMinCellX >= ORC_GRID_COLS) return 0;
+  int nMaxCellX = (int)ceilf((x - f->mnMinX + r) * wInv);
+  if (nMaxCellX > ORC_GRID_COLS - 1) nMaxCellX = ORC_GRID_COLS - 1;
+  if (nMaxCellX < 0) return 0;
+  int nMinCellY = (int)floorf((y - f->mnMinY - r) * hInv);
+  if (nMinCellY < 0) nMinCellY = 0;
+  if (nMinCellY >= ORC_GRID_ROWS) return 0;
+  int nMaxCellY = (int)ceilf((y - f->mnMinY + r) * hInv);
+  if (nMaxCellY > ORC_GRID_ROWS - 1) nMaxCellY = ORC_GRID_ROWS - 1;
+  if (nMaxCellY < 0) return 0;
+  const int bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+  for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+    for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+      const int c = ix * ORC_GRID_ROWS + iy;
+      for (int j = f->cell_off[c]; j < f->cell_off[c + 1]; j++) {
+        const int id = f->cell_idx[j];
+        if (bCheckLevels) {
+          if (f->octave[id] < minLevel) continue;
+          if (maxLevel >= 0 && f->octave[id] > maxLevel) continue;
+        }
+        const float distx = f->x[id] - x, disty = f->y[id] - y;
+        if (fabsf(distx) < r && fabsf(disty) < r) { if (n < cap) out[n] = id; n++; }
+      }
+    }
+  return n;
+}
+
+/* src/ORBmatcher.cc:140-150 */
+static float radius_by_viewing_cos(float viewCos) { return viewCos > 0.998 ? 2.5f : 4.0f; }
+
+int orc_search_by_projection_mappoints(orc_frame *F, const float *sf, const uint8_t *blocked0, int nMP,
+                                       const uint8_t *in_view, const int32_t *level, const float *view_cos,
+                                       const float *proj_x, const float *proj_y, const float *proj_xr,
+                                       const uint8_t *mp_desc, const uint8_t *mp_obs_positive, float th, float nnratio,
+                                       int32_t *match) {
+  int nmatches = 0;
+  const int bFactor = th != 1.0;
+  uint8_t *blocked = (uint8_t *)malloc((size_t)(F->N > 0 ? F->N : 1));
+  memcpy(blocked, blocked0, (size_t)F->N);
+  for (int i = 0; i < F->N; i++) match[i] = -1;
+  int32_t *vIdx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(F->N > 0 ? F->N : 1));
+  for (int iMP = 0; iMP < nMP; iMP++) {
+    if (!in_view[iMP]) continue;
+    const int nPredictedLevel = level[iMP];
+    float r = radius_by_viewing_cos(view_cos[iMP]);
+    if (bFactor) r *= th;
+    const int nc = orc_features_in_area(F, proj_x[iMP], proj_y[iMP], r * sf[nPredictedLevel], nPredictedLevel - 1,
+                                        nPredictedLevel, vIdx, F->N);
+    if (nc == 0) continue;
+    const uint8_t *d0 = mp_desc + (size_t)iMP * 32;
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int c = 0; c < nc; c++) {
+      const int idx = vIdx[c];
+      if (blocked[idx]) continue;
+      if (F->uRight && F->uRight[idx] > 0) {
+        const float er = fabsf(proj_xr[iMP] - F->uRight[idx]);
+        if (er > r * sf[nPredictedLevel]) continue;
+      }
+      const int dist = orc_descriptor_distance(d0, F->desc + (size_t)idx * 32);
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = F->octave[idx]; bestIdx = idx; }
+      else if (dist < bestDist2) { bestLevel2 = F->octave[idx]; bestDist2 = dist; }
+    }
+    if (bestDist <= TH_HIGH) {
+      if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+      match[bestIdx] = iMP;
+      blocked[bestIdx] = mp_obs_positive ? mp_obs_positive[iMP] : 1;
+      nmatches++;
+    }
+  }
+  free(vIdx);
+  free(blocked);
+  return nmatches;
+}
+
+int orc_search_by_projection_lastframe(orc_frame *Cur, const float *sf, float mbf, int nLast, const uint8_t *valid,
+                                       const float *u, const float *v, const float *invzc, const int32_t *last_octave,
+                                       const float *last_angle, const uint8_t *mp_desc, const uint8_t *obs_positive,
+                                       int mode, float th, int check_ori, int32_t *match_cur) {
+  int nmatches = 0;
+  rothist rh;
+  rh_init(&rh, nLast > Cur->N ? nLast : Cur->N);
+  for (int i = 0; i < Cur->N; i++) match_cur[i] = -1;
+  uint8_t *blocked = (uint8_t *)calloc((size_t)(Cur->N > 0 ? Cur->N : 1), 1);
+  int32_t *vIdx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(Cur->N > 0 ? Cur->N : 1));
+  for (int i = 0; i < nLast; i++) {
+    if (!valid[i]) continue;
+    const int nLastOctave = last_octave[i];
+    const float radius = th * sf[nLastOctave];
+    int nc;
+    if (mode == 1) nc = orc_features_in_area(Cur, u[i], v[i], radius, nLastOctave, -1, vIdx, Cur->N);
+    else if (mode == 2) nc = orc_features_in_area(Cur, u[i], v[i], radius, 0, nLastOctave, vIdx, Cur->N);
+    else nc = orc_features_in_area(Cur, u[i], v[i], radius, nLastOctave - 1, nLastOctave + 1, vIdx, Cur->N);
+    if (nc == 0) continue;
+    const uint8_t *dMP = mp_desc + (size_t)i * 32;
+    int bestDist = 256, bestIdx2 = -1;
+    for (int c = 0; c < nc; c++) {
+      const int i2 = vIdx[c];
+      if (blocked[i2]) continue; /* mvpMapPoints[i2] set with Observations()>0 */
+      if (Cur->uRight && Cur->uRight[i2] > 0) {
+        const float ur = u[i] - mbf * invzc[i];
+        const float er = fabsf(ur - Cur->uRight[i2]);
+        if (er > radius) continue;
+      }
+      const int dist = orc_descriptor_distance(dMP, Cur->desc + (size_t)i2 * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= TH_HIGH) {
+      match_cur[bestIdx2] = i;
+      blocked[bestIdx2] = obs_positive ? obs_positive[i] : 1;
+      nmatches++;
+      if (check_ori) rh_push(&rh, last_angle[i], Cur->angle[bestIdx2], bestIdx2);
+    }
+  }
+  if (check_ori) nmatches -= rh_prune(&rh, match_cur);
+  rh_free(&rh);
+  free(vIdx);
+  free(blocked);
+  return nmatches;
+}

@@ -144,6 +144,47 @@ int orc_distinctive_descriptor(const uint8_t *desc, int n);
 void orc_cvt_gray(const uint8_t *src, int w, int h, int sstride, int channels, int rgb_order,
                   uint8_t *dst, int dstride);
 
+/* ---- Frame grid + projection searches ---- */
+#define ORC_GRID_COLS 64 /* include/Frame.h:44-45 */
+#define ORC_GRID_ROWS 48
+typedef struct orc_frame {
+  int N;
+  const float *x, *y;      /* mvKeysUn[i].pt */
+  const int32_t *octave;   /* mvKeysUn[i].octave */
+  const float *angle;      /* mvKeysUn[i].angle */
+  const float *uRight;     /* mvuRight (may be NULL: all -1) */
+  const uint8_t *desc;     /* mDescriptors */
+  float mnMinX, mnMaxX, mnMinY, mnMaxY; /* image bounds (src/Frame.cc:697-728) */
+  /* built by orc_frame_build_grid: */
+  int32_t *cell_off;       /* [64*48+1], cell id = ix*48 + iy (mGrid[ix][iy]) */
+  int32_t *cell_idx;
+} orc_frame;
+void orc_frame_build_grid(orc_frame *f);  /* AssignFeaturesToGrid + PosInGrid, src/Frame.cc:246-267,417-427 */
+void orc_frame_free_grid(orc_frame *f);
+/* GetFeaturesInArea, src/Frame.cc:358-415: returns count, writes up to cap indices in scan order */
+int orc_features_in_area(const orc_frame *f, float x, float y, float r, int minLevel, int maxLevel, int32_t *out, int cap);
+
+/* SearchByProjection(Frame &F, const vector<MapPoint*>&, th), src/ORBmatcher.cc:51-138.  Per map point:
+ * in_view (mbTrackInView && !isBad), level (mnTrackScaleLevel), view_cos, proj_x/y/xr, desc.
+ * blocked[idx] != 0 <=> F.mvpMapPoints[idx] exists with Observations()>0 before the call;
+ * mp_obs_positive[iMP] = pMP->Observations()>0 (NULL: all positive, the local-map case).
+ * match[idx] = map point index or -1.  Returns nmatches. */
+int orc_search_by_projection_mappoints(orc_frame *F, const float *scale_factors, const uint8_t *blocked,
+                                       int nMP, const uint8_t *in_view, const int32_t *level, const float *view_cos,
+                                       const float *proj_x, const float *proj_y, const float *proj_xr,
+                                       const uint8_t *mp_desc, const uint8_t *mp_obs_positive, float th, float nnratio,
+                                       int32_t *match);
+
+/* SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono), src/ORBmatcher.cc:1484-1633,
+ * after the caller's projection: per last-frame point valid (has map point, not outlier, invzc >= 0, (u,v)
+ * inside the image), u, v, invzc, last octave/angle, map point descriptor, obs_positive (Observations()>0).
+ * mode: 0 normal, 1 forward, 2 backward.  match_cur[i2] = last index or -1.  Returns nmatches. */
+int orc_search_by_projection_lastframe(orc_frame *Cur, const float *scale_factors, float mbf, int nLast,
+                                       const uint8_t *valid, const float *u, const float *v, const float *invzc,
+                                       const int32_t *last_octave, const float *last_angle, const uint8_t *mp_desc,
+                                       const uint8_t *obs_positive, int mode, float th, int check_ori,
+                                       int32_t *match_cur);
+
 /* ---- DBoW2 vocabulary (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h) ---- */
 typedef struct orc_vocab {
   int k, L, scoring, weighting;

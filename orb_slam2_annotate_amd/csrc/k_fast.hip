@@ -123,13 +123,15 @@ __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
 #pragma unroll
         for (int st = 0; st < 2; st++) {  // stream 0: pixels (0,2); stream 1: pixels (1,3)
           const s16x2 c = as_s2(__builtin_amdgcn_perm(m1, m0, sel2(4 + st)));
-          const s16x2 dS = c - as_s2(__builtin_amdgcn_perm(dn, dn, sel2(st)));      // ring 0  (0,+3)
-          const s16x2 dE = c - as_s2(__builtin_amdgcn_perm(m2, m1, sel2(3 + st)));  // ring 4  (+3,0)
-          const s16x2 dN = c - as_s2(__builtin_amdgcn_perm(up, up, sel2(st)));      // ring 8  (0,-3)
-          const s16x2 dW = c - as_s2(__builtin_amdgcn_perm(m1, m0, sel2(1 + st)));  // ring 12 (-3,0)
-          // sign bit set <=> darker than v-t (d > t) / brighter than v+t (d < -t)
-          const uint32_t dk = (as_u(T - dS) | as_u(T - dN)) & (as_u(T - dE) | as_u(T - dW));
-          const uint32_t br = (as_u(dS + T) | as_u(dN + T)) & (as_u(dE + T) | as_u(dW + T));
+          const s16x2 rS = as_s2(__builtin_amdgcn_perm(dn, dn, sel2(st)));      // ring 0  (0,+3)
+          const s16x2 rE = as_s2(__builtin_amdgcn_perm(m2, m1, sel2(3 + st)));  // ring 4  (+3,0)
+          const s16x2 rN = as_s2(__builtin_amdgcn_perm(up, up, sel2(st)));      // ring 8  (0,-3)
+          const s16x2 rW = as_s2(__builtin_amdgcn_perm(m1, m0, sel2(1 + st)));  // ring 12 (-3,0)
+          // sign bit set <=> ring pixel darker than v-t:  t - (v - x) = (t - v) + x < 0
+          //                  ring pixel brighter than v+t: (v - x) + t = (v + t) - x < 0
+          const s16x2 lo = T - c, hi = c + T;
+          const uint32_t dk = (as_u(lo + rS) | as_u(lo + rN)) & (as_u(lo + rE) | as_u(lo + rW));
+          const uint32_t br = (as_u(hi - rS) | as_u(hi - rN)) & (as_u(hi - rE) | as_u(hi - rW));
           const uint32_t p = dk | br;
           pass |= (((p >> 15) & 1u) | ((p >> 29) & 4u)) << st;
         }
