@@ -325,6 +325,62 @@ int orbfe_cvt_gray_batch_device(int device, const uint8_t *d_src, int n_frames, 
 int orbfe_distinctive_descriptors(int device, const uint8_t *descriptors, const int32_t *offsets,
                                   int n_points, int32_t *best_index);
 
+/* ------------------------------------------------------------------------- */
+/* Tracking-thread projection searches                */
+/* ------------------------------------------------------------------------- */
+
+/* The fields of an ORB_SLAM2::Frame the searches read (include/Frame.h:120-190): the undistorted
+ * keypoints mvKeysUn split into arrays, mvuRight, mDescriptors and the undistorted image bounds
+ * mnMinX..mnMaxY (src/Frame.cc:697-728).  At most 16384 keypoints. */
+typedef struct orbfe_frame_view {
+  int32_t n;
+  const float *x, *y;       /* mvKeysUn[i].pt */
+  const int32_t *octave;    /* mvKeysUn[i].octave */
+  const float *angle;       /* mvKeysUn[i].angle (only read with check_orientation) */
+  const float *u_right;     /* mvuRight, NULL for monocular frames */
+  const uint8_t *desc;      /* mDescriptors, n x 32 */
+  float min_x, max_x, min_y, max_y;
+} orbfe_frame_view;
+
+/* Frame::AssignFeaturesToGrid + Frame::GetFeaturesInArea (src/Frame.cc:246-267, 358-427) for
+ * n_queries windows at once: count[q] features lie in the window of query q; the first
+ * min(count[q], capacity) of them -- in the reference's order (grid column, grid row, feature
+ * index) -- are written to indices[q*capacity ..].  ORBFE_ERR_CAPACITY (counts still exact) when a
+ * window holds more than `capacity` features. */
+int orbfe_features_in_area(int device, const orbfe_frame_view *frame, int n_queries, const float *x,
+                           const float *y, const float *r, const int32_t *min_level,
+                           const int32_t *max_level, int capacity, int32_t *count, int32_t *indices);
+
+/* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th)
+ * (src/ORBmatcher.cc:51-138).  Map point i is described by what Frame::isInFrustum left on it:
+ * in_view (mbTrackInView && !isBad()), level (mnTrackScaleLevel), view_cos (mTrackViewCos), proj_x /
+ * proj_y / proj_xr (mTrackProjX/Y/XR), mp_desc (GetDescriptor()), mp_obs_positive (Observations()>0,
+ * NULL = all).  blocked[idx] != 0 <=> F.mvpMapPoints[idx] already holds a point with observations
+ * (NULL = none).  match[idx] = map point assigned to frame feature idx or -1; *n_matches as the
+ * reference counts them. */
+int orbfe_search_by_projection(int device, const orbfe_frame_view *F, const float *scale_factors,
+                               int n_levels, const uint8_t *blocked, int n_mp, const uint8_t *in_view,
+                               const int32_t *level, const float *view_cos, const float *proj_x,
+                               const float *proj_y, const float *proj_xr, const uint8_t *mp_desc,
+                               const uint8_t *mp_obs_positive, float th, float nnratio,
+                               int32_t *match, int32_t *n_matches);
+
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th,
+ * const bool bMono) (src/ORBmatcher.cc:1484-1633) after the caller's pose arithmetic: last-frame
+ * point i is valid when it has a non-outlier map point with invzc >= 0 projecting to (u, v) inside
+ * the image; last_octave / last_angle are LastFrame.mvKeysUn[i]; mp_desc its map point's
+ * descriptor; obs_positive[i] = Observations()>0 (NULL = all).  mode 0: levels
+ * [octave-1, octave+1]; 1 (bForward): >= octave; 2 (bBackward): <= octave.  mbf / invzc are read
+ * only for frames with u_right.  match_cur[i2] = last-frame index or -1. */
+int orbfe_search_by_projection_last_frame(int device, const orbfe_frame_view *Cur,
+                                          const float *scale_factors, int n_levels, float mbf,
+                                          int n_last, const uint8_t *valid, const float *u,
+                                          const float *v, const float *invzc,
+                                          const int32_t *last_octave, const float *last_angle,
+                                          const uint8_t *mp_desc, const uint8_t *obs_positive,
+                                          int mode, float th, int check_orientation,
+                                          int32_t *match_cur, int32_t *n_matches);
+
 #ifdef __cplusplus
 }
 #endif

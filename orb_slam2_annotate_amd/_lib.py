@@ -27,6 +27,12 @@ class OrbfeError(RuntimeError):
         self.code = code
 
 
+class FrameViewC(C.Structure):
+    _fields_ = [("n", C.c_int32), ("x", C.c_void_p), ("y", C.c_void_p), ("octave", C.c_void_p),
+                ("angle", C.c_void_p), ("u_right", C.c_void_p), ("desc", C.c_void_p),
+                ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float)]
+
+
 class FeatVecC(C.Structure):
     _fields_ = [("n_nodes", C.c_int32), ("node_ids", C.c_void_p), ("offsets", C.c_void_p),
                 ("indices", C.c_void_p)]
@@ -48,7 +54,8 @@ EXPORTS = [
     "orbfe_search_for_triangulation", "orbfe_compute_stereo_matches", "orbfe_stereo_match_batch_device", "orbfe_vocabulary_load_text", "orbfe_vocabulary_destroy",
     "orbfe_vocabulary_info", "orbfe_vocabulary_transform", "orbfe_vocabulary_featvec_batch_device",
     "orbfe_bow_match_consecutive_batch_device", "orbfe_cvt_gray", "orbfe_cvt_gray_batch_device",
-    "orbfe_distinctive_descriptors",
+    "orbfe_distinctive_descriptors", "orbfe_features_in_area", "orbfe_search_by_projection",
+    "orbfe_search_by_projection_last_frame",
 ]
 
 _lib = None
@@ -138,6 +145,11 @@ def load():
     L.orbfe_cvt_gray.argtypes = [ci, vp, ci, ci, ci, ci, ci, vp, ci]
     L.orbfe_cvt_gray_batch_device.argtypes = [ci, vp, ci, ci, ci, ci, cs, ci, ci, vp, ci, cs]
     L.orbfe_distinctive_descriptors.argtypes = [ci, vp, vp, ci, vp]
+    fwp = C.POINTER(FrameViewC)
+    L.orbfe_features_in_area.argtypes = [ci, fwp, ci, vp, vp, vp, vp, vp, ci, vp, vp]
+    L.orbfe_search_by_projection.argtypes = [ci, fwp, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, vp, vp]
+    L.orbfe_search_by_projection_last_frame.argtypes = [ci, fwp, vp, ci, cf, ci, vp, vp, vp, vp, vp, vp, vp, vp,
+                                                        ci, cf, ci, vp, vp]
     L.orbfe_debug_octree_host.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, ci]
     L.orbfe_debug_geometry.argtypes = [ci, cf, ci, ci, ci, ci, ci, vp, vp, vp, ci]
     L.orbfe_debug_resize_tables.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp]

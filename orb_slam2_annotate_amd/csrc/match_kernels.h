@@ -79,6 +79,22 @@ struct BowBatch {  // consecutive-frame SearchByBoW over a device-resident batch
   int32_t* match; int8_t* bin;  // [nPairs*capacity], match pre-set to -1
 };
 
+// Frame grid + window search (k_window.hip)
+constexpr int GRID_MAX_FEATURES = 16384;  // keys carry a 16-bit index and are sorted in 64 KB of LDS
+struct GridFrame {
+  const float* x; const float* y; const int32_t* octave; const float* uRight /* NULL: monocular */;
+  const uint8_t* desc; int n;
+  float minX, minY, wInv, hInv;  // mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv
+};
+struct WindowQueries {
+  const float* x; const float* y; const float* r; const int32_t* minLevel; const int32_t* maxLevel;
+  const uint8_t* active /* NULL: all */; const float* ur /* NULL: no stereo check */;
+  const uint8_t* desc /* NULL: indices only */; int n; int K;
+};
+void launch_grid_build(hipStream_t s, const GridFrame& f, uint32_t* sortedKey, int32_t* cellOff);
+void launch_window_search(hipStream_t s, const GridFrame& f, const uint32_t* sortedKey, const int32_t* cellOff,
+                          const WindowQueries& q, int32_t* count, uint32_t* cand);
+
 void launch_search_by_bow(hipStream_t s, const BowArgs& a, int nPairs, int maxCnt2);
 void launch_search_by_bow_batch(hipStream_t s, const BowBatch& b, int nPairs, int checkOri, int32_t* d_nMatches);
 void launch_search_triangulation(hipStream_t s, const TriArgs& a);

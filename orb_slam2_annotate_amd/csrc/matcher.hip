@@ -361,3 +361,253 @@ extern "C" int orbfe_compute_stereo_matches(orbfe_extractor* left, int frameL, o
   MHIP(hipStreamSynchronize(ar->stream));
   return cnt;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Frame grid, GetFeaturesInArea and the two tracking-thread projection searches
+// (SURVEY.md 8(f) rank 1).  The device gathers every window and takes the Hamming distances
+// (k_window.hip); the claim logic below is the reference's sequential loop over the compact
+// per-query candidate lists -- it depends on the order of the map points and stays on the host.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct WindowResult {
+  std::vector<int32_t> count;
+  std::vector<uint32_t> cand;  // [nq * K] (dist << 16 | feature index) in scan order
+  int K = 0;
+};
+
+bool frame_ok(const orbfe_frame_view* f) {
+  if (!f || f->n < 0 || f->n > GRID_MAX_FEATURES) return false;
+  if (!(f->max_x > f->min_x) || !(f->max_y > f->min_y)) return false;
+  if (f->n > 0 && (!f->x || !f->y || !f->octave)) return false;
+  return true;
+}
+
+// Upload the frame + queries, build the grid, search every window; grows K until every list fits.
+int window_search(int device, const orbfe_frame_view* f, int nq, const float* qx, const float* qy, const float* qr,
+                  const int32_t* qmin, const int32_t* qmax, const uint8_t* qactive, const float* qur,
+                  const uint8_t* qdesc, int K0, WindowResult* res) {
+  int K = K0 < 8 ? 8 : K0;
+  for (;;) {
+    Arena* ar;
+    const size_t n = (size_t)f->n, q = (size_t)nq;
+    size_t bytes = 4 * pad(n * 4) + pad(n * 32) + pad(n * 4) + pad(3073 * 4) + 6 * pad(q * 4) + pad(q) + pad(q * 32) +
+                   pad(q * 4) + pad(q * (size_t)K * 4);
+    MHIP(arena_begin(device, bytes, &ar));
+    GridFrame g{};
+    float *dx, *dy, *dur = nullptr;
+    int32_t* doct;
+    uint8_t* ddesc = nullptr;
+    MHIP(up(ar, &dx, f->x, n));
+    MHIP(up(ar, &dy, f->y, n));
+    MHIP(up(ar, &doct, f->octave, n));
+    if (f->u_right) MHIP(up(ar, &dur, f->u_right, n));
+    if (f->desc && qdesc) MHIP(up(ar, &ddesc, f->desc, n * 32));
+    g.x = dx; g.y = dy; g.octave = doct; g.uRight = dur; g.desc = ddesc; g.n = f->n;
+    g.minX = f->min_x; g.minY = f->min_y;
+    g.wInv = 64.0f / (f->max_x - f->min_x);  // src/Frame.cc:109-110 (FRAME_GRID_COLS / ROWS)
+    g.hInv = 48.0f / (f->max_y - f->min_y);
+    uint32_t* dkey = carve<uint32_t>(ar, n ? n : 1);
+    int32_t* dcell = carve<int32_t>(ar, 3073);
+    launch_grid_build(ar->stream, g, dkey, dcell);
+    MHIP(hipGetLastError());
+    WindowQueries wq{};
+    float *dqx, *dqy, *dqr, *dqur = nullptr;
+    int32_t *dqmin, *dqmax;
+    uint8_t *dqact = nullptr, *dqdesc = nullptr;
+    MHIP(up(ar, &dqx, qx, q));
+    MHIP(up(ar, &dqy, qy, q));
+    MHIP(up(ar, &dqr, qr, q));
+    MHIP(up(ar, &dqmin, qmin, q));
+    MHIP(up(ar, &dqmax, qmax, q));
+    if (qactive) MHIP(up(ar, &dqact, qactive, q));
+    if (qur && f->u_right) MHIP(up(ar, &dqur, qur, q));
+    if (ddesc) MHIP(up(ar, &dqdesc, qdesc, q * 32));
+    wq.x = dqx; wq.y = dqy; wq.r = dqr; wq.minLevel = dqmin; wq.maxLevel = dqmax; wq.active = dqact; wq.ur = dqur;
+    wq.desc = dqdesc; wq.n = nq; wq.K = K;
+    int32_t* dcount = carve<int32_t>(ar, q ? q : 1);
+    uint32_t* dcand = carve<uint32_t>(ar, q * (size_t)K + 1);
+    launch_window_search(ar->stream, g, dkey, dcell, wq, dcount, dcand);
+    MHIP(hipGetLastError());
+    res->count.assign(q, 0);
+    res->cand.resize(q * (size_t)K);
+    res->K = K;
+    if (nq > 0) {
+      MHIP(hipMemcpyAsync(res->count.data(), dcount, q * 4, hipMemcpyDeviceToHost, ar->stream));
+      MHIP(hipMemcpyAsync(res->cand.data(), dcand, q * (size_t)K * 4, hipMemcpyDeviceToHost, ar->stream));
+    }
+    MHIP(hipStreamSynchronize(ar->stream));
+    int mx = 0;
+    for (int i = 0; i < nq; i++) mx = res->count[i] > mx ? res->count[i] : mx;
+    if (mx <= K) return ORBFE_OK;
+    K = mx;  // a window held more features than the list: search again with room for the largest
+  }
+}
+
+// ComputeThreeMaxima, src/ORBmatcher.cc:1635-1690, over bin sizes
+void three_maxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = (int)histo[i].size();
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+    else if (s > max3) { max3 = s; ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+}  // namespace
+
+extern "C" int orbfe_features_in_area(int device, const orbfe_frame_view* frame, int n_queries, const float* x,
+                                      const float* y, const float* r, const int32_t* min_level,
+                                      const int32_t* max_level, int capacity, int32_t* count, int32_t* indices) {
+  if (!frame_ok(frame) || n_queries < 0 || capacity < 0 ||
+      (n_queries > 0 && (!x || !y || !r || !min_level || !max_level || !count || (capacity > 0 && !indices))))
+    return mfail(ORBFE_ERR_INVALID, "features_in_area: bad argument");
+  if (n_queries == 0) return ORBFE_OK;
+  WindowResult res;
+  const int rc = window_search(device, frame, n_queries, x, y, r, min_level, max_level, nullptr, nullptr, nullptr,
+                               capacity, &res);
+  if (rc != ORBFE_OK) return rc;
+  bool over = false;
+  for (int i = 0; i < n_queries; i++) {
+    count[i] = res.count[i];
+    const int m = res.count[i] < capacity ? res.count[i] : capacity;
+    if (res.count[i] > capacity) over = true;
+    for (int c = 0; c < m; c++) indices[(size_t)i * capacity + c] = (int32_t)(res.cand[(size_t)i * res.K + c] & 0xffffu);
+  }
+  if (over) return mfail(ORBFE_ERR_CAPACITY, "features_in_area: a window holds more features than capacity (counts are exact)");
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_search_by_projection(int device, const orbfe_frame_view* F, const float* scale_factors,
+                                          int n_levels, const uint8_t* blocked, int n_mp, const uint8_t* in_view,
+                                          const int32_t* level, const float* view_cos, const float* proj_x,
+                                          const float* proj_y, const float* proj_xr, const uint8_t* mp_desc,
+                                          const uint8_t* mp_obs_positive, float th, float nnratio, int32_t* match,
+                                          int32_t* n_matches) {
+  if (!frame_ok(F) || !scale_factors || n_levels <= 0 || n_mp < 0 || !n_matches || (F->n > 0 && (!match || !F->desc)) ||
+      (n_mp > 0 && (!in_view || !level || !view_cos || !proj_x || !proj_y || !mp_desc)) || (F->u_right && n_mp > 0 && !proj_xr))
+    return mfail(ORBFE_ERR_INVALID, "search_by_projection: bad argument");
+  for (int i = 0; i < n_mp; i++)
+    if (in_view[i] && (level[i] < 0 || level[i] >= n_levels))
+      return mfail(ORBFE_ERR_INVALID, "search_by_projection: predicted level outside the pyramid");
+  for (int i = 0; i < F->n; i++) match[i] = -1;
+  *n_matches = 0;
+  if (n_mp == 0 || F->n == 0) return ORBFE_OK;
+  const bool bFactor = th != 1.0;
+  std::vector<float> qr(n_mp);
+  std::vector<int32_t> qmin(n_mp), qmax(n_mp);
+  for (int i = 0; i < n_mp; i++) {
+    float r = view_cos[i] > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos, src/ORBmatcher.cc:140-146
+    if (bFactor) r *= th;
+    const int lv = in_view[i] ? level[i] : 0;
+    qr[i] = r * scale_factors[lv];
+    qmin[i] = lv - 1;
+    qmax[i] = lv;
+  }
+  WindowResult res;
+  const int rc = window_search(device, F, n_mp, proj_x, proj_y, qr.data(), qmin.data(), qmax.data(), in_view, proj_xr,
+                               mp_desc, 32, &res);
+  if (rc != ORBFE_OK) return rc;
+  std::vector<uint8_t> blk(F->n, 0);
+  if (blocked) std::memcpy(blk.data(), blocked, (size_t)F->n);
+  int nmatches = 0;
+  for (int i = 0; i < n_mp; i++) {
+    if (!in_view[i]) continue;
+    const int nc = res.count[i];
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int c = 0; c < nc; c++) {
+      const uint32_t e = res.cand[(size_t)i * res.K + c];
+      const int idx = (int)(e & 0xffffu), dist = (int)(e >> 16);
+      if (blk[idx]) continue;
+      if (dist < bestDist) {
+        bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = F->octave[idx]; bestIdx = idx;
+      } else if (dist < bestDist2) {
+        bestLevel2 = F->octave[idx]; bestDist2 = dist;
+      }
+    }
+    if (bestDist <= 100) {  // TH_HIGH
+      if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+      match[bestIdx] = i;
+      blk[bestIdx] = mp_obs_positive ? mp_obs_positive[i] : 1;
+      nmatches++;
+    }
+  }
+  *n_matches = nmatches;
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_search_by_projection_last_frame(int device, const orbfe_frame_view* Cur, const float* scale_factors,
+                                                     int n_levels, float mbf, int n_last, const uint8_t* valid,
+                                                     const float* u, const float* v, const float* invzc,
+                                                     const int32_t* last_octave, const float* last_angle,
+                                                     const uint8_t* mp_desc, const uint8_t* obs_positive, int mode,
+                                                     float th, int check_orientation, int32_t* match_cur,
+                                                     int32_t* n_matches) {
+  if (!frame_ok(Cur) || !scale_factors || n_levels <= 0 || n_last < 0 || !n_matches || mode < 0 || mode > 2 ||
+      (Cur->n > 0 && (!match_cur || !Cur->desc)) || (check_orientation && Cur->n > 0 && !Cur->angle) ||
+      (n_last > 0 && (!valid || !u || !v || !last_octave || !mp_desc || (check_orientation && !last_angle))) ||
+      (Cur->u_right && n_last > 0 && !invzc))
+    return mfail(ORBFE_ERR_INVALID, "search_by_projection_last_frame: bad argument");
+  for (int i = 0; i < n_last; i++)
+    if (valid[i] && (last_octave[i] < 0 || last_octave[i] >= n_levels))
+      return mfail(ORBFE_ERR_INVALID, "search_by_projection_last_frame: octave outside the pyramid");
+  for (int i = 0; i < Cur->n; i++) match_cur[i] = -1;
+  *n_matches = 0;
+  if (n_last == 0 || Cur->n == 0) return ORBFE_OK;
+  std::vector<float> qr(n_last), qur;
+  std::vector<int32_t> qmin(n_last), qmax(n_last);
+  if (Cur->u_right) qur.resize(n_last);
+  for (int i = 0; i < n_last; i++) {
+    const int o = valid[i] ? last_octave[i] : 0;
+    qr[i] = th * scale_factors[o];  // src/ORBmatcher.cc:1543
+    if (mode == 1) { qmin[i] = o; qmax[i] = -1; }            // bForward:  GetFeaturesInArea(u,v,radius,nLastOctave)
+    else if (mode == 2) { qmin[i] = 0; qmax[i] = o; }        // bBackward: (u,v,radius,0,nLastOctave)
+    else { qmin[i] = o - 1; qmax[i] = o + 1; }
+    if (Cur->u_right) qur[i] = u[i] - mbf * invzc[i];        // :1562
+  }
+  WindowResult res;
+  const int rc = window_search(device, Cur, n_last, u, v, qr.data(), qmin.data(), qmax.data(), valid,
+                               Cur->u_right ? qur.data() : nullptr, mp_desc, 32, &res);
+  if (rc != ORBFE_OK) return rc;
+  constexpr int HISTO_LENGTH = 30;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  std::vector<uint8_t> blk(Cur->n, 0);
+  int nmatches = 0;
+  for (int i = 0; i < n_last; i++) {
+    if (!valid[i]) continue;
+    const int nc = res.count[i];
+    int bestDist = 256, bestIdx2 = -1;
+    for (int c = 0; c < nc; c++) {
+      const uint32_t e = res.cand[(size_t)i * res.K + c];
+      const int i2 = (int)(e & 0xffffu), dist = (int)(e >> 16);
+      if (blk[i2]) continue;
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= 100) {  // TH_HIGH
+      match_cur[bestIdx2] = i;
+      blk[bestIdx2] = obs_positive ? obs_positive[i] : 1;
+      nmatches++;
+      if (check_orientation) {
+        float rot = last_angle[i] - Cur->angle[bestIdx2];
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)roundf(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        rotHist[bin].push_back(bestIdx2);
+      }
+    }
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0; j < rotHist[i].size(); j++) { match_cur[rotHist[i][j]] = -1; nmatches--; }
+    }
+  }
+  *n_matches = nmatches;
+  return ORBFE_OK;
+}

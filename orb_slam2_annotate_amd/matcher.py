@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import FeatVecC, check, ptr
+from ._lib import FeatVecC, FrameViewC, check, ptr
 
 
 class FeatureVector:
@@ -29,6 +29,52 @@ class FeatureVector:
         ids, counts = np.unique(nof, return_counts=True)
         order = np.argsort(nof, kind="stable")
         return cls(ids, np.concatenate([[0], np.cumsum(counts)]), order)
+
+
+class FrameView:
+    """The fields of ``ORB_SLAM2::Frame`` the projection searches read (include/Frame.h:120-190):
+    mvKeysUn as arrays, mvuRight, mDescriptors, image bounds mnMinX..mnMaxY."""
+
+    def __init__(self, x, y, octave, desc, bounds, angle=None, u_right=None):
+        self.x, self.y = _f32(x), _f32(y)
+        self.octave = np.ascontiguousarray(octave, dtype=np.int32)
+        self.desc = _u8(desc).reshape(-1, 32)
+        self.angle = None if angle is None else _f32(angle)
+        self.u_right = None if u_right is None else _f32(u_right)
+        self.N = len(self.x)
+        self.bounds = tuple(float(b) for b in bounds)  # (mnMinX, mnMaxX, mnMinY, mnMaxY)
+        self.c = FrameViewC(self.N, ptr(self.x), ptr(self.y), ptr(self.octave),
+                            None if self.angle is None else ptr(self.angle),
+                            None if self.u_right is None else ptr(self.u_right), ptr(self.desc), *self.bounds)
+
+    @classmethod
+    def from_keypoints(cls, kps, desc, width, height, u_right=None):
+        """kps: structured/[:,7] keypoint records as the extractor returns them; undistorted bounds of a
+        distortion-free camera (src/Frame.cc:719-725)."""
+        k = np.asarray(kps)
+        if k.dtype.names:
+            x, y, ang, octv = k["x"], k["y"], k["angle"], k["octave"]
+        else:
+            x, y, ang, octv = k[:, 0], k[:, 1], k[:, 3], k[:, 5]
+        return cls(x, y, octv, desc, (0.0, float(width), 0.0, float(height)), angle=ang, u_right=u_right)
+
+    def GetFeaturesInArea(self, x, y, r, minLevel=-1, maxLevel=-1, capacity: int = 64, device: int = 0):
+        """Frame::GetFeaturesInArea (src/Frame.cc:358-415) for arrays of windows ->
+        list of index arrays in the reference's order."""
+        x, y, r = _f32(np.atleast_1d(x)), _f32(np.atleast_1d(y)), _f32(np.atleast_1d(r))
+        nq = len(x)
+        lo = np.ascontiguousarray(np.broadcast_to(np.asarray(minLevel, dtype=np.int32), (nq,)))
+        hi = np.ascontiguousarray(np.broadcast_to(np.asarray(maxLevel, dtype=np.int32), (nq,)))
+        while True:
+            count = np.zeros(max(nq, 1), dtype=np.int32)
+            idx = np.zeros((max(nq, 1), max(capacity, 1)), dtype=np.int32)
+            rc = _lib.load().orbfe_features_in_area(device, C.byref(self.c), nq, ptr(x), ptr(y), ptr(r), ptr(lo),
+                                                    ptr(hi), capacity, ptr(count), ptr(idx))
+            if rc == _lib.ERR_CAPACITY:
+                capacity = int(count.max())
+                continue
+            check(rc)
+            return [idx[q, :count[q]].copy() for q in range(nq)]
 
 
 def _f32(a):
@@ -87,6 +133,42 @@ class ORBmatcher:
                                                  ptr(desc2), ptr(m2), ptr(a2), n2, C.byref(fv2.c),
                                                  self.mfNNratio, int(self.mbCheckOrientation), ptr(out)))
         return n, out[:n1]
+
+    def SearchByProjection(self, F: FrameView, scale_factors, in_view, level, view_cos, proj_x, proj_y, mp_desc,
+                           th: float = 1.0, proj_xr=None, blocked=None, mp_obs_positive=None):
+        """SearchByProjection(Frame&, vector<MapPoint*>&, th) (src/ORBmatcher.cc:51-138) ->
+        (nmatches, match[F.N]) with match[idx] = map point index or -1."""
+        sf = _f32(scale_factors)
+        iv, lv, vc = _u8(in_view), np.ascontiguousarray(level, dtype=np.int32), _f32(view_cos)
+        px, py, md = _f32(proj_x), _f32(proj_y), _u8(mp_desc).reshape(-1, 32)
+        pxr = None if proj_xr is None else _f32(proj_xr)
+        blk = None if blocked is None else _u8(blocked)
+        obs = None if mp_obs_positive is None else _u8(mp_obs_positive)
+        match = np.full(max(F.N, 1), -1, dtype=np.int32)
+        n = C.c_int32(0)
+        check(self._L.orbfe_search_by_projection(
+            self.device, C.byref(F.c), ptr(sf), len(sf), None if blk is None else ptr(blk), len(iv), ptr(iv), ptr(lv),
+            ptr(vc), ptr(px), ptr(py), None if pxr is None else ptr(pxr), ptr(md), None if obs is None else ptr(obs),
+            float(th), self.mfNNratio, ptr(match), C.byref(n)))
+        return n.value, match[:F.N]
+
+    def SearchByProjectionLastFrame(self, Cur: FrameView, scale_factors, valid, u, v, last_octave, last_angle,
+                                    mp_desc, th: float, mode: int = 0, mbf: float = 0.0, invzc=None,
+                                    obs_positive=None):
+        """SearchByProjection(CurrentFrame, LastFrame, th, bMono) (src/ORBmatcher.cc:1484-1633) after the
+        caller's projection -> (nmatches, match_cur[Cur.N]) with match_cur[i2] = last-frame index or -1."""
+        sf = _f32(scale_factors)
+        va, uu, vv = _u8(valid), _f32(u), _f32(v)
+        lo, la, md = np.ascontiguousarray(last_octave, dtype=np.int32), _f32(last_angle), _u8(mp_desc).reshape(-1, 32)
+        iz = None if invzc is None else _f32(invzc)
+        obs = None if obs_positive is None else _u8(obs_positive)
+        match = np.full(max(Cur.N, 1), -1, dtype=np.int32)
+        n = C.c_int32(0)
+        check(self._L.orbfe_search_by_projection_last_frame(
+            self.device, C.byref(Cur.c), ptr(sf), len(sf), float(mbf), len(va), ptr(va), ptr(uu), ptr(vv),
+            None if iz is None else ptr(iz), ptr(lo), ptr(la), ptr(md), None if obs is None else ptr(obs), int(mode),
+            float(th), int(self.mbCheckOrientation), ptr(match), C.byref(n)))
+        return n.value, match[:Cur.N]
 
     def SearchForTriangulation(self, desc1, has_mp1, x1, y1, angle1, stereo1, fv1, desc2, has_mp2, x2, y2,
                                angle2, octave2, stereo2, fv2, F12, ex, ey, scale_factors2, level_sigma2_2,

@@ -290,3 +290,72 @@ class Vocabulary:
         word = np.zeros(max(n, 1), np.uint32); weight = np.zeros(max(n, 1), np.float64); node = np.zeros(max(n, 1), np.uint32)
         used = lib().orc_vocab_transform(self.v, _p(d), n, int(levelsup), _p(word), _p(weight), _p(node))
         return used, word[:n], weight[:n], node[:n]
+
+
+class OrcFrame(C.Structure):
+    _fields_ = [("N", C.c_int), ("x", C.c_void_p), ("y", C.c_void_p), ("octave", C.c_void_p), ("angle", C.c_void_p),
+                ("uRight", C.c_void_p), ("desc", C.c_void_p), ("mnMinX", C.c_float), ("mnMaxX", C.c_float),
+                ("mnMinY", C.c_float), ("mnMaxY", C.c_float), ("cell_off", C.c_void_p), ("cell_idx", C.c_void_p)]
+
+
+class Frame:
+    """oracle restatement of the Frame grid (src/Frame.cc:246-267, 358-427)"""
+
+    def __init__(self, x, y, octave, desc, bounds, angle=None, u_right=None):
+        f = lambda a, t: np.ascontiguousarray(a, dtype=t)
+        self.x, self.y, self.octave = f(x, np.float32), f(y, np.float32), f(octave, np.int32)
+        self.desc = f(desc, np.uint8).reshape(-1, 32)
+        self.angle = f(angle if angle is not None else np.zeros(len(self.x)), np.float32)
+        self.u_right = None if u_right is None else f(u_right, np.float32)
+        self.N = len(self.x)
+        self.c = OrcFrame(self.N, _p(self.x), _p(self.y), _p(self.octave), _p(self.angle), _p(self.u_right),
+                          _p(self.desc), *[float(b) for b in bounds], None, None)
+        L = lib()
+        L.orc_frame_build_grid.argtypes = [C.POINTER(OrcFrame)]
+        L.orc_frame_free_grid.argtypes = [C.POINTER(OrcFrame)]
+        L.orc_features_in_area.argtypes = [C.POINTER(OrcFrame), C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_int]
+        L.orc_frame_build_grid(C.byref(self.c))
+
+    def __del__(self):
+        if getattr(self, "c", None) is not None and self.c.cell_off:
+            lib().orc_frame_free_grid(C.byref(self.c))
+
+    def features_in_area(self, x, y, r, min_level=-1, max_level=-1):
+        out = np.zeros(max(self.N, 1), dtype=np.int32)
+        n = lib().orc_features_in_area(C.byref(self.c), float(x), float(y), float(r), int(min_level), int(max_level),
+                                       _p(out), self.N)
+        return out[:n].copy()
+
+
+def search_by_projection_mappoints(F: Frame, sf, blocked, in_view, level, view_cos, px, py, pxr, mp_desc, obs, th,
+                                   nnratio):
+    f = lambda a, t: None if a is None else np.ascontiguousarray(a, dtype=t)
+    sf = f(sf, np.float32)
+    a = [f(in_view, np.uint8), f(level, np.int32), f(view_cos, np.float32), f(px, np.float32), f(py, np.float32),
+         f(pxr, np.float32), f(mp_desc, np.uint8), f(obs, np.uint8)]
+    blocked = f(blocked if blocked is not None else np.zeros(max(F.N, 1)), np.uint8)
+    out = np.zeros(max(F.N, 1), dtype=np.int32)
+    L = lib()
+    L.orc_search_by_projection_mappoints.argtypes = [C.POINTER(OrcFrame), C.c_void_p, C.c_void_p, C.c_int] + \
+        [C.c_void_p] * 8 + [C.c_float, C.c_float, C.c_void_p]
+    n = L.orc_search_by_projection_mappoints(C.byref(F.c), _p(sf), _p(blocked), len(a[0]), *[_p(v) for v in a],
+                                             float(th), float(nnratio), _p(out))
+    return n, out[:F.N].copy()
+
+
+def search_by_projection_lastframe(Cur: Frame, sf, mbf, valid, u, v, invzc, last_octave, last_angle, mp_desc, obs,
+                                   mode, th, check_ori):
+    f = lambda a, t: None if a is None else np.ascontiguousarray(a, dtype=t)
+    sf = f(sf, np.float32)
+    valid = f(valid, np.uint8)
+    a = [valid, f(u, np.float32), f(v, np.float32),
+         f(invzc if invzc is not None else np.zeros(len(valid)), np.float32), f(last_octave, np.int32),
+         f(last_angle, np.float32), f(mp_desc, np.uint8), f(obs, np.uint8)]
+    out = np.zeros(max(Cur.N, 1), dtype=np.int32)
+    L = lib()
+    L.orc_search_by_projection_lastframe.argtypes = [C.POINTER(OrcFrame), C.c_void_p, C.c_float, C.c_int] + \
+        [C.c_void_p] * 8 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
+    n = L.orc_search_by_projection_lastframe(C.byref(Cur.c), _p(sf), float(mbf), len(valid), *[_p(v) for v in a],
+                                             int(mode), float(th), int(check_ori), _p(out))
+    return n, out[:Cur.N].copy()

@@ -1,0 +1,185 @@
+"""GPU parity tests of the Frame grid / GetFeaturesInArea primitive and the two tracking-thread
+projection searches (include/orbfe.h, "Tracking-thread projection searches") against the CPU
+oracle -- bit-exact match arrays and counts."""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from orb_slam2_annotate_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+SF = (1.2 ** np.arange(8)).astype(np.float32)
+BOUNDS = (0.0, 640.0, 0.0, 480.0)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import orb_slam2_annotate_amd as m
+    return m
+
+
+def _random_frame(rng, n, stereo=False, spread=5.0):
+    x = rng.uniform(-spread, 640 + spread, n).astype(np.float32)
+    y = rng.uniform(-spread, 480 + spread, n).astype(np.float32)
+    octv = rng.integers(0, 8, n).astype(np.int32)
+    ang = rng.uniform(0, 360, n).astype(np.float32)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    ur = np.where(rng.random(n) < 0.7, x - rng.uniform(1, 40, n), -1).astype(np.float32) if stereo else None
+    return x, y, octv, ang, desc, ur
+
+
+def _both(amd, x, y, octv, ang, desc, ur, bounds=BOUNDS):
+    return (amd.FrameView(x, y, octv, desc, bounds, angle=ang, u_right=ur),
+            orc.Frame(x, y, octv, desc, bounds, angle=ang, u_right=ur))
+
+
+@pytest.mark.parametrize("seed,n,bounds", [(0, 1000, BOUNDS), (1, 2300, (-12.5, 655.25, -8.0, 490.5)), (2, 1, BOUNDS),
+                                           (3, 16384, BOUNDS)])
+def test_features_in_area(amd, seed, n, bounds):
+    rng = np.random.default_rng(seed)
+    x, y, octv, ang, desc, _ = _random_frame(rng, n)
+    F, Fo = _both(amd, x, y, octv, ang, desc, None, bounds)
+    nq = 400
+    qx = rng.uniform(-30, 700, nq).astype(np.float32)
+    qy = rng.uniform(-30, 520, nq).astype(np.float32)
+    r = rng.choice(np.array([0.5, 3.0, 15.0, 64.0, 900.0], np.float32), nq)
+    lv = np.array([(-1, -1), (0, -1), (2, -1), (0, 3), (1, 2), (3, 1)], np.int32)[rng.integers(0, 6, nq)]
+    got = F.GetFeaturesInArea(qx, qy, r, lv[:, 0], lv[:, 1], capacity=16)  # grows past 16 by itself
+    for q in range(nq):
+        want = Fo.features_in_area(qx[q], qy[q], r[q], lv[q, 0], lv[q, 1])
+        assert got[q].tolist() == want.tolist(), q
+
+
+def test_features_in_area_capacity_error_and_empty(amd):
+    import ctypes as C
+    from orb_slam2_annotate_amd import _lib
+    rng = np.random.default_rng(4)
+    x, y, octv, ang, desc, _ = _random_frame(rng, 500)
+    F = amd.FrameView(x, y, octv, desc, BOUNDS, angle=ang)
+    f32 = lambda v: np.array([v], np.float32)
+    i32 = lambda v: np.array([v], np.int32)
+    count = np.zeros(1, np.int32); idx = np.zeros(4, np.int32)
+    L = _lib.load()
+    rc = L.orbfe_features_in_area(0, C.byref(F.c), 1, _lib.ptr(f32(320)), _lib.ptr(f32(240)), _lib.ptr(f32(1000)),
+                                  _lib.ptr(i32(-1)), _lib.ptr(i32(-1)), 4, _lib.ptr(count), _lib.ptr(idx))
+    assert rc == _lib.ERR_CAPACITY
+    gridded = ((np.round((x - 0) * np.float32(0.1)) < 64) & (np.round(x * np.float32(0.1)) >= 0) &
+               (np.round(y * np.float32(0.1)) < 48) & (np.round(y * np.float32(0.1)) >= 0))
+    assert count[0] == orc.Frame(x, y, octv, desc, BOUNDS).features_in_area(320, 240, 1000).size <= gridded.sum()
+    # empty frame, no queries
+    E = amd.FrameView(np.zeros(0), np.zeros(0), np.zeros(0), np.zeros((0, 32)), BOUNDS)
+    assert [a.tolist() for a in E.GetFeaturesInArea([10.0], [10.0], [50.0])] == [[]]
+    assert F.GetFeaturesInArea(np.zeros(0), np.zeros(0), np.zeros(0)) == []
+    # degenerate bounds are rejected
+    with pytest.raises(amd.OrbfeError):
+        amd.FrameView(x, y, octv, desc, (0, 0, 0, 480)).GetFeaturesInArea([1.0], [1.0], [1.0])
+
+
+def _map_points(rng, x, y, octv, desc, n_mp, noise_px, bit_noise=3):
+    n = len(x)
+    src = rng.integers(0, n, n_mp)
+    px = (x[src] + rng.normal(0, noise_px, n_mp)).astype(np.float32)
+    py = (y[src] + rng.normal(0, noise_px, n_mp)).astype(np.float32)
+    md = desc[src].copy()
+    flip = rng.integers(0, 256, (n_mp, 32), dtype=np.uint8)
+    for _ in range(bit_noise - 1):
+        flip &= rng.integers(0, 256, (n_mp, 32), dtype=np.uint8)
+    md ^= flip
+    return src, px, py, md
+
+
+@pytest.mark.parametrize("seed,stereo,th", [(10, False, 1.0), (11, True, 1.0), (12, False, 3.0), (13, True, 5.0)])
+def test_search_by_projection_mappoints(amd, seed, stereo, th):
+    rng = np.random.default_rng(seed)
+    x, y, octv, ang, desc, ur = _random_frame(rng, 1500, stereo, spread=0.0)
+    F, Fo = _both(amd, x, y, octv, ang, desc, ur)
+    n_mp = 2500
+    src, px, py, md = _map_points(rng, x, y, octv, desc, n_mp, 1.5)
+    level = np.clip(octv[src] + rng.integers(0, 2, n_mp), 0, 7).astype(np.int32)
+    in_view = (rng.random(n_mp) < 0.85).astype(np.uint8)
+    view_cos = rng.uniform(0.99, 1.0, n_mp).astype(np.float32)
+    pxr = (px - rng.uniform(1, 40, n_mp)).astype(np.float32) if stereo else None
+    if stereo:  # make most stereo projections consistent with the feature they came from
+        ok = ur[src] > 0
+        pxr[ok] = ur[src][ok] + rng.normal(0, 1.0, ok.sum()).astype(np.float32)
+    blocked = (rng.random(1500) < 0.1).astype(np.uint8)
+    obs = (rng.random(n_mp) < 0.9).astype(np.uint8)
+    m = amd.ORBmatcher(0.8, True)
+    for b, o in [(blocked, obs), (None, None)]:
+        n_ref, ref = orc.search_by_projection_mappoints(Fo, SF, b, in_view, level, view_cos, px, py, pxr, md, o, th, 0.8)
+        n_got, got = m.SearchByProjection(F, SF, in_view, level, view_cos, px, py, md, th=th, proj_xr=pxr, blocked=b,
+                                          mp_obs_positive=o)
+        assert n_got == n_ref
+        assert got.tolist() == ref.tolist()
+        assert n_ref > 300
+
+
+@pytest.mark.parametrize("seed,stereo,mode,check_ori", [(20, False, 0, True), (21, True, 0, True), (22, True, 1, True),
+                                                        (23, True, 2, False), (24, False, 1, False)])
+def test_search_by_projection_last_frame(amd, seed, stereo, mode, check_ori):
+    rng = np.random.default_rng(seed)
+    x, y, octv, ang, desc, ur = _random_frame(rng, 1800, stereo, spread=0.0)
+    Cur, Co = _both(amd, x, y, octv, ang, desc, ur)
+    nl = 1700
+    src, u, v, md = _map_points(rng, x, y, octv, desc, nl, 3.0)
+    lo = np.clip(octv[src] + rng.integers(-1, 2, nl), 0, 7).astype(np.int32)
+    la = ((ang[src] + rng.normal(0, 6, nl)) % 360).astype(np.float32)
+    la[rng.random(nl) < 0.15] = rng.uniform(0, 360)  # outliers for the rotation histogram
+    valid = (rng.random(nl) < 0.9).astype(np.uint8)
+    mbf = 40.0
+    invzc = rng.uniform(0.02, 0.5, nl).astype(np.float32)
+    if stereo:
+        ok = ur[src] > 0
+        invzc[ok] = ((u[ok] - ur[src][ok]) / mbf + rng.normal(0, 0.02, ok.sum())).astype(np.float32)
+    obs = (rng.random(nl) < 0.8).astype(np.uint8)
+    th = 7.0 if stereo else 15.0
+    m = amd.ORBmatcher(0.9, check_ori)
+    for o in (obs, None):
+        n_ref, ref = orc.search_by_projection_lastframe(Co, SF, mbf, valid, u, v, invzc, lo, la, md, o, mode, th, check_ori)
+        n_got, got = m.SearchByProjectionLastFrame(Cur, SF, valid, u, v, lo, la, md, th, mode=mode, mbf=mbf, invzc=invzc,
+                                                   obs_positive=o)
+        assert n_got == n_ref
+        assert got.tolist() == ref.tolist()
+        assert n_ref > 200
+
+
+def test_projection_on_extracted_frames(amd):
+    """End to end on real extractor output: frame t projected into frame t+1 with the identity motion
+    model (TrackWithMotionModel with zero velocity, src/Tracking.cc:865-918 -> th = 15, mono)."""
+    fr = synth.render_sequence(31, 2, 640, 480, step=2.0)
+    e = amd.ORBextractor(1000, 1.2, 8, 20, 7)
+    (k1, d1), (k2, d2) = e.extract_batch(np.stack(fr))
+    Cur = amd.FrameView.from_keypoints(k2, d2, 640, 480)
+    Co = orc.Frame(k2["x"], k2["y"], k2["octave"], d2, BOUNDS, angle=k2["angle"])
+    valid = np.ones(len(k1), np.uint8)
+    m = amd.ORBmatcher(0.9, True)
+    n_ref, ref = orc.search_by_projection_lastframe(Co, SF, 0.0, valid, k1["x"], k1["y"], None, k1["octave"], k1["angle"],
+                                                    d1, None, 0, 15.0, True)
+    n_got, got = m.SearchByProjectionLastFrame(Cur, SF, valid, k1["x"], k1["y"], k1["octave"], k1["angle"], d1, 15.0)
+    assert (n_got, got.tolist()) == (n_ref, ref.tolist())
+    assert n_ref > 100
+    # and the local-map search on the same pair
+    level = k1["octave"].astype(np.int32)
+    vc = np.full(len(k1), 0.9995, np.float32)
+    n_ref, ref = orc.search_by_projection_mappoints(Co, SF, None, valid, level, vc, k1["x"], k1["y"], None, d1, None, 3.0, 0.8)
+    n_got, got = amd.ORBmatcher(0.8).SearchByProjection(Cur, SF, valid, level, vc, k1["x"], k1["y"], d1, th=3.0)
+    assert (n_got, got.tolist()) == (n_ref, ref.tolist())
+    assert n_ref > 100
+
+
+def test_projection_invalid_arguments(amd):
+    rng = np.random.default_rng(40)
+    x, y, octv, ang, desc, _ = _random_frame(rng, 50)
+    F = amd.FrameView(x, y, octv, desc, BOUNDS, angle=ang)
+    m = amd.ORBmatcher(0.8)
+    one = np.ones(1, np.uint8)
+    with pytest.raises(amd.OrbfeError):  # predicted level outside the pyramid
+        m.SearchByProjection(F, SF, one, [9], [1.0], [10.0], [10.0], desc[:1])
+    with pytest.raises(amd.OrbfeError):
+        m.SearchByProjectionLastFrame(F, SF, one, [1.0], [1.0], [8], [0.0], desc[:1], 15.0)
+    with pytest.raises(amd.OrbfeError):
+        m.SearchByProjectionLastFrame(F, SF, one, [1.0], [1.0], [1], [0.0], desc[:1], 15.0, mode=3)
+    # nothing in view -> no matches, all -1
+    n, match = m.SearchByProjection(F, SF, np.zeros(3, np.uint8), [0, 0, 0], [1.0] * 3, [1.0] * 3, [1.0] * 3, desc[:3])
+    assert n == 0 and (match == -1).all()
