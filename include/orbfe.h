@@ -381,6 +381,58 @@ int orbfe_search_by_projection_last_frame(int device, const orbfe_frame_view *Cu
                                           int mode, float th, int check_orientation,
                                           int32_t *match_cur, int32_t *n_matches);
 
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound,
+ * const float th, const int ORBdist) (src/ORBmatcher.cc:1641-1775, relocalisation) after the caller's
+ * projection: point i is valid when pKF's map point i exists, is good, is not in sAlreadyFound,
+ * projects to (u, v) inside the image and lies inside its distance range; level = PredictScale;
+ * kf_angle = pKF->mvKeysUn[i].angle.  blocked[i2] != 0 <=> CurrentFrame.mvpMapPoints[i2] != NULL
+ * (NULL = none). */
+int orbfe_search_by_projection_keyframe(int device, const orbfe_frame_view *Cur,
+                                        const float *scale_factors, int n_levels,
+                                        const uint8_t *blocked, int n, const uint8_t *valid,
+                                        const float *u, const float *v, const int32_t *level,
+                                        const float *kf_angle, const uint8_t *mp_desc, float th,
+                                        int orb_dist, int check_orientation, int32_t *match_cur,
+                                        int32_t *n_matches);
+
+/* ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints,
+ * vector<MapPoint*> &vpMatched, int th) (src/ORBmatcher.cc:335-449, loop closing) after the caller's
+ * Sim3 projection.  matched[idx] != 0 <=> vpMatched[idx] != NULL before the call (NULL = none);
+ * match[idx] = point newly matched to keypoint idx or -1. */
+int orbfe_search_by_projection_sim3(int device, const orbfe_frame_view *KF, const float *scale_factors,
+                                    int n_levels, const uint8_t *matched, int n, const uint8_t *valid,
+                                    const float *u, const float *v, const int32_t *level,
+                                    const uint8_t *mp_desc, float th, int32_t *match,
+                                    int32_t *n_matches);
+
+/* ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched,
+ * vector<int> &vnMatches12, int windowSize) (src/ORBmatcher.cc:469-603).  prev_x / prev_y are
+ * vbPrevMatched, updated in place like the reference; match12[i1] = i2 or -1. */
+int orbfe_search_for_initialization(int device, const orbfe_frame_view *F1, const orbfe_frame_view *F2,
+                                    float *prev_x, float *prev_y, int window_size, float nnratio,
+                                    int check_orientation, int32_t *match12, int32_t *n_matches);
+
+/* The search ORBmatcher::Fuse runs per map point (src/ORBmatcher.cc:940-1110 with chi2_gate != 0,
+ * the Sim3 overload :1112-1249 with chi2_gate == 0): best_idx[i] = keypoint of pKF with octave in
+ * [level-1, level], passing the reprojection gate (5.99 mono / 7.8 stereo on e2 *
+ * inv_level_sigma2[octave]) and the least descriptor distance <= TH_LOW, or -1.  What happens to a hit
+ * (Replace / AddObservation) is map bookkeeping and stays with the caller. */
+int orbfe_fuse_search(int device, const orbfe_frame_view *KF, const float *scale_factors,
+                      const float *inv_level_sigma2, int n_levels, int n, const uint8_t *valid,
+                      const float *u, const float *v, const float *ur, const int32_t *level,
+                      const uint8_t *mp_desc, float th, int chi2_gate, int32_t *best_idx);
+
+/* ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1251-1482) after the caller's two projections:
+ * valid1[i1] <=> keypoint i1 of KF1 has a good map point, not matched yet, that projects into KF2 at
+ * (u1, v1) inside the image and its distance range, level1 = PredictScale, desc1 = its descriptor;
+ * the "2" arrays are the KF2 -> KF1 direction.  match12[i1] = i2 for mutually consistent pairs. */
+int orbfe_search_by_sim3(int device, const orbfe_frame_view *KF1, const orbfe_frame_view *KF2,
+                         const float *scale_factors1, const float *scale_factors2, int n_levels,
+                         const uint8_t *valid1, const float *u1, const float *v1, const int32_t *level1,
+                         const uint8_t *desc1, const uint8_t *valid2, const float *u2, const float *v2,
+                         const int32_t *level2, const uint8_t *desc2, float th, int32_t *match12,
+                         int32_t *n_found);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1442,3 +1442,207 @@ int orc_search_by_projection_lastframe(orc_frame *Cur, const float *sf, float mb
   free(blocked);
   return nmatches;
 }
+
+int orc_search_by_projection_reloc(orc_frame *Cur, const float *sf, int n, const uint8_t *valid, const float *u,
+                                   const float *v, const int32_t *level, const float *kf_angle,
+                                   const uint8_t *mp_desc, const uint8_t *blocked0, float th, int orb_dist,
+                                   int check_ori, int32_t *match_cur) {
+  int nmatches = 0;
+  rothist rh;
+  rh_init(&rh, n);
+  for (int i = 0; i < Cur->N; i++) match_cur[i] = -1;
+  uint8_t *blocked = (uint8_t *)calloc((size_t)(Cur->N > 0 ? Cur->N : 1), 1);
+  if (blocked0) memcpy(blocked, blocked0, (size_t)Cur->N);
+  int32_t *vIdx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(Cur->N > 0 ? Cur->N : 1));
+  for (int i = 0; i < n; i++) {
+    if (!valid[i]) continue;
+    const int nPredictedLevel = level[i];
+    const float radius = th * sf[nPredictedLevel];
+    const int nc = orc_features_in_area(Cur, u[i], v[i], radius, nPredictedLevel - 1, nPredictedLevel + 1, vIdx, Cur->N);
+    if (nc == 0) continue;
+    const uint8_t *dMP = mp_desc + (size_t)i * 32;
+    int bestDist = 256, bestIdx2 = -1;
+    for (int c = 0; c < nc; c++) {
+      const int i2 = vIdx[c];
+      if (blocked[i2]) continue; /* CurrentFrame.mvpMapPoints[i2] != NULL */
+      const int dist = orc_descriptor_distance(dMP, Cur->desc + (size_t)i2 * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= orb_dist) {
+      match_cur[bestIdx2] = i;
+      blocked[bestIdx2] = 1;
+      nmatches++;
+      if (check_ori) rh_push(&rh, kf_angle[i], Cur->angle[bestIdx2], bestIdx2);
+    }
+  }
+  if (check_ori) nmatches -= rh_prune(&rh, match_cur);
+  rh_free(&rh);
+  free(vIdx);
+  free(blocked);
+  return nmatches;
+}
+
+int orc_search_by_projection_sim3(orc_frame *KF, const float *sf, int n, const uint8_t *valid, const float *u,
+                                  const float *v, const int32_t *level, const uint8_t *mp_desc,
+                                  const uint8_t *matched0, float th, int32_t *match) {
+  int nmatches = 0;
+  for (int i = 0; i < KF->N; i++) match[i] = -1;
+  uint8_t *matched = (uint8_t *)calloc((size_t)(KF->N > 0 ? KF->N : 1), 1);
+  if (matched0) memcpy(matched, matched0, (size_t)KF->N);
+  int32_t *vIdx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(KF->N > 0 ? KF->N : 1));
+  for (int i = 0; i < n; i++) {
+    if (!valid[i]) continue;
+    const int nPredictedLevel = level[i];
+    const float radius = th * sf[nPredictedLevel];
+    const int nc = orc_features_in_area(KF, u[i], v[i], radius, -1, -1, vIdx, KF->N); /* KeyFrame::GetFeaturesInArea */
+    if (nc == 0) continue;
+    const uint8_t *dMP = mp_desc + (size_t)i * 32;
+    int bestDist = 256, bestIdx = -1;
+    for (int c = 0; c < nc; c++) {
+      const int idx = vIdx[c];
+      if (matched[idx]) continue;
+      const int kpLevel = KF->octave[idx];
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      const int dist = orc_descriptor_distance(dMP, KF->desc + (size_t)idx * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    if (bestDist <= TH_LOW) { match[bestIdx] = i; matched[bestIdx] = 1; nmatches++; }
+  }
+  free(vIdx);
+  free(matched);
+  return nmatches;
+}
+
+int orc_search_for_initialization(const orc_frame *F1, orc_frame *F2, float *prev_x, float *prev_y, int window,
+                                  float nnratio, int check_ori, int32_t *match12) {
+  int nmatches = 0;
+  for (int i = 0; i < F1->N; i++) match12[i] = -1;
+  rothist rh;
+  rh_init(&rh, F1->N);
+  const int n2 = F2->N > 0 ? F2->N : 1;
+  int *vMatchedDistance = (int *)malloc(sizeof(int) * (size_t)n2);
+  int *vnMatches21 = (int *)malloc(sizeof(int) * (size_t)n2);
+  for (int i = 0; i < F2->N; i++) { vMatchedDistance[i] = INT_MAX; vnMatches21[i] = -1; }
+  int32_t *vIdx = (int32_t *)malloc(sizeof(int32_t) * (size_t)n2);
+  for (int i1 = 0; i1 < F1->N; i1++) {
+    const int level1 = F1->octave[i1];
+    if (level1 > 0) continue;
+    const int nc = orc_features_in_area(F2, prev_x[i1], prev_y[i1], (float)window, level1, level1, vIdx, F2->N);
+    if (nc == 0) continue;
+    const uint8_t *d1 = F1->desc + (size_t)i1 * 32;
+    int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+    for (int c = 0; c < nc; c++) {
+      const int i2 = vIdx[c];
+      const int dist = orc_descriptor_distance(d1, F2->desc + (size_t)i2 * 32);
+      if (vMatchedDistance[i2] <= dist) continue;
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+      else if (dist < bestDist2) bestDist2 = dist;
+    }
+    if (bestDist <= TH_LOW) {
+      if ((float)bestDist < (float)bestDist2 * nnratio) {
+        if (vnMatches21[bestIdx2] >= 0) { match12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+        match12[i1] = bestIdx2;
+        vnMatches21[bestIdx2] = i1;
+        vMatchedDistance[bestIdx2] = bestDist;
+        nmatches++;
+        if (check_ori) rh_push(&rh, F1->angle[i1], F2->angle[bestIdx2], i1);
+      }
+    }
+  }
+  if (check_ori) { /* :568-592: only entries still matched are cleared and counted */
+    int i1 = -1, i2 = -1, i3 = -1;
+    orc_three_maxima(rh.n, HISTO_LENGTH, &i1, &i2, &i3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == i1 || i == i2 || i == i3) continue;
+      for (int j = 0; j < rh.n[i]; j++) {
+        const int idx1 = rh.v[i][j];
+        if (match12[idx1] >= 0) { match12[idx1] = -1; nmatches--; }
+      }
+    }
+  }
+  for (int i1 = 0; i1 < F1->N; i1++)
+    if (match12[i1] >= 0) { prev_x[i1] = F2->x[match12[i1]]; prev_y[i1] = F2->y[match12[i1]]; }
+  rh_free(&rh);
+  free(vIdx);
+  free(vMatchedDistance);
+  free(vnMatches21);
+  return nmatches;
+}
+
+void orc_fuse_search(orc_frame *KF, const float *sf, const float *inv_level_sigma2, int n, const uint8_t *valid,
+                     const float *u, const float *v, const float *ur, const int32_t *level, const uint8_t *mp_desc,
+                     float th, int chi2, int32_t *best_idx) {
+  int32_t *vIdx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(KF->N > 0 ? KF->N : 1));
+  for (int i = 0; i < n; i++) {
+    best_idx[i] = -1;
+    if (!valid[i]) continue;
+    const int nPredictedLevel = level[i];
+    const float radius = th * sf[nPredictedLevel];
+    const int nc = orc_features_in_area(KF, u[i], v[i], radius, -1, -1, vIdx, KF->N);
+    const uint8_t *dMP = mp_desc + (size_t)i * 32;
+    int bestDist = 256, bestIdx = -1;
+    for (int c = 0; c < nc; c++) {
+      const int idx = vIdx[c];
+      const int kpLevel = KF->octave[idx];
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      if (chi2) {
+        const float kpx = KF->x[idx], kpy = KF->y[idx];
+        if (KF->uRight && KF->uRight[idx] >= 0) {
+          const float kpr = KF->uRight[idx];
+          const float ex = u[i] - kpx, ey = v[i] - kpy, er = ur[i] - kpr;
+          const float e2 = ex * ex + ey * ey + er * er;
+          if (e2 * inv_level_sigma2[kpLevel] > 7.8) continue;
+        } else {
+          const float ex = u[i] - kpx, ey = v[i] - kpy;
+          const float e2 = ex * ex + ey * ey;
+          if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+        }
+      }
+      const int dist = orc_descriptor_distance(dMP, KF->desc + (size_t)idx * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    if (bestDist <= TH_LOW) best_idx[i] = bestIdx;
+  }
+  free(vIdx);
+}
+
+static void sim3_one_way(orc_frame *KF, const float *sf, int n, const uint8_t *valid, const float *u, const float *v,
+                         const int32_t *level, const uint8_t *desc, float th, int *vnMatch) {
+  int32_t *vIdx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(KF->N > 0 ? KF->N : 1));
+  for (int i = 0; i < n; i++) {
+    vnMatch[i] = -1;
+    if (!valid[i]) continue;
+    const int nPredictedLevel = level[i];
+    const float radius = th * sf[nPredictedLevel];
+    const int nc = orc_features_in_area(KF, u[i], v[i], radius, -1, -1, vIdx, KF->N);
+    const uint8_t *dMP = desc + (size_t)i * 32;
+    int bestDist = INT_MAX, bestIdx = -1;
+    for (int c = 0; c < nc; c++) {
+      const int idx = vIdx[c];
+      if (KF->octave[idx] < nPredictedLevel - 1 || KF->octave[idx] > nPredictedLevel) continue;
+      const int dist = orc_descriptor_distance(dMP, KF->desc + (size_t)idx * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    if (bestDist <= TH_HIGH) vnMatch[i] = bestIdx;
+  }
+  free(vIdx);
+}
+
+int orc_search_by_sim3(orc_frame *KF1, orc_frame *KF2, const float *sf1, const float *sf2, const uint8_t *valid1,
+                       const float *u1, const float *v1, const int32_t *level1, const uint8_t *desc1,
+                       const uint8_t *valid2, const float *u2, const float *v2, const int32_t *level2,
+                       const uint8_t *desc2, float th, int32_t *match12) {
+  int *vnMatch1 = (int *)malloc(sizeof(int) * (size_t)(KF1->N > 0 ? KF1->N : 1));
+  int *vnMatch2 = (int *)malloc(sizeof(int) * (size_t)(KF2->N > 0 ? KF2->N : 1));
+  sim3_one_way(KF2, sf2, KF1->N, valid1, u1, v1, level1, desc1, th, vnMatch1); /* KF1 points searched in KF2 */
+  sim3_one_way(KF1, sf1, KF2->N, valid2, u2, v2, level2, desc2, th, vnMatch2);
+  int nFound = 0;
+  for (int i1 = 0; i1 < KF1->N; i1++) {
+    match12[i1] = -1;
+    const int idx2 = vnMatch1[i1];
+    if (idx2 >= 0 && vnMatch2[idx2] == i1) { match12[i1] = idx2; nFound++; }
+  }
+  free(vnMatch1);
+  free(vnMatch2);
+  return nFound;
+}

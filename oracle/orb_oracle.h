@@ -185,6 +185,42 @@ int orc_search_by_projection_lastframe(orc_frame *Cur, const float *scale_factor
                                        const uint8_t *obs_positive, int mode, float th, int check_ori,
                                        int32_t *match_cur);
 
+/* SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist),
+ * src/ORBmatcher.cc:1641-1775 (relocalisation), after the caller's projection: valid = map point exists, not bad,
+ * not already found, in image, inside its distance range; level = PredictScale; kf_angle = pKF->mvKeysUn[i].angle;
+ * blocked[i2] != 0 <=> CurrentFrame.mvpMapPoints[i2] != NULL before the call. */
+int orc_search_by_projection_reloc(orc_frame *Cur, const float *scale_factors, int n, const uint8_t *valid,
+                                   const float *u, const float *v, const int32_t *level, const float *kf_angle,
+                                   const uint8_t *mp_desc, const uint8_t *blocked, float th, int orb_dist,
+                                   int check_ori, int32_t *match_cur);
+
+/* SearchByProjection(KeyFrame *pKF, cv::Mat Scw, vpPoints, vpMatched, th), src/ORBmatcher.cc:335-449 (loop
+ * closing), after the caller's projection.  matched[idx] != 0 <=> vpMatched[idx] != NULL before the call.
+ * match[idx] = index of the point newly matched to keypoint idx, or -1. */
+int orc_search_by_projection_sim3(orc_frame *KF, const float *scale_factors, int n, const uint8_t *valid,
+                                  const float *u, const float *v, const int32_t *level, const uint8_t *mp_desc,
+                                  const uint8_t *matched, float th, int32_t *match);
+
+/* SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize), src/ORBmatcher.cc:469-603.
+ * prev_x / prev_y are vbPrevMatched (updated in place as the reference does).  match12[i1] = i2 or -1. */
+int orc_search_for_initialization(const orc_frame *F1, orc_frame *F2, float *prev_x, float *prev_y, int window,
+                                  float nnratio, int check_ori, int32_t *match12);
+
+/* The search both Fuse overloads run per map point (src/ORBmatcher.cc:940-1110 with the chi-square gate,
+ * :1112-1249 without): best keypoint of the window with octave in [level-1, level]; best_idx[i] = keypoint with
+ * bestDist <= TH_LOW or -1.  ur: projected right coordinate (read only when chi2 != 0 and KF->uRight). */
+void orc_fuse_search(orc_frame *KF, const float *scale_factors, const float *inv_level_sigma2, int n,
+                     const uint8_t *valid, const float *u, const float *v, const float *ur, const int32_t *level,
+                     const uint8_t *mp_desc, float th, int chi2, int32_t *best_idx);
+
+/* SearchBySim3, src/ORBmatcher.cc:1251-1482, after the caller's two projections: valid1[i1] = KF1 keypoint i1 has
+ * a good, not-yet-matched map point that projects into KF2 at (u1,v1) with predicted level level1 (desc1 = its
+ * descriptor); same for KF2 -> KF1.  match12[i1] = i2 of the mutually consistent pair or -1; returns nFound. */
+int orc_search_by_sim3(orc_frame *KF1, orc_frame *KF2, const float *sf1, const float *sf2, const uint8_t *valid1,
+                       const float *u1, const float *v1, const int32_t *level1, const uint8_t *desc1,
+                       const uint8_t *valid2, const float *u2, const float *v2, const int32_t *level2,
+                       const uint8_t *desc2, float th, int32_t *match12);
+
 /* ---- DBoW2 vocabulary (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h) ---- */
 typedef struct orc_vocab {
   int k, L, scoring, weighting;

@@ -55,7 +55,8 @@ EXPORTS = [
     "orbfe_vocabulary_info", "orbfe_vocabulary_transform", "orbfe_vocabulary_featvec_batch_device",
     "orbfe_bow_match_consecutive_batch_device", "orbfe_cvt_gray", "orbfe_cvt_gray_batch_device",
     "orbfe_distinctive_descriptors", "orbfe_features_in_area", "orbfe_search_by_projection",
-    "orbfe_search_by_projection_last_frame",
+    "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_keyframe",
+    "orbfe_search_by_projection_sim3", "orbfe_search_for_initialization", "orbfe_fuse_search", "orbfe_search_by_sim3",
 ]
 
 _lib = None
@@ -150,6 +151,11 @@ def load():
     L.orbfe_search_by_projection.argtypes = [ci, fwp, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, vp, vp]
     L.orbfe_search_by_projection_last_frame.argtypes = [ci, fwp, vp, ci, cf, ci, vp, vp, vp, vp, vp, vp, vp, vp,
                                                         ci, cf, ci, vp, vp]
+    L.orbfe_search_by_projection_keyframe.argtypes = [ci, fwp, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, cf, ci, ci, vp, vp]
+    L.orbfe_search_by_projection_sim3.argtypes = [ci, fwp, vp, ci, vp, ci, vp, vp, vp, vp, vp, cf, vp, vp]
+    L.orbfe_search_for_initialization.argtypes = [ci, fwp, fwp, vp, vp, ci, cf, ci, vp, vp]
+    L.orbfe_fuse_search.argtypes = [ci, fwp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, cf, ci, vp]
+    L.orbfe_search_by_sim3.argtypes = [ci, fwp, fwp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, vp, vp]
     L.orbfe_debug_octree_host.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, ci]
     L.orbfe_debug_geometry.argtypes = [ci, cf, ci, ci, ci, ci, ci, vp, vp, vp, ci]
     L.orbfe_debug_resize_tables.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp]

@@ -4,6 +4,7 @@
 // on three threads concurrently, src/LocalMapping.cc:261, src/LoopClosing.cc:294).
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -609,5 +610,276 @@ extern "C" int orbfe_search_by_projection_last_frame(int device, const orbfe_fra
     }
   }
   *n_matches = nmatches;
+  return ORBFE_OK;
+}
+
+namespace {
+
+// radius = th * scale_factors[level] and the level window [level + lo, level + hi] of each query
+// (hi_open: no level filter at all, KeyFrame::GetFeaturesInArea, src/KeyFrame.cc:611-650)
+int level_queries(const char* who, int n, const uint8_t* valid, const int32_t* level, const float* sf, int n_levels,
+                  float th, int lo, int hi, bool no_filter, std::vector<float>* qr, std::vector<int32_t>* qmin,
+                  std::vector<int32_t>* qmax) {
+  qr->resize(n); qmin->resize(n); qmax->resize(n);
+  for (int i = 0; i < n; i++) {
+    int lv = 0;
+    if (valid[i]) {
+      lv = level[i];
+      if (lv < 0 || lv >= n_levels) return mfail(ORBFE_ERR_INVALID, std::string(who) + ": level outside the pyramid");
+    }
+    (*qr)[i] = th * sf[lv];
+    (*qmin)[i] = no_filter ? -1 : lv + lo;
+    (*qmax)[i] = no_filter ? -1 : lv + hi;
+  }
+  return ORBFE_OK;
+}
+
+struct RotHist {
+  static constexpr int L = 30;
+  std::vector<int> bins[L];
+  void push(float a1, float a2, int idx) {  // src/ORBmatcher.cc:1601-1610
+    float rot = a1 - a2;
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)roundf(rot * (1.0f / L));
+    if (bin == L) bin = 0;
+    bins[bin].push_back(idx);
+  }
+};
+
+}  // namespace
+
+extern "C" int orbfe_search_by_projection_keyframe(int device, const orbfe_frame_view* Cur, const float* scale_factors,
+                                                   int n_levels, const uint8_t* blocked, int n, const uint8_t* valid,
+                                                   const float* u, const float* v, const int32_t* level,
+                                                   const float* kf_angle, const uint8_t* mp_desc, float th,
+                                                   int orb_dist, int check_orientation, int32_t* match_cur,
+                                                   int32_t* n_matches) {
+  if (!frame_ok(Cur) || !scale_factors || n_levels <= 0 || n < 0 || !n_matches ||
+      (Cur->n > 0 && (!match_cur || !Cur->desc)) || (check_orientation && Cur->n > 0 && !Cur->angle) ||
+      (n > 0 && (!valid || !u || !v || !level || !mp_desc || (check_orientation && !kf_angle))))
+    return mfail(ORBFE_ERR_INVALID, "search_by_projection_keyframe: bad argument");
+  std::vector<float> qr;
+  std::vector<int32_t> qmin, qmax;
+  int rc = level_queries("search_by_projection_keyframe", n, valid, level, scale_factors, n_levels, th, -1, +1, false,
+                         &qr, &qmin, &qmax);
+  if (rc != ORBFE_OK) return rc;
+  for (int i = 0; i < Cur->n; i++) match_cur[i] = -1;
+  *n_matches = 0;
+  if (n == 0 || Cur->n == 0) return ORBFE_OK;
+  WindowResult res;
+  rc = window_search(device, Cur, n, u, v, qr.data(), qmin.data(), qmax.data(), valid, nullptr, mp_desc, 32, &res);
+  if (rc != ORBFE_OK) return rc;
+  std::vector<uint8_t> blk(Cur->n, 0);
+  if (blocked) std::memcpy(blk.data(), blocked, (size_t)Cur->n);
+  RotHist rh;
+  int nmatches = 0;
+  for (int i = 0; i < n; i++) {
+    if (!valid[i]) continue;
+    int bestDist = 256, bestIdx2 = -1;
+    for (int c = 0; c < res.count[i]; c++) {
+      const uint32_t e = res.cand[(size_t)i * res.K + c];
+      const int i2 = (int)(e & 0xffffu), dist = (int)(e >> 16);
+      if (blk[i2]) continue;
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= orb_dist) {
+      match_cur[bestIdx2] = i;
+      blk[bestIdx2] = 1;
+      nmatches++;
+      if (check_orientation) rh.push(kf_angle[i], Cur->angle[bestIdx2], bestIdx2);
+    }
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rh.bins, RotHist::L, ind1, ind2, ind3);
+    for (int i = 0; i < RotHist::L; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx : rh.bins[i]) { match_cur[idx] = -1; nmatches--; }
+    }
+  }
+  *n_matches = nmatches;
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_search_by_projection_sim3(int device, const orbfe_frame_view* KF, const float* scale_factors,
+                                               int n_levels, const uint8_t* matched, int n, const uint8_t* valid,
+                                               const float* u, const float* v, const int32_t* level,
+                                               const uint8_t* mp_desc, float th, int32_t* match, int32_t* n_matches) {
+  if (!frame_ok(KF) || !scale_factors || n_levels <= 0 || n < 0 || !n_matches || (KF->n > 0 && (!match || !KF->desc)) ||
+      (n > 0 && (!valid || !u || !v || !level || !mp_desc)))
+    return mfail(ORBFE_ERR_INVALID, "search_by_projection_sim3: bad argument");
+  std::vector<float> qr;
+  std::vector<int32_t> qmin, qmax;
+  // the reference gathers the window without a level filter and then keeps octaves [level-1, level]
+  // (src/ORBmatcher.cc:410-428): the same set, in the same order, as filtering inside the window
+  int rc = level_queries("search_by_projection_sim3", n, valid, level, scale_factors, n_levels, th, -1, 0, false, &qr,
+                         &qmin, &qmax);
+  if (rc != ORBFE_OK) return rc;
+  for (int i = 0; i < KF->n; i++) match[i] = -1;
+  *n_matches = 0;
+  if (n == 0 || KF->n == 0) return ORBFE_OK;
+  WindowResult res;
+  rc = window_search(device, KF, n, u, v, qr.data(), qmin.data(), qmax.data(), valid, nullptr, mp_desc, 32, &res);
+  if (rc != ORBFE_OK) return rc;
+  std::vector<uint8_t> blk(KF->n, 0);
+  if (matched) std::memcpy(blk.data(), matched, (size_t)KF->n);
+  int nmatches = 0;
+  for (int i = 0; i < n; i++) {
+    if (!valid[i]) continue;
+    int bestDist = 256, bestIdx = -1;
+    for (int c = 0; c < res.count[i]; c++) {
+      const uint32_t e = res.cand[(size_t)i * res.K + c];
+      const int idx = (int)(e & 0xffffu), dist = (int)(e >> 16);
+      if (blk[idx]) continue;
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    if (bestDist <= 50) { match[bestIdx] = i; blk[bestIdx] = 1; nmatches++; }  // TH_LOW
+  }
+  *n_matches = nmatches;
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_search_for_initialization(int device, const orbfe_frame_view* F1, const orbfe_frame_view* F2,
+                                               float* prev_x, float* prev_y, int window_size, float nnratio,
+                                               int check_orientation, int32_t* match12, int32_t* n_matches) {
+  if (!frame_ok(F1) || !frame_ok(F2) || !n_matches || window_size < 0 ||
+      (F1->n > 0 && (!match12 || !prev_x || !prev_y || !F1->desc)) || (F2->n > 0 && !F2->desc) ||
+      (check_orientation && ((F1->n > 0 && !F1->angle) || (F2->n > 0 && !F2->angle))))
+    return mfail(ORBFE_ERR_INVALID, "search_for_initialization: bad argument");
+  const int n1 = F1->n;
+  for (int i = 0; i < n1; i++) match12[i] = -1;
+  *n_matches = 0;
+  if (n1 == 0 || F2->n == 0) return ORBFE_OK;
+  std::vector<float> qr(n1, (float)window_size);
+  std::vector<int32_t> qlv(n1, 0);
+  std::vector<uint8_t> active(n1);
+  for (int i = 0; i < n1; i++) active[i] = F1->octave[i] > 0 ? 0 : 1;  // only level-0 keypoints (:482-484)
+  for (int i = 0; i < n1; i++) qlv[i] = active[i] ? F1->octave[i] : 0;
+  WindowResult res;
+  const int rc = window_search(device, F2, n1, prev_x, prev_y, qr.data(), qlv.data(), qlv.data(), active.data(), nullptr,
+                               F1->desc, 128, &res);
+  if (rc != ORBFE_OK) return rc;
+  std::vector<int> vMatchedDistance(F2->n, INT_MAX), vnMatches21(F2->n, -1);
+  RotHist rh;
+  int nmatches = 0;
+  for (int i1 = 0; i1 < n1; i1++) {
+    if (!active[i1]) continue;
+    int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+    for (int c = 0; c < res.count[i1]; c++) {
+      const uint32_t e = res.cand[(size_t)i1 * res.K + c];
+      const int i2 = (int)(e & 0xffffu), dist = (int)(e >> 16);
+      if (vMatchedDistance[i2] <= dist) continue;
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+      else if (dist < bestDist2) bestDist2 = dist;
+    }
+    if (bestDist <= 50) {  // TH_LOW
+      if ((float)bestDist < (float)bestDist2 * nnratio) {
+        if (vnMatches21[bestIdx2] >= 0) { match12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+        match12[i1] = bestIdx2;
+        vnMatches21[bestIdx2] = i1;
+        vMatchedDistance[bestIdx2] = bestDist;
+        nmatches++;
+        if (check_orientation) rh.push(F1->angle[i1], F2->angle[bestIdx2], i1);
+      }
+    }
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rh.bins, RotHist::L, ind1, ind2, ind3);
+    for (int i = 0; i < RotHist::L; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx1 : rh.bins[i])
+        if (match12[idx1] >= 0) { match12[idx1] = -1; nmatches--; }
+    }
+  }
+  for (int i1 = 0; i1 < n1; i1++)  // "Update prev matched" (:595-600)
+    if (match12[i1] >= 0) { prev_x[i1] = F2->x[match12[i1]]; prev_y[i1] = F2->y[match12[i1]]; }
+  *n_matches = nmatches;
+  return ORBFE_OK;
+}
+
+namespace {
+// best keypoint of every window with octave in [level-1, level] (first minimum in scan order), the
+// inner search shared by Fuse x2 and SearchBySim3; gate = chi-square test of Fuse (src/ORBmatcher.cc:1029-1060)
+int window_best(const char* who, int device, const orbfe_frame_view* KF, const float* sf, int n_levels,
+                const float* inv_level_sigma2, int n, const uint8_t* valid, const float* u, const float* v,
+                const float* ur, const int32_t* level, const uint8_t* desc, float th, bool gate, int max_dist,
+                int32_t* best) {
+  std::vector<float> qr;
+  std::vector<int32_t> qmin, qmax;
+  int rc = level_queries(who, n, valid, level, sf, n_levels, th, -1, 0, false, &qr, &qmin, &qmax);
+  if (rc != ORBFE_OK) return rc;
+  for (int i = 0; i < n; i++) best[i] = -1;
+  if (n == 0 || KF->n == 0) return ORBFE_OK;
+  WindowResult res;
+  rc = window_search(device, KF, n, u, v, qr.data(), qmin.data(), qmax.data(), valid, nullptr, desc, 32, &res);
+  if (rc != ORBFE_OK) return rc;
+  for (int i = 0; i < n; i++) {
+    if (!valid[i]) continue;
+    int bestDist = 256, bestIdx = -1;
+    for (int c = 0; c < res.count[i]; c++) {
+      const uint32_t e = res.cand[(size_t)i * res.K + c];
+      const int idx = (int)(e & 0xffffu), dist = (int)(e >> 16);
+      if (gate) {
+        const int kpLevel = KF->octave[idx];
+        const float kpx = KF->x[idx], kpy = KF->y[idx];
+        if (KF->u_right && KF->u_right[idx] >= 0) {
+          const float kpr = KF->u_right[idx];
+          const float ex = u[i] - kpx, ey = v[i] - kpy, er = ur[i] - kpr;
+          const float e2 = ex * ex + ey * ey + er * er;
+          if (e2 * inv_level_sigma2[kpLevel] > 7.8) continue;
+        } else {
+          const float ex = u[i] - kpx, ey = v[i] - kpy;
+          const float e2 = ex * ex + ey * ey;
+          if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+        }
+      }
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    if (bestDist <= max_dist) best[i] = bestIdx;
+  }
+  return ORBFE_OK;
+}
+}  // namespace
+
+extern "C" int orbfe_fuse_search(int device, const orbfe_frame_view* KF, const float* scale_factors,
+                                 const float* inv_level_sigma2, int n_levels, int n, const uint8_t* valid,
+                                 const float* u, const float* v, const float* ur, const int32_t* level,
+                                 const uint8_t* mp_desc, float th, int chi2_gate, int32_t* best_idx) {
+  if (!frame_ok(KF) || !scale_factors || n_levels <= 0 || n < 0 || (KF->n > 0 && !KF->desc) ||
+      (n > 0 && (!valid || !u || !v || !level || !mp_desc || !best_idx)) ||
+      (chi2_gate && (!inv_level_sigma2 || (KF->u_right && n > 0 && !ur))))
+    return mfail(ORBFE_ERR_INVALID, "fuse_search: bad argument");
+  for (int i = 0; i < KF->n; i++)
+    if (chi2_gate && (KF->octave[i] < 0 || KF->octave[i] >= n_levels))
+      return mfail(ORBFE_ERR_INVALID, "fuse_search: keypoint octave outside the pyramid");
+  return window_best("fuse_search", device, KF, scale_factors, n_levels, inv_level_sigma2, n, valid, u, v, ur, level,
+                     mp_desc, th, chi2_gate != 0, 50 /* TH_LOW */, best_idx);
+}
+
+extern "C" int orbfe_search_by_sim3(int device, const orbfe_frame_view* KF1, const orbfe_frame_view* KF2,
+                                    const float* scale_factors1, const float* scale_factors2, int n_levels,
+                                    const uint8_t* valid1, const float* u1, const float* v1, const int32_t* level1,
+                                    const uint8_t* desc1, const uint8_t* valid2, const float* u2, const float* v2,
+                                    const int32_t* level2, const uint8_t* desc2, float th, int32_t* match12,
+                                    int32_t* n_found) {
+  if (!frame_ok(KF1) || !frame_ok(KF2) || !scale_factors1 || !scale_factors2 || n_levels <= 0 || !n_found ||
+      (KF1->n > 0 && (!valid1 || !u1 || !v1 || !level1 || !desc1 || !match12 || !KF1->desc)) ||
+      (KF2->n > 0 && (!valid2 || !u2 || !v2 || !level2 || !desc2 || !KF2->desc)))
+    return mfail(ORBFE_ERR_INVALID, "search_by_sim3: bad argument");
+  std::vector<int32_t> m1(KF1->n ? KF1->n : 1), m2(KF2->n ? KF2->n : 1);
+  int rc = window_best("search_by_sim3", device, KF2, scale_factors2, n_levels, nullptr, KF1->n, valid1, u1, v1, nullptr,
+                       level1, desc1, th, false, 100 /* TH_HIGH */, m1.data());
+  if (rc != ORBFE_OK) return rc;
+  rc = window_best("search_by_sim3", device, KF1, scale_factors1, n_levels, nullptr, KF2->n, valid2, u2, v2, nullptr,
+                   level2, desc2, th, false, 100, m2.data());
+  if (rc != ORBFE_OK) return rc;
+  int nFound = 0;
+  for (int i1 = 0; i1 < KF1->n; i1++) {
+    match12[i1] = -1;
+    const int idx2 = m1[i1];
+    if (idx2 >= 0 && m2[idx2] == i1) { match12[i1] = idx2; nFound++; }
+  }
+  *n_found = nFound;
   return ORBFE_OK;
 }

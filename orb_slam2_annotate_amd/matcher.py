@@ -170,6 +170,74 @@ class ORBmatcher:
             float(th), int(self.mbCheckOrientation), ptr(match), C.byref(n)))
         return n.value, match[:Cur.N]
 
+    def SearchByProjectionKeyFrame(self, Cur: FrameView, scale_factors, valid, u, v, level, kf_angle, mp_desc,
+                                   th: float, ORBdist: int, blocked=None):
+        """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:1641-1775)
+        after the caller's projection -> (nmatches, match_cur[Cur.N])."""
+        sf, va, uu, vv = _f32(scale_factors), _u8(valid), _f32(u), _f32(v)
+        lv, ka, md = np.ascontiguousarray(level, dtype=np.int32), _f32(kf_angle), _u8(mp_desc).reshape(-1, 32)
+        blk = None if blocked is None else _u8(blocked)
+        match = np.full(max(Cur.N, 1), -1, dtype=np.int32)
+        n = C.c_int32(0)
+        check(self._L.orbfe_search_by_projection_keyframe(
+            self.device, C.byref(Cur.c), ptr(sf), len(sf), ptr(blk), len(va), ptr(va), ptr(uu), ptr(vv), ptr(lv),
+            ptr(ka), ptr(md), float(th), int(ORBdist), int(self.mbCheckOrientation), ptr(match), C.byref(n)))
+        return n.value, match[:Cur.N]
+
+    def SearchByProjectionSim3(self, KF: FrameView, scale_factors, valid, u, v, level, mp_desc, th: float,
+                               matched=None):
+        """SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (src/ORBmatcher.cc:335-449) after the
+        caller's projection -> (nmatches, match[KF.N]) (new matches only)."""
+        sf, va, uu, vv = _f32(scale_factors), _u8(valid), _f32(u), _f32(v)
+        lv, md = np.ascontiguousarray(level, dtype=np.int32), _u8(mp_desc).reshape(-1, 32)
+        mt = None if matched is None else _u8(matched)
+        match = np.full(max(KF.N, 1), -1, dtype=np.int32)
+        n = C.c_int32(0)
+        check(self._L.orbfe_search_by_projection_sim3(self.device, C.byref(KF.c), ptr(sf), len(sf), ptr(mt), len(va),
+                                                      ptr(va), ptr(uu), ptr(vv), ptr(lv), ptr(md), float(th),
+                                                      ptr(match), C.byref(n)))
+        return n.value, match[:KF.N]
+
+    def SearchForInitialization(self, F1: FrameView, F2: FrameView, vbPrevMatched, windowSize: int = 10):
+        """src/ORBmatcher.cc:469-603 -> (nmatches, vnMatches12[F1.N]); vbPrevMatched ([N1,2] float32) is
+        updated in place."""
+        prev = np.asarray(vbPrevMatched)
+        px, py = _f32(prev[:, 0]).copy(), _f32(prev[:, 1]).copy()
+        match = np.full(max(F1.N, 1), -1, dtype=np.int32)
+        n = C.c_int32(0)
+        check(self._L.orbfe_search_for_initialization(self.device, C.byref(F1.c), C.byref(F2.c), ptr(px), ptr(py),
+                                                      int(windowSize), self.mfNNratio, int(self.mbCheckOrientation),
+                                                      ptr(match), C.byref(n)))
+        prev[:, 0], prev[:, 1] = px, py
+        return n.value, match[:F1.N]
+
+    def FuseSearch(self, KF: FrameView, scale_factors, valid, u, v, level, mp_desc, th: float = 3.0,
+                   inv_level_sigma2=None, ur=None):
+        """The per-map-point search of Fuse (src/ORBmatcher.cc:940-1110; the Sim3 overload :1112-1249 when
+        inv_level_sigma2 is None) -> bestIdx[n] (-1: no keypoint within TH_LOW)."""
+        sf, va, uu, vv = _f32(scale_factors), _u8(valid), _f32(u), _f32(v)
+        lv, md = np.ascontiguousarray(level, dtype=np.int32), _u8(mp_desc).reshape(-1, 32)
+        sg = None if inv_level_sigma2 is None else _f32(inv_level_sigma2)
+        r = None if ur is None else _f32(ur)
+        best = np.full(max(len(va), 1), -1, dtype=np.int32)
+        check(self._L.orbfe_fuse_search(self.device, C.byref(KF.c), ptr(sf), ptr(sg), len(sf), len(va), ptr(va),
+                                        ptr(uu), ptr(vv), ptr(r), ptr(lv), ptr(md), float(th), int(sg is not None),
+                                        ptr(best)))
+        return best[:len(va)]
+
+    def SearchBySim3(self, KF1: FrameView, KF2: FrameView, sf1, sf2, valid1, u1, v1, level1, desc1, valid2, u2, v2,
+                     level2, desc2, th: float):
+        """src/ORBmatcher.cc:1251-1482 after the caller's two projections -> (nFound, match12[KF1.N])."""
+        sf1, sf2 = _f32(sf1), _f32(sf2)
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        a = [_u8(valid1), _f32(u1), _f32(v1), i32(level1), _u8(desc1), _u8(valid2), _f32(u2), _f32(v2), i32(level2),
+             _u8(desc2)]
+        match = np.full(max(KF1.N, 1), -1, dtype=np.int32)
+        n = C.c_int32(0)
+        check(self._L.orbfe_search_by_sim3(self.device, C.byref(KF1.c), C.byref(KF2.c), ptr(sf1), ptr(sf2), len(sf1),
+                                           *[ptr(x) for x in a], float(th), ptr(match), C.byref(n)))
+        return n.value, match[:KF1.N]
+
     def SearchForTriangulation(self, desc1, has_mp1, x1, y1, angle1, stereo1, fv1, desc2, has_mp2, x2, y2,
                                angle2, octave2, stereo2, fv2, F12, ex, ey, scale_factors2, level_sigma2_2,
                                bOnlyStereo=False):

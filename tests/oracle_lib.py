@@ -359,3 +359,68 @@ def search_by_projection_lastframe(Cur: Frame, sf, mbf, valid, u, v, invzc, last
     n = L.orc_search_by_projection_lastframe(C.byref(Cur.c), _p(sf), float(mbf), len(valid), *[_p(v) for v in a],
                                              int(mode), float(th), int(check_ori), _p(out))
     return n, out[:Cur.N].copy()
+
+
+def _f(a, t):
+    return None if a is None else np.ascontiguousarray(a, dtype=t)
+
+
+def search_by_projection_reloc(Cur: Frame, sf, valid, u, v, level, kf_angle, mp_desc, blocked, th, orb_dist, check_ori):
+    a = [_f(valid, np.uint8), _f(u, np.float32), _f(v, np.float32), _f(level, np.int32), _f(kf_angle, np.float32),
+         _f(mp_desc, np.uint8), _f(blocked, np.uint8)]
+    sf = _f(sf, np.float32)
+    out = np.zeros(max(Cur.N, 1), dtype=np.int32)
+    L = lib()
+    L.orc_search_by_projection_reloc.argtypes = [C.POINTER(OrcFrame), C.c_void_p, C.c_int] + [C.c_void_p] * 7 + \
+        [C.c_float, C.c_int, C.c_int, C.c_void_p]
+    n = L.orc_search_by_projection_reloc(C.byref(Cur.c), _p(sf), len(a[0]), *[_p(x) for x in a], float(th),
+                                         int(orb_dist), int(check_ori), _p(out))
+    return n, out[:Cur.N].copy()
+
+
+def search_by_projection_sim3(KF: Frame, sf, valid, u, v, level, mp_desc, matched, th):
+    a = [_f(valid, np.uint8), _f(u, np.float32), _f(v, np.float32), _f(level, np.int32), _f(mp_desc, np.uint8),
+         _f(matched, np.uint8)]
+    sf = _f(sf, np.float32)
+    out = np.zeros(max(KF.N, 1), dtype=np.int32)
+    L = lib()
+    L.orc_search_by_projection_sim3.argtypes = [C.POINTER(OrcFrame), C.c_void_p, C.c_int] + [C.c_void_p] * 6 + \
+        [C.c_float, C.c_void_p]
+    n = L.orc_search_by_projection_sim3(C.byref(KF.c), _p(sf), len(a[0]), *[_p(x) for x in a], float(th), _p(out))
+    return n, out[:KF.N].copy()
+
+
+def search_for_initialization(F1: Frame, F2: Frame, prev, window, nnratio, check_ori):
+    px, py = _f(prev[:, 0], np.float32).copy(), _f(prev[:, 1], np.float32).copy()
+    out = np.zeros(max(F1.N, 1), dtype=np.int32)
+    L = lib()
+    L.orc_search_for_initialization.argtypes = [C.POINTER(OrcFrame), C.POINTER(OrcFrame), C.c_void_p, C.c_void_p,
+                                                C.c_int, C.c_float, C.c_int, C.c_void_p]
+    n = L.orc_search_for_initialization(C.byref(F1.c), C.byref(F2.c), _p(px), _p(py), int(window), float(nnratio),
+                                        int(check_ori), _p(out))
+    return n, out[:F1.N].copy(), np.stack([px, py], axis=1)
+
+
+def fuse_search(KF: Frame, sf, inv_sigma2, valid, u, v, ur, level, mp_desc, th, chi2):
+    a = [_f(valid, np.uint8), _f(u, np.float32), _f(v, np.float32), _f(ur, np.float32), _f(level, np.int32),
+         _f(mp_desc, np.uint8)]
+    sf, sg = _f(sf, np.float32), _f(inv_sigma2, np.float32)
+    out = np.zeros(max(len(a[0]), 1), dtype=np.int32)
+    L = lib()
+    L.orc_fuse_search.argtypes = [C.POINTER(OrcFrame), C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + \
+        [C.c_float, C.c_int, C.c_void_p]
+    L.orc_fuse_search.restype = None
+    L.orc_fuse_search(C.byref(KF.c), _p(sf), _p(sg), len(a[0]), *[_p(x) for x in a], float(th), int(chi2), _p(out))
+    return out[:len(a[0])].copy()
+
+
+def search_by_sim3(KF1: Frame, KF2: Frame, sf1, sf2, valid1, u1, v1, level1, desc1, valid2, u2, v2, level2, desc2, th):
+    a = [_f(valid1, np.uint8), _f(u1, np.float32), _f(v1, np.float32), _f(level1, np.int32), _f(desc1, np.uint8),
+         _f(valid2, np.uint8), _f(u2, np.float32), _f(v2, np.float32), _f(level2, np.int32), _f(desc2, np.uint8)]
+    sf1, sf2 = _f(sf1, np.float32), _f(sf2, np.float32)
+    out = np.zeros(max(KF1.N, 1), dtype=np.int32)
+    L = lib()
+    L.orc_search_by_sim3.argtypes = [C.POINTER(OrcFrame), C.POINTER(OrcFrame), C.c_void_p, C.c_void_p] + \
+        [C.c_void_p] * 10 + [C.c_float, C.c_void_p]
+    n = L.orc_search_by_sim3(C.byref(KF1.c), C.byref(KF2.c), _p(sf1), _p(sf2), *[_p(x) for x in a], float(th), _p(out))
+    return n, out[:KF1.N].copy()

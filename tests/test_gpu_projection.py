@@ -183,3 +183,118 @@ def test_projection_invalid_arguments(amd):
     # nothing in view -> no matches, all -1
     n, match = m.SearchByProjection(F, SF, np.zeros(3, np.uint8), [0, 0, 0], [1.0] * 3, [1.0] * 3, [1.0] * 3, desc[:3])
     assert n == 0 and (match == -1).all()
+
+
+def _projected(rng, x, y, octv, ang, desc, n, noise_px=2.0):
+    src, u, v, md = _map_points(rng, x, y, octv, desc, n, noise_px)
+    level = np.clip(octv[src] + rng.integers(0, 2, n), 0, 7).astype(np.int32)
+    valid = (rng.random(n) < 0.85).astype(np.uint8)
+    a = ((ang[src] + rng.normal(0, 6, n)) % 360).astype(np.float32)
+    a[rng.random(n) < 0.15] = rng.uniform(0, 360)
+    return src, u, v, md, level, valid, a
+
+
+@pytest.mark.parametrize("seed,th,orb_dist,check_ori", [(50, 10.0, 100, True), (51, 3.0, 64, True), (52, 10.0, 100, False)])
+def test_search_by_projection_keyframe(amd, seed, th, orb_dist, check_ori):
+    rng = np.random.default_rng(seed)
+    x, y, octv, ang, desc, _ = _random_frame(rng, 1600, spread=0.0)
+    Cur, Co = _both(amd, x, y, octv, ang, desc, None)
+    src, u, v, md, level, valid, ka = _projected(rng, x, y, octv, ang, desc, 1400)
+    blocked = (rng.random(1600) < 0.3).astype(np.uint8)
+    m = amd.ORBmatcher(0.9, check_ori)
+    for b in (blocked, None):
+        n_ref, ref = orc.search_by_projection_reloc(Co, SF, valid, u, v, level, ka, md, b, th, orb_dist, check_ori)
+        n_got, got = m.SearchByProjectionKeyFrame(Cur, SF, valid, u, v, level, ka, md, th, orb_dist, blocked=b)
+        assert (n_got, got.tolist()) == (n_ref, ref.tolist())
+        assert n_ref > 150
+
+
+@pytest.mark.parametrize("seed,th", [(60, 10.0), (61, 3.0)])
+def test_search_by_projection_sim3(amd, seed, th):
+    rng = np.random.default_rng(seed)
+    x, y, octv, ang, desc, _ = _random_frame(rng, 1600, spread=0.0)
+    KF, Ko = _both(amd, x, y, octv, ang, desc, None)
+    src, u, v, md, level, valid, _ = _projected(rng, x, y, octv, ang, desc, 2000)
+    matched = (rng.random(1600) < 0.3).astype(np.uint8)
+    m = amd.ORBmatcher(0.75, True)
+    for mt in (matched, None):
+        n_ref, ref = orc.search_by_projection_sim3(Ko, SF, valid, u, v, level, md, mt, th)
+        n_got, got = m.SearchByProjectionSim3(KF, SF, valid, u, v, level, md, th, matched=mt)
+        assert (n_got, got.tolist()) == (n_ref, ref.tolist())
+        assert n_ref > 150
+
+
+@pytest.mark.parametrize("seed,window,check_ori", [(70, 100, True), (71, 30, True), (72, 100, False)])
+def test_search_for_initialization(amd, seed, window, check_ori):
+    """mono initialisation extracts 2*nFeatures (src/Tracking.cc:124-127); window 100 is the reference's
+    call (src/Tracking.cc:632)."""
+    fr = synth.render_sequence(seed, 2, 640, 480, step=4.0)
+    e = amd.ORBextractor(2000, 1.2, 8, 20, 7)
+    (k1, d1), (k2, d2) = e.extract_batch(np.stack(fr))
+    F1 = amd.FrameView.from_keypoints(k1, d1, 640, 480)
+    F2 = amd.FrameView.from_keypoints(k2, d2, 640, 480)
+    O1 = orc.Frame(k1["x"], k1["y"], k1["octave"], d1, BOUNDS, angle=k1["angle"])
+    O2 = orc.Frame(k2["x"], k2["y"], k2["octave"], d2, BOUNDS, angle=k2["angle"])
+    prev = np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32)
+    n_ref, ref, prev_ref = orc.search_for_initialization(O1, O2, prev.copy(), window, 0.9, check_ori)
+    prev_got = prev.copy()
+    n_got, got = amd.ORBmatcher(0.9, check_ori).SearchForInitialization(F1, F2, prev_got, window)
+    assert (n_got, got.tolist()) == (n_ref, ref.tolist())
+    assert np.array_equal(prev_got, prev_ref)
+    assert n_ref > 100
+    # second call with the updated vbPrevMatched, as Tracking::MonocularInitialization does frame after frame
+    n_ref2, ref2, _ = orc.search_for_initialization(O1, O2, prev_ref.copy(), window, 0.9, check_ori)
+    n_got2, got2 = amd.ORBmatcher(0.9, check_ori).SearchForInitialization(F1, F2, prev_got, window)
+    assert (n_got2, got2.tolist()) == (n_ref2, ref2.tolist())
+
+
+@pytest.mark.parametrize("seed,stereo,chi2", [(80, False, True), (81, True, True), (82, True, False)])
+def test_fuse_search(amd, seed, stereo, chi2):
+    rng = np.random.default_rng(seed)
+    x, y, octv, ang, desc, ur = _random_frame(rng, 1500, stereo, spread=0.0)
+    if stereo:
+        ur = np.where(ur > 0, ur, -1.0).astype(np.float32)
+    KF, Ko = _both(amd, x, y, octv, ang, desc, ur)
+    src, u, v, md, level, valid, _ = _projected(rng, x, y, octv, ang, desc, 2500, noise_px=1.2)
+    pur = (u - rng.uniform(1, 40, len(u))).astype(np.float32)
+    if stereo:
+        ok = ur[src] >= 0
+        pur[ok] = (ur[src][ok] + rng.normal(0, 1.0, ok.sum())).astype(np.float32)
+    inv_sigma2 = (1.0 / (SF * SF)).astype(np.float32)
+    ref = orc.fuse_search(Ko, SF, inv_sigma2, valid, u, v, pur, level, md, 3.0, chi2)
+    got = amd.ORBmatcher(0.6).FuseSearch(KF, SF, valid, u, v, level, md, th=3.0,
+                                         inv_level_sigma2=inv_sigma2 if chi2 else None, ur=pur)
+    assert got.tolist() == ref.tolist()
+    assert (ref >= 0).sum() > 300
+    if chi2:  # the gate really rejects something the ungated search accepts
+        ungated = orc.fuse_search(Ko, SF, inv_sigma2, valid, u, v, pur, level, md, 3.0, False)
+        assert (ungated != ref).any()
+
+
+def test_search_by_sim3(amd):
+    rng = np.random.default_rng(90)
+    x1, y1, o1, a1, d1, _ = _random_frame(rng, 1400, spread=0.0)
+    # KF2 sees the same structure shifted, with descriptor noise
+    n2 = 1500
+    src = rng.integers(0, 1400, n2)
+    x2 = np.clip(x1[src] + 6 + rng.normal(0, 1.0, n2), 0, 639).astype(np.float32)
+    y2 = np.clip(y1[src] - 4 + rng.normal(0, 1.0, n2), 0, 479).astype(np.float32)
+    o2 = o1[src].copy()
+    a2 = a1[src].copy()
+    d2 = d1[src] ^ (rng.integers(0, 256, (n2, 32), dtype=np.uint8) & rng.integers(0, 256, (n2, 32), dtype=np.uint8) &
+                    rng.integers(0, 256, (n2, 32), dtype=np.uint8))
+    K1, O1 = _both(amd, x1, y1, o1, a1, d1, None)
+    K2, O2 = _both(amd, x2, y2, o2, a2, d2, None)
+    # projections: KF1 points land in KF2 at +(6,-4); KF2 points land in KF1 at -(6,-4)
+    u1 = (x1 + 6 + rng.normal(0, 1.5, 1400)).astype(np.float32)
+    v1 = (y1 - 4 + rng.normal(0, 1.5, 1400)).astype(np.float32)
+    u2 = (x2 - 6 + rng.normal(0, 1.5, n2)).astype(np.float32)
+    v2 = (y2 + 4 + rng.normal(0, 1.5, n2)).astype(np.float32)
+    l1 = np.clip(o1 + rng.integers(0, 2, 1400), 0, 7).astype(np.int32)
+    l2 = np.clip(o2 + rng.integers(0, 2, n2), 0, 7).astype(np.int32)
+    va1 = (rng.random(1400) < 0.8).astype(np.uint8)
+    va2 = (rng.random(n2) < 0.8).astype(np.uint8)
+    n_ref, ref = orc.search_by_sim3(O1, O2, SF, SF, va1, u1, v1, l1, d1, va2, u2, v2, l2, d2, 7.5)
+    n_got, got = amd.ORBmatcher(0.75).SearchBySim3(K1, K2, SF, SF, va1, u1, v1, l1, d1, va2, u2, v2, l2, d2, 7.5)
+    assert (n_got, got.tolist()) == (n_ref, ref.tolist())
+    assert n_ref > 100

@@ -171,3 +171,69 @@ def test_lastframe_python_transcription():
         assert n == nm
         assert m.tolist() == match.tolist()
         assert n > 20
+
+
+def test_initialization_python_transcription():
+    """literal transcription of src/ORBmatcher.cc:469-603 on a small case (duplicates, re-assignment,
+    the 'only still-matched entries are pruned' rule)"""
+    rng = np.random.default_rng(9)
+    n1 = n2 = 500
+    x, y, octv, ang, desc, _ = _scene(rng, n2, False)
+    octv = np.where(rng.random(n2) < 0.6, 0, octv).astype(np.int32)
+    F2 = O.Frame(x, y, octv, desc, (0, 640, 0, 480), angle=ang)
+    src = rng.integers(0, n2, n1)
+    x1 = (x[src] + rng.normal(0, 4, n1)).astype(np.float32)
+    y1 = (y[src] + rng.normal(0, 4, n1)).astype(np.float32)
+    o1 = np.where(rng.random(n1) < 0.7, 0, 1).astype(np.int32)
+    a1 = ((ang[src] + rng.normal(0, 8, n1)) % 360).astype(np.float32)
+    d1 = desc[src] ^ (rng.integers(0, 256, (n1, 32), dtype=np.uint8) & rng.integers(0, 256, (n1, 32), dtype=np.uint8) &
+                      rng.integers(0, 256, (n1, 32), dtype=np.uint8))
+    F1 = O.Frame(x1, y1, o1, d1, (0, 640, 0, 480), angle=a1)
+    prev = np.stack([x1, y1], axis=1).copy()
+    n, m12, prev_out = O.search_for_initialization(F1, F2, prev, 30, 0.9, True)
+    grid, winv, hinv = py_grid(x, y, (0, 640, 0, 480))
+    BIG = 2 ** 31 - 1
+    match12 = [-1] * n1
+    match21 = [-1] * n2
+    mdist = [BIG] * n2
+    hist = [[] for _ in range(30)]
+    nm = 0
+    for i1 in range(n1):
+        if o1[i1] > 0:
+            continue
+        cand = py_area(grid, winv, hinv, x, y, octv, (0, 640, 0, 480), prev[i1, 0], prev[i1, 1], 30.0, 0, 0)
+        best, best2, bi = BIG, BIG, -1
+        for i2 in cand:
+            d = int(np.unpackbits(d1[i1] ^ desc[i2]).sum())
+            if mdist[i2] <= d:
+                continue
+            if d < best:
+                best2, best, bi = best, d, i2
+            elif d < best2:
+                best2 = d
+        if best <= 50 and np.float32(best) < np.float32(best2) * np.float32(0.9):
+            if match21[bi] >= 0:
+                match12[match21[bi]] = -1
+                nm -= 1
+            match12[i1] = bi
+            match21[bi] = i1
+            mdist[bi] = best
+            nm += 1
+            rot = np.float32(a1[i1]) - np.float32(ang[bi])
+            if rot < 0:
+                rot = np.float32(rot + np.float32(360.0))
+            b = c_round(float(np.float32(rot * np.float32(1.0 / 30))))
+            hist[0 if b == 30 else b].append(i1)
+    k1, k2, k3 = O.three_maxima([len(h) for h in hist])
+    for b in range(30):
+        if b in (k1, k2, k3):
+            continue
+        for i1 in hist[b]:
+            if match12[i1] >= 0:
+                match12[i1] = -1
+                nm -= 1
+    assert (n, m12.tolist()) == (nm, match12)
+    assert n > 50
+    for i1 in range(n1):
+        want = (x[match12[i1]], y[match12[i1]]) if match12[i1] >= 0 else (prev[i1, 0], prev[i1, 1])
+        assert tuple(prev_out[i1]) == want
