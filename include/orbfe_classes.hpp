@@ -128,6 +128,51 @@ struct FeatureVectorCSR {
   }
 };
 
+// The arrays of a Frame / KeyFrame the projection searches read (include/Frame.h:120-190), split out of
+// std::vector<cv::KeyPoint> mvKeysUn once per frame; owns the storage behind an orbfe_frame_view.
+class FrameArrays {
+ public:
+  // bounds = mnMinX, mnMaxX, mnMinY, mnMaxY (src/Frame.cc:697-728); mvuRight may be empty (monocular)
+  FrameArrays(const std::vector<KeyPoint>& mvKeysUn, const std::vector<uint8_t>& mDescriptors, float mnMinX,
+              float mnMaxX, float mnMinY, float mnMaxY, const std::vector<float>& mvuRight = std::vector<float>())
+      : desc(mDescriptors), uRight(mvuRight) {
+    const size_t n = mvKeysUn.size();
+    x.resize(n); y.resize(n); angle.resize(n); octave.resize(n);
+    for (size_t i = 0; i < n; i++) {
+      x[i] = mvKeysUn[i].x; y[i] = mvKeysUn[i].y; angle[i] = mvKeysUn[i].angle; octave[i] = mvKeysUn[i].octave;
+    }
+    c.n = (int32_t)n;
+    c.x = x.data(); c.y = y.data(); c.octave = octave.data(); c.angle = angle.data();
+    c.u_right = uRight.empty() ? nullptr : uRight.data();
+    c.desc = desc.data();
+    c.min_x = mnMinX; c.max_x = mnMaxX; c.min_y = mnMinY; c.max_y = mnMaxY;
+  }
+  FrameArrays(const FrameArrays&) = delete;
+  FrameArrays& operator=(const FrameArrays&) = delete;
+  int N() const { return c.n; }
+
+  // vector<size_t> Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel) const
+  std::vector<size_t> GetFeaturesInArea(float qx, float qy, float r, int minLevel = -1, int maxLevel = -1,
+                                        int device = 0) const {
+    int32_t count = 0;
+    std::vector<int32_t> idx(64);
+    for (;;) {
+      const int rc = orbfe_features_in_area(device, &c, 1, &qx, &qy, &r, &minLevel, &maxLevel, (int)idx.size(), &count,
+                                            idx.data());
+      if (rc == ORBFE_ERR_CAPACITY) { idx.resize(count); continue; }
+      check(rc, "GetFeaturesInArea");
+      break;
+    }
+    return std::vector<size_t>(idx.begin(), idx.begin() + count);
+  }
+
+  std::vector<float> x, y, angle;
+  std::vector<int32_t> octave;
+  std::vector<uint8_t> desc;
+  std::vector<float> uRight;
+  orbfe_frame_view c;
+};
+
 class ORBmatcher {
  public:
   static const int TH_LOW = 50;
@@ -164,6 +209,56 @@ class ORBmatcher {
                                     mfNNratio, mbCheckOrientation, match12.data());
     check(rc, "SearchByBoW(KF,KF)");
     return rc;
+  }
+
+  // int SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, const float th = 3):
+  // the per-point fields are what Frame::isInFrustum stored on each MapPoint; match[idx] = point or -1.
+  int SearchByProjection(const FrameArrays& F, const std::vector<float>& mvScaleFactors,
+                         const std::vector<uint8_t>& mbTrackInView, const std::vector<int32_t>& mnTrackScaleLevel,
+                         const std::vector<float>& mTrackViewCos, const std::vector<float>& mTrackProjX,
+                         const std::vector<float>& mTrackProjY, const std::vector<float>& mTrackProjXR,
+                         const std::vector<uint8_t>& mpDescriptors, const std::vector<uint8_t>& frameHasObservedPoint,
+                         std::vector<int32_t>& match, float th = 3.0f) {
+    match.assign(F.N(), -1);
+    int32_t n = 0;
+    check(orbfe_search_by_projection(device_, &F.c, mvScaleFactors.data(), (int)mvScaleFactors.size(),
+                                     frameHasObservedPoint.empty() ? nullptr : frameHasObservedPoint.data(),
+                                     (int)mbTrackInView.size(), mbTrackInView.data(), mnTrackScaleLevel.data(),
+                                     mTrackViewCos.data(), mTrackProjX.data(), mTrackProjY.data(),
+                                     mTrackProjXR.empty() ? nullptr : mTrackProjXR.data(), mpDescriptors.data(), nullptr,
+                                     th, mfNNratio, match.data(), &n),
+          "SearchByProjection(Frame,MapPoints)");
+    return n;
+  }
+
+  // int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono)
+  // after the projection loop prologue (src/ORBmatcher.cc:1525-1541); mode 0/1/2 = normal/bForward/bBackward.
+  int SearchByProjection(const FrameArrays& CurrentFrame, const std::vector<float>& mvScaleFactors, float mbf,
+                         const std::vector<uint8_t>& valid, const std::vector<float>& u, const std::vector<float>& v,
+                         const std::vector<float>& invzc, const std::vector<int32_t>& lastOctave,
+                         const std::vector<float>& lastAngle, const std::vector<uint8_t>& mpDescriptors, int mode,
+                         float th, std::vector<int32_t>& matchCur) {
+    matchCur.assign(CurrentFrame.N(), -1);
+    int32_t n = 0;
+    check(orbfe_search_by_projection_last_frame(device_, &CurrentFrame.c, mvScaleFactors.data(),
+                                                (int)mvScaleFactors.size(), mbf, (int)valid.size(), valid.data(),
+                                                u.data(), v.data(), invzc.empty() ? nullptr : invzc.data(),
+                                                lastOctave.data(), lastAngle.data(), mpDescriptors.data(), nullptr, mode,
+                                                th, mbCheckOrientation, matchCur.data(), &n),
+          "SearchByProjection(Frame,Frame)");
+    return n;
+  }
+
+  // int SearchForInitialization(Frame& F1, Frame& F2, vector<cv::Point2f>& vbPrevMatched,
+  //                             vector<int>& vnMatches12, int windowSize = 10)
+  int SearchForInitialization(const FrameArrays& F1, const FrameArrays& F2, std::vector<float>& prevX,
+                              std::vector<float>& prevY, std::vector<int32_t>& vnMatches12, int windowSize = 10) {
+    vnMatches12.assign(F1.N(), -1);
+    int32_t n = 0;
+    check(orbfe_search_for_initialization(device_, &F1.c, &F2.c, prevX.data(), prevY.data(), windowSize, mfNNratio,
+                                          mbCheckOrientation, vnMatches12.data(), &n),
+          "SearchForInitialization");
+    return n;
   }
 
   float mfNNratio;

@@ -45,6 +45,27 @@ int main(int argc, char** argv) {
               (unsigned long long)fnv(dL.data(), dL.size()), (unsigned long long)fnv(u.data(), u.size() * 4),
               (unsigned long long)fnv(d.data(), d.size() * 4), (unsigned long long)hp, eL.GetLevels(),
               (double)eL.GetScaleFactors()[1], ORBmatcher::DescriptorDistance(dL.data(), dL.data() + 32));
+  // tracking-thread searches on the pair taken as two consecutive monocular frames
+  {
+    FrameArrays F1(kL, dL, 0.0f, (float)W, 0.0f, (float)H), F2(kR, dR, 0.0f, (float)W, 0.0f, (float)H);
+    std::vector<float> px(kL.size()), py(kL.size());
+    for (size_t i = 0; i < kL.size(); i++) { px[i] = kL[i].x; py[i] = kL[i].y; }
+    std::vector<int32_t> m12, mc;
+    ORBmatcher init(0.9f, true);
+    const int nInit = init.SearchForInitialization(F1, F2, px, py, m12, 100);
+    std::vector<uint8_t> valid(kL.size(), 1);
+    std::vector<int32_t> oct(kL.size());
+    for (size_t i = 0; i < kL.size(); i++) oct[i] = kL[i].octave;
+    const std::vector<float> sf = eL.GetScaleFactors();
+    const int nProj = init.SearchByProjection(F2, sf, 0.0f, valid, F1.x, F1.y, std::vector<float>(), oct, F1.angle, dL, 0,
+                                              15.0f, mc);
+    const std::vector<size_t> area = F2.GetFeaturesInArea(160.0f, 100.0f, 40.0f, 0, 2);
+    std::vector<int32_t> area32(area.begin(), area.end());
+    std::printf("ninit=%d init=%016llx nproj=%d proj=%016llx area=%016llx narea=%zu\n", nInit,
+                (unsigned long long)fnv(m12.data(), m12.size() * 4), nProj,
+                (unsigned long long)fnv(mc.data(), mc.size() * 4),
+                (unsigned long long)fnv(area32.data(), area32.size() * 4), area.size());
+  }
   // empty image: silent return, outputs untouched
   std::vector<KeyPoint> k0(3);
   std::vector<uint8_t> d0(96);

@@ -42,3 +42,17 @@ def test_cpp_classes_match_oracle(tmp_path):
     assert int(kv["pyr"], 16) == _fnv(pL.tobytes())
     assert int(kv["levels"]) == 8
     assert int(kv["dist"]) == orc.descriptor_distance(dL[0], dL[1])
+    # tracking-thread searches through the C++ layer == oracle on the same keypoints
+    b = (0.0, 320.0, 0.0, 200.0)
+    F1 = orc.Frame(kL["x"], kL["y"], kL["octave"], dL, b, angle=kL["angle"])
+    F2 = orc.Frame(kR["x"], kR["y"], kR["octave"], dR, b, angle=kR["angle"])
+    prev = np.stack([kL["x"], kL["y"]], axis=1).astype(np.float32)
+    n_init, m12, _ = orc.search_for_initialization(F1, F2, prev, 100, 0.9, True)
+    assert int(kv["ninit"]) == n_init and int(kv["init"], 16) == _fnv(m12.astype(np.int32).tobytes())
+    sf = np.array(o.scale_factors(), np.float32)
+    n_proj, mc = orc.search_by_projection_lastframe(F2, sf, 0.0, np.ones(len(kL), np.uint8), kL["x"], kL["y"], None,
+                                                    kL["octave"], kL["angle"], dL, None, 0, 15.0, True)
+    assert int(kv["nproj"]) == n_proj and int(kv["proj"], 16) == _fnv(mc.astype(np.int32).tobytes())
+    area = F2.features_in_area(160.0, 100.0, 40.0, 0, 2)
+    assert int(kv["narea"]) == len(area) and int(kv["area"], 16) == _fnv(area.astype(np.int32).tobytes())
+    assert n_init > 0 and n_proj > 0
