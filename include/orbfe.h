@@ -433,6 +433,22 @@ int orbfe_search_by_sim3(int device, const orbfe_frame_view *KF1, const orbfe_fr
                          const int32_t *level2, const uint8_t *desc2, float th, int32_t *match12,
                          int32_t *n_found);
 
+/* cv::remap(im, imRect, M1, M2, cv::INTER_LINEAR) with CV_32F maps and the default constant-0
+ * border, 8-bit single channel: the EuRoC rectification of Examples/Stereo/stereo_euroc.cc:136-137
+ * (the maps come from cv::initUndistortRectifyMap at :97-98, once, and are handed over here once).
+ * Destination size = map size (width x height, map_stride floats per row). */
+typedef struct orbfe_rectifier orbfe_rectifier;
+int orbfe_rectifier_create(int device, const float *map_x, const float *map_y, int width, int height,
+                       int map_stride, orbfe_rectifier **out);
+void orbfe_rectifier_destroy(orbfe_rectifier *r);
+/* Host buffers, one frame. */
+int orbfe_remap(orbfe_rectifier *r, const uint8_t *src, int src_width, int src_height, int src_stride,
+                uint8_t *dst, int dst_stride);
+/* Device-resident frames: rectified images are written where orbfe_extract_batch_device reads them. */
+int orbfe_remap_batch_device(orbfe_rectifier *r, const uint8_t *d_src, int n_frames, int src_width,
+                             int src_height, int src_stride, size_t src_frame_stride, uint8_t *d_dst,
+                             int dst_stride, size_t dst_frame_stride);
+
 #ifdef __cplusplus
 }
 #endif

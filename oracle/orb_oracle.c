@@ -1646,3 +1646,42 @@ int orc_search_by_sim3(orc_frame *KF1, orc_frame *KF2, const float *sf1, const f
   free(vnMatch2);
   return nFound;
 }
+
+/* ------------------------------------------------------------------ */
+/* cv::remap, CV_32FC1 map pair, INTER_LINEAR, BORDER_CONSTANT, 8UC1    */
+/* (Examples/Stereo/stereo_euroc.cc:136-137)                            */
+/* ------------------------------------------------------------------ */
+static int cvround_sse(float v) { /* cvtss2si: half to even; out of range / NaN -> 0x80000000 */
+  if (!(v >= -2147483648.0f && v < 2147483648.0f)) return INT_MIN;
+  return (int)nearbyintf(v);
+}
+static int sat_short(int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; }
+
+void orc_remap_linear(const uint8_t *src, int sw, int sh, int sstride, const float *mapx, const float *mapy,
+                      int map_stride, int dw, int dh, uint8_t *dst, int dstride) {
+  const unsigned width1 = (unsigned)(sw - 1 > 0 ? sw - 1 : 0), height1 = (unsigned)(sh - 1 > 0 ? sh - 1 : 0);
+  for (int y = 0; y < dh; y++)
+    for (int x = 0; x < dw; x++) {
+      const int isx = cvround_sse(mapx[(size_t)y * map_stride + x] * 32), isy = cvround_sse(mapy[(size_t)y * map_stride + x] * 32);
+      const int fx = isx & 31, fy = isy & 31;
+      const int sx = sat_short(isx >> 5), sy = sat_short(isy >> 5);
+      const int w0 = (32 - fy) * (32 - fx) * 32, w1 = (32 - fy) * fx * 32, w2 = fy * (32 - fx) * 32, w3 = fy * fx * 32;
+      int v0, v1, v2, v3;
+      if ((unsigned)sx < width1 && (unsigned)sy < height1) {
+        const uint8_t *S = src + (size_t)sy * sstride + sx;
+        v0 = S[0]; v1 = S[1]; v2 = S[sstride]; v3 = S[sstride + 1];
+      } else if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) {
+        dst[(size_t)y * dstride + x] = 0;
+        continue;
+      } else { /* borderInterpolate(BORDER_CONSTANT) = -1 outside, tap replaced by the border value 0 */
+        const int x0 = (sx >= 0 && sx < sw) ? sx : -1, x1 = (sx + 1 >= 0 && sx + 1 < sw) ? sx + 1 : -1;
+        const int y0 = (sy >= 0 && sy < sh) ? sy : -1, y1 = (sy + 1 >= 0 && sy + 1 < sh) ? sy + 1 : -1;
+        v0 = (x0 >= 0 && y0 >= 0) ? src[(size_t)y0 * sstride + x0] : 0;
+        v1 = (x1 >= 0 && y0 >= 0) ? src[(size_t)y0 * sstride + x1] : 0;
+        v2 = (x0 >= 0 && y1 >= 0) ? src[(size_t)y1 * sstride + x0] : 0;
+        v3 = (x1 >= 0 && y1 >= 0) ? src[(size_t)y1 * sstride + x1] : 0;
+      }
+      const int val = (v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3 + (1 << 14)) >> 15;
+      dst[(size_t)y * dstride + x] = (uint8_t)(val > 255 ? 255 : val);
+    }
+}

@@ -221,6 +221,15 @@ int orc_search_by_sim3(orc_frame *KF1, orc_frame *KF2, const float *sf1, const f
                        const uint8_t *valid2, const float *u2, const float *v2, const int32_t *level2,
                        const uint8_t *desc2, float th, int32_t *match12);
 
+/* ---- cv::remap(src, dst, map1 CV_32FC1, map2 CV_32FC1, INTER_LINEAR) with the default BORDER_CONSTANT(0),
+ * 8UC1: the EuRoC rectification at Examples/Stereo/stereo_euroc.cc:136-137.  OpenCV is a third-party dependency
+ * absent from the reference tree (CMakeLists.txt asks for 3.0, falls back to 2.4.3); this restates its
+ * published algorithm (imgproc/src/imgwarp.cpp, RemapInvoker + remapBilinear<FixedPtCast<int,uchar,15>>):
+ * maps are rounded to 1/32 px (cvRound(v*32)), coordinates saturate to int16, weights are the exact products
+ * (32-fy)(32-fx)*32 of 2^15, result (sum + 2^14) >> 15; a tap outside the source reads 0.  Parity unpinned. */
+void orc_remap_linear(const uint8_t *src, int sw, int sh, int sstride, const float *mapx, const float *mapy,
+                      int map_stride, int dw, int dh, uint8_t *dst, int dstride);
+
 /* ---- DBoW2 vocabulary (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h) ---- */
 typedef struct orc_vocab {
   int k, L, scoring, weighting;

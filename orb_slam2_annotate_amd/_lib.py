@@ -57,6 +57,7 @@ EXPORTS = [
     "orbfe_distinctive_descriptors", "orbfe_features_in_area", "orbfe_search_by_projection",
     "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_keyframe",
     "orbfe_search_by_projection_sim3", "orbfe_search_for_initialization", "orbfe_fuse_search", "orbfe_search_by_sim3",
+    "orbfe_rectifier_create", "orbfe_rectifier_destroy", "orbfe_remap", "orbfe_remap_batch_device",
 ]
 
 _lib = None
@@ -156,6 +157,11 @@ def load():
     L.orbfe_search_for_initialization.argtypes = [ci, fwp, fwp, vp, vp, ci, cf, ci, vp, vp]
     L.orbfe_fuse_search.argtypes = [ci, fwp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, cf, ci, vp]
     L.orbfe_search_by_sim3.argtypes = [ci, fwp, fwp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, vp, vp]
+    L.orbfe_rectifier_create.argtypes = [ci, vp, vp, ci, ci, ci, C.POINTER(C.c_void_p)]
+    L.orbfe_rectifier_destroy.argtypes = [vp]
+    L.orbfe_rectifier_destroy.restype = None
+    L.orbfe_remap.argtypes = [vp, vp, ci, ci, ci, vp, ci]
+    L.orbfe_remap_batch_device.argtypes = [vp, vp, ci, ci, ci, ci, cs, vp, ci, cs]
     L.orbfe_debug_octree_host.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, ci]
     L.orbfe_debug_geometry.argtypes = [ci, cf, ci, ci, ci, ci, ci, vp, vp, vp, ci]
     L.orbfe_debug_resize_tables.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp]

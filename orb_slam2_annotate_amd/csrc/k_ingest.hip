@@ -8,6 +8,7 @@
 
 #include "../../include/orbfe.h"
 #include "kernels.h"
+#include "orb_spec.h"
 
 int orbfe_set_error_(int code, const char* msg);
 static int ifail(int code, const std::string& m) { return orbfe_set_error_(code, m.c_str()); }
@@ -147,5 +148,176 @@ extern "C" int orbfe_distinctive_descriptors(int device, const uint8_t* descript
   if (doff) (void)hipFree(doff);
   if (dbest) (void)hipFree(dbest);
   if (err != hipSuccess) return ifail(ORBFE_ERR_HIP, std::string("distinctive_descriptors: ") + hipGetErrorString(err));
+  return ORBFE_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// cv::remap(src, dst, M1 CV_32F, M2 CV_32F, INTER_LINEAR) -- the EuRoC stereo rectification in
+// front of the extractor (Examples/Stereo/stereo_euroc.cc:97-98 builds the maps once, :136-137
+// applies them to every frame).  The float maps are converted once, at create time, to what
+// cv::remap converts them to for every tile of every frame: integer source coordinate saturated
+// to int16 (packed sx | sy << 16) and a 10-bit sub-pixel phase (fy*32 + fx); the per-frame kernel
+// then moves 6 map bytes + 1 source byte + 1 output byte per pixel.
+// ---------------------------------------------------------------------------------------------
+struct orbfe_rectifier {
+  int device = 0;
+  int width = 0, height = 0;  // destination size = map size
+  uint32_t* xy = nullptr;     // [height][pitch]
+  uint16_t* phase = nullptr;  // [height][pitch]
+  int pitch = 0;              // multiple of 4
+};
+
+namespace {
+
+__device__ __forceinline__ int cvround_sse(float v) {  // cvtss2si: out of range / NaN -> INT_MIN
+  if (!(v >= -2147483648.0f && v < 2147483648.0f)) return (int)0x80000000;
+  return __float2int_rn(v);
+}
+__device__ __forceinline__ int sat_short(int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; }
+
+__global__ __launch_bounds__(256) void k_remap_convert(const float* __restrict__ mx, const float* __restrict__ my,
+                                                       int mstride, int w, int h, int pitch,
+                                                       uint32_t* __restrict__ xy, uint16_t* __restrict__ phase) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= pitch) return;
+  uint32_t c = 0x80008000u;  // padding columns: (-32768, -32768) -> border
+  uint16_t p = 0;
+  if (x < w) {
+    const int isx = cvround_sse(mx[(size_t)y * mstride + x] * 32.0f), isy = cvround_sse(my[(size_t)y * mstride + x] * 32.0f);
+    c = ((uint32_t)sat_short(isx >> 5) & 0xffffu) | ((uint32_t)sat_short(isy >> 5) << 16);
+    p = (uint16_t)((isy & 31) * 32 + (isx & 31));
+  }
+  xy[(size_t)y * pitch + x] = c;
+  phase[(size_t)y * pitch + x] = p;
+}
+
+// 4 output pixels per thread (one dword store); block = 64 x 4 threads = 256 x 4 pixels.  Blocks of
+// one tile over all frames are adjacent in the grid, so the map tile is fetched from HBM once.
+__global__ __launch_bounds__(256) void k_remap(const uint32_t* __restrict__ xy, const uint16_t* __restrict__ phase,
+                                               int pitch, int w, int h, int tilesX, int nFrames,
+                                               const uint8_t* __restrict__ src, int sw, int sh, int sstride,
+                                               size_t sFrame, uint8_t* __restrict__ dst, int dstride, size_t dFrame) {
+  const int f = blockIdx.x % nFrames, tile = blockIdx.x / nFrames;
+  const int x0 = ((tile % tilesX) * 64 + (threadIdx.x & 63)) * 4, y = (tile / tilesX) * 4 + (threadIdx.x >> 6);
+  if (x0 >= w || y >= h) return;
+  const uint4 c4 = *reinterpret_cast<const uint4*>(xy + (size_t)y * pitch + x0);
+  const uint2 p4 = *reinterpret_cast<const uint2*>(phase + (size_t)y * pitch + x0);
+  const uint32_t cs[4] = {c4.x, c4.y, c4.z, c4.w};
+  const uint32_t ps[4] = {p4.x & 0xffffu, p4.x >> 16, p4.y & 0xffffu, p4.y >> 16};
+  const uint8_t* S0 = src + (size_t)f * sFrame;
+  const unsigned width1 = (unsigned)(sw - 1 > 0 ? sw - 1 : 0), height1 = (unsigned)(sh - 1 > 0 ? sh - 1 : 0);
+  uint32_t packed = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int sx = (int)(int16_t)(cs[k] & 0xffffu), sy = (int)(int16_t)(cs[k] >> 16);
+    const int fx = (int)(ps[k] & 31u), fy = (int)(ps[k] >> 5);
+    int v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    if ((unsigned)sx < width1 && (unsigned)sy < height1) {
+      const uint8_t* S = S0 + (size_t)sy * sstride + sx;
+      v0 = S[0]; v1 = S[1]; v2 = S[sstride]; v3 = S[sstride + 1];
+    } else if (!(sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0)) {
+      const bool x0in = sx >= 0 && sx < sw, x1in = sx + 1 >= 0 && sx + 1 < sw;
+      const bool y0in = sy >= 0 && sy < sh, y1in = sy + 1 >= 0 && sy + 1 < sh;
+      if (x0in && y0in) v0 = S0[(size_t)sy * sstride + sx];
+      if (x1in && y0in) v1 = S0[(size_t)sy * sstride + sx + 1];
+      if (x0in && y1in) v2 = S0[(size_t)(sy + 1) * sstride + sx];
+      if (x1in && y1in) v3 = S0[(size_t)(sy + 1) * sstride + sx + 1];
+    }
+    // sum of v*w with w = (32-fy)(32-fx)*32 ...; (32 t + 2^14) >> 15 == (t + 512) >> 10
+    const int t = (v0 * (32 - fx) + v1 * fx) * (32 - fy) + (v2 * (32 - fx) + v3 * fx) * fy;
+    packed |= (uint32_t)((t + 512) >> 10) << (8 * k);
+  }
+  uint8_t* d = dst + (size_t)f * dFrame + (size_t)y * dstride + x0;
+  if (x0 + 3 < w && ((reinterpret_cast<uintptr_t>(d) & 3) == 0)) {
+    *reinterpret_cast<uint32_t*>(d) = packed;
+  } else {
+    for (int k = 0; k < 4 && x0 + k < w; k++) d[k] = (uint8_t)(packed >> (8 * k));
+  }
+}
+
+int remap_launch(orbfe_rectifier* r, const uint8_t* d_src, int n_frames, int sw, int sh, int sstride, size_t sFrame,
+                 uint8_t* d_dst, int dstride, size_t dFrame, hipStream_t stream) {
+  const int tilesX = (r->width + 255) / 256, tilesY = (r->height + 3) / 4;
+  hipLaunchKernelGGL(k_remap, dim3((unsigned)tilesX * tilesY * n_frames), dim3(256), 0, stream, r->xy, r->phase, r->pitch,
+                     r->width, r->height, tilesX, n_frames, d_src, sw, sh, sstride, sFrame, d_dst, dstride, dFrame);
+  IHIP(hipGetLastError());
+  return ORBFE_OK;
+}
+
+}  // namespace
+
+extern "C" int orbfe_rectifier_create(int device, const float* map_x, const float* map_y, int width, int height,
+                                  int map_stride, orbfe_rectifier** out) {
+  if (!map_x || !map_y || !out || width <= 0 || height <= 0 || map_stride < width || width > 32767 || height > 32767)
+    return ifail(ORBFE_ERR_INVALID, "remap_create: bad argument");
+  IHIP(hipSetDevice(device));
+  orbfe_rectifier* r = new orbfe_rectifier();
+  r->device = device; r->width = width; r->height = height; r->pitch = (width + 3) & ~3;
+  float *dmx = nullptr, *dmy = nullptr;
+  const size_t mb = (size_t)width * height * 4, n = (size_t)r->pitch * height;
+  hipError_t err = hipMalloc((void**)&r->xy, n * 4);
+  if (err == hipSuccess) err = hipMalloc((void**)&r->phase, n * 2);
+  if (err == hipSuccess) err = hipMalloc((void**)&dmx, mb);
+  if (err == hipSuccess) err = hipMalloc((void**)&dmy, mb);
+  if (err == hipSuccess) err = hipMemcpy2D(dmx, (size_t)width * 4, map_x, (size_t)map_stride * 4, (size_t)width * 4, height, hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMemcpy2D(dmy, (size_t)width * 4, map_y, (size_t)map_stride * 4, (size_t)width * 4, height, hipMemcpyHostToDevice);
+  if (err == hipSuccess) {
+    hipLaunchKernelGGL(k_remap_convert, dim3((r->pitch + 255) / 256, height), dim3(256), 0, 0, dmx, dmy, width, width,
+                       height, r->pitch, r->xy, r->phase);
+    err = hipGetLastError();
+  }
+  if (err == hipSuccess) err = hipDeviceSynchronize();
+  if (dmx) (void)hipFree(dmx);
+  if (dmy) (void)hipFree(dmy);
+  if (err != hipSuccess) {
+    if (r->xy) (void)hipFree(r->xy);
+    if (r->phase) (void)hipFree(r->phase);
+    delete r;
+    return ifail(err == hipErrorOutOfMemory ? ORBFE_ERR_NOMEM : ORBFE_ERR_HIP, std::string("remap_create: ") + hipGetErrorString(err));
+  }
+  *out = r;
+  return ORBFE_OK;
+}
+
+extern "C" void orbfe_rectifier_destroy(orbfe_rectifier* r) {
+  if (!r) return;
+  (void)hipSetDevice(r->device);
+  (void)hipFree(r->xy);
+  (void)hipFree(r->phase);
+  delete r;
+}
+
+extern "C" int orbfe_remap(orbfe_rectifier* r, const uint8_t* src, int src_width, int src_height, int src_stride,
+                           uint8_t* dst, int dst_stride) {
+  if (!r || !src || !dst || src_width <= 0 || src_height <= 0 || src_stride < src_width || dst_stride < r->width)
+    return ifail(ORBFE_ERR_INVALID, "remap: bad argument");
+  IHIP(hipSetDevice(r->device));
+  uint8_t *ds = nullptr, *dd = nullptr;
+  IHIP(hipMalloc((void**)&ds, (size_t)src_width * src_height));
+  hipError_t err = hipMalloc((void**)&dd, (size_t)r->pitch * r->height);
+  if (err == hipSuccess) err = hipMemcpy2D(ds, src_width, src, src_stride, src_width, src_height, hipMemcpyHostToDevice);
+  int rc = ORBFE_OK;
+  if (err == hipSuccess) rc = remap_launch(r, ds, 1, src_width, src_height, src_width, 0, dd, r->pitch, 0, 0);
+  if (err == hipSuccess && rc == ORBFE_OK) err = hipDeviceSynchronize();
+  if (err == hipSuccess && rc == ORBFE_OK) err = hipMemcpy2D(dst, dst_stride, dd, r->pitch, r->width, r->height, hipMemcpyDeviceToHost);
+  (void)hipFree(ds);
+  if (dd) (void)hipFree(dd);
+  if (err != hipSuccess) return ifail(ORBFE_ERR_HIP, std::string("remap: ") + hipGetErrorString(err));
+  return rc;
+}
+
+extern "C" int orbfe_remap_batch_device(orbfe_rectifier* r, const uint8_t* d_src, int n_frames, int src_width,
+                                        int src_height, int src_stride, size_t src_frame_stride, uint8_t* d_dst,
+                                        int dst_stride, size_t dst_frame_stride) {
+  if (!r || !d_src || !d_dst || n_frames < 0 || src_width <= 0 || src_height <= 0 || src_stride < src_width ||
+      dst_stride < r->width)
+    return ifail(ORBFE_ERR_INVALID, "remap_batch_device: bad argument");
+  if (n_frames == 0) return ORBFE_OK;
+  IHIP(hipSetDevice(r->device));
+  const int rc = remap_launch(r, d_src, n_frames, src_width, src_height, src_stride, src_frame_stride, d_dst, dst_stride,
+                              dst_frame_stride, 0);
+  if (rc != ORBFE_OK) return rc;
+  IHIP(hipDeviceSynchronize());
   return ORBFE_OK;
 }

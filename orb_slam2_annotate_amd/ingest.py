@@ -29,3 +29,44 @@ def ComputeDistinctiveDescriptors(descriptor_lists, device: int = 0):
     best = np.full(max(len(lens), 1), -1, dtype=np.int32)
     check(_lib.load().orbfe_distinctive_descriptors(device, ptr(flat), ptr(offsets), len(lens), ptr(best)))
     return best[: len(lens)]
+
+
+class Rectifier:
+    """cv::remap(im, imRect, M1, M2, cv::INTER_LINEAR) with the two CV_32F maps of
+    cv::initUndistortRectifyMap (Examples/Stereo/stereo_euroc.cc:97-98, 136-137).  The maps are
+    handed over once; `__call__` rectifies one host image, `batch_device` a device-resident batch."""
+
+    def __init__(self, map_x: np.ndarray, map_y: np.ndarray, device: int = 0):
+        import ctypes as C
+        mx = np.ascontiguousarray(map_x, dtype=np.float32)
+        my = np.ascontiguousarray(map_y, dtype=np.float32)
+        if mx.shape != my.shape or mx.ndim != 2:
+            raise ValueError("map_x / map_y must be two HxW float32 arrays")
+        self.height, self.width = mx.shape
+        self._h = C.c_void_p()
+        check(_lib.load().orbfe_rectifier_create(device, ptr(mx), ptr(my), self.width, self.height, self.width,
+                                                 C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().orbfe_rectifier_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __call__(self, image: np.ndarray) -> np.ndarray:
+        if image.ndim != 2 or image.dtype != np.uint8:
+            raise ValueError("remap: 8-bit single-channel image expected")
+        h, w = image.shape
+        stride = image.strides[0] if image.strides[1] == 1 else None
+        if stride is None:
+            image = np.ascontiguousarray(image)
+            stride = w
+        out = np.zeros((self.height, self.width), dtype=np.uint8)
+        check(_lib.load().orbfe_remap(self._h, ptr(image), w, h, stride, ptr(out), self.width))
+        return out
+
+    def batch_device(self, d_src: int, n_frames: int, src_width: int, src_height: int, src_stride: int,
+                     src_frame_stride: int, d_dst: int, dst_stride: int, dst_frame_stride: int):
+        check(_lib.load().orbfe_remap_batch_device(self._h, d_src, n_frames, src_width, src_height, src_stride,
+                                                   src_frame_stride, d_dst, dst_stride, dst_frame_stride))

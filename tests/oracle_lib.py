@@ -424,3 +424,32 @@ def search_by_sim3(KF1: Frame, KF2: Frame, sf1, sf2, valid1, u1, v1, level1, des
         [C.c_void_p] * 10 + [C.c_float, C.c_void_p]
     n = L.orc_search_by_sim3(C.byref(KF1.c), C.byref(KF2.c), _p(sf1), _p(sf2), *[_p(x) for x in a], float(th), _p(out))
     return n, out[:KF1.N].copy()
+
+
+def remap_linear(src, map_x, map_y):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    mx, my = _f(map_x, np.float32), _f(map_y, np.float32)
+    dh, dw = mx.shape
+    out = np.zeros((dh, dw), dtype=np.uint8)
+    L = lib()
+    L.orc_remap_linear.restype = None
+    L.orc_remap_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_int, C.c_void_p, C.c_int]
+    L.orc_remap_linear(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(mx), _p(my), dw, dw, dh, _p(out), dw)
+    return out
+
+
+def rectify_maps(w, h, fx, fy, cx, cy, k1, k2, p1, p2, k3=0.0, rot_deg=0.4, new_f_scale=1.0):
+    """Test-data generator (NOT a restatement of cv::initUndistortRectifyMap): maps of a radial-tangential
+    camera with a small rectifying rotation, same model and float32 output type as the EuRoC setup."""
+    a = np.deg2rad(rot_deg)
+    R = np.array([[np.cos(a), -np.sin(a), 0.002], [np.sin(a), np.cos(a), -0.003], [-0.002, 0.003, 1.0]])
+    nfx, nfy = fx * new_f_scale, fy * new_f_scale
+    u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    pts = np.stack([(u - cx) / nfx, (v - cy) / nfy, np.ones_like(u)], axis=-1) @ np.linalg.inv(R).T
+    x, y = pts[..., 0] / pts[..., 2], pts[..., 1] / pts[..., 2]
+    r2 = x * x + y * y
+    kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+    mx = fx * (x * kr + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)) + cx
+    my = fy * (y * kr + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y) + cy
+    return mx.astype(np.float32), my.astype(np.float32)
