@@ -449,6 +449,27 @@ int orbfe_remap_batch_device(orbfe_rectifier *r, const uint8_t *d_src, int n_fra
                              int src_height, int src_stride, size_t src_frame_stride, uint8_t *d_dst,
                              int dst_stride, size_t dst_frame_stride);
 
+/* cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK) as Frame::UndistortKeyPoints and
+ * Frame::ComputeImageBounds call it (src/Frame.cc:443-475, 481-510).  K4 = fx, fy, cx, cy (the
+ * CV_32F entries of mK); dist = k1, k2, p1, p2[, k3[, k4, k5, k6]] (n_dist 0, 4, 5 or 8); xy /
+ * out_xy are n (x, y) float pairs. */
+int orbfe_undistort_points(int device, const float *xy, int n, const float *K4, const float *dist,
+                           int n_dist, float *out_xy);
+/* mvKeysUn of a device-resident extractor batch (the layout orbfe_extract_batch_device writes):
+ * records copied, pt undistorted. */
+int orbfe_undistort_keypoints_batch_device(int device, const orbfe_keypoint *d_keypoints,
+                                           const int32_t *d_n, int n_frames, int capacity,
+                                           const float *K4, const float *dist, int n_dist,
+                                           orbfe_keypoint *d_keypoints_un);
+/* Frame::ComputeImageBounds (src/Frame.cc:481-510): bounds4 = mnMinX, mnMaxX, mnMinY, mnMaxY. */
+int orbfe_compute_image_bounds(int device, int cols, int rows, const float *K4, const float *dist,
+                               int n_dist, float *bounds4);
+/* Frame::ComputeStereoFromRGBD (src/Frame.cc:689-713): kx / ky = mvKeys[i].pt, kux = mvKeysUn[i].pt.x,
+ * depth_image = imDepth (CV_32F, after the mDepthMapFactor scaling of src/Tracking.cc:226-227). */
+int orbfe_stereo_from_rgbd(int device, const float *kx, const float *ky, const float *kux, int n,
+                           const float *depth_image, int width, int height, int stride_floats,
+                           float mbf, float *u_right, float *depth);
+
 #ifdef __cplusplus
 }
 #endif

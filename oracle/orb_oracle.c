@@ -1685,3 +1685,57 @@ void orc_remap_linear(const uint8_t *src, int sw, int sh, int sstride, const flo
       dst[(size_t)y * dstride + x] = (uint8_t)(val > 255 ? 255 : val);
     }
 }
+
+/* ------------------------------------------------------------------ */
+/* cv::undistortPoints (cvUndistortPoints), Frame.cc:443-510, 689-713   */
+/* ------------------------------------------------------------------ */
+void orc_undistort_points(const float *xy, int n, const float *K4, const float *dist, int n_dist, float *out_xy) {
+  double k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < n_dist && i < 8; i++) k[i] = (double)dist[i];
+  const double fx = (double)K4[0], fy = (double)K4[1], cx = (double)K4[2], cy = (double)K4[3];
+  const double ifx = 1. / fx, ify = 1. / fy;
+  const int iters = n_dist > 0 ? 5 : 1;
+  /* RR = P * I = K: rows (fx 0 cx), (0 fy cy), (0 0 1) */
+  for (int i = 0; i < n; i++) {
+    double x = (double)xy[2 * i], y = (double)xy[2 * i + 1], x0, y0;
+    x0 = x = (x - cx) * ifx;
+    y0 = y = (y - cy) * ify;
+    for (int j = 0; j < iters; j++) {
+      const double r2 = x * x + y * y;
+      const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+      const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+      const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+    const double xx = fx * x + 0.0 * y + cx;
+    const double yy = 0.0 * x + fy * y + cy;
+    const double ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+    out_xy[2 * i] = (float)(xx * ww);
+    out_xy[2 * i + 1] = (float)(yy * ww);
+  }
+}
+
+void orc_image_bounds(int cols, int rows, const float *K4, const float *dist, int n_dist, float *b) {
+  if (n_dist > 0 && dist[0] != 0.0) {
+    const float in[8] = {0.0f, 0.0f, (float)cols, 0.0f, 0.0f, (float)rows, (float)cols, (float)rows};
+    float out[8];
+    orc_undistort_points(in, 4, K4, dist, n_dist, out);
+    b[0] = out[4] < out[0] ? out[4] : out[0];   /* std::min(a,b): b < a ? b : a */
+    b[1] = out[2] < out[6] ? out[6] : out[2];   /* std::max(a,b): a < b ? b : a */
+    b[2] = out[3] < out[1] ? out[3] : out[1];
+    b[3] = out[5] < out[7] ? out[7] : out[5];
+  } else {
+    b[0] = 0.0f; b[1] = (float)cols; b[2] = 0.0f; b[3] = (float)rows;
+  }
+}
+
+void orc_stereo_from_rgbd(const float *kx, const float *ky, const float *kux, int n, const float *depth_img, int w,
+                          int h, int stride_floats, float mbf, float *uRight, float *depth) {
+  (void)w; (void)h;
+  for (int i = 0; i < n; i++) {
+    uRight[i] = -1; depth[i] = -1;
+    const float d = depth_img[(size_t)(int)ky[i] * stride_floats + (int)kx[i]];
+    if (d > 0) { depth[i] = d; uRight[i] = kux[i] - mbf / d; }
+  }
+}

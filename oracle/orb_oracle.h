@@ -230,6 +230,20 @@ int orc_search_by_sim3(orc_frame *KF1, orc_frame *KF2, const float *sf1, const f
 void orc_remap_linear(const uint8_t *src, int sw, int sh, int sstride, const float *mapx, const float *mapy,
                       int map_stride, int dw, int dh, uint8_t *dst, int dstride);
 
+/* ---- cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK) as called by Frame::UndistortKeyPoints /
+ * ComputeImageBounds (src/Frame.cc:443-475, 481-510).  OpenCV (third party, absent; 3.0 / 2.4.3 per
+ * CMakeLists.txt) -- restated from its published cvUndistortPoints (imgproc/src/undistort.cpp): float inputs
+ * widened to double, 5 fixed-point iterations of the radial-tangential model, re-projection with P = K,
+ * results narrowed to float.  K = fx, fy, cx, cy (floats, as mK is CV_32F); dist = k1,k2,p1,p2[,k3[,k4,k5,k6]].
+ * Parity unpinned. */
+void orc_undistort_points(const float *xy, int n, const float *K4, const float *dist, int n_dist, float *out_xy);
+/* Frame::ComputeImageBounds (src/Frame.cc:481-510) -> mnMinX, mnMaxX, mnMinY, mnMaxY */
+void orc_image_bounds(int cols, int rows, const float *K4, const float *dist, int n_dist, float *bounds4);
+/* Frame::ComputeStereoFromRGBD (src/Frame.cc:689-713): d = imDepth.at<float>(v,u) with the float
+ * coordinates of the DISTORTED keypoint truncated to int; mvuRight = kpU.x - mbf/d for d > 0. */
+void orc_stereo_from_rgbd(const float *kx, const float *ky, const float *kux, int n, const float *depth_img, int w,
+                          int h, int stride_floats, float mbf, float *uRight, float *depth);
+
 /* ---- DBoW2 vocabulary (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h) ---- */
 typedef struct orc_vocab {
   int k, L, scoring, weighting;

@@ -58,6 +58,8 @@ EXPORTS = [
     "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_keyframe",
     "orbfe_search_by_projection_sim3", "orbfe_search_for_initialization", "orbfe_fuse_search", "orbfe_search_by_sim3",
     "orbfe_rectifier_create", "orbfe_rectifier_destroy", "orbfe_remap", "orbfe_remap_batch_device",
+    "orbfe_undistort_points", "orbfe_undistort_keypoints_batch_device", "orbfe_compute_image_bounds",
+    "orbfe_stereo_from_rgbd",
 ]
 
 _lib = None
@@ -162,6 +164,10 @@ def load():
     L.orbfe_rectifier_destroy.restype = None
     L.orbfe_remap.argtypes = [vp, vp, ci, ci, ci, vp, ci]
     L.orbfe_remap_batch_device.argtypes = [vp, vp, ci, ci, ci, ci, cs, vp, ci, cs]
+    L.orbfe_undistort_points.argtypes = [ci, vp, ci, vp, vp, ci, vp]
+    L.orbfe_undistort_keypoints_batch_device.argtypes = [ci, vp, vp, ci, ci, vp, vp, ci, vp]
+    L.orbfe_compute_image_bounds.argtypes = [ci, ci, ci, vp, vp, ci, vp]
+    L.orbfe_stereo_from_rgbd.argtypes = [ci, vp, vp, vp, ci, vp, ci, ci, ci, cf, vp, vp]
     L.orbfe_debug_octree_host.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, ci]
     L.orbfe_debug_geometry.argtypes = [ci, cf, ci, ci, ci, ci, ci, vp, vp, vp, ci]
     L.orbfe_debug_resize_tables.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp]

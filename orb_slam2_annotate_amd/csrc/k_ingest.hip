@@ -321,3 +321,171 @@ extern "C" int orbfe_remap_batch_device(orbfe_rectifier* r, const uint8_t* d_src
   IHIP(hipDeviceSynchronize());
   return ORBFE_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Frame::UndistortKeyPoints / ComputeImageBounds (cv::undistortPoints with P = K,
+// src/Frame.cc:443-510) and Frame::ComputeStereoFromRGBD (src/Frame.cc:689-713): the per-keypoint
+// loops between the extractor and the matchers.  Double precision, no FMA contraction (the
+// library is built with -ffp-contract=off), IEEE division: bit-identical to the host arithmetic.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct UndistortParams {
+  double fx, fy, cx, cy, ifx, ify;
+  double k[8];
+  int iters;
+};
+
+__device__ __forceinline__ void undistort_one(const UndistortParams& p, float xin, float yin, float* xo, float* yo) {
+  double x = (double)xin, y = (double)yin, x0, y0;
+  x0 = x = (x - p.cx) * p.ifx;
+  y0 = y = (y - p.cy) * p.ify;
+  for (int j = 0; j < p.iters; j++) {
+    const double r2 = x * x + y * y;
+    const double icdist =
+        (1 + ((p.k[7] * r2 + p.k[6]) * r2 + p.k[5]) * r2) / (1 + ((p.k[4] * r2 + p.k[1]) * r2 + p.k[0]) * r2);
+    const double deltaX = 2 * p.k[2] * x * y + p.k[3] * (r2 + 2 * x * x);
+    const double deltaY = p.k[2] * (r2 + 2 * y * y) + 2 * p.k[3] * x * y;
+    x = (x0 - deltaX) * icdist;
+    y = (y0 - deltaY) * icdist;
+  }
+  const double xx = p.fx * x + 0.0 * y + p.cx;  // RR = P * I = K
+  const double yy = 0.0 * x + p.fy * y + p.cy;
+  const double ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+  *xo = (float)(xx * ww);
+  *yo = (float)(yy * ww);
+}
+
+__global__ __launch_bounds__(256) void k_undistort_points(UndistortParams p, const float* __restrict__ xy, int n,
+                                                          float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  undistort_one(p, xy[2 * i], xy[2 * i + 1], &out[2 * i], &out[2 * i + 1]);
+}
+
+// mvKeysUn for a device-resident extractor batch: 28-byte records copied, pt replaced
+__global__ __launch_bounds__(256) void k_undistort_keypoints(UndistortParams p, const float* __restrict__ kp,
+                                                             const int32_t* __restrict__ nKp, int capacity,
+                                                             float* __restrict__ out) {
+  const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nKp[f] || i >= capacity) return;
+  const float* s = kp + ((size_t)f * capacity + i) * 7;
+  float* d = out + ((size_t)f * capacity + i) * 7;
+  float x, y;
+  undistort_one(p, s[0], s[1], &x, &y);
+  d[0] = x; d[1] = y;
+#pragma unroll
+  for (int k = 2; k < 7; k++) d[k] = s[k];
+}
+
+__global__ __launch_bounds__(256) void k_stereo_from_rgbd(const float* __restrict__ kx, const float* __restrict__ ky,
+                                                          const float* __restrict__ kux, int n,
+                                                          const float* __restrict__ depthImg, int stride, float mbf,
+                                                          float* __restrict__ uRight, float* __restrict__ depth) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float d = depthImg[(size_t)(int)ky[i] * stride + (int)kx[i]];
+  float ur = -1.0f, dd = -1.0f;
+  if (d > 0) { dd = d; ur = kux[i] - mbf / d; }
+  uRight[i] = ur;
+  depth[i] = dd;
+}
+
+bool undistort_params(const float* K4, const float* dist, int n_dist, UndistortParams* p) {
+  if (!K4 || n_dist < 0 || n_dist > 8 || (n_dist > 0 && !dist) || !(n_dist == 0 || n_dist == 4 || n_dist == 5 || n_dist == 8))
+    return false;
+  p->fx = (double)K4[0]; p->fy = (double)K4[1]; p->cx = (double)K4[2]; p->cy = (double)K4[3];
+  p->ifx = 1. / p->fx; p->ify = 1. / p->fy;
+  for (int i = 0; i < 8; i++) p->k[i] = i < n_dist ? (double)dist[i] : 0.0;
+  p->iters = n_dist > 0 ? 5 : 1;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int orbfe_undistort_points(int device, const float* xy, int n, const float* K4, const float* dist,
+                                      int n_dist, float* out_xy) {
+  UndistortParams p;
+  if (n < 0 || (n > 0 && (!xy || !out_xy)) || !undistort_params(K4, dist, n_dist, &p))
+    return ifail(ORBFE_ERR_INVALID, "undistort_points: bad argument");
+  if (n == 0) return ORBFE_OK;
+  IHIP(hipSetDevice(device));
+  float *din = nullptr, *dout = nullptr;
+  IHIP(hipMalloc((void**)&din, (size_t)n * 8));
+  hipError_t err = hipMalloc((void**)&dout, (size_t)n * 8);
+  if (err == hipSuccess) err = hipMemcpy(din, xy, (size_t)n * 8, hipMemcpyHostToDevice);
+  if (err == hipSuccess) {
+    hipLaunchKernelGGL(k_undistort_points, dim3((n + 255) / 256), dim3(256), 0, 0, p, din, n, dout);
+    err = hipGetLastError();
+  }
+  if (err == hipSuccess) err = hipMemcpy(out_xy, dout, (size_t)n * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(din);
+  if (dout) (void)hipFree(dout);
+  if (err != hipSuccess) return ifail(ORBFE_ERR_HIP, std::string("undistort_points: ") + hipGetErrorString(err));
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_undistort_keypoints_batch_device(int device, const orbfe_keypoint* d_keypoints,
+                                                      const int32_t* d_n, int n_frames, int capacity,
+                                                      const float* K4, const float* dist, int n_dist,
+                                                      orbfe_keypoint* d_keypoints_un) {
+  UndistortParams p;
+  if (!d_keypoints || !d_n || !d_keypoints_un || n_frames < 0 || capacity <= 0 || !undistort_params(K4, dist, n_dist, &p))
+    return ifail(ORBFE_ERR_INVALID, "undistort_keypoints_batch_device: bad argument");
+  if (n_frames == 0) return ORBFE_OK;
+  IHIP(hipSetDevice(device));
+  hipLaunchKernelGGL(k_undistort_keypoints, dim3((capacity + 255) / 256, n_frames), dim3(256), 0, 0, p,
+                     reinterpret_cast<const float*>(d_keypoints), d_n, capacity, reinterpret_cast<float*>(d_keypoints_un));
+  IHIP(hipGetLastError());
+  IHIP(hipDeviceSynchronize());
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_compute_image_bounds(int device, int cols, int rows, const float* K4, const float* dist,
+                                          int n_dist, float* bounds4) {
+  if (!bounds4 || cols <= 0 || rows <= 0) return ifail(ORBFE_ERR_INVALID, "compute_image_bounds: bad argument");
+  if (n_dist > 0 && dist && dist[0] != 0.0) {
+    const float in[8] = {0.0f, 0.0f, (float)cols, 0.0f, 0.0f, (float)rows, (float)cols, (float)rows};
+    float out[8];
+    const int rc = orbfe_undistort_points(device, in, 4, K4, dist, n_dist, out);
+    if (rc != ORBFE_OK) return rc;
+    bounds4[0] = out[4] < out[0] ? out[4] : out[0];  // min(mat(0,0), mat(2,0)), src/Frame.cc:496-499
+    bounds4[1] = out[2] < out[6] ? out[6] : out[2];
+    bounds4[2] = out[3] < out[1] ? out[3] : out[1];
+    bounds4[3] = out[5] < out[7] ? out[7] : out[5];
+  } else {
+    bounds4[0] = 0.0f; bounds4[1] = (float)cols; bounds4[2] = 0.0f; bounds4[3] = (float)rows;
+  }
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_stereo_from_rgbd(int device, const float* kx, const float* ky, const float* kux, int n,
+                                      const float* depth_image, int width, int height, int stride_floats, float mbf,
+                                      float* u_right, float* depth) {
+  if (n < 0 || width <= 0 || height <= 0 || stride_floats < width || !depth_image ||
+      (n > 0 && (!kx || !ky || !kux || !u_right || !depth)))
+    return ifail(ORBFE_ERR_INVALID, "stereo_from_rgbd: bad argument");
+  for (int i = 0; i < n; i++)
+    if (!(kx[i] >= 0 && ky[i] >= 0 && (int)kx[i] < width && (int)ky[i] < height))
+      return ifail(ORBFE_ERR_INVALID, "stereo_from_rgbd: keypoint outside the depth image");
+  if (n == 0) return ORBFE_OK;
+  IHIP(hipSetDevice(device));
+  float* buf = nullptr;
+  const size_t img = (size_t)width * height;
+  IHIP(hipMalloc((void**)&buf, (img + 5 * (size_t)n) * 4));
+  float *dimg = buf, *dkx = buf + img, *dky = dkx + n, *dkux = dky + n, *dur = dkux + n, *ddp = dur + n;
+  hipError_t err = hipMemcpy2D(dimg, (size_t)width * 4, depth_image, (size_t)stride_floats * 4, (size_t)width * 4, height, hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMemcpy(dkx, kx, (size_t)n * 4, hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMemcpy(dky, ky, (size_t)n * 4, hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMemcpy(dkux, kux, (size_t)n * 4, hipMemcpyHostToDevice);
+  if (err == hipSuccess) {
+    hipLaunchKernelGGL(k_stereo_from_rgbd, dim3((n + 255) / 256), dim3(256), 0, 0, dkx, dky, dkux, n, dimg, width, mbf, dur, ddp);
+    err = hipGetLastError();
+  }
+  if (err == hipSuccess) err = hipMemcpy(u_right, dur, (size_t)n * 4, hipMemcpyDeviceToHost);
+  if (err == hipSuccess) err = hipMemcpy(depth, ddp, (size_t)n * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(buf);
+  if (err != hipSuccess) return ifail(ORBFE_ERR_HIP, std::string("stereo_from_rgbd: ") + hipGetErrorString(err));
+  return ORBFE_OK;
+}

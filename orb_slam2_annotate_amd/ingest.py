@@ -70,3 +70,52 @@ class Rectifier:
                      src_frame_stride: int, d_dst: int, dst_stride: int, dst_frame_stride: int):
         check(_lib.load().orbfe_remap_batch_device(self._h, d_src, n_frames, src_width, src_height, src_stride,
                                                    src_frame_stride, d_dst, dst_stride, dst_frame_stride))
+
+
+def _cam(K, dist):
+    K = np.asarray(K, dtype=np.float32)
+    K4 = np.ascontiguousarray([K[0, 0], K[1, 1], K[0, 2], K[1, 2]] if K.ndim == 2 else K, dtype=np.float32)
+    d = np.ascontiguousarray(np.asarray(dist, dtype=np.float32).reshape(-1))
+    return K4, d
+
+
+def undistortPoints(xy, K, dist, device: int = 0) -> np.ndarray:
+    """cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK) (src/Frame.cc:463): xy [n,2] float32;
+    K a 3x3 matrix or (fx, fy, cx, cy); dist = k1,k2,p1,p2[,k3]."""
+    pts = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+    K4, d = _cam(K, dist)
+    out = np.zeros_like(pts)
+    check(_lib.load().orbfe_undistort_points(device, ptr(pts), len(pts), ptr(K4), ptr(d), len(d), ptr(out)))
+    return out
+
+
+def UndistortKeyPoints(keypoints, K, dist, device: int = 0):
+    """Frame::UndistortKeyPoints (src/Frame.cc:443-475): mvKeys records -> mvKeysUn records."""
+    K4, d = _cam(K, dist)
+    kps = np.array(keypoints, copy=True)
+    if len(d) == 0 or d[0] == 0.0 or len(kps) == 0:
+        return kps
+    un = undistortPoints(np.stack([kps["x"], kps["y"]], axis=1), K4, d, device)
+    kps["x"], kps["y"] = un[:, 0], un[:, 1]
+    return kps
+
+
+def ComputeImageBounds(cols: int, rows: int, K, dist, device: int = 0):
+    """Frame::ComputeImageBounds (src/Frame.cc:481-510) -> (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+    K4, d = _cam(K, dist)
+    b = np.zeros(4, dtype=np.float32)
+    check(_lib.load().orbfe_compute_image_bounds(device, cols, rows, ptr(K4), ptr(d), len(d), ptr(b)))
+    return tuple(float(v) for v in b)
+
+
+def ComputeStereoFromRGBD(keypoints, keypoints_un, depth_image, mbf: float, device: int = 0):
+    """Frame::ComputeStereoFromRGBD (src/Frame.cc:689-713) -> (mvuRight, mvDepth)."""
+    dimg = np.ascontiguousarray(depth_image, dtype=np.float32)
+    kx = np.ascontiguousarray(keypoints["x"], dtype=np.float32)
+    ky = np.ascontiguousarray(keypoints["y"], dtype=np.float32)
+    kux = np.ascontiguousarray(keypoints_un["x"], dtype=np.float32)
+    n = len(kx)
+    ur, dp = np.full(max(n, 1), -1, np.float32), np.full(max(n, 1), -1, np.float32)
+    check(_lib.load().orbfe_stereo_from_rgbd(device, ptr(kx), ptr(ky), ptr(kux), n, ptr(dimg), dimg.shape[1],
+                                             dimg.shape[0], dimg.shape[1], float(mbf), ptr(ur), ptr(dp)))
+    return ur[:n], dp[:n]

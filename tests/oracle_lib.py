@@ -453,3 +453,38 @@ def rectify_maps(w, h, fx, fy, cx, cy, k1, k2, p1, p2, k3=0.0, rot_deg=0.4, new_
     mx = fx * (x * kr + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)) + cx
     my = fy * (y * kr + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y) + cy
     return mx.astype(np.float32), my.astype(np.float32)
+
+
+def undistort_points(xy, K4, dist):
+    pts = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+    K4 = _f(K4, np.float32); d = _f(np.asarray(dist).reshape(-1), np.float32)
+    out = np.zeros_like(pts)
+    L = lib()
+    L.orc_undistort_points.restype = None
+    L.orc_undistort_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.orc_undistort_points(_p(pts), len(pts), _p(K4), _p(d), len(d), _p(out))
+    return out
+
+
+def image_bounds(cols, rows, K4, dist):
+    K4 = _f(K4, np.float32); d = _f(np.asarray(dist).reshape(-1), np.float32)
+    b = np.zeros(4, np.float32)
+    L = lib()
+    L.orc_image_bounds.restype = None
+    L.orc_image_bounds.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.orc_image_bounds(cols, rows, _p(K4), _p(d), len(d), _p(b))
+    return tuple(float(v) for v in b)
+
+
+def stereo_from_rgbd(kx, ky, kux, depth_img, mbf):
+    kx, ky, kux = _f(kx, np.float32), _f(ky, np.float32), _f(kux, np.float32)
+    dimg = _f(depth_img, np.float32)
+    n = len(kx)
+    ur, dp = np.zeros(max(n, 1), np.float32), np.zeros(max(n, 1), np.float32)
+    L = lib()
+    L.orc_stereo_from_rgbd.restype = None
+    L.orc_stereo_from_rgbd.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                                         C.c_void_p, C.c_void_p]
+    L.orc_stereo_from_rgbd(_p(kx), _p(ky), _p(kux), n, _p(dimg), dimg.shape[1], dimg.shape[0], dimg.shape[1], float(mbf),
+                           _p(ur), _p(dp))
+    return ur[:n], dp[:n]

@@ -127,3 +127,89 @@ def test_remap_batch_device_feeds_the_extractor():
     n0 = int(d_n[0].item())
     assert n0 == len(k0)
     assert np.array_equal(d_desc[0, :n0].cpu().numpy(), dsc0)
+
+
+TUM1_K = np.array([517.306408, 516.469215, 318.643040, 255.313989], np.float32)  # Examples/Monocular/TUM1.yaml
+TUM1_D = np.array([0.262383, -0.953104, -0.005358, 0.002628, 1.163314], np.float32)
+
+
+@pytest.mark.parametrize("n_dist", [0, 4, 5, 8])
+def test_undistort_points_bit_exact(n_dist):
+    import orb_slam2_annotate_amd as amd
+    rng = np.random.default_rng(60 + n_dist)
+    pts = np.stack([rng.uniform(-20, 660, 5000), rng.uniform(-20, 500, 5000)], axis=1).astype(np.float32)
+    d = np.concatenate([TUM1_D, [0.01, -0.02, 0.003]]).astype(np.float32)[:n_dist]
+    ref = orc.undistort_points(pts, TUM1_K, d)
+    got = amd.undistortPoints(pts, TUM1_K, d)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    # 3x3 K accepted too
+    K = np.array([[TUM1_K[0], 0, TUM1_K[2]], [0, TUM1_K[1], TUM1_K[3]], [0, 0, 1]], np.float32)
+    assert np.array_equal(amd.undistortPoints(pts[:10], K, d), ref[:10])
+    assert amd.undistortPoints(np.zeros((0, 2), np.float32), K, d).shape == (0, 2)
+
+
+def test_undistort_keypoints_bounds_and_grid():
+    """TUM1 mono pipeline after extraction: UndistortKeyPoints, ComputeImageBounds, AssignFeaturesToGrid."""
+    import orb_slam2_annotate_amd as amd
+    from orb_slam2_annotate_amd import synth
+    e = amd.ORBextractor(1000, 1.2, 8, 20, 7)
+    kps, desc = e(synth.render_frame(77, 640, 480))
+    un = amd.UndistortKeyPoints(kps, TUM1_K, TUM1_D)
+    ref = orc.undistort_points(np.stack([kps["x"], kps["y"]], axis=1), TUM1_K, TUM1_D)
+    assert np.array_equal(un["x"], ref[:, 0]) and np.array_equal(un["y"], ref[:, 1])
+    for f in ("size", "angle", "response", "octave", "class_id"):
+        assert np.array_equal(un[f], kps[f])
+    assert amd.UndistortKeyPoints(kps, TUM1_K, np.zeros(5, np.float32)) is not kps
+    assert np.array_equal(amd.UndistortKeyPoints(kps, TUM1_K, np.zeros(5, np.float32)), kps)
+    b = amd.ComputeImageBounds(640, 480, TUM1_K, TUM1_D)
+    assert b == orc.image_bounds(640, 480, TUM1_K, TUM1_D)
+    assert b != (0.0, 640.0, 0.0, 480.0) and b[0] < b[1] and b[2] < b[3]
+    assert amd.ComputeImageBounds(640, 480, TUM1_K, np.zeros(4, np.float32)) == (0.0, 640.0, 0.0, 480.0)
+    # the undistorted frame on its real bounds through the grid
+    F = amd.FrameView(un["x"], un["y"], un["octave"], desc, b, angle=un["angle"])
+    Fo = orc.Frame(un["x"], un["y"], un["octave"], desc, b, angle=un["angle"])
+    got = F.GetFeaturesInArea([100.0, 320.0, 600.0], [80.0, 240.0, 400.0], [40.0, 25.0, 60.0])
+    for g, (x, y, r) in zip(got, [(100, 80, 40), (320, 240, 25), (600, 400, 60)]):
+        assert g.tolist() == Fo.features_in_area(x, y, r).tolist() and len(g) > 0
+
+
+def test_undistort_keypoints_batch_device_and_rgbd():
+    torch = pytest.importorskip("torch")
+    import orb_slam2_annotate_amd as amd
+    from orb_slam2_annotate_amd import synth
+    B, w, h = 3, 640, 480
+    imgs = np.stack([synth.render_frame(90 + i, w, h) for i in range(B)])
+    e = amd.ORBextractor(1000, 1.2, 8, 20, 7)
+    cap = e.max_keypoints()
+    dev = torch.device("cuda", 0)
+    d_img = torch.from_numpy(imgs).to(dev)
+    d_kp = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+    d_un = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros((B,), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    e.extract_batch_device(d_img.data_ptr(), B, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr())
+    L = amd._lib.load()
+    amd._lib.check(L.orbfe_undistort_keypoints_batch_device(0, C.c_void_p(d_kp.data_ptr()), C.c_void_p(d_n.data_ptr()), B,
+                                                            cap, amd._lib.ptr(TUM1_K), amd._lib.ptr(TUM1_D), 5,
+                                                            C.c_void_p(d_un.data_ptr())))
+    n = d_n.cpu().numpy()
+    kp = d_kp.cpu().numpy()
+    un = d_un.cpu().numpy()
+    for f in range(B):
+        ref = orc.undistort_points(kp[f, :n[f], :2], TUM1_K, TUM1_D)
+        assert np.array_equal(un[f, :n[f], :2], ref)
+        assert np.array_equal(un[f, :n[f], 2:].view(np.uint32), kp[f, :n[f], 2:].view(np.uint32))
+        assert not un[f, n[f]:].any()
+    # ComputeStereoFromRGBD on frame 0
+    rng = np.random.default_rng(3)
+    depth = np.where(rng.random((h, w)) < 0.8, rng.uniform(0.4, 8.0, (h, w)), 0.0).astype(np.float32)
+    k0 = np.zeros(n[0], dtype=amd.KP_DTYPE); k0["x"], k0["y"] = kp[0, :n[0], 0], kp[0, :n[0], 1]
+    u0 = np.zeros(n[0], dtype=amd.KP_DTYPE); u0["x"], u0["y"] = un[0, :n[0], 0], un[0, :n[0], 1]
+    ur, dp = amd.ComputeStereoFromRGBD(k0, u0, depth, 40.0)
+    ur_ref, dp_ref = orc.stereo_from_rgbd(k0["x"], k0["y"], u0["x"], depth, 40.0)
+    assert np.array_equal(ur, ur_ref) and np.array_equal(dp, dp_ref)
+    assert (dp > 0).sum() > 100 and (dp < 0).sum() > 10
+    with pytest.raises(amd.OrbfeError):
+        bad = k0.copy(); bad["x"][0] = 640.0
+        amd.ComputeStereoFromRGBD(bad, u0, depth, 40.0)
