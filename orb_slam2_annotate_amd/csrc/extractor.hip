@@ -353,7 +353,7 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, bool timed, LevelView level0, i
   {  // FAST grid stage, :846-896 (timed alone: the dominant kernel of the pipeline)
     StageTimer t(e, ORBFE_STAGE_FAST, 1, nFrames, timed);
     launch_fast_cells(s, pyr, e->d_cells, nCells, nFrames, e->tab.iniThFAST, e->tab.minThFAST, slots,
-                      g.totalSlots, cellCount);
+                      g.totalSlots, cellCount, g.maxCellW, g.maxCellH);
   }
   if (!e->hostOctree) {  // candidate ordering + DistributeOctTree, :566-808, one workgroup per (frame, level)
     StageTimer t(e, ORBFE_STAGE_OCTREE, 2, nFrames, timed);

@@ -16,10 +16,8 @@
 namespace orbfe {
 
 namespace {
-constexpr int kMaxCell = 60;    // cell side bound: wCell = ceil(width/nCols) < 60
+// cell side bound: wCell = ceil(width/nCols) < 60, so py fits 6 bits and px 8 bits of a list entry
 constexpr int kPitchDw = 24;    // LDS row pitch in dwords (96 B): 4 rows x 8 groups hit 32 distinct banks
-constexpr int kTileRows = kMaxCell + 6;
-constexpr int kScoreRows = kMaxCell + 2;
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
@@ -38,27 +36,33 @@ constexpr uint32_t sel2(int o) { return (uint32_t)o | 0x0c00u | ((uint32_t)(o + 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 
-// One workgroup per (frame, grid cell).  The tile lives in LDS with the cell's first pixel at
-// byte column 4, so a group of 4 horizontally adjacent pixels reads aligned dwords.
-//   A. cheap necessary test, packed 16-bit, 4 pixels per thread: a 9-of-16 arc always covers two
+// One WAVEFRONT (64-thread workgroup) per (frame, grid cell).  A cell is ~31x32 pixels: 256 four-pixel
+// groups, ~190 work-list entries -- a 64-lane unit packs those 99 % full where a 256-thread group
+// ran its last pass 3/4 empty, and nothing crosses a wave any more: no barriers, no wave totals.
+// The tile lives in LDS with the cell's first pixel at byte column 4, so a group of 4
+// horizontally adjacent pixels reads aligned dwords.
+//   A. cheap necessary test, packed 16-bit, 4 pixels per lane: a 9-of-16 arc always covers two
 //      ADJACENT cardinal ring points (0,4,8,12), so a corner needs (c0|c8)&(c4|c12) in one
 //      polarity.  ~19 % of pixels pass; they are appended to an LDS work list IN RASTER ORDER
-//      (ballot prefix inside a wave, wave totals through LDS).
+//      (ballot prefix).
 //   B. exact cv::FAST response S-1 for the listed pixels, one pixel per lane (dense lanes).
 //   C. cell-local 3x3 strict NMS of the corners (one lane per corner) + threshold classes.
 //   D. per-cell 20->7 fallback, then ordered compaction of the survivors = emission order.
-__global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
-                                                    const CellDesc* __restrict__ cells,
-                                                    int nCells, int nFrames, int iniTh, int minTh,
-                                                    Candidate* __restrict__ slots,
-                                                    int slotsPerFrame,
-                                                    uint16_t* __restrict__ cellCount) {
-  __shared__ uint32_t tile[kTileRows * kPitchDw];    // pixels: origin (x0-4, y0-3)
-  __shared__ uint32_t score[kScoreRows * kPitchDw];  // FAST responses: origin (x0-4, y0-1)
-  __shared__ uint16_t queue[kMaxCell * kMaxCell];    // work list: py<<8 | px, bits 14/15 = NMS classes
-  __shared__ int waveTot[2][4];                      // double-buffered wave totals of the scans
+// Dynamic LDS: tile [tileRows][24 dw] | score [scoreRows][24 dw] | queue [queueLen] u16, sized by
+// the largest cell of the frame geometry.
+__global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
+                                                   const CellDesc* __restrict__ cells,
+                                                   int nCells, int nFrames, int iniTh, int minTh,
+                                                   Candidate* __restrict__ slots,
+                                                   int slotsPerFrame,
+                                                   uint16_t* __restrict__ cellCount,
+                                                   int tileRows, int scoreRows) {
+  extern __shared__ uint32_t lds[];
+  uint32_t* tile = lds;                                   // pixels: origin (x0-4, y0-3)
+  uint32_t* score = lds + tileRows * kPitchDw;            // FAST responses: origin (x0-4, y0-1)
+  uint16_t* queue = reinterpret_cast<uint16_t*>(score + scoreRows * kPitchDw);  // py<<8 | px, bits 14/15 = NMS classes
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = threadIdx.x;
   // XCD-aware work mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, so
   // block b takes work item (b % 8) * chunk + b / 8 -- every XCD walks a contiguous run of
   // (frame, cell) items and neighbouring cells, which share halo rows, meet in the same L2.
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
     if ((lv.pitch & 3) == 0) {
       const int a = (int)(addr0 & 3);     // same misalignment for every row
       const uint8_t* al = img - a;
-      for (int i = tid; i < th * tdw; i += 256) {
+      for (int i = lane; i < th * tdw; i += 64) {
         const int ty = (int)(((uint32_t)i * invT) >> 16), tx = i - ty * tdw;
         const uint32_t* row = reinterpret_cast<const uint32_t*>(al + (size_t)ty * lv.pitch);
         const uint32_t lo = row[tx];
@@ -95,23 +99,22 @@ __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
         tile[ty * kPitchDw + tx] = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)a);
       }
     } else {  // caller-owned level 0 with an odd stride: byte loads
-      for (int i = tid; i < th * tdw; i += 256) {
+      for (int i = lane; i < th * tdw; i += 64) {
         const int ty = (int)(((uint32_t)i * invT) >> 16), tx = i - ty * tdw;
         const uint8_t* p = img + (size_t)ty * lv.pitch + 4 * tx;
         tile[ty * kPitchDw + tx] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
       }
     }
-    for (int i = tid; i < (ch + 2) * kPitchDw; i += 256) score[i] = 0;
+    for (int i = lane; i < (ch + 2) * kPitchDw; i += 64) score[i] = 0;
   }
   __syncthreads();
 
   // ---- A: cardinal-pair test at the lower threshold; ordered work list ----
-  int nq = 0;  // identical in every thread
+  int nq = 0;  // wave-uniform
   {
     const s16x2 T = {(short)tlo, (short)tlo};
-    int it = 0;
-    for (int g0 = 0; g0 < ngroups; g0 += 256, it++) {  // block-uniform trip count
-      const int g = g0 + tid;
+    for (int g0 = 0; g0 < ngroups; g0 += 64) {
+      const int g = g0 + lane;
       uint32_t pass = 0;
       int gy = 0, gx = 0;
       if (g < ngroups) {
@@ -140,13 +143,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
       }
       const int c = __popc(pass);  // 0..4
       const unsigned long long b0 = __ballot(c & 1), b1 = __ballot(c & 2), b2 = __ballot(c & 4);
-      const int before = __popcll(b0 & ltMask) + 2 * __popcll(b1 & ltMask) + 4 * __popcll(b2 & ltMask);
-      int* wt = waveTot[it & 1];
-      if (lane == 0) wt[wave] = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
-      __syncthreads();
-      int q = nq + before;
-      for (int w = 0; w < wave; w++) q += wt[w];
-      nq += wt[0] + wt[1] + wt[2] + wt[3];
+      int q = nq + __popcll(b0 & ltMask) + 2 * __popcll(b1 & ltMask) + 4 * __popcll(b2 & ltMask);
+      nq += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
 #pragma unroll
       for (int j = 0; j < 4; j++)
         if (pass & (1u << j)) queue[q++] = (uint16_t)((gy << 8) | (4 * gx + j));
@@ -158,7 +156,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
   {
     const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
     uint8_t* sbytes = reinterpret_cast<uint8_t*>(score);
-    for (int q = tid; q < nq; q += 256) {
+    for (int q = lane; q < nq; q += 64) {
       const int e = queue[q], px = e & 255, py = e >> 8;
       const uint8_t* c = tb + (py + 3) * P + 4 + px;
       const int v = c[0];
@@ -193,7 +191,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
   //      and 15 (>= iniThFAST) of the list entry ----
   const uint8_t* sbytes = reinterpret_cast<const uint8_t*>(score);
   int anyHigh = 0;
-  for (int q = tid; q < nq; q += 256) {
+  for (int q = lane; q < nq; q += 64) {
     const int e = queue[q];
     if (e == 0xffff) continue;
     const uint8_t* c = sbytes + ((e >> 8) + 1) * P + 4 + (e & 255);
@@ -205,23 +203,20 @@ __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
     anyHigh |= flags >> 15;
   }
   // per-cell threshold fallback (:874-882): corners >= iniThFAST if any survived NMS, else >= minThFAST
-  const int useHigh = __syncthreads_or(anyHigh);
+  const int useHigh = __ballot(anyHigh) != 0ull;
+  __syncthreads();
 
   // ---- D: ordered compaction of the survivors (the list is in raster order, :884-893) ----
   Candidate* out = slots + (size_t)f * slotsPerFrame + cd.slotBase;
   const int bit = useHigh ? 0x8000 : 0x4000;
-  int run = 0, it2 = 0;  // identical in every thread
-  for (int q0 = 0; q0 < nq; q0 += 256, it2++) {
-    const int q = q0 + tid;
+  int run = 0;  // wave-uniform
+  for (int q0 = 0; q0 < nq; q0 += 64) {
+    const int q = q0 + lane;
     const int e = q < nq ? queue[q] : 0xffff;
     const bool sel = e != 0xffff && (e & bit);
     const unsigned long long bal = __ballot(sel);
-    int* wt = waveTot[it2 & 1];
-    if (lane == 0) wt[wave] = __popcll(bal);
-    __syncthreads();
-    int o = run + __popcll(bal & ltMask);
-    for (int w = 0; w < wave; w++) o += wt[w];
-    run += wt[0] + wt[1] + wt[2] + wt[3];
+    const int o = run + __popcll(bal & ltMask);
+    run += __popcll(bal);
     if (sel) {
       const int px = e & 255, py = (e >> 8) & 63;
       Candidate cnd;
@@ -230,18 +225,21 @@ __global__ __launch_bounds__(256) void k_fast_cells(PyramidViews pyr,
       out[o] = cnd;
     }
   }
-  if (tid == 0) cellCount[(size_t)f * nCells + cellId] = (uint16_t)run;
+  if (lane == 0) cellCount[(size_t)f * nCells + cellId] = (uint16_t)run;
 }
 
 void launch_fast_cells(hipStream_t s, PyramidViews pyr, const CellDesc* d_cells, int nCells,
                        int nFrames, int iniTh, int minTh, Candidate* d_slots, int slotsPerFrame,
-                       uint16_t* d_cellCount) {
+                       uint16_t* d_cellCount, int maxCellW, int maxCellH) {
   if (nCells <= 0 || nFrames <= 0) return;
   iniTh = iniTh < 0 ? 0 : (iniTh > 255 ? 255 : iniTh);  // cv::FAST clamps the threshold
   minTh = minTh < 0 ? 0 : (minTh > 255 ? 255 : minTh);
   const unsigned total = (unsigned)nCells * (unsigned)nFrames;
-  hipLaunchKernelGGL(k_fast_cells, dim3((total + 7u) / 8u * 8u), dim3(256), 0, s, pyr, d_cells, nCells, nFrames,
-                     iniTh, minTh, d_slots, slotsPerFrame, d_cellCount);
+  const int tileRows = maxCellH + 6, scoreRows = maxCellH + 2;
+  const int queueLen = (((maxCellW + 3) & ~3) * maxCellH + 1) & ~1;
+  const size_t ldsBytes = (size_t)(tileRows + scoreRows) * kPitchDw * 4 + (size_t)queueLen * 2;
+  hipLaunchKernelGGL(k_fast_cells, dim3((total + 7u) / 8u * 8u), dim3(64), ldsBytes, s, pyr, d_cells, nCells, nFrames,
+                     iniTh, minTh, d_slots, slotsPerFrame, d_cellCount, tileRows, scoreRows);
 }
 
 // Ordered compaction: cells of a level in cell-row-major order, raster inside each cell.

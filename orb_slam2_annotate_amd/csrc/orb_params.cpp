@@ -87,6 +87,7 @@ void FrameGeom::build(const ExtractorTables& t, int W_, int H_) {
   H = H_;
   nlevels = t.nlevels;
   cells.clear();
+  maxCellW = maxCellH = 0;
   uint32_t off = 0;
   int slots = 0, kps = 0;
   for (int l = 0; l < nlevels; l++) {
@@ -137,6 +138,8 @@ void FrameGeom::build(const ExtractorTables& t, int W_, int H_) {
           // strict 3x3 NMS keeps no two 8-adjacent pixels -> at most ceil(w/2)*ceil(h/2)
           slots += ((c.w + 1) / 2) * ((c.h + 1) / 2);
           cells.push_back(c);
+          if (c.w > maxCellW) maxCellW = c.w;
+          if (c.h > maxCellH) maxCellH = c.h;
         }
       }
     } else {

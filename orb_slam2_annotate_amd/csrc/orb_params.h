@@ -56,6 +56,7 @@ struct FrameGeom {
   uint32_t pyrBytes = 0;   // bytes of levels 1..n-1 (+ level 0 when owned) per frame
   int totalSlots = 0;      // candidate slots per frame
   int totalKpCap = 0;      // keypoint slots per frame
+  int maxCellW = 0, maxCellH = 0;  // largest FAST detection rectangle (sizes the FAST kernel's LDS)
   void build(const ExtractorTables& t, int W, int H);
 };
 
