@@ -76,6 +76,8 @@ struct orbfe_extractor {
   int16_t* d_alpha[kMaxLevels] = {};
   int32_t* d_yofs[kMaxLevels] = {};
   int16_t* d_beta[kMaxLevels] = {};
+  uint32_t* d_colrec[kMaxLevels] = {};
+  uint32_t* d_rowrec[kMaxLevels] = {};
   // per-batch workspace
   uint8_t* d_pyr = nullptr;
   uint8_t* d_blur = nullptr;
@@ -126,7 +128,7 @@ void dfree(T** p) {
 void free_geometry(orbfe_extractor* e) {
   dfree(&e->d_cells);
   dfree(&e->d_lvgeom);
-  for (int l = 0; l < kMaxLevels; l++) { dfree(&e->d_xofs[l]); dfree(&e->d_alpha[l]); dfree(&e->d_yofs[l]); dfree(&e->d_beta[l]); }
+  for (int l = 0; l < kMaxLevels; l++) { dfree(&e->d_xofs[l]); dfree(&e->d_alpha[l]); dfree(&e->d_yofs[l]); dfree(&e->d_beta[l]); dfree(&e->d_colrec[l]); dfree(&e->d_rowrec[l]); }
 }
 void free_workspace(orbfe_extractor* e) {
   dfree(&e->d_pyr); dfree(&e->d_blur); dfree(&e->d_slots); dfree(&e->d_cand);
@@ -175,6 +177,12 @@ int ensure_geometry(orbfe_extractor* e, int W, int H) {
     HIPCHK(hipMemcpy(e->d_alpha[l], t.alpha.data(), t.alpha.size() * 2, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_yofs[l], t.yofs.data(), t.yofs.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_beta[l], t.beta.data(), t.beta.size() * 2, hipMemcpyHostToDevice));
+    if (!t.colrec.empty()) {
+      if ((rc = dalloc(&e->d_colrec[l], t.colrec.size()))) return rc;
+      if ((rc = dalloc(&e->d_rowrec[l], t.rowrec.size()))) return rc;
+      HIPCHK(hipMemcpy(e->d_colrec[l], t.colrec.data(), t.colrec.size() * 4, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(e->d_rowrec[l], t.rowrec.data(), t.rowrec.size() * 4, hipMemcpyHostToDevice));
+    }
   }
   return ORBFE_OK;
 }
@@ -347,7 +355,8 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, bool timed, LevelView level0, i
     StageTimer t(e, ORBFE_STAGE_PYRAMID, g.nlevels - 1, nFrames, timed);
     for (int l = 1; l < g.nlevels; l++) {
       LevelViewMut dst{const_cast<uint8_t*>(pyr.lv[l].base), g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
-      launch_resize(s, pyr.lv[l - 1], dst, e->d_xofs[l], e->d_alpha[l], e->d_yofs[l], e->d_beta[l], nFrames);
+      launch_resize(s, pyr.lv[l - 1], dst, e->d_xofs[l], e->d_alpha[l], e->d_yofs[l], e->d_beta[l], e->d_colrec[l],
+                    e->d_rowrec[l], nFrames);
     }
   }
   {  // FAST grid stage, :846-896 (timed alone: the dominant kernel of the pipeline)
@@ -749,8 +758,12 @@ extern "C" int orbfe_resize_linear(int device, const uint8_t* src, int sw, int s
   uint8_t *d_src = nullptr, *d_dst = nullptr;
   int32_t *d_xofs = nullptr, *d_yofs = nullptr;
   int16_t *d_alpha = nullptr, *d_beta = nullptr;
+  uint32_t *d_colrec = nullptr, *d_rowrec = nullptr;
   int rc = ORBFE_OK;
-  auto cleanup = [&]() { dfree(&d_src); dfree(&d_dst); dfree(&d_xofs); dfree(&d_yofs); dfree(&d_alpha); dfree(&d_beta); };
+  auto cleanup = [&]() {
+    dfree(&d_src); dfree(&d_dst); dfree(&d_xofs); dfree(&d_yofs); dfree(&d_alpha); dfree(&d_beta);
+    dfree(&d_colrec); dfree(&d_rowrec);
+  };
   if ((rc = dalloc(&d_src, (size_t)sp * sh)) || (rc = dalloc(&d_dst, (size_t)dp * dh)) ||
       (rc = dalloc(&d_xofs, t.xofs.size())) || (rc = dalloc(&d_yofs, t.yofs.size())) ||
       (rc = dalloc(&d_alpha, t.alpha.size())) || (rc = dalloc(&d_beta, t.beta.size()))) { cleanup(); return rc; }
@@ -759,8 +772,14 @@ extern "C" int orbfe_resize_linear(int device, const uint8_t* src, int sw, int s
   if (err == hipSuccess) err = hipMemcpy(d_yofs, t.yofs.data(), t.yofs.size() * 4, hipMemcpyHostToDevice);
   if (err == hipSuccess) err = hipMemcpy(d_alpha, t.alpha.data(), t.alpha.size() * 2, hipMemcpyHostToDevice);
   if (err == hipSuccess) err = hipMemcpy(d_beta, t.beta.data(), t.beta.size() * 2, hipMemcpyHostToDevice);
+  if (err == hipSuccess && !t.colrec.empty()) {
+    if ((rc = dalloc(&d_colrec, t.colrec.size())) || (rc = dalloc(&d_rowrec, t.rowrec.size()))) { cleanup(); return rc; }
+    err = hipMemcpy(d_colrec, t.colrec.data(), t.colrec.size() * 4, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(d_rowrec, t.rowrec.data(), t.rowrec.size() * 4, hipMemcpyHostToDevice);
+  }
   if (err == hipSuccess) {
-    launch_resize(nullptr, LevelView{d_src, 0, sp, sw, sh}, LevelViewMut{d_dst, 0, dp, dw, dh}, d_xofs, d_alpha, d_yofs, d_beta, 1);
+    launch_resize(nullptr, LevelView{d_src, 0, sp, sw, sh}, LevelViewMut{d_dst, 0, dp, dw, dh}, d_xofs, d_alpha, d_yofs, d_beta,
+                  d_colrec, d_rowrec, 1);
     err = hipGetLastError();
   }
   if (err == hipSuccess) err = hipDeviceSynchronize();

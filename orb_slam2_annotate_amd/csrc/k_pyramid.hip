@@ -103,6 +103,72 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelViewMut dst,
   }
 }
 
+// Flat form: one thread = 4 adjacent output columns x kFlatRows consecutive output rows, threads
+// numbered row-block-major over the level, so a wavefront is 64 consecutive column groups wherever
+// the rows break -- lanes stay busy on levels whose width is not a multiple of 256 pixels (257,
+// 309, 370 ... lost up to half of the lanes of the strip form above).  All per-column / per-row
+// coefficients come packed from host-built tables (ResizeTables::colrec / rowrec); every source
+// row pair is interpolated per output row (no cross-row reuse, hence no per-lane control flow) and
+// all 2*kFlatRows row windows are requested before the first is used, so one memory round trip
+// serves 16 output pixels; (b*h)>>16 is one v_mul_hi_u32 against b<<16.
+constexpr int kFlatRows = 4;
+__global__ __launch_bounds__(256) void k_resize_flat(LevelView src, LevelViewMut dst,
+                                                     const uint4* __restrict__ colrec,
+                                                     const uint4* __restrict__ rowrec, int ngx,
+                                                     uint32_t magic, int total) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int f = blockIdx.y;
+  if (gid >= total) return;
+  const int rb = (int)__umulhi((uint32_t)gid, magic);  // gid / ngx, exact for gid * ngx < 2^32
+  const int gx = gid - rb * ngx;
+  const int dy0 = rb * kFlatRows;
+  const uint4 s4 = colrec[3 * gx], a4 = colrec[3 * gx + 1];
+  const int sxb = (int)colrec[3 * gx + 2].x;
+  uint4 rr[kFlatRows];
+#pragma unroll
+  for (int r = 0; r < kFlatRows; r++) rr[r] = rowrec[dy0 + r < dst.h ? dy0 + r : dst.h - 1];
+  const uint32_t sel[4] = {s4.x, s4.y, s4.z, s4.w}, al[4] = {a4.x, a4.y, a4.z, a4.w};
+  const uint8_t* S = src.base + (size_t)f * src.frameStride + sxb;
+  const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(S) & 3);
+  S -= mis;
+  uint32_t w[2 * kFlatRows][3];  // raw 12-byte windows of the 2*kFlatRows source rows
+#pragma unroll
+  for (int r = 0; r < kFlatRows; r++) {
+    const uint32_t* pa = reinterpret_cast<const uint32_t*>(S + (size_t)rr[r].x * src.pitch);
+    const uint32_t* pb = reinterpret_cast<const uint32_t*>(S + (size_t)rr[r].y * src.pitch);
+    w[2 * r][0] = pa[0]; w[2 * r][1] = pa[1]; w[2 * r][2] = mis ? pa[2] : 0u;
+    w[2 * r + 1][0] = pb[0]; w[2 * r + 1][1] = pb[1]; w[2 * r + 1][2] = mis ? pb[2] : 0u;
+  }
+  uint8_t* D = dst.base + (size_t)f * dst.frameStride + 4 * gx;
+#pragma unroll
+  for (int r = 0; r < kFlatRows; r++) {
+    uint32_t hA[4], hB[4];
+    {
+      const uint32_t lo = __builtin_amdgcn_alignbyte(w[2 * r][1], w[2 * r][0], mis);
+      const uint32_t hi = __builtin_amdgcn_alignbyte(w[2 * r][2], w[2 * r][1], mis);
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        hA[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(hi, lo, sel[k])),
+                                       __builtin_bit_cast(u16x2, al[k]), 0u, false) >> 4;
+    }
+    {
+      const uint32_t lo = __builtin_amdgcn_alignbyte(w[2 * r + 1][1], w[2 * r + 1][0], mis);
+      const uint32_t hi = __builtin_amdgcn_alignbyte(w[2 * r + 1][2], w[2 * r + 1][1], mis);
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        hB[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(hi, lo, sel[k])),
+                                       __builtin_bit_cast(u16x2, al[k]), 0u, false) >> 4;
+    }
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t v = (__umulhi(hA[k], rr[r].z) + __umulhi(hB[k], rr[r].w) + 2u) >> 2;
+      packed |= v << (8 * k);
+    }
+    if (dy0 + r < dst.h) *reinterpret_cast<uint32_t*>(D + (size_t)(dy0 + r) * dst.pitch) = packed;
+  }
+}
+
 // Generic path (any pitch/alignment/scale): 4 output pixels per thread, byte loads.
 __global__ __launch_bounds__(256) void k_resize_generic(LevelView src, LevelViewMut dst,
                                                         const int32_t* __restrict__ xofs,
@@ -141,9 +207,16 @@ __global__ __launch_bounds__(256) void k_resize_generic(LevelView src, LevelView
 
 void launch_resize(hipStream_t s, LevelView src, LevelViewMut dst, const int32_t* d_xofs,
                    const int16_t* d_alpha, const int32_t* d_yofs, const int16_t* d_beta,
-                   int nFrames) {
+                   const uint32_t* d_colrec, const uint32_t* d_rowrec, int nFrames) {
   const bool fast = (src.pitch & 3) == 0 && src.w >= 8 && (long long)src.w <= 2LL * dst.w;
-  if (fast) {
+  const int ngx = (dst.w + 3) / 4;
+  const long long total = (long long)ngx * ((dst.h + kFlatRows - 1) / kFlatRows);
+  if (fast && d_colrec && d_rowrec && total * ngx < (1LL << 32) && total > 0) {
+    const uint32_t magic = (uint32_t)((1ULL << 32) / (uint32_t)ngx) + 1u;
+    hipLaunchKernelGGL(k_resize_flat, dim3((unsigned)((total + 255) / 256), nFrames), dim3(256), 0, s, src, dst,
+                       reinterpret_cast<const uint4*>(d_colrec), reinterpret_cast<const uint4*>(d_rowrec), ngx, magic,
+                       (int)total);
+  } else if (fast) {
     dim3 grid((dst.w + 255) / 256, (dst.h + 4 * kRowsPerThread - 1) / (4 * kRowsPerThread), nFrames);
     hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, src, dst, d_xofs, d_alpha, d_yofs, d_beta);
   } else {

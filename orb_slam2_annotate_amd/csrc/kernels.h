@@ -43,7 +43,7 @@ struct LevelKp {
 // ---- pyramid (ComputePyramid, :1203-1234) ----
 void launch_resize(hipStream_t s, LevelView src, LevelViewMut dst, const int32_t* d_xofs,
                    const int16_t* d_alpha, const int32_t* d_yofs, const int16_t* d_beta,
-                   int nFrames);
+                   const uint32_t* d_colrec, const uint32_t* d_rowrec, int nFrames);
 void launch_copy2d(hipStream_t s, LevelView src, LevelViewMut dst, int nFrames);
 
 // ---- FAST grid stage (:846-896) ----

@@ -80,6 +80,42 @@ void build_resize_tables(int sw, int sh, int dw, int dh, ResizeTables* t) {
     t->beta[2 * dy] = sat_short((1.f - fy) * 2048);
     t->beta[2 * dy + 1] = sat_short(fy * 2048);
   }
+  t->colrec.clear();
+  t->rowrec.clear();
+  if (sw >= 8 && (long long)sw <= 2LL * dw) {  // the 4 columns' taps span <= 8 source bytes
+    const int ngx = (dw + 3) / 4;
+    t->colrec.resize(12 * (size_t)ngx);
+    for (int g = 0; g < ngx; g++) {
+      int sx[4];
+      uint32_t* rec = &t->colrec[12 * (size_t)g];
+      for (int k = 0; k < 4; k++) {
+        const int dx = 4 * g + k < dw ? 4 * g + k : dw - 1;
+        sx[k] = t->xofs[dx];
+        rec[4 + k] = (uint32_t)(uint16_t)t->alpha[2 * dx] | ((uint32_t)(uint16_t)t->alpha[2 * dx + 1] << 16);
+      }
+      int sxb = sx[0];
+      if (sxb > sw - 8) sxb = sw - 8;  // keep the 8-byte window inside the row
+      if (sxb < 0) sxb = 0;
+      for (int k = 0; k < 4; k++) {
+        const uint32_t o = (uint32_t)(sx[k] - sxb);
+        const uint32_t o1 = o + 1 < 8 ? o + 1 : o;  // tap sx+1 beyond the window only when its weight is 0
+        rec[k] = o | 0x0c00u | (o1 << 16) | 0x0c000000u;
+      }
+      rec[8] = (uint32_t)sxb;
+      rec[9] = rec[10] = rec[11] = 0;
+    }
+    t->rowrec.resize(4 * (size_t)dh);
+    for (int dy = 0; dy < dh; dy++) {
+      const int sy = t->yofs[dy];
+      const int r0 = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);
+      const int r1 = sy + 1 < 0 ? 0 : (sy + 1 >= sh ? sh - 1 : sy + 1);
+      uint32_t* rec = &t->rowrec[4 * (size_t)dy];
+      rec[0] = (uint32_t)r0;
+      rec[1] = (uint32_t)r1;
+      rec[2] = (uint32_t)(uint16_t)t->beta[2 * dy] << 16;
+      rec[3] = (uint32_t)(uint16_t)t->beta[2 * dy + 1] << 16;
+    }
+  }
 }
 
 void FrameGeom::build(const ExtractorTables& t, int W_, int H_) {

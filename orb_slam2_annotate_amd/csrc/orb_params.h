@@ -46,6 +46,10 @@ struct LevelGeom {
 struct ResizeTables {  // cv::resize INTER_LINEAR fixed-point coefficients (level l-1 -> l)
   std::vector<int32_t> xofs, yofs;
   std::vector<int16_t> alpha, beta;  // 2 per output column / row
+  // the same coefficients packed for k_resize_flat (empty when its preconditions do not hold):
+  // colrec: 12 dwords per group of 4 output columns = v_perm selectors x4 | (a0,a1) u16 pairs x4 | window start, 0,0,0
+  // rowrec: 4 dwords per output row = clamped source rows r0, r1 | b0 << 16 | b1 << 16
+  std::vector<uint32_t> colrec, rowrec;
 };
 
 struct FrameGeom {
