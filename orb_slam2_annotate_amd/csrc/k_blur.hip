@@ -4,8 +4,10 @@
 // one rounding (x + 2^15) >> 16.  Both passes are exact integer sums, so their order is free:
 //   1. a 64x64 output tile stages (64+6) x (64+8) source bytes in LDS as aligned dwords
 //      (reflect-101 resolved while loading);
-//   2. VERTICAL pass, packed 16-bit: a thread takes 4 adjacent columns of one row, two pixels
-//      per VALU lane-op (v_pk_add_u16 / v_pk_mad_u16), result kept in LDS as natural-order u16;
+//   2. VERTICAL pass, packed 16-bit: a thread takes 4 adjacent columns of 4 rows (the byte -> u16
+//      split of the 10 source dwords is shared), two pixels per VALU lane-op (v_pk_add_u16 /
+//      v_pk_mad_u16), result kept in LDS as natural-order u16; row blocks below the level's last
+//      row are skipped;
 //   3. HORIZONTAL pass on u16 pairs with v_dot2_u32_u16 (two taps per instruction, 32-bit
 //      accumulate), rounding, one 32-bit coalesced store per 4 pixels.
 // HBM-bound by design: every source byte is read once per tile (+ halo), every output once.
@@ -63,68 +65,81 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   const unsigned rem = w0 - (unsigned)f * perFrame;
   const int tyI = (int)(rem / (unsigned)tilesX);
   const int bx = (int)(rem - (unsigned)tyI * (unsigned)tilesX) * kBW, by = tyI * kBH;
+  const int rowsValid = dst.h - by < kBH ? dst.h - by : kBH;  // output rows of this tile inside the level
+  const int rowBlocks = (rowsValid + 3) >> 2;                 // 4-row blocks the vertical pass computes
+  const int stageRows = 4 * rowBlocks + 6;                    // <= kTH
   const uint8_t* S = src.base + (size_t)f * src.frameStride;
   const bool aligned = (src.pitch & 3) == 0 && (reinterpret_cast<uintptr_t>(S) & 3) == 0;
-  // ---- 1. stage ----
-  if (aligned && bx >= 4 && bx + kBW + 4 <= src.w && by >= 3 && by + kBH + 3 <= src.h) {
-    // interior tile (block-uniform): no reflection, every dword is an aligned in-row load
-    const uint8_t* T = S + (size_t)(by - 3) * src.pitch + (bx - 4);
-    for (int i = tid; i < kTH * kTDW; i += 256) {
-      const int ty = i / kTDW, tj = i - ty * kTDW;
-      tin[i] = *reinterpret_cast<const uint32_t*>(T + (size_t)ty * src.pitch + 4 * tj);
-    }
-  } else {
-    for (int i = tid; i < kTH * kTDW; i += 256) {
-      const int ty = i / kTDW, tj = i - ty * kTDW;
-      const int sy = reflect101c(by - 3 + ty, src.h);
+  // ---- 1. stage: thread (ty0, tj) = (tid / 18, tid % 18) walks down the tile 14 rows at a time ----
+  if (tid < 14 * kTDW) {
+    const int ty0 = (int)(((uint32_t)tid * 3641u) >> 16), tj = tid - ty0 * kTDW;  // tid / 18 for tid < 252
+    if (aligned && bx >= 4 && bx + kBW + 4 <= src.w && by >= 3 && by + kBH + 3 <= src.h) {
+      // interior tile (block-uniform): no reflection, every dword is an aligned in-row load
+      const uint8_t* T = S + (size_t)(by - 3 + ty0) * src.pitch + (bx - 4) + 4 * tj;
+#pragma unroll
+      for (int k = 0; k < 5; k++)
+        tin[(ty0 + 14 * k) * kTDW + tj] = *reinterpret_cast<const uint32_t*>(T + (size_t)(14 * k) * src.pitch);
+    } else {
       const int c = bx - 4 + 4 * tj;
-      const uint8_t* row = S + (size_t)sy * src.pitch;
-      uint32_t v;
-      if ((src.pitch & 3) == 0 && c >= 0 && c + 3 < src.w) {
-        const uintptr_t ad = reinterpret_cast<uintptr_t>(row + c);
-        const uint32_t a = (uint32_t)(ad & 3);
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(ad - a);
-        const uint32_t lo = p[0];
-        const uint32_t hi = a ? p[1] : 0u;  // stays inside the row: c+3 < w <= pitch
-        v = __builtin_amdgcn_alignbyte(hi, lo, a);
-      } else {
-        v = (uint32_t)row[reflect101c(c, src.w)] | ((uint32_t)row[reflect101c(c + 1, src.w)] << 8) |
-            ((uint32_t)row[reflect101c(c + 2, src.w)] << 16) | ((uint32_t)row[reflect101c(c + 3, src.w)] << 24);
+      const bool inRow = (src.pitch & 3) == 0 && c >= 0 && c + 3 < src.w;
+      int cx[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) cx[k] = reflect101c(c + k, src.w);
+      for (int ty = ty0; ty < stageRows; ty += 14) {
+        const int sy = reflect101c(by - 3 + ty, src.h);
+        const uint8_t* row = S + (size_t)sy * src.pitch;
+        uint32_t v;
+        if (inRow) {
+          const uintptr_t ad = reinterpret_cast<uintptr_t>(row + c);
+          const uint32_t a = (uint32_t)(ad & 3);
+          const uint32_t* p = reinterpret_cast<const uint32_t*>(ad - a);
+          const uint32_t lo = p[0];
+          const uint32_t hi = a ? p[1] : 0u;  // stays inside the row: c+3 < w <= pitch
+          v = __builtin_amdgcn_alignbyte(hi, lo, a);
+        } else {
+          v = (uint32_t)row[cx[0]] | ((uint32_t)row[cx[1]] << 8) | ((uint32_t)row[cx[2]] << 16) | ((uint32_t)row[cx[3]] << 24);
+        }
+        tin[ty * kTDW + tj] = v;
       }
-      tin[i] = v;
     }
   }
   __syncthreads();
-  // ---- 2. vertical pass: 8.8 sums of 4 adjacent columns, packed two pixels per lane-op ----
-  for (int i = tid; i < kBH * kTDW; i += 256) {
-    uint32_t r[7];
+  // ---- 2. vertical pass: a thread owns 4 adjacent columns x 4 output rows; the 10 source dwords are
+  //         split into u16 pairs once and shared by the 4 rows; 8.8 sums, two pixels per lane-op ----
+  for (int i = tid; i < rowBlocks * kTDW; i += 256) {
+    const int rb = (int)(((uint32_t)i * 3641u) >> 16), tj = i - rb * kTDW;  // i / 18 for i < 288
+    const uint32_t* tp = &tin[(4 * rb) * kTDW + tj];
+    u16x2 te[10], to[10];  // even bytes (0,2) and odd bytes (1,3) of each source dword
 #pragma unroll
-    for (int j = 0; j < 7; j++) r[j] = tin[i + j * kTDW];
-    u16x2 acc[2];
-#pragma unroll
-    for (int s = 0; s < 2; s++) {  // s=0: bytes 0,2; s=1: bytes 1,3
-      u16x2 t[7];
-#pragma unroll
-      for (int j = 0; j < 7; j++)
-        t[j] = as_u2(s == 0 ? (r[j] & 0x00ff00ffu) : __builtin_amdgcn_perm(r[j], r[j], 0x0c030c01u));
-      const u16x2 k18 = {18, 18}, k34 = {34, 34}, k48 = {48, 48}, k56 = {56, 56};
-      u16x2 a = (t[0] + t[6]) * k18;
-      a = (t[1] + t[5]) * k34 + a;
-      a = (t[2] + t[4]) * k48 + a;
-      acc[s] = t[3] * k56 + a;
+    for (int j = 0; j < 10; j++) {
+      const uint32_t r = tp[j * kTDW];
+      te[j] = as_u2(r & 0x00ff00ffu);
+      to[j] = as_u2(__builtin_amdgcn_perm(r, r, 0x0c030c01u));
     }
-    const uint32_t A = as_u(acc[0]), B = as_u(acc[1]);  // A = (v0,v2), B = (v1,v3)
-    uint2 o;
-    o.x = __builtin_amdgcn_perm(B, A, 0x05040100u);     // (v0, v1)
-    o.y = __builtin_amdgcn_perm(B, A, 0x07060302u);     // (v2, v3)
-    vbuf[i] = o;
+    const u16x2 k18 = {18, 18}, k34 = {34, 34}, k48 = {48, 48}, k56 = {56, 56};
+    uint2* vo = &vbuf[(4 * rb) * kTDW + tj];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      u16x2 a = (te[r] + te[r + 6]) * k18;
+      a = (te[r + 1] + te[r + 5]) * k34 + a;
+      a = (te[r + 2] + te[r + 4]) * k48 + a;
+      const uint32_t A = as_u(te[r + 3] * k56 + a);   // (v0, v2)
+      u16x2 b = (to[r] + to[r + 6]) * k18;
+      b = (to[r + 1] + to[r + 5]) * k34 + b;
+      b = (to[r + 2] + to[r + 4]) * k48 + b;
+      const uint32_t B = as_u(to[r + 3] * k56 + b);   // (v1, v3)
+      uint2 o;
+      o.x = __builtin_amdgcn_perm(B, A, 0x05040100u);  // (v0, v1)
+      o.y = __builtin_amdgcn_perm(B, A, 0x07060302u);  // (v2, v3)
+      vo[r * kTDW] = o;
+    }
   }
   __syncthreads();
   // ---- 3. horizontal pass on u16 pairs: out[x] = (sum_i K[i] * v[x+4+i-3] + 2^15) >> 16 ----
-  for (int i = tid; i < kBH * (kBW / 4); i += 256) {
+  uint8_t* D = dst.base + (size_t)f * dst.frameStride + (size_t)by * dst.pitch + bx;
+  for (int i = tid; i < rowsValid * (kBW / 4); i += 256) {
     const int row = i >> 4, gx = i & 15;
-    const int y = by + row, x = bx + 4 * gx;
-    if (y >= dst.h || x >= dst.w) continue;
+    if (bx + 4 * gx >= dst.w) continue;
     const uint2* vp = &vbuf[row * kTDW + gx];
     const uint2 e0 = vp[0], e1 = vp[1], e2 = vp[2];
     // d_k = (v'[2k], v'[2k+1]) with v' indexed from tile column 4*gx
@@ -146,8 +161,10 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
     o3 = dot2(d3, pk(48, 56), o3);
     o3 = dot2(d4, pk(48, 34), o3);
     o3 = dot2(d5, pk(18, 0), o3);
-    const uint32_t packed = (o0 >> 16) | ((o1 >> 16) << 8) | ((o2 >> 16) << 16) | ((o3 >> 16) << 24);
-    *reinterpret_cast<uint32_t*>(dst.base + (size_t)f * dst.frameStride + (size_t)y * dst.pitch + x) = packed;
+    // the rounded sums are < 2^24: byte 2 of each is the result; two v_perm gather them
+    const uint32_t lo = __builtin_amdgcn_perm(o1, o0, 0x0c0c0602u);   // (o0.b2, o1.b2, 0, 0)
+    const uint32_t hi = __builtin_amdgcn_perm(o3, o2, 0x06020c0cu);   // (0, 0, o2.b2, o3.b2)
+    *reinterpret_cast<uint32_t*>(D + (size_t)row * dst.pitch + 4 * gx) = lo | hi;
   }
 }
 
