@@ -23,6 +23,8 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ s16x2 as_s2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
 __device__ __forceinline__ uint32_t as_u(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
 
 // Bresenham circle of radius 3 in cv::FAST's order.
 constexpr int kRingDx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
@@ -105,7 +107,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
         tile[ty * kPitchDw + tx] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
       }
     }
-    for (int i = lane; i < (ch + 2) * kPitchDw; i += 64) score[i] = 0;
+    uint4* sz = reinterpret_cast<uint4*>(score);  // row pitch 96 B: (ch+2)*6 aligned 16-byte stores
+    for (int i = lane; i < (ch + 2) * (kPitchDw / 4); i += 64) sz[i] = make_uint4(0u, 0u, 0u, 0u);
   }
   __syncthreads();
 
@@ -130,12 +133,12 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
           const s16x2 rE = as_s2(__builtin_amdgcn_perm(m2, m1, sel2(3 + st)));  // ring 4  (+3,0)
           const s16x2 rN = as_s2(__builtin_amdgcn_perm(up, up, sel2(st)));      // ring 8  (0,-3)
           const s16x2 rW = as_s2(__builtin_amdgcn_perm(m1, m0, sel2(1 + st)));  // ring 12 (-3,0)
-          // sign bit set <=> ring pixel darker than v-t:  t - (v - x) = (t - v) + x < 0
-          //                  ring pixel brighter than v+t: (v - x) + t = (v + t) - x < 0
+          // sign bit set <=> ring value x darker than v-t:  (t - v) + x < 0;  brighter than v+t: (v + t) - x < 0
+          // both axes hold a dark point <=> max(min(S,N), min(E,W)) < v-t; bright: min(max, max) > v+t
           const s16x2 lo = T - c, hi = c + T;
-          const uint32_t dk = (as_u(lo + rS) | as_u(lo + rN)) & (as_u(lo + rE) | as_u(lo + rW));
-          const uint32_t br = (as_u(hi - rS) | as_u(hi - rN)) & (as_u(hi - rE) | as_u(hi - rW));
-          const uint32_t p = dk | br;
+          const s16x2 mD = pk_max(pk_min(rS, rN), pk_min(rE, rW));
+          const s16x2 mB = pk_min(pk_max(rS, rN), pk_max(rE, rW));
+          const uint32_t p = as_u(lo + mD) | as_u(hi - mB);
           pass |= (((p >> 15) & 1u) | ((p >> 29) & 4u)) << st;
         }
         const int valid = cw - 4 * gx;
