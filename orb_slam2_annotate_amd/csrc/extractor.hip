@@ -282,7 +282,7 @@ int run_host_octree(orbfe_extractor* e, int nFrames) {
                                 sizeof(Candidate) * e->h_candCount[i], hipMemcpyDeviceToHost, s));
       }
     HIPCHK(hipStreamSynchronize(s));
-    e->h_levelKp.assign((size_t)nFrames * g.totalKpCap, LevelKp{0, 0, 0});
+    e->h_levelKp.assign((size_t)nFrames * g.totalKpCap, LevelKp{0, 0, 0, 0});
     e->h_levelCount.assign((size_t)nFrames * nl, 0);
     std::atomic<int> next{0};
     const int nTasks = nFrames * nl;

@@ -9,8 +9,9 @@
 //      m01 = dy*sum(I); integer, order-free, DPP reduction across the 62 lanes;
 //   2. one THREAD per keypoint: cv::fastAtan2 and the double-precision sincos_spec, so the
 //      transcendental part is not replicated across 64 lanes;
-//   3. descriptors, one wavefront per keypoint: lane l evaluates tests l, l+64, l+128, l+192
-//      (rotation in packed fp32 mul/add, no FMA); a wave ballot IS 8 descriptor bytes.
+//   3. descriptors, one wavefront per keypoint: the 37x48-byte blurred patch is staged in LDS with
+//      16-byte requests, lane l evaluates tests l, l+64, l+128, l+192 on it (rotation in packed
+//      fp32 mul/add, no FMA); a wave ballot IS 8 descriptor bytes.
 #include "kernels.h"
 
 namespace orbfe {
@@ -18,6 +19,10 @@ namespace orbfe {
 namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kKpPerBlock = 64;
+struct __attribute__((aligned(4))) U4 { uint32_t x, y, z, w; };  // 16-byte load at 4-byte alignment
+// blurred patch of one keypoint staged in LDS: rows y-18..y+18, 48 bytes from the 4-byte aligned
+// column ws <= x-18 (the steered pattern stays inside radius sqrt(13^2+13^2) < 18.5)
+constexpr int kPatchRows = 37, kPatchDw = 12;
 
 __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
@@ -34,15 +39,24 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
                                                      const int32_t* __restrict__ umax,
                                                      float* __restrict__ kpOut,
                                                      uint8_t* __restrict__ descOut,
-                                                     int32_t* __restrict__ nOut) {
+                                                     int32_t* __restrict__ nOut, int blocksPerFrame,
+                                                     int nFrames) {
   __shared__ int s_m10[kKpPerBlock], s_m01[kKpPerBlock];
   __shared__ int s_x[kKpPerBlock], s_y[kKpPerBlock], s_level[kKpPerBlock], s_out[kKpPerBlock];
   __shared__ unsigned s_score[kKpPerBlock];
   __shared__ float s_angle[kKpPerBlock], s_cos[kKpPerBlock], s_sin[kKpPerBlock];
+  __shared__ __attribute__((aligned(16))) uint32_t s_patch[4 * 2 * kPatchRows * kPatchDw];  // per wave: 2 patches
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int f = blockIdx.y;
-  const int slot0 = blockIdx.x * kKpPerBlock;
+  // XCD-aware work mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, so block
+  // b takes work item (b % 8) * chunk + b / 8 with work = frame * blocksPerFrame + slot chunk: all
+  // workgroups of a frame run on ONE XCD, back to back, and that L2 fetches every line of the
+  // frame's pyramid once however many keypoint patches overlap it.
+  const unsigned chunkW = gridDim.x >> 3;
+  const unsigned work = (blockIdx.x & 7u) * chunkW + (blockIdx.x >> 3);
+  if (work >= (unsigned)blocksPerFrame * (unsigned)nFrames) return;
+  const int f = (int)(work / (unsigned)blocksPerFrame);
+  const int slot0 = (int)(work - (unsigned)f * (unsigned)blocksPerFrame) * kKpPerBlock;
   const int32_t* cnt = levelCount + (size_t)f * a.nlevels;
 
   // ---- slot -> (level, index, output row); thread t < 64 resolves slot0 + t ----
@@ -56,9 +70,9 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
       }
       for (int k = 0; k < l; k++) base += cnt[k];
       const int i = slot - a.kpStart[l];
-      if (i < cnt[l] && base + i < a.outCapacity) {
-        out = base + i;
+      if (i < cnt[l]) {
         const LevelKp kp = levelKp[(size_t)f * a.kpSlotsPerFrame + slot];
+        if (base + (int)kp.rank < a.outCapacity) out = base + (int)kp.rank;
         s_x[tid] = kp.x;
         s_y[tid] = kp.y;
         s_score[tid] = kp.score;
@@ -107,7 +121,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
 #if defined(DESC_ABLATE) && (DESC_ABLATE & 2)
             dw[u][0] = mis[u] + (uint32_t)(uintptr_t)al; dw[u][1] = dw[u][0] * 3; dw[u][2] = dw[u][0] * 5; dw[u][3] = dw[u][0] * 7;
 #else
-            dw[u][0] = al[0]; dw[u][1] = al[1]; dw[u][2] = al[2]; dw[u][3] = al[3];
+            const U4 q = *reinterpret_cast<const U4*>(al);  // one 16-byte request instead of four
+            dw[u][0] = q.x; dw[u][1] = q.y; dw[u][2] = q.z; dw[u][3] = q.w;
             dw[u][4] = mis[u] ? al[4] : 0u;
 #endif
           } else {
@@ -159,18 +174,54 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
     float4 P[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) P[j] = patternF[lane + 64 * j];  // (x0,y0,x1,y1) of test lane+64j
-    // two keypoints per iteration: their 16 sample loads are in flight together
+    // two keypoints per iteration.  Their blurred patches are staged in LDS with 16-byte requests
+    // (3 lanes per row: 111 lanes = 2 instructions per keypoint, each patch line touched once) and
+    // the 512 samples are LDS byte reads; sampling global memory directly cost one L1 line lookup
+    // per lane per sample (8 x 64 per keypoint) and was the slowest part of the kernel.
+    uint32_t* myPatch = &s_patch[wave * 2 * kPatchRows * kPatchDw];
     for (int j0 = wave * 16; j0 < wave * 16 + 16; j0 += 2) {
       int t0v[2][4], t1v[2][4];
+      U4 stage[2][2];
+      int colOff[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int j = j0 + u;
+        colOff[u] = 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) stage[u][h] = U4{0u, 0u, 0u, 0u};
+        if (s_out[j] < 0) continue;  // wave-uniform
+        const LevelView bl = a.blur.lv[s_level[j]];
+        int ws = (s_x[j] - 18) & ~3;
+        if (ws > bl.pitch - 4 * kPatchDw) ws = bl.pitch - 4 * kPatchDw;  // stay inside the row pitch
+        colOff[u] = s_x[j] - ws;
+        const uint8_t* pb = bl.base + (size_t)f * bl.frameStride + (size_t)(s_y[j] - 18) * bl.pitch + ws;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int idx = lane + 64 * h;
+          const int row = (idx * 43) >> 7, part = idx - 3 * row;  // idx / 3 for idx < 128
+          if (idx < 3 * kPatchRows) stage[u][h] = *reinterpret_cast<const U4*>(pb + (size_t)row * bl.pitch + 16 * part);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int idx = lane + 64 * h;
+          if (idx < 3 * kPatchRows)
+            *reinterpret_cast<uint4*>(&myPatch[u * kPatchRows * kPatchDw + 4 * idx]) =
+                make_uint4(stage[u][h].x, stage[u][h].y, stage[u][h].z, stage[u][h].w);
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const int j = j0 + u;
 #pragma unroll
         for (int t = 0; t < 4; t++) { t0v[u][t] = 0; t1v[u][t] = 0; }
         if (s_out[j] < 0) continue;  // wave-uniform
-        const LevelView bl = a.blur.lv[s_level[j]];
         const float ca = s_cos[j], sb = s_sin[j];
-        const uint8_t* cb = bl.base + (size_t)f * bl.frameStride + (size_t)s_y[j] * bl.pitch + s_x[j];
+        const uint8_t* cb = reinterpret_cast<const uint8_t*>(myPatch + u * kPatchRows * kPatchDw) + 18 * 4 * kPatchDw + colOff[u];
         const f32x2 ba = {sb, ca}, ab = {ca, sb};
 #pragma unroll
         for (int t = 0; t < 4; t++) {
@@ -178,14 +229,12 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
           const f32x2 r0 = p0 * ba, c0 = p0 * ab, r1 = p1 * ba, c1 = p1 * ab;  // (x*b, y*a), (x*a, y*b)
           const int rr0 = cv_round(__fadd_rn(r0.x, r0.y)), cc0 = cv_round(__fsub_rn(c0.x, c0.y));
           const int rr1 = cv_round(__fadd_rn(r1.x, r1.y)), cc1 = cv_round(__fsub_rn(c1.x, c1.y));
-#if defined(DESC_ABLATE) && (DESC_ABLATE & 1)
-          t0v[u][t] = rr0 + cc0; t1v[u][t] = rr1 + cc1 + (int)cb[0];
-#else
-          t0v[u][t] = cb[rr0 * bl.pitch + cc0];
-          t1v[u][t] = cb[rr1 * bl.pitch + cc1];
-#endif
+          t0v[u][t] = cb[rr0 * (4 * kPatchDw) + cc0];
+          t1v[u][t] = cb[rr1 * (4 * kPatchDw) + cc1];
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const int j = j0 + u;
@@ -220,9 +269,10 @@ void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d
                         const int32_t* d_umax, int nFrames, void* d_kpOut, uint8_t* d_descOut,
                         int32_t* d_nOut) {
   if (nFrames <= 0 || a.kpSlotsPerFrame <= 0) return;
-  dim3 grid((a.kpSlotsPerFrame + kKpPerBlock - 1) / kKpPerBlock, nFrames);
-  hipLaunchKernelGGL(k_orient_desc, grid, dim3(256), 0, s, a, d_levelKp, d_levelCount, d_patternF,
-                     d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut);
+  const int blocksPerFrame = (a.kpSlotsPerFrame + kKpPerBlock - 1) / kKpPerBlock;
+  const unsigned total = (unsigned)blocksPerFrame * (unsigned)nFrames;
+  hipLaunchKernelGGL(k_orient_desc, dim3((total + 7u) / 8u * 8u), dim3(256), 0, s, a, d_levelKp, d_levelCount,
+                     d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames);
 }
 
 // Weight/mask bytes of a 16-pixel half row of the orientation disc, for every half-width d:

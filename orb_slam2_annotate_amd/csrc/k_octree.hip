@@ -266,16 +266,30 @@ __global__ __launch_bounds__(256) void k_octree(OctreeArgs a) {
     atomicMax(reinterpret_cast<unsigned int*>(&best[nodeOf[k]]),
               (cand[k].score << 24) | (0xffffffu - (unsigned)k));
   __syncthreads();
-  for (int p = tid; p < L && p < g.kpCap; p += 256) {
-    const unsigned b = (unsigned)best[p];
-    const Candidate c = cand[0xffffffu - (b & 0xffffffu)];
-    LevelKp o;
-    o.x = (uint16_t)((c.xy & 0xffffu) + kMinBorder);  // :909-910
-    o.y = (uint16_t)((c.xy >> 16) + kMinBorder);
-    o.score = c.score;
-    out[p] = o;
+  // The keypoints leave in SPATIAL order (128-byte column strip, then row): consecutive slots are
+  // what one k_orient_desc workgroup processes, and neighbours in memory share the cache lines of
+  // their patches.  `rank` keeps the reference's list position, which decides the output row.
+  const int nKp = L < g.kpCap ? L : g.kpCap;
+  uint32_t* skey = reinterpret_cast<uint32_t*>(scanB);
+  for (int p = tid; p < nKp; p += 256) {
+    const Candidate c = cand[0xffffffu - ((unsigned)best[p] & 0xffffffu)];
+    const uint32_t x = (c.xy & 0xffffu) + kMinBorder, y = (c.xy >> 16) + kMinBorder;  // :909-910
+    skey[p] = ((x >> 7) << 26) | ((y & 0x1fffu) << 13) | (x & 0x1fffu);
   }
-  if (tid == 0) *outCount = L < g.kpCap ? L : g.kpCap;
+  __syncthreads();
+  for (int p = tid; p < nKp; p += 256) {
+    const uint32_t key = skey[p];
+    int pos = 0;
+    for (int q = 0; q < nKp; q++) pos += skey[q] < key;  // keys are distinct (one keypoint per pixel)
+    const Candidate c = cand[0xffffffu - ((unsigned)best[p] & 0xffffffu)];
+    LevelKp o;
+    o.x = (uint16_t)((c.xy & 0xffffu) + kMinBorder);
+    o.y = (uint16_t)((c.xy >> 16) + kMinBorder);
+    o.score = (uint16_t)c.score;
+    o.rank = (uint16_t)p;
+    out[pos] = o;
+  }
+  if (tid == 0) *outCount = nKp;
 }
 
 size_t octree_lds_bytes(int maxL) {

@@ -37,7 +37,8 @@ struct Candidate {
 // Keypoint selected by the octree, level coordinates (already + minBorder, :909-916).
 struct LevelKp {
   uint16_t x, y;
-  uint32_t score;
+  uint16_t score;  // FAST response (0..255)
+  uint16_t rank;   // position in the reference's output order of the level (the slot order is spatial)
 };
 
 // ---- pyramid (ComputePyramid, :1203-1234) ----

@@ -150,7 +150,8 @@ int distribute_octree_host(const Candidate* cand, int n, int minX, int maxX, int
     if (nout < outCap) {
       out[nout].x = (uint16_t)((cand[best].xy & 0xffffu) + minX);
       out[nout].y = (uint16_t)((cand[best].xy >> 16) + minY);
-      out[nout].score = bestScore;
+      out[nout].score = (uint16_t)bestScore;
+      out[nout].rank = (uint16_t)nout;
     }
     nout++;
   }
