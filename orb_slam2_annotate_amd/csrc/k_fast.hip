@@ -23,6 +23,7 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ s16x2 as_s2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
 __device__ __forceinline__ uint32_t as_u(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+struct __attribute__((aligned(4))) U4 { uint32_t x, y, z, w; };  // 16-byte load at 4-byte alignment
 __device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
 
@@ -91,14 +92,31 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
     const int th = ch + 6;
     const uintptr_t addr0 = reinterpret_cast<uintptr_t>(img);
     if ((lv.pitch & 3) == 0) {
-      const int a = (int)(addr0 & 3);     // same misalignment for every row
+      // a lane moves 16 bytes: (row, part) -> 5 aligned source dwords -> 4 byte-shifted tile dwords
+      const uint32_t a = (uint32_t)(addr0 & 3);     // same misalignment for every row
       const uint8_t* al = img - a;
-      for (int i = lane; i < th * tdw; i += 64) {
-        const int ty = (int)(((uint32_t)i * invT) >> 16), tx = i - ty * tdw;
-        const uint32_t* row = reinterpret_cast<const uint32_t*>(al + (size_t)ty * lv.pitch);
-        const uint32_t lo = row[tx];
-        const uint32_t hi = a ? row[tx + 1] : 0u;
-        tile[ty * kPitchDw + tx] = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)a);
+      const int parts = (tdw + 3) >> 2;             // 16-byte pieces per tile row (<= 5)
+      const uint32_t invP = 65536u / (uint32_t)parts + 1u;
+      // bytes of the row still inside the pitch, counted from `al`: never read beyond the level's rows
+      const int rowBytes = lv.pitch - ((x0 - 4) - (int)a);
+      for (int i = lane; i < th * parts; i += 64) {
+        const int ty = (int)(((uint32_t)i * invP) >> 16), part = i - ty * parts;
+        const uint32_t* row = reinterpret_cast<const uint32_t*>(al + (uint32_t)ty * (uint32_t)lv.pitch) + 4 * part;
+        uint32_t d[5];
+        if (16 * part + 20 <= rowBytes) {
+          const U4 q = *reinterpret_cast<const U4*>(row);
+          d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+          d[4] = a ? row[4] : 0u;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 5; k++) d[k] = (16 * part + 4 * k + 4 <= rowBytes) ? row[k] : 0u;
+        }
+        uint4 o;
+        o.x = __builtin_amdgcn_alignbyte(d[1], d[0], a);
+        o.y = __builtin_amdgcn_alignbyte(d[2], d[1], a);
+        o.z = __builtin_amdgcn_alignbyte(d[3], d[2], a);
+        o.w = __builtin_amdgcn_alignbyte(d[4], d[3], a);
+        *reinterpret_cast<uint4*>(&tile[ty * kPitchDw + 4 * part]) = o;  // pitch 24 dw >= 4*parts
       }
     } else {  // caller-owned level 0 with an odd stride: byte loads
       for (int i = lane; i < th * tdw; i += 64) {
