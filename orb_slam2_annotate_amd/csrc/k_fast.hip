@@ -23,6 +23,16 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ s16x2 as_s2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
 __device__ __forceinline__ uint32_t as_u(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+// wave64 inclusive scan in the DPP network (checked on gfx950 by tools/ubench/dpp_scan.hip)
+__device__ __forceinline__ int wave_incl_scan(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1, 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2, 3
+  return x;
+}
 struct __attribute__((aligned(4))) U4 { uint32_t x, y, z, w; };  // 16-byte load at 4-byte alignment
 __device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
@@ -79,10 +89,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
   const int cw = cd.w, ch = cd.h, x0 = cd.x0, y0 = cd.y0;
   const int tlo = iniTh < minTh ? iniTh : minTh;
   const int ngx = (cw + 3) >> 2;          // 4-pixel groups per row
-  const int ngroups = ngx * ch;
   const int tdw = ngx + 2;                // tile dwords per row
-  // exact i / ngx and i / tdw for i < 4096 by multiply-shift (divisors <= 17)
-  const uint32_t invG = 65536u / (uint32_t)ngx + 1u, invT = 65536u / (uint32_t)tdw + 1u;
+  // exact i / d for i < 4096 by multiply-shift (divisors <= 17)
+  const uint32_t invT = 65536u / (uint32_t)tdw + 1u;
   const unsigned long long ltMask = (1ull << lane) - 1ull;
   constexpr int P = kPitchDw * 4;         // LDS row pitch in bytes
 
@@ -130,45 +139,58 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
   }
   __syncthreads();
 
-  // ---- A: cardinal-pair test at the lower threshold; ordered work list ----
+  // ---- A: cardinal-pair test at the lower threshold; ordered work list.  A lane owns 8 adjacent
+  //      pixels (two tile dwords); list positions come from a DPP inclusive scan of the lane counts ----
   int nq = 0;  // wave-uniform
   {
     const s16x2 T = {(short)tlo, (short)tlo};
-    for (int g0 = 0; g0 < ngroups; g0 += 64) {
+    const int ng8 = (cw + 7) >> 3;          // 8-pixel groups per row
+    const int ngroups8 = ng8 * ch;
+    const uint32_t invG8 = 65536u / (uint32_t)ng8 + 1u;
+    for (int g0 = 0; g0 < ngroups8; g0 += 64) {
       const int g = g0 + lane;
       uint32_t pass = 0;
       int gy = 0, gx = 0;
-      if (g < ngroups) {
-        gy = (int)(((uint32_t)g * invG) >> 16);
-        gx = g - gy * ngx;
-        const uint32_t* mid = &tile[(gy + 3) * kPitchDw + gx];
-        const uint32_t up = tile[gy * kPitchDw + gx + 1], dn = tile[(gy + 6) * kPitchDw + gx + 1];
-        const uint32_t m0 = mid[0], m1 = mid[1], m2 = mid[2];
+      if (g < ngroups8) {
+        gy = (int)(((uint32_t)g * invG8) >> 16);
+        gx = g - gy * ng8;
+        const uint32_t* mid = &tile[(gy + 3) * kPitchDw + 2 * gx];
+        const uint32_t* upp = &tile[gy * kPitchDw + 2 * gx + 1];
+        const uint32_t* dnp = &tile[(gy + 6) * kPitchDw + 2 * gx + 1];
+        const uint32_t m[4] = {mid[0], mid[1], mid[2], mid[3]};
+        const uint32_t ups[2] = {upp[0], upp[1]}, dns[2] = {dnp[0], dnp[1]};
 #pragma unroll
-        for (int st = 0; st < 2; st++) {  // stream 0: pixels (0,2); stream 1: pixels (1,3)
-          const s16x2 c = as_s2(__builtin_amdgcn_perm(m1, m0, sel2(4 + st)));
-          const s16x2 rS = as_s2(__builtin_amdgcn_perm(dn, dn, sel2(st)));      // ring 0  (0,+3)
-          const s16x2 rE = as_s2(__builtin_amdgcn_perm(m2, m1, sel2(3 + st)));  // ring 4  (+3,0)
-          const s16x2 rN = as_s2(__builtin_amdgcn_perm(up, up, sel2(st)));      // ring 8  (0,-3)
-          const s16x2 rW = as_s2(__builtin_amdgcn_perm(m1, m0, sel2(1 + st)));  // ring 12 (-3,0)
-          // sign bit set <=> ring value x darker than v-t:  (t - v) + x < 0;  brighter than v+t: (v + t) - x < 0
-          // both axes hold a dark point <=> max(min(S,N), min(E,W)) < v-t; bright: min(max, max) > v+t
-          const s16x2 lo = T - c, hi = c + T;
-          const s16x2 mD = pk_max(pk_min(rS, rN), pk_min(rE, rW));
-          const s16x2 mB = pk_min(pk_max(rS, rN), pk_max(rE, rW));
-          const uint32_t p = as_u(lo + mD) | as_u(hi - mB);
-          pass |= (((p >> 15) & 1u) | ((p >> 29) & 4u)) << st;
+        for (int hh = 0; hh < 2; hh++) {    // the two dwords of the 8-pixel group
+          const uint32_t m0 = m[hh], m1 = m[hh + 1], m2 = m[hh + 2], up = ups[hh], dn = dns[hh];
+#pragma unroll
+          for (int st = 0; st < 2; st++) {  // stream 0: pixels (0,2); stream 1: pixels (1,3)
+            const s16x2 c = as_s2(__builtin_amdgcn_perm(m1, m0, sel2(4 + st)));
+            const s16x2 rS = as_s2(__builtin_amdgcn_perm(dn, dn, sel2(st)));      // ring 0  (0,+3)
+            const s16x2 rE = as_s2(__builtin_amdgcn_perm(m2, m1, sel2(3 + st)));  // ring 4  (+3,0)
+            const s16x2 rN = as_s2(__builtin_amdgcn_perm(up, up, sel2(st)));      // ring 8  (0,-3)
+            const s16x2 rW = as_s2(__builtin_amdgcn_perm(m1, m0, sel2(1 + st)));  // ring 12 (-3,0)
+            // sign bit set <=> ring value x darker than v-t:  (t - v) + x < 0;  brighter than v+t: (v + t) - x < 0
+            // both axes hold a dark point <=> max(min(S,N), min(E,W)) < v-t; bright: min(max, max) > v+t
+            const s16x2 lo = T - c, hi = c + T;
+            const s16x2 mD = pk_max(pk_min(rS, rN), pk_min(rE, rW));
+            const s16x2 mB = pk_min(pk_max(rS, rN), pk_max(rE, rW));
+            const uint32_t p = as_u(lo + mD) | as_u(hi - mB);
+            pass |= (((p >> 15) & 1u) | ((p >> 29) & 4u)) << (st + 4 * hh);
+          }
         }
-        const int valid = cw - 4 * gx;
-        if (valid < 4) pass &= (1u << valid) - 1u;
+        const int valid = cw - 8 * gx;
+        if (valid < 8) pass &= (1u << valid) - 1u;
       }
-      const int c = __popc(pass);  // 0..4
-      const unsigned long long b0 = __ballot(c & 1), b1 = __ballot(c & 2), b2 = __ballot(c & 4);
-      int q = nq + __popcll(b0 & ltMask) + 2 * __popcll(b1 & ltMask) + 4 * __popcll(b2 & ltMask);
-      nq += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-        if (pass & (1u << j)) queue[q++] = (uint16_t)((gy << 8) | (4 * gx + j));
+      const int c = __popc(pass);  // 0..8
+      const int incl = wave_incl_scan(c);
+      int q = nq + incl - c;
+      nq += __builtin_amdgcn_readlane(incl, 63);
+      const uint32_t e0 = (uint32_t)((gy << 8) | (8 * gx));
+      while (pass) {               // raster order inside the lane: ascending bit = ascending x
+        const int j = __builtin_ctz(pass);
+        queue[q++] = (uint16_t)(e0 + j);
+        pass &= pass - 1u;
+      }
     }
   }
   __syncthreads();
