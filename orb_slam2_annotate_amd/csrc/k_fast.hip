@@ -58,7 +58,8 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b)
 //      ADJACENT cardinal ring points (0,4,8,12), so a corner needs (c0|c8)&(c4|c12) in one
 //      polarity.  ~19 % of pixels pass; they are appended to an LDS work list IN RASTER ORDER
 //      (ballot prefix).
-//   B. exact cv::FAST response S-1 for the listed pixels, one pixel per lane (dense lanes).
+//   B. exact cv::FAST response S-1 for the listed pixels, one pixel per lane (dense lanes); the
+//      list shrinks in place to the corners.
 //   C. cell-local 3x3 strict NMS of the corners (one lane per corner) + threshold classes.
 //   D. per-cell 20->7 fallback, then ordered compaction of the survivors = emission order.
 // Dynamic LDS: tile [tileRows][24 dw] | score [scoreRows][24 dw] | queue [queueLen] u16, sized by
@@ -195,37 +196,50 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
   }
   __syncthreads();
 
-  // ---- B: exact response of the listed pixels (cornerScore<16>: S-1, corner iff S > t) ----
+  // ---- B: exact response of the listed pixels (cornerScore<16>: S-1, corner iff S > t); the list is
+  //      compacted in place to the corners (order kept: a pass writes no further than it has read) ----
+  int nc = 0;  // wave-uniform
   {
     const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
     uint8_t* sbytes = reinterpret_cast<uint8_t*>(score);
-    for (int q = lane; q < nq; q += 64) {
-      const int e = queue[q], px = e & 255, py = e >> 8;
-      const uint8_t* c = tb + (py + 3) * P + 4 + px;
-      const int v = c[0];
-      int d[16];
+    for (int q0 = 0; q0 < nq; q0 += 64) {
+      const int q = q0 + lane;
+      bool isCorner = false;
+      int e = 0, S = 0;
+      if (q < nq) {
+        e = queue[q];
+        const int px = e & 255, py = e >> 8;
+        const uint8_t* c = tb + (py + 3) * P + 4 + px;
+        const int v = c[0];
+        int d[16];
 #pragma unroll
-      for (int k = 0; k < 16; k++) d[k] = v - (int)c[kRingDx[k] + kRingDy[k] * P];
-      int lo3[16], hi3[16];
+        for (int k = 0; k < 16; k++) d[k] = v - (int)c[kRingDx[k] + kRingDy[k] * P];
+        int lo3[16], hi3[16];
 #pragma unroll
-      for (int k = 0; k < 16; k++) {
-        lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-        hi3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+        for (int k = 0; k < 16; k++) {
+          lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+          hi3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+        }
+        int lo9[16], hi9[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          lo9[k] = min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
+          hi9[k] = max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
+        }
+        int sd = max3i(lo9[0], lo9[1], lo9[2]), sb = min3i(hi9[0], hi9[1], hi9[2]);
+#pragma unroll
+        for (int k = 3; k < 15; k += 2) { sd = max3i(sd, lo9[k], lo9[k + 1]); sb = min3i(sb, hi9[k], hi9[k + 1]); }
+        sd = max(sd, lo9[15]);
+        sb = min(sb, hi9[15]);
+        S = max(sd, -sb);
+        isCorner = S > tlo;
       }
-      int lo9[16], hi9[16];
-#pragma unroll
-      for (int k = 0; k < 16; k++) {
-        lo9[k] = min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
-        hi9[k] = max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
+      const unsigned long long bal = __ballot(isCorner);
+      if (isCorner) {
+        sbytes[((e >> 8) + 1) * P + 4 + (e & 255)] = (uint8_t)(S - 1);
+        queue[nc + __popcll(bal & ltMask)] = (uint16_t)e;
       }
-      int sd = max3i(lo9[0], lo9[1], lo9[2]), sb = min3i(hi9[0], hi9[1], hi9[2]);
-#pragma unroll
-      for (int k = 3; k < 15; k += 2) { sd = max3i(sd, lo9[k], lo9[k + 1]); sb = min3i(sb, hi9[k], hi9[k + 1]); }
-      sd = max(sd, lo9[15]);
-      sb = min(sb, hi9[15]);
-      const int S = max(sd, -sb);
-      if (S > tlo) sbytes[(py + 1) * P + 4 + px] = (uint8_t)(S - 1);
-      else queue[q] = 0xffffu;  // not a corner: drop from the list
+      nc += __popcll(bal);
     }
   }
   __syncthreads();
@@ -234,15 +248,14 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
   //      and 15 (>= iniThFAST) of the list entry ----
   const uint8_t* sbytes = reinterpret_cast<const uint8_t*>(score);
   int anyHigh = 0;
-  for (int q = lane; q < nq; q += 64) {
+  for (int q = lane; q < nc; q += 64) {
     const int e = queue[q];
-    if (e == 0xffff) continue;
     const uint8_t* c = sbytes + ((e >> 8) + 1) * P + 4 + (e & 255);
     const int v = c[0];
     const int nb = max3i(max3i(c[-P - 1], c[-P], c[-P + 1]), max3i(c[-1], c[1], c[P - 1]), max(c[P], c[P + 1]));
     int flags = 0;
     if (v > nb) flags = ((v >= minTh) << 14) | ((v >= iniTh) << 15);
-    queue[q] = (uint16_t)(flags ? (e | flags) : 0xffff);
+    queue[q] = (uint16_t)(e | flags);
     anyHigh |= flags >> 15;
   }
   // per-cell threshold fallback (:874-882): corners >= iniThFAST if any survived NMS, else >= minThFAST
@@ -253,10 +266,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
   Candidate* out = slots + (size_t)f * slotsPerFrame + cd.slotBase;
   const int bit = useHigh ? 0x8000 : 0x4000;
   int run = 0;  // wave-uniform
-  for (int q0 = 0; q0 < nq; q0 += 64) {
+  for (int q0 = 0; q0 < nc; q0 += 64) {
     const int q = q0 + lane;
-    const int e = q < nq ? queue[q] : 0xffff;
-    const bool sel = e != 0xffff && (e & bit);
+    const int e = q < nc ? queue[q] : 0;
+    const bool sel = (e & bit) != 0;
     const unsigned long long bal = __ballot(sel);
     const int o = run + __popcll(bal & ltMask);
     run += __popcll(bal);
