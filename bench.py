@@ -61,7 +61,7 @@ def algorithmic_bytes(sizes, n_kp):
 
 
 STAGE_KERNELS = {  # kernels (and launches per step) behind each timed stage
-    "pyramid": [("k_resize", 7)], "fast": [("k_fast_cells", 1)],
+    "pyramid": [("k_resize_flat", 7)], "fast": [("k_fast_cells", 1)],
     "octree": [("k_gather_candidates", 1), ("k_octree", 1)], "blur": [("k_blur7", 1)],
     "orient_desc": [("k_orient_desc", 1)],
 }
@@ -87,6 +87,30 @@ def pmc_traffic(stage, workload, batch, frames_per_launch):
             return None
         tot += best["kernels"][k]["traffic_bytes_per_launch"] * n
     return tot * frames_per_launch / best["batch"]
+
+
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4  # wave64 VALU instructions/s: 256 CUs x 4 SIMDs, 4 cycles per wave64 op
+
+
+def pmc_valu(stage, workload):
+    """VALU wave-instructions per frame of the stage's kernels from the committed SQ_INSTS_VALU summary
+    (profiles/*_valu.json, tools/collect_valu.py); None when no summary matches."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("*_valu.json")):
+        try:
+            t = json.loads(f.read_text())
+        except Exception:
+            continue
+        if t.get("workload") == workload:
+            best = t
+    if best is None:
+        return None, None
+    tot = 0.0
+    for k, _ in STAGE_KERNELS[stage]:
+        if k not in best["kernels"]:
+            return None, None
+        tot += best["kernels"][k]["valu_wave_instr_per_frame"]
+    return tot, best.get("total_valu_wave_instr_per_frame")
 
 
 def cpu_baseline(frames, wl, seconds=12.0):
@@ -117,7 +141,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="frames resident per GPU and processed per step")
+    ap.add_argument("--batch", type=int, default=1024, help="frames resident per GPU and processed per step")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="tum")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="verify frame 0 of the batch against the oracle")
@@ -310,6 +334,15 @@ def main():
                 "stage_ms_per_step_exclusive": {s_: warm[s_][0] / n_warm for s_ in gpu_stages},
             },
         }
+        # what actually limits the dominant kernel: VALU issue, from the committed PMC summary
+        v_stage, v_total = pmc_valu(dom, args.workload)
+        if v_stage is not None:
+            excl_s = warm[dom][0] / n_warm * 1e-3
+            out["roofline"]["valu_issue"] = {
+                "wave_instr_per_frame": v_stage, "peak": VALU_ISSUE_PEAK, "unit": "wave64 VALU instr/s",
+                "achieved_exclusive": v_stage * NI / excl_s, "frac_exclusive": v_stage * NI / excl_s / VALU_ISSUE_PEAK,
+                "pipeline_wave_instr_per_frame": v_total,
+                "pipeline_frac": (v_total * imgs_per_frame * value / world / VALU_ISSUE_PEAK) if v_total else None}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, wl)
             if stereo:
