@@ -237,7 +237,7 @@ def main():
     dom = max(gpu_stages, key=lambda s_: warm[s_][0])
     # timed region: K steps enqueued back to back (each step = one pass of ORBextractor::operator()
     # over the resident batch, split over `streams` sub-batch streams); only the dominant stage keeps
-    # its events, recorded on sub-batch 0's stream
+    # its events: one pair per sub-batch launch, recorded on that sub-batch's own stream
     ext.set_streams(max(1, min(4, args.streams)))
     ext.profile(False)
     step(wait=True)  # one untimed pass on the new stream split
@@ -295,8 +295,10 @@ def main():
         alg = algorithmic_bytes(sizes, n_kp)
         alg["octree"] = 0
         # dominant kernel = the stage with the largest event time; timed live in the timed region
-        # the timed launches are those of sub-batch 0 of every call (prof[dom][2] frames in total)
-        dom_ms_per_step = prof[dom][0] / max(args.steps, 1)
+        # every sub-batch launch of the dominant stage is timed: prof[dom] = (ms, launches, frames) in total
+        n_groups = max(prof[dom][1] / sum(n for _, n in STAGE_KERNELS[dom]), 1)  # timed launches of the stage
+        dom_ms_per_group = prof[dom][0] / n_groups
+        dom_frames_per_group = prof[dom][2] / n_groups
         ach = alg[dom] * prof[dom][2] / (prof[dom][0] * 1e-3) / 1e9 if prof[dom][0] > 0 else 0.0
         imgs_per_frame = NI / B
         value = total_frames / dt_max
@@ -319,10 +321,10 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "+".join(k for k, _ in STAGE_KERNELS[dom]), "stage": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(dom, args.workload, B, prof[dom][2] / max(args.steps, 1)),
-                "algorithmic_bytes_per_launch_group": alg[dom] * prof[dom][2] / max(args.steps, 1),
-                "algorithmic_bytes_per_frame": alg[dom], "ms_per_launch_group": dom_ms_per_step,
-                "frames_per_launch": prof[dom][2] / max(args.steps, 1),
+                "traffic": pmc_traffic(dom, args.workload, B, dom_frames_per_group),
+                "algorithmic_bytes_per_launch_group": alg[dom] * dom_frames_per_group,
+                "algorithmic_bytes_per_frame": alg[dom], "ms_per_launch_group": dom_ms_per_group,
+                "frames_per_launch": dom_frames_per_group, "launch_groups_timed": n_groups,
                 "pipeline": {"algorithmic_bytes_per_image": alg["extract_total"],
                              "achieved": alg["extract_total"] * imgs_per_frame * value / world / 1e9,
                              "frac": alg["extract_total"] * imgs_per_frame * value / world / 1e9 / HBM_PEAK_GBS},

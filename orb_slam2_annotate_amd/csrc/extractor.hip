@@ -53,10 +53,11 @@ struct orbfe_extractor {
   double stageFrames[ORBFE_STAGE_COUNT] = {};
   // stage timing: a ring of event pairs per stage so that asynchronous calls can stay in flight
   static constexpr int kEvRing = 16;
-  hipEvent_t evA[kEvRing][ORBFE_STAGE_COUNT] = {}, evB[kEvRing][ORBFE_STAGE_COUNT] = {};
-  bool evUsed[kEvRing][ORBFE_STAGE_COUNT] = {};
-  int evLaunches[kEvRing][ORBFE_STAGE_COUNT] = {};
-  int evFrames[kEvRing][ORBFE_STAGE_COUNT] = {};
+  static constexpr int kEvSubs = 4;  // one event pair per (call slot, sub-batch stream, stage)
+  hipEvent_t evA[kEvRing][kEvSubs][ORBFE_STAGE_COUNT] = {}, evB[kEvRing][kEvSubs][ORBFE_STAGE_COUNT] = {};
+  bool evUsed[kEvRing][kEvSubs][ORBFE_STAGE_COUNT] = {};
+  int evLaunches[kEvRing][kEvSubs][ORBFE_STAGE_COUNT] = {};
+  int evFrames[kEvRing][kEvSubs][ORBFE_STAGE_COUNT] = {};
   int evSlot = 0;
   unsigned stageMask = 0;
   bool hostOctree = false;  // debug cross-check only (orbfe_extractor_debug_host_octree)
@@ -224,33 +225,37 @@ int ensure_outputs(orbfe_extractor* e, int nFrames, int capacity) {
 // stream synchronisation, so profiling does not perturb the timed region.
 struct StageTimer {
   orbfe_extractor* e;
-  int stage;
+  int stage, sub;
+  hipStream_t s;
   bool on;
-  StageTimer(orbfe_extractor* e_, int st, int n = 1, int frames = 0, bool timed = true)
-      : e(e_), stage(st), on(timed && ((e_->stageMask >> st) & 1u)) {
+  // sub = index of the sub-batch (its stream is s); every sub-batch of a call is timed on its own stream
+  StageTimer(orbfe_extractor* e_, int st, int n, int frames, int sub_, hipStream_t s_)
+      : e(e_), stage(st), sub(sub_), s(s_),
+        on(sub_ >= 0 && sub_ < orbfe_extractor::kEvSubs && ((e_->stageMask >> st) & 1u)) {
     if (!on) return;
-    (void)hipEventRecord(e->evA[e->evSlot][stage], e->stream);
-    e->evLaunches[e->evSlot][stage] = n;
-    e->evFrames[e->evSlot][stage] = frames;
+    (void)hipEventRecord(e->evA[e->evSlot][sub][stage], s);
+    e->evLaunches[e->evSlot][sub][stage] = n;
+    e->evFrames[e->evSlot][sub][stage] = frames;
   }
   ~StageTimer() {
     if (!on) return;
-    (void)hipEventRecord(e->evB[e->evSlot][stage], e->stream);
-    e->evUsed[e->evSlot][stage] = true;
+    (void)hipEventRecord(e->evB[e->evSlot][sub][stage], s);
+    e->evUsed[e->evSlot][sub][stage] = true;
   }
 };
 void resolve_slot(orbfe_extractor* e, int slot) {
-  for (int st = 0; st < ORBFE_STAGE_COUNT; st++) {
-    if (!e->evUsed[slot][st]) continue;
-    e->evUsed[slot][st] = false;
-    float ms = 0;
-    if (hipEventSynchronize(e->evB[slot][st]) == hipSuccess &&
-        hipEventElapsedTime(&ms, e->evA[slot][st], e->evB[slot][st]) == hipSuccess) {
-      e->stageMs[st] += ms;
-      e->stageLaunches[st] += e->evLaunches[slot][st];
-      e->stageFrames[st] += e->evFrames[slot][st];
+  for (int sub = 0; sub < orbfe_extractor::kEvSubs; sub++)
+    for (int st = 0; st < ORBFE_STAGE_COUNT; st++) {
+      if (!e->evUsed[slot][sub][st]) continue;
+      e->evUsed[slot][sub][st] = false;
+      float ms = 0;
+      if (hipEventSynchronize(e->evB[slot][sub][st]) == hipSuccess &&
+          hipEventElapsedTime(&ms, e->evA[slot][sub][st], e->evB[slot][sub][st]) == hipSuccess) {
+        e->stageMs[st] += ms;
+        e->stageLaunches[st] += e->evLaunches[slot][sub][st];
+        e->stageFrames[st] += e->evFrames[slot][sub][st];
+      }
     }
-  }
 }
 void resolve_stage_times(orbfe_extractor* e) {
   for (int slot = 0; slot < orbfe_extractor::kEvRing; slot++) resolve_slot(e, slot);
@@ -314,7 +319,7 @@ int run_host_octree(orbfe_extractor* e, int nFrames) {
 
 // The device pipeline for frames [f0, f0+nFrames) of a call, enqueued on stream `s`.
 // level0: view of the call's input frames in HBM (frame 0 of the call).
-int run_chunk(orbfe_extractor* e, hipStream_t s, bool timed, LevelView level0, int f0, int nFrames,
+int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int f0, int nFrames,
               orbfe_keypoint* d_kp, uint8_t* d_desc, int capacity, int32_t* d_nOut, PyramidViews* pyrOut,
               PyramidViews* blurOut) {
   const FrameGeom& g = e->geom;
@@ -352,7 +357,7 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, bool timed, LevelView level0, i
   LevelKp* levelKp = e->d_levelKp + F * g.totalKpCap;
   int32_t* levelCount = e->d_levelCount + F * g.nlevels;
   {  // ComputePyramid, :1203-1234
-    StageTimer t(e, ORBFE_STAGE_PYRAMID, g.nlevels - 1, nFrames, timed);
+    StageTimer t(e, ORBFE_STAGE_PYRAMID, g.nlevels - 1, nFrames, sub, s);
     for (int l = 1; l < g.nlevels; l++) {
       LevelViewMut dst{const_cast<uint8_t*>(pyr.lv[l].base), g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
       launch_resize(s, pyr.lv[l - 1], dst, e->d_xofs[l], e->d_alpha[l], e->d_yofs[l], e->d_beta[l], e->d_colrec[l],
@@ -360,12 +365,12 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, bool timed, LevelView level0, i
     }
   }
   {  // FAST grid stage, :846-896 (timed alone: the dominant kernel of the pipeline)
-    StageTimer t(e, ORBFE_STAGE_FAST, 1, nFrames, timed);
+    StageTimer t(e, ORBFE_STAGE_FAST, 1, nFrames, sub, s);
     launch_fast_cells(s, pyr, e->d_cells, nCells, nFrames, e->tab.iniThFAST, e->tab.minThFAST, slots,
                       g.totalSlots, cellCount, g.maxCellW, g.maxCellH);
   }
   if (!e->hostOctree) {  // candidate ordering + DistributeOctTree, :566-808, one workgroup per (frame, level)
-    StageTimer t(e, ORBFE_STAGE_OCTREE, 2, nFrames, timed);
+    StageTimer t(e, ORBFE_STAGE_OCTREE, 2, nFrames, sub, s);
     launch_gather_candidates(s, e->d_cells, e->d_lvgeom, g.nlevels, nFrames, slots, g.totalSlots, cellCount,
                              nCells, cand, candCount, cellPrefix);
     OctreeArgs oa = {};
@@ -387,7 +392,7 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, bool timed, LevelView level0, i
     if (rc) return rc;
   }
   {  // GaussianBlur of every level, :1169-1175 -- the levels are independent: one launch
-    StageTimer t(e, ORBFE_STAGE_BLUR, 1, nFrames, timed);
+    StageTimer t(e, ORBFE_STAGE_BLUR, 1, nFrames, sub, s);
     LevelViewMut dsts[kMaxLevels];
     for (int l = 0; l < g.nlevels; l++)
       dsts[l] = LevelViewMut{const_cast<uint8_t*>(blur.lv[l].base), g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
@@ -395,7 +400,7 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, bool timed, LevelView level0, i
   }
 
   {  // computeOrientation + computeDescriptors + output records
-    StageTimer t(e, ORBFE_STAGE_ORIENT_DESC, 1, nFrames, timed);
+    StageTimer t(e, ORBFE_STAGE_ORIENT_DESC, 1, nFrames, sub, s);
     OrientDescArgs a = {};
     a.pyr = pyr;
     a.blur = blur;
@@ -437,7 +442,7 @@ int run_pipeline(orbfe_extractor* e, LevelView level0, int nFrames, orbfe_keypoi
     const int n = f0 + per <= nFrames ? per : nFrames - f0;
     if (n <= 0) break;
     hipStream_t s = i == 0 ? e->stream : e->extra[i - 1];
-    int rc = run_chunk(e, s, i == 0, level0, f0, n, d_kp, d_desc, capacity, d_nOut, i == 0 ? &e->lastPyr : nullptr,
+    int rc = run_chunk(e, s, i, level0, f0, n, d_kp, d_desc, capacity, d_nOut, i == 0 ? &e->lastPyr : nullptr,
                        i == 0 ? &e->lastBlur : nullptr);
     if (rc) return rc;
   }
@@ -477,10 +482,11 @@ extern "C" int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlev
     if (v >= 1 && v <= orbfe_extractor::kMaxStreams) e->nStreams = v;
   }
   for (int r = 0; r < orbfe_extractor::kEvRing; r++)
-    for (int i = 0; i < ORBFE_STAGE_COUNT && err == hipSuccess; i++) {
-      err = hipEventCreate(&e->evA[r][i]);
-      if (err == hipSuccess) err = hipEventCreate(&e->evB[r][i]);
-    }
+    for (int u = 0; u < orbfe_extractor::kEvSubs; u++)
+      for (int i = 0; i < ORBFE_STAGE_COUNT && err == hipSuccess; i++) {
+        err = hipEventCreate(&e->evA[r][u][i]);
+        if (err == hipSuccess) err = hipEventCreate(&e->evB[r][u][i]);
+      }
   float patF[1024];
   for (int i = 0; i < 1024; i++) patF[i] = (float)kOrbBitPattern31[i];
   uint8_t momTab[1024];
@@ -520,10 +526,11 @@ extern "C" void orbfe_extractor_destroy(orbfe_extractor* e) {
   dfree(&e->d_momentTab);
   dfree(&e->d_umax);
   for (int r = 0; r < orbfe_extractor::kEvRing; r++)
-    for (int i = 0; i < ORBFE_STAGE_COUNT; i++) {
-      if (e->evA[r][i]) (void)hipEventDestroy(e->evA[r][i]);
-      if (e->evB[r][i]) (void)hipEventDestroy(e->evB[r][i]);
-    }
+    for (int u = 0; u < orbfe_extractor::kEvSubs; u++)
+      for (int i = 0; i < ORBFE_STAGE_COUNT; i++) {
+        if (e->evA[r][u][i]) (void)hipEventDestroy(e->evA[r][u][i]);
+        if (e->evB[r][u][i]) (void)hipEventDestroy(e->evB[r][u][i]);
+      }
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -625,7 +632,7 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* images, in
   const FrameGeom& g = e->geom;
   next_event_slot(e);
   {
-    StageTimer t(e, ORBFE_STAGE_H2D, 0);
+    StageTimer t(e, ORBFE_STAGE_H2D, 0, 0, 0, e->stream);
     // level 0 lives at the head of the per-frame pyramid slab (pitch-aligned copy)
     for (int f = 0; f < n_frames; f++)
       HIPCHK(hipMemcpy2DAsync(e->d_pyr + (size_t)f * g.pyrBytes + g.lv[0].off, g.lv[0].pitch,
@@ -637,7 +644,7 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* images, in
   if ((rc = run_pipeline(e, l0, n_frames, e->d_kpOut, e->d_descOut, capacity, e->d_nOut))) return rc;
   if ((rc = sync_all(e))) return rc;
   {
-    StageTimer t(e, ORBFE_STAGE_D2H, 0);
+    StageTimer t(e, ORBFE_STAGE_D2H, 0, 0, 0, e->stream);
     std::vector<int32_t> cnt(n_frames);
     HIPCHK(hipMemcpyAsync(cnt.data(), e->d_nOut, sizeof(int32_t) * n_frames, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
