@@ -107,10 +107,10 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelViewMut dst,
 // numbered row-block-major over the level, so a wavefront is 64 consecutive column groups wherever
 // the rows break -- lanes stay busy on levels whose width is not a multiple of 256 pixels (257,
 // 309, 370 ... lost up to half of the lanes of the strip form above).  All per-column / per-row
-// coefficients come packed from host-built tables (ResizeTables::colrec / rowrec); every source
-// row pair is interpolated per output row (no cross-row reuse, hence no per-lane control flow) and
-// all 2*kFlatRows row windows are requested before the first is used, so one memory round trip
-// serves 16 output pixels; (b*h)>>16 is one v_mul_hi_u32 against b<<16.
+// coefficients come packed from host-built tables (ResizeTables::colrec / rowrec); all row windows
+// are requested before the first is used, so one memory round trip serves 16 output pixels; an
+// interpolated source row is reused by the next output row when the whole wave agrees (scalar
+// branch, no per-lane control flow); (b*h)>>16 is one v_mul_hi_u32 against b<<16.
 constexpr int kFlatRows = 4;
 __global__ __launch_bounds__(256) void k_resize_flat(LevelView src, LevelViewMut dst,
                                                      const uint4* __restrict__ colrec,
@@ -131,19 +131,32 @@ __global__ __launch_bounds__(256) void k_resize_flat(LevelView src, LevelViewMut
   const uint8_t* S = src.base + (size_t)f * src.frameStride + sxb;
   const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(S) & 3);
   S -= mis;
-  uint32_t w[2 * kFlatRows][3];  // raw 12-byte windows of the 2*kFlatRows source rows
+  // Output row r blends source rows (rr[r].x, rr[r].y); at pyramid scales rr[r].x is usually
+  // rr[r-1].y.  When that holds for every lane of the wave (a scalar condition: the lanes of a wave
+  // share their rows except where a wave straddles two row blocks) the interpolated row is reused
+  // instead of being fetched and interpolated again.
+  bool reuse[kFlatRows];
+  reuse[0] = false;
+#pragma unroll
+  for (int r = 1; r < kFlatRows; r++) reuse[r] = __all(rr[r].x == rr[r - 1].y) != 0;
+  uint32_t w[2 * kFlatRows][3];  // raw 12-byte windows of the source rows still needed
 #pragma unroll
   for (int r = 0; r < kFlatRows; r++) {
-    const uint32_t* pa = reinterpret_cast<const uint32_t*>(S + (size_t)rr[r].x * src.pitch);
+    if (!reuse[r]) {
+      const uint32_t* pa = reinterpret_cast<const uint32_t*>(S + (size_t)rr[r].x * src.pitch);
+      w[2 * r][0] = pa[0]; w[2 * r][1] = pa[1]; w[2 * r][2] = mis ? pa[2] : 0u;
+    }
     const uint32_t* pb = reinterpret_cast<const uint32_t*>(S + (size_t)rr[r].y * src.pitch);
-    w[2 * r][0] = pa[0]; w[2 * r][1] = pa[1]; w[2 * r][2] = mis ? pa[2] : 0u;
     w[2 * r + 1][0] = pb[0]; w[2 * r + 1][1] = pb[1]; w[2 * r + 1][2] = mis ? pb[2] : 0u;
   }
   uint8_t* D = dst.base + (size_t)f * dst.frameStride + 4 * gx;
+  uint32_t hA[4], hB[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
   for (int r = 0; r < kFlatRows; r++) {
-    uint32_t hA[4], hB[4];
-    {
+    if (reuse[r]) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) hA[k] = hB[k];
+    } else {
       const uint32_t lo = __builtin_amdgcn_alignbyte(w[2 * r][1], w[2 * r][0], mis);
       const uint32_t hi = __builtin_amdgcn_alignbyte(w[2 * r][2], w[2 * r][1], mis);
 #pragma unroll
