@@ -364,6 +364,18 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
                     e->d_rowrec[l], nFrames);
     }
   }
+  // GaussianBlur of every level, :1169-1175 -- the levels are independent: one launch.  It only needs
+  // the pyramid, so odd sub-batches run it BEFORE the FAST stage: neighbouring streams are then in
+  // different phases (VALU-bound blur/FAST next to latency-bound octree/descriptors) instead of in step.
+  auto do_blur = [&]() {
+    StageTimer t(e, ORBFE_STAGE_BLUR, 1, nFrames, sub, s);
+    LevelViewMut dsts[kMaxLevels];
+    for (int l = 0; l < g.nlevels; l++)
+      dsts[l] = LevelViewMut{const_cast<uint8_t*>(blur.lv[l].base), g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
+    launch_blur7_levels(s, pyr.lv, dsts, g.nlevels, nFrames);
+  };
+  const bool blurFirst = (sub & 1) != 0;  // measured +1.7 % frames/s (A/B on one box, 4 runs each)
+  if (blurFirst) do_blur();
   {  // FAST grid stage, :846-896 (timed alone: the dominant kernel of the pipeline)
     StageTimer t(e, ORBFE_STAGE_FAST, 1, nFrames, sub, s);
     launch_fast_cells(s, pyr, e->d_cells, nCells, nFrames, e->tab.iniThFAST, e->tab.minThFAST, slots,
@@ -391,13 +403,7 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
     int rc = run_host_octree(e, nFrames);  // single-stream debug path: f0 == 0
     if (rc) return rc;
   }
-  {  // GaussianBlur of every level, :1169-1175 -- the levels are independent: one launch
-    StageTimer t(e, ORBFE_STAGE_BLUR, 1, nFrames, sub, s);
-    LevelViewMut dsts[kMaxLevels];
-    for (int l = 0; l < g.nlevels; l++)
-      dsts[l] = LevelViewMut{const_cast<uint8_t*>(blur.lv[l].base), g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
-    launch_blur7_levels(s, pyr.lv, dsts, g.nlevels, nFrames);
-  }
+  if (!blurFirst) do_blur();
 
   {  // computeOrientation + computeDescriptors + output records
     StageTimer t(e, ORBFE_STAGE_ORIENT_DESC, 1, nFrames, sub, s);
