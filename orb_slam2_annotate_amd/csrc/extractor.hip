@@ -96,9 +96,15 @@ struct orbfe_extractor {
   LevelKp* d_levelKp = nullptr;
   int32_t* d_levelCount = nullptr;
   // device-side outputs used by the host-buffer API
+  // outputs of the host-buffer API: ONE block [keypoints | descriptors | counts], so a small batch
+  // comes back in a single D2H copy through the pinned staging buffer
+  uint8_t* d_outBlock = nullptr;
+  size_t outBlockBytes = 0;      // bytes from the block start to the end of the counts of the last call
   orbfe_keypoint* d_kpOut = nullptr;
   uint8_t* d_descOut = nullptr;
   int32_t* d_nOut = nullptr;
+  uint8_t* h_outStage = nullptr;  // pinned
+  size_t outStageBytes = 0;
   int outCap = 0;
   // host staging
   std::vector<int32_t> h_candCount, h_levelCount;
@@ -138,7 +144,8 @@ void free_workspace(orbfe_extractor* e) {
   e->capFrames = 0;
 }
 void free_outputs(orbfe_extractor* e) {
-  dfree(&e->d_kpOut); dfree(&e->d_descOut); dfree(&e->d_nOut);
+  dfree(&e->d_outBlock);
+  e->d_kpOut = nullptr; e->d_descOut = nullptr; e->d_nOut = nullptr;
   e->outCap = 0;
 }
 
@@ -210,12 +217,16 @@ int ensure_workspace(orbfe_extractor* e, int nFrames) {
 
 int ensure_outputs(orbfe_extractor* e, int nFrames, int capacity) {
   const int need = nFrames * capacity;
-  if (need <= e->outCap && e->d_nOut) return ORBFE_OK;
+  if (need == e->outCap && e->d_nOut) return ORBFE_OK;  // exact layout: a small batch stays one compact block
   free_outputs(e);
   int rc;
-  if ((rc = dalloc(&e->d_kpOut, (size_t)need))) return rc;
-  if ((rc = dalloc(&e->d_descOut, (size_t)need * 32))) return rc;
-  if ((rc = dalloc(&e->d_nOut, (size_t)(nFrames > 4096 ? nFrames : 4096)))) return rc;
+  const size_t kpBytes = ((size_t)need * sizeof(orbfe_keypoint) + 255) & ~(size_t)255;
+  const size_t descBytes = ((size_t)need * 32 + 255) & ~(size_t)255;
+  const size_t cntBytes = (size_t)(nFrames > 4096 ? nFrames : 4096) * 4;
+  if ((rc = dalloc(&e->d_outBlock, kpBytes + descBytes + cntBytes))) return rc;
+  e->d_kpOut = reinterpret_cast<orbfe_keypoint*>(e->d_outBlock);
+  e->d_descOut = e->d_outBlock + kpBytes;
+  e->d_nOut = reinterpret_cast<int32_t*>(e->d_outBlock + kpBytes + descBytes);
   e->outCap = need;
   return ORBFE_OK;
 }
@@ -524,6 +535,7 @@ extern "C" void orbfe_extractor_destroy(orbfe_extractor* e) {
   free_geometry(e);
   free_workspace(e);
   free_outputs(e);
+  if (e->h_outStage) (void)hipHostFree(e->h_outStage);
   dfree(&e->d_patternF);
   dfree(&e->d_stereoSad);
   dfree(&e->d_scaleTab);
@@ -651,22 +663,49 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* images, in
   if ((rc = sync_all(e))) return rc;
   {
     StageTimer t(e, ORBFE_STAGE_D2H, 0, 0, 0, e->stream);
-    std::vector<int32_t> cnt(n_frames);
-    HIPCHK(hipMemcpyAsync(cnt.data(), e->d_nOut, sizeof(int32_t) * n_frames, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
     bool overflow = false;
-    for (int f = 0; f < n_frames; f++) {
-      int n = cnt[f];
-      if (n > capacity) { overflow = true; n = capacity; }
-      n_out[f] = n;
-      if (n > 0) {
-        HIPCHK(hipMemcpyAsync(keypoints + (size_t)f * capacity, e->d_kpOut + (size_t)f * capacity,
-                              sizeof(orbfe_keypoint) * n, hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(hipMemcpyAsync(descriptors + (size_t)f * capacity * 32, e->d_descOut + (size_t)f * capacity * 32,
-                              (size_t)n * 32, hipMemcpyDeviceToHost, e->stream));
+    const size_t blockBytes = (size_t)(reinterpret_cast<uint8_t*>(e->d_nOut) - e->d_outBlock) + sizeof(int32_t) * (size_t)n_frames;
+    if (blockBytes <= (size_t)512 * 1024) {
+      // small batch (the live-camera case): everything in ONE copy into pinned memory, then scattered
+      // by the CPU -- one DMA + one synchronisation instead of 1 + 2*n_frames copies and two syncs
+      if (e->outStageBytes < blockBytes) {
+        if (e->h_outStage) (void)hipHostFree(e->h_outStage);
+        e->h_outStage = nullptr;
+        e->outStageBytes = 0;
+        HIPCHK(hipHostMalloc((void**)&e->h_outStage, (size_t)512 * 1024, hipHostMallocDefault));
+        e->outStageBytes = (size_t)512 * 1024;
       }
+      HIPCHK(hipMemcpyAsync(e->h_outStage, e->d_outBlock, blockBytes, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      const uint8_t* hk = e->h_outStage;
+      const uint8_t* hd = e->h_outStage + (e->d_descOut - e->d_outBlock);
+      const int32_t* hc = reinterpret_cast<const int32_t*>(e->h_outStage + (reinterpret_cast<uint8_t*>(e->d_nOut) - e->d_outBlock));
+      for (int f = 0; f < n_frames; f++) {
+        int n = hc[f];
+        if (n > capacity) { overflow = true; n = capacity; }
+        n_out[f] = n;
+        if (n > 0) {
+          std::memcpy(keypoints + (size_t)f * capacity, hk + (size_t)f * capacity * sizeof(orbfe_keypoint), sizeof(orbfe_keypoint) * (size_t)n);
+          std::memcpy(descriptors + (size_t)f * capacity * 32, hd + (size_t)f * capacity * 32, (size_t)n * 32);
+        }
+      }
+    } else {
+      std::vector<int32_t> cnt(n_frames);
+      HIPCHK(hipMemcpyAsync(cnt.data(), e->d_nOut, sizeof(int32_t) * n_frames, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      for (int f = 0; f < n_frames; f++) {
+        int n = cnt[f];
+        if (n > capacity) { overflow = true; n = capacity; }
+        n_out[f] = n;
+        if (n > 0) {
+          HIPCHK(hipMemcpyAsync(keypoints + (size_t)f * capacity, e->d_kpOut + (size_t)f * capacity,
+                                sizeof(orbfe_keypoint) * n, hipMemcpyDeviceToHost, e->stream));
+          HIPCHK(hipMemcpyAsync(descriptors + (size_t)f * capacity * 32, e->d_descOut + (size_t)f * capacity * 32,
+                                (size_t)n * 32, hipMemcpyDeviceToHost, e->stream));
+        }
+      }
+      HIPCHK(hipStreamSynchronize(e->stream));
     }
-    HIPCHK(hipStreamSynchronize(e->stream));
     if (overflow) return fail(ORBFE_ERR_CAPACITY, "keypoint capacity too small");
   }
   resolve_stage_times(e);

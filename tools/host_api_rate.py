@@ -24,3 +24,14 @@ for B in (1, 8, 32, 128):
             e.extract_batch(frames[:B])
     dt = time.perf_counter() - t0
     print(f"host API, batch {B:3d}: {reps * B / dt:9.0f} frames/s  ({1e3 * dt / reps / B:.3f} ms/frame)")
+
+# where one single-frame call spends its time (stage events + wall clock)
+e.profile(True)
+t0 = time.perf_counter()
+for _ in range(200):
+    e(frames[0])
+dt = (time.perf_counter() - t0) / 200
+p = e.profile_get()
+e.profile(False)
+print("single frame with stage events: %.3f ms/call;" % (1e3 * dt),
+      " ".join(f"{k}={v[0] / 200 * 1e3:.0f}us" for k, v in p.items()))
