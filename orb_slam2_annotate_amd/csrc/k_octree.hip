@@ -64,10 +64,15 @@ __device__ __forceinline__ Rect child_rect(const Rect r, int q) {
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void k_octree(OctreeArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  __shared__ int waveTot[4];
-  __shared__ int sh[4];
+// REG: the candidates of the level (n <= 256 * kRegCand) live in registers -- candidate j*256 + tid in
+// slot j -- instead of being re-read from / re-written to global memory in every pass: a pass is a
+// chain of dependent LDS accesses only (measured on one 640x480 frame, level 0, n = 2262: the
+// histogram pass 11 k -> 3 k cycles, re-homing 6.4 k -> 2 k).  Larger candidate sets (noise images)
+// take the global-memory form of the same loops.
+constexpr int kRegCand = 16;
+
+template <bool REG>
+__device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, int* waveTot, int* sh) {
   const int tid = threadIdx.x;
   const int l = blockIdx.x, f = blockIdx.y;
   const LevelGeom g = a.lvg[l];
@@ -102,11 +107,32 @@ __global__ __launch_bounds__(256) void k_octree(OctreeArgs a) {
   int cur = 0;
   for (int i = tid; i < nIni; i += 256) scanB[i] = 0;
   __syncthreads();
-  for (int k = tid; k < n; k += 256) {
-    int b = (int)__fdiv_rn((float)(cand[k].xy & 0xffffu), hX);
-    if (b >= nIni) b = nIni - 1;
-    nodeOf[k] = (uint16_t)b;
-    atomicAdd(&scanB[b], 1);
+  uint32_t kxy[kRegCand];   // REG: candidate coordinates / current node of candidate j*256 + tid
+  uint32_t knode[kRegCand];
+  if constexpr (REG) {
+#pragma unroll
+    for (int j = 0; j < kRegCand; j++) {
+      const int k = j * 256 + tid;
+      kxy[j] = 0; knode[j] = 0;
+      if (k < n) {
+        kxy[j] = cand[k].xy;
+        int b = (int)__fdiv_rn((float)(kxy[j] & 0xffffu), hX);
+        if (b >= nIni) b = nIni - 1;
+        knode[j] = (uint32_t)b;
+      }
+      // root counts: one LDS atomic per wave and root instead of one per candidate on 1-3 addresses
+      for (int b = 0; b < nIni; b++) {
+        const unsigned long long m = __ballot(k < n && knode[j] == (uint32_t)b);
+        if ((tid & 63) == 0 && m) atomicAdd(&scanB[b], __popcll(m));
+      }
+    }
+  } else {
+    for (int k = tid; k < n; k += 256) {
+      int b = (int)__fdiv_rn((float)(cand[k].xy & 0xffffu), hX);
+      if (b >= nIni) b = nIni - 1;
+      nodeOf[k] = (uint16_t)b;
+      atomicAdd(&scanB[b], 1);
+    }
   }
   __syncthreads();
   for (int i = tid; i < nIni; i += 256) { scanA[i] = scanB[i] > 0 ? 1 : 0; }
@@ -124,7 +150,12 @@ __global__ __launch_bounds__(256) void k_octree(OctreeArgs a) {
     }
   }
   __syncthreads();
-  for (int k = tid; k < n; k += 256) nodeOf[k] = (uint16_t)scanA[nodeOf[k]];
+  if constexpr (REG) {
+#pragma unroll
+    for (int j = 0; j < kRegCand; j++) knode[j] = (uint32_t)scanA[knode[j]];
+  } else {
+    for (int k = tid; k < n; k += 256) nodeOf[k] = (uint16_t)scanA[nodeOf[k]];
+  }
   __syncthreads();
 
   int C = 0;            // nodes at the head of the list created by the previous pass
@@ -141,11 +172,20 @@ __global__ __launch_bounds__(256) void k_octree(OctreeArgs a) {
     }
     __syncthreads();
     // B. speculative 4-way histogram of the candidates' keys (DivideNode :531-546)
-    for (int k = tid; k < n; k += 256) {
-      const int p = nodeOf[k];
-      if (inS[p]) {
-        const uint32_t xy = cand[k].xy;
-        atomicAdd(&child[4 * p + quadrant(rc[p], (int)(xy & 0xffffu), (int)(xy >> 16))], 1);
+    if constexpr (REG) {
+#pragma unroll
+      for (int j = 0; j < kRegCand; j++) {
+        const int p = (int)knode[j];
+        if (j * 256 + tid < n && inS[p])
+          atomicAdd(&child[4 * p + quadrant(rc[p], (int)(kxy[j] & 0xffffu), (int)(kxy[j] >> 16))], 1);
+      }
+    } else {
+      for (int k = tid; k < n; k += 256) {
+        const int p = nodeOf[k];
+        if (inS[p]) {
+          const uint32_t xy = cand[k].xy;
+          atomicAdd(&child[4 * p + quadrant(rc[p], (int)(xy & 0xffffu), (int)(xy >> 16))], 1);
+        }
       }
     }
     __syncthreads();
@@ -160,16 +200,23 @@ __global__ __launch_bounds__(256) void k_octree(OctreeArgs a) {
       __syncthreads();
     } else {
       // rank by (count desc, list position asc) among the candidates (all have p < C)
+      // one wavefront per candidate p (p = wave, wave+4, ...), its lanes sweep p2: a ballot counts
+      // the candidates that walk before p
       int nE = 0;
-      for (int p = tid; p < C; p += 256) {
-        if (!inS[p]) continue;
-        const int c = cn[p];
-        int r = 0;
-        for (int p2 = 0; p2 < C; p2++)
-          if (inS[p2]) { const int c2 = cn[p2]; r += (c2 > c) || (c2 == c && p2 < p); }
-        order[r] = (uint16_t)p;
-        rankOf[p] = (uint16_t)r;
-        nE++;
+      {
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int p = wave; p < C; p += 4) {
+          if (!inS[p]) continue;  // wave-uniform
+          const int c = cn[p];
+          int r = 0;
+          for (int p0 = 0; p0 < C; p0 += 64) {
+            const int p2 = p0 + lane;
+            bool before = false;
+            if (p2 < C && inS[p2]) { const int c2 = cn[p2]; before = (c2 > c) || (c2 == c && p2 < p); }
+            r += __popcll(__ballot(before));
+          }
+          if (lane == 0) { order[r] = (uint16_t)p; rankOf[p] = (uint16_t)r; nE++; }
+        }
       }
       if (tid == 0) sh[0] = 0;
       __syncthreads();
@@ -237,16 +284,26 @@ __global__ __launch_bounds__(256) void k_octree(OctreeArgs a) {
     if (expand) atomicAdd(&sh[2], expand);
     __syncthreads();
     // F. re-home the keys
-    for (int k = tid; k < n; k += 256) {
-      const int p = nodeOf[k];
-      int np;
-      if (inS[p]) {
-        const uint32_t xy = cand[k].xy;
-        np = child[4 * p + quadrant(rc[p], (int)(xy & 0xffffu), (int)(xy >> 16))];
-      } else {
-        np = scanB[p];
+    if constexpr (REG) {
+#pragma unroll
+      for (int j = 0; j < kRegCand; j++) {
+        const int p = (int)knode[j];
+        if (j * 256 + tid < n)
+          knode[j] = (uint32_t)(inS[p] ? child[4 * p + quadrant(rc[p], (int)(kxy[j] & 0xffffu), (int)(kxy[j] >> 16))]
+                                       : scanB[p]);
       }
-      nodeOf[k] = (uint16_t)np;
+    } else {
+      for (int k = tid; k < n; k += 256) {
+        const int p = nodeOf[k];
+        int np;
+        if (inS[p]) {
+          const uint32_t xy = cand[k].xy;
+          np = child[4 * p + quadrant(rc[p], (int)(xy & 0xffffu), (int)(xy >> 16))];
+        } else {
+          np = scanB[p];
+        }
+        nodeOf[k] = (uint16_t)np;
+      }
     }
     const int nToExpand = sh[2];
     __syncthreads();
@@ -262,9 +319,18 @@ __global__ __launch_bounds__(256) void k_octree(OctreeArgs a) {
   int* best = scanA;
   for (int p = tid; p < L; p += 256) best[p] = 0;
   __syncthreads();
-  for (int k = tid; k < n; k += 256)
-    atomicMax(reinterpret_cast<unsigned int*>(&best[nodeOf[k]]),
-              (cand[k].score << 24) | (0xffffffu - (unsigned)k));
+  if constexpr (REG) {
+#pragma unroll
+    for (int j = 0; j < kRegCand; j++) {
+      const int k = j * 256 + tid;
+      if (k < n)
+        atomicMax(reinterpret_cast<unsigned int*>(&best[knode[j]]), (cand[k].score << 24) | (0xffffffu - (unsigned)k));
+    }
+  } else {
+    for (int k = tid; k < n; k += 256)
+      atomicMax(reinterpret_cast<unsigned int*>(&best[nodeOf[k]]),
+                (cand[k].score << 24) | (0xffffffu - (unsigned)k));
+  }
   __syncthreads();
   // The keypoints leave in SPATIAL order (128-byte column strip, then row): consecutive slots are
   // what one k_orient_desc workgroup processes, and neighbours in memory share the cache lines of
@@ -292,6 +358,26 @@ __global__ __launch_bounds__(256) void k_octree(OctreeArgs a) {
   if (tid == 0) *outCount = nKp;
 }
 
+// Two builds of the same body: k_octree keeps the candidates in global memory (28 VGPRs, as many
+// workgroups per CU as LDS allows -- the throughput form for large batches), k_octree_reg keeps them
+// in registers when a level has at most 256 * kRegCand candidates (~100 VGPRs, 4 workgroups per CU,
+// but a 20 % shorter critical path -- the latency form for the live-camera case of a few frames).
+__global__ __launch_bounds__(256) void k_octree(OctreeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ int waveTot[4];
+  __shared__ int sh[4];
+  octree_body<false>(a, smem, waveTot, sh);
+}
+
+__global__ __launch_bounds__(256) void k_octree_reg(OctreeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ int waveTot[4];
+  __shared__ int sh[4];
+  const int n = a.candCount[(size_t)blockIdx.y * a.nlevels + blockIdx.x];  // block-uniform
+  if (n <= 256 * kRegCand) octree_body<true>(a, smem, waveTot, sh);
+  else octree_body<false>(a, smem, waveTot, sh);
+}
+
 size_t octree_lds_bytes(int maxL) {
   // 2 rect (8) + 2 cnt (4) + child (16) + scanA (4) + scanB (4) + order (2) + rankOf (2) + inS (1)
   return (size_t)maxL * (2 * 8 + 2 * 4 + 16 + 4 + 4 + 2 + 2 + 1) + 64;
@@ -300,14 +386,16 @@ size_t octree_lds_bytes(int maxL) {
 hipError_t launch_octree(hipStream_t s, const OctreeArgs& a, int nlevels, int nFrames) {
   if (nFrames <= 0) return hipSuccess;
   const size_t lds = octree_lds_bytes(a.maxL);
-  static thread_local size_t configured = 0;
-  if (lds > 64 * 1024 && lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const bool latencyForm = nFrames <= 8;  // too few workgroups to fill the GPU anyway
+  static thread_local size_t configured[2] = {0, 0};
+  const void* fn = latencyForm ? reinterpret_cast<const void*>(k_octree_reg) : reinterpret_cast<const void*>(k_octree);
+  if (lds > 64 * 1024 && lds > configured[latencyForm]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    configured = lds;
+    configured[latencyForm] = lds;
   }
-  hipLaunchKernelGGL(k_octree, dim3(nlevels, nFrames), dim3(256), lds, s, a);
+  if (latencyForm) hipLaunchKernelGGL(k_octree_reg, dim3(nlevels, nFrames), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(k_octree, dim3(nlevels, nFrames), dim3(256), lds, s, a);
   return hipSuccess;
 }
 

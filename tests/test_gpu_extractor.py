@@ -181,6 +181,21 @@ def test_streams_and_async_give_identical_results(amd):
             _kp_equal(ref[f][0], res[f][0])
 
 
+def test_large_batch_uses_the_throughput_kernels(amd):
+    """Launches of more than 8 frames take the global-memory form of k_octree (the register form serves
+    small launches); 1 stream = one 20-frame launch, 8 streams = sub-batches of 3."""
+    imgs = np.stack([synth.render_frame(160 + i, 320, 240) for i in range(20)])
+    o = orc.Oracle(400, 1.2, 8, 20, 7)
+    ref = [o.extract(im) for im in imgs]
+    for n in (1, 8):
+        e = amd.ORBextractor(400, 1.2, 8, 20, 7)
+        e.set_streams(n)
+        res = e.extract_batch(imgs)
+        for f in range(len(imgs)):
+            _kp_equal(ref[f][0], res[f][0])
+            assert np.array_equal(ref[f][1], res[f][1])
+
+
 def test_large_and_tiny_images(amd):
     # full-HD frame with a large quota (octree node list in LDS ~1.1k nodes), and images so small
     # that the upper pyramid levels have no FAST grid at all
