@@ -18,7 +18,6 @@ namespace orbfe {
 
 namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int kKpPerBlock = 64;
 struct __attribute__((aligned(4))) U4 { uint32_t x, y, z, w; };  // 16-byte load at 4-byte alignment
 // blurred patch of one keypoint staged in LDS: rows y-18..y+18, 48 bytes from the 4-byte aligned
 // column ws <= x-18 (the steered pattern stays inside radius sqrt(13^2+13^2) < 18.5)
@@ -31,6 +30,9 @@ __device__ __forceinline__ int wave_sum(int v) {
 }
 }  // namespace
 
+// kKpPerBlock = 64 for throughput (16 keypoints per wavefront, 16 workgroups per VGA frame), 16 for
+// launches of a few frames (4 per wavefront, 4x the workgroups: the serial chain per wave is 4x shorter).
+template <int kKpPerBlock>
 __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
                                                      const LevelKp* __restrict__ levelKp,
                                                      const int32_t* __restrict__ levelCount,
@@ -102,7 +104,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
     }
     // 16 keypoints per wave, 4 at a time: the 4 x 5 row loads are issued back to back so one
     // memory latency covers four keypoints (the kernel is latency-bound, not VALU-bound)
-    for (int j0 = wave * 16; j0 < wave * 16 + 16; j0 += 4) {
+    constexpr int kKpPerWave = kKpPerBlock / 4;
+    for (int j0 = wave * kKpPerWave; j0 < wave * kKpPerWave + kKpPerWave; j0 += 4) {
       uint32_t dw[4][5];
       uint32_t mis[4];
 #pragma unroll
@@ -179,7 +182,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
     // the 512 samples are LDS byte reads; sampling global memory directly cost one L1 line lookup
     // per lane per sample (8 x 64 per keypoint) and was the slowest part of the kernel.
     uint32_t* myPatch = &s_patch[wave * 2 * kPatchRows * kPatchDw];
-    for (int j0 = wave * 16; j0 < wave * 16 + 16; j0 += 2) {
+    constexpr int kKpPerWave3 = kKpPerBlock / 4;
+    for (int j0 = wave * kKpPerWave3; j0 < wave * kKpPerWave3 + kKpPerWave3; j0 += 2) {
       int t0v[2][4], t1v[2][4];
       U4 stage[2][2];
       int colOff[2];
@@ -269,10 +273,16 @@ void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d
                         const int32_t* d_umax, int nFrames, void* d_kpOut, uint8_t* d_descOut,
                         int32_t* d_nOut) {
   if (nFrames <= 0 || a.kpSlotsPerFrame <= 0) return;
-  const int blocksPerFrame = (a.kpSlotsPerFrame + kKpPerBlock - 1) / kKpPerBlock;
+  const bool latencyForm = nFrames <= 8;
+  const int kpb = latencyForm ? 16 : 64;
+  const int blocksPerFrame = (a.kpSlotsPerFrame + kpb - 1) / kpb;
   const unsigned total = (unsigned)blocksPerFrame * (unsigned)nFrames;
-  hipLaunchKernelGGL(k_orient_desc, dim3((total + 7u) / 8u * 8u), dim3(256), 0, s, a, d_levelKp, d_levelCount,
-                     d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames);
+  if (latencyForm)
+    hipLaunchKernelGGL(k_orient_desc<16>, dim3((total + 7u) / 8u * 8u), dim3(256), 0, s, a, d_levelKp, d_levelCount,
+                       d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames);
+  else
+    hipLaunchKernelGGL(k_orient_desc<64>, dim3((total + 7u) / 8u * 8u), dim3(256), 0, s, a, d_levelKp, d_levelCount,
+                       d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames);
 }
 
 // Weight/mask bytes of a 16-pixel half row of the orientation disc, for every half-width d:
