@@ -335,14 +335,16 @@ __global__ __launch_bounds__(256) void k_gather_candidates(const CellDesc* __res
     __syncthreads();
   }
   if (tid == 0) candCount[(size_t)f * nlevels + l] = run;
-  // one thread per cell: most cells hold a handful of candidates, so the copies run in parallel
-  // instead of a latency-bound walk over the cells
+  // four threads per cell: most cells hold a handful of candidates, so the copies run in parallel
+  // (and each thread's chain of dependent copies is short) instead of a walk over the cells
+  // (pre[] of other threads is visible: every scan round ends with a barrier)
   const Candidate* sl = slots + (size_t)f * slotsPerFrame;
   Candidate* out = cand + (size_t)f * slotsPerFrame + g.slotStart;
-  for (int c = tid; c < g.nCells; c += 256) {
+  for (int t = tid; t < 4 * g.nCells; t += 256) {
+    const int c = t >> 2, part = t & 3;
     const int n = cnt[c], b = pre[c];
     const Candidate* src = sl + cells[g.cellStart + c].slotBase;
-    for (int i = 0; i < n; i++) out[b + i] = src[i];
+    for (int i = part; i < n; i += 4) out[b + i] = src[i];
   }
 }
 
