@@ -100,7 +100,9 @@ class Oracle:
     def extract(self, img: np.ndarray, capacity: int | None = None, want_pyramid=False):
         img = np.ascontiguousarray(img, dtype=np.uint8)
         H, W = img.shape
-        cap = capacity or (self.e.nfeatures * 2 + 64)
+        # wide, flat images start the octree with many roots: a level can return 4*nIni keypoints whatever
+        # its quota is, so the bound also covers 4 * ceil(W/H) per level
+        cap = capacity or (self.e.nfeatures * 2 + 64 + 4 * 8 * (W // max(H - 38, 1) + 2))
         kps = np.zeros(cap, dtype=KP_DTYPE)
         desc = np.zeros((cap, 32), dtype=np.uint8)
         n = C.c_int()

@@ -125,6 +125,10 @@ def test_empty_and_errors(amd):
     with pytest.raises(amd.OrbfeError) as ei:
         e(synth.render_frame(1), capacity=10)
     assert ei.value.code == -2
+    # documented limit: a level's octree node list must fit in LDS (<= ~2890 keypoints per level)
+    with pytest.raises(amd.OrbfeError) as ei:
+        amd.ORBextractor(3000, 1.3, 1, 20, 7)(synth.render_frame(2, 320, 240))
+    assert ei.value.code == -1 and "LDS" in str(ei.value)
 
 
 def test_tables_match_oracle(amd):

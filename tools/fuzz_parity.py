@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Randomised differential test of the whole extractor against the CPU oracle: random image sizes,
+extractor parameters and image content (rendered shapes, noise, blends, gradients, blocky textures).
+    python tools/fuzz_parity.py [seconds] [seed]
+Exits non-zero on the first mismatch and prints the failing configuration."""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import oracle_lib as orc  # noqa: E402
+import orb_slam2_annotate_amd as amd  # noqa: E402
+from orb_slam2_annotate_amd import synth  # noqa: E402
+
+
+def content(rng, w, h):
+    kind = rng.integers(0, 6)
+    if kind == 0:
+        return synth.render_frame(int(rng.integers(1 << 30)), w, h, n_shapes=int(rng.integers(5, 400)))
+    if kind == 1:
+        return rng.integers(0, 256, (h, w), dtype=np.uint8)
+    if kind == 2:  # shapes + noise
+        a = synth.render_frame(int(rng.integers(1 << 30)), w, h).astype(np.int16)
+        return np.clip(a + rng.normal(0, rng.uniform(1, 25), (h, w)), 0, 255).astype(np.uint8)
+    if kind == 3:  # blocky texture (many equal scores -> NMS / octree ties)
+        b = int(rng.integers(2, 9))
+        t = rng.integers(0, 256, ((h + b - 1) // b, (w + b - 1) // b), dtype=np.uint8)
+        return np.kron(t, np.ones((b, b), np.uint8))[:h, :w].copy()
+    if kind == 4:  # low-contrast gradient with sparse impulses (threshold fallback cells)
+        y, x = np.mgrid[0:h, 0:w]
+        a = ((x * 0.11 + y * 0.07) % 256).astype(np.int16)
+        m = rng.random((h, w)) < 0.002
+        a[m] += rng.integers(8, 60, m.sum())
+        return np.clip(a, 0, 255).astype(np.uint8)
+    a = np.full((h, w), int(rng.integers(0, 256)), np.uint8)  # near-constant
+    a[rng.random((h, w)) < 0.0005] = int(rng.integers(0, 256))
+    return a
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    n = 0
+    skipped = 0
+    while time.time() - t0 < seconds:
+        w, h = int(rng.integers(64, 900)), int(rng.integers(64, 700))
+        if rng.random() < 0.2:
+            w, h = [(640, 480), (752, 480), (1241, 376), (320, 240)][rng.integers(0, 4)]
+        params = (int(rng.choice([100, 500, 1000, 2000, 3000])), float(rng.choice([1.1, 1.2, 1.3, 1.5])),
+                  int(rng.integers(1, 9)), int(rng.choice([20, 30, 12, 7])), int(rng.choice([7, 5, 10, 3])))
+        img = content(rng, w, h)
+        try:
+            o = orc.Oracle(*params)
+            e = amd.ORBextractor(*params)
+            kr, dr = o.extract(img)
+            kg, dg = e(img)
+            ok = len(kr) == len(kg) and np.array_equal(dr, dg) and all(
+                np.array_equal(kr[f], kg[f]) for f in ("x", "y", "size", "angle", "response", "octave"))
+        except amd.OrbfeError as ex:
+            if "does not fit in LDS" in str(ex):  # documented limit: per-level quota <= ~2890 keypoints
+                skipped += 1
+                continue
+            print("EXCEPTION", ex)
+            ok = False
+        except Exception as ex:  # noqa: BLE001
+            print("EXCEPTION", type(ex).__name__, ex)
+            ok = False
+        if not ok:
+            print(f"MISMATCH seed={seed} case={n} size={w}x{h} params={params}")
+            np.save(ROOT / "gpurun_out" / f"fuzz_fail_{seed}_{n}.npy", img)
+            sys.exit(1)
+        n += 1
+    print(f"fuzz_parity: {n} random cases bit-exact in {time.time() - t0:.0f} s (seed {seed}; {skipped} beyond the octree LDS limit skipped)")
+
+
+if __name__ == "__main__":
+    main()
