@@ -16,14 +16,20 @@ from collections import defaultdict
 from pathlib import Path
 
 
+def kname(full):
+    """orbfe::k_x(args) / void orbfe::k_y<64>(args) -> k_x / k_y"""
+    n = full.split("(")[0].replace("void ", "").replace("orbfe::", "")
+    return n.split("<")[0]
+
+
 def per_kernel(dirname, counter):
     files = glob.glob(f"{dirname}/*/*counter_collection.csv")
     if not files:
         raise SystemExit(f"no counter_collection.csv under {dirname}")
     acc = defaultdict(list)
-    for r in csv.DictReader(open(files[0])):
+    for r in csv.DictReader(open(max(files, key=lambda f: __import__('os').path.getmtime(f)))):
         if r["Counter_Name"] == counter and "orbfe::" in r["Kernel_Name"]:
-            acc[r["Kernel_Name"].split("(")[0].replace("orbfe::", "")].append(float(r["Counter_Value"]))
+            acc[kname(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 

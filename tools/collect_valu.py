@@ -16,15 +16,21 @@ from pathlib import Path
 LAUNCHES_PER_STEP = {"k_resize_flat": 7, "k_resize": 7}
 
 
+def kname(full):
+    """orbfe::k_x(args) / void orbfe::k_y<64>(args) -> k_x / k_y"""
+    n = full.split("(")[0].replace("void ", "").replace("orbfe::", "")
+    return n.split("<")[0]
+
+
 def main():
     d, out, batch, workload = sys.argv[1:5]
     files = glob.glob(f"{d}/*/*counter_collection.csv")
     if not files:
         raise SystemExit(f"no counter_collection.csv under {d}")
     acc = defaultdict(lambda: defaultdict(list))
-    for r in csv.DictReader(open(files[0])):
+    for r in csv.DictReader(open(max(files, key=lambda f: __import__('os').path.getmtime(f)))):
         if "orbfe::" in r["Kernel_Name"]:
-            acc[r["Kernel_Name"].split("(")[0].replace("orbfe::", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            acc[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     res = {"batch": int(batch), "workload": workload,
            "unit": "VALU wave64 instructions (SQ_INSTS_VALU) per frame; issue peak = 256 CU x 4 SIMD x 2.4 GHz / 4 cycles",
            "kernels": {}}
