@@ -121,13 +121,9 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
           if ((lv.pitch & 3) == 0) {
             mis[u] = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3);
             const uint32_t* al = reinterpret_cast<const uint32_t*>(p - mis[u]);
-#if defined(DESC_ABLATE) && (DESC_ABLATE & 2)
-            dw[u][0] = mis[u] + (uint32_t)(uintptr_t)al; dw[u][1] = dw[u][0] * 3; dw[u][2] = dw[u][0] * 5; dw[u][3] = dw[u][0] * 7;
-#else
             const U4 q = *reinterpret_cast<const U4*>(al);  // one 16-byte request instead of four
             dw[u][0] = q.x; dw[u][1] = q.y; dw[u][2] = q.z; dw[u][3] = q.w;
             dw[u][4] = mis[u] ? al[4] : 0u;
-#endif
           } else {
 #pragma unroll
             for (int k = 0; k < 4; k++)
