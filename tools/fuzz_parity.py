@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised differential test of the whole extractor against the CPU oracle: random image sizes,
 extractor parameters and image content (rendered shapes, noise, blends, gradients, blocky textures).
-    python tools/fuzz_parity.py [seconds] [seed]
+    python tools/fuzz_parity.py [seconds] [seed] [batch]
+With a third argument every case is a BATCH of 9..24 frames on 1..8 sub-batch streams (the throughput
+kernels: global-memory octree, 64-keypoint descriptor workgroups, multi-copy D2H).
 Exits non-zero on the first mismatch and prints the failing configuration."""
 import sys
 import time
@@ -44,6 +46,7 @@ def content(rng, w, h):
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    batch_mode = len(sys.argv) > 3
     rng = np.random.default_rng(seed)
     t0 = time.time()
     n = 0
@@ -58,10 +61,23 @@ def main():
         try:
             o = orc.Oracle(*params)
             e = amd.ORBextractor(*params)
-            kr, dr = o.extract(img)
-            kg, dg = e(img)
-            ok = len(kr) == len(kg) and np.array_equal(dr, dg) and all(
-                np.array_equal(kr[f], kg[f]) for f in ("x", "y", "size", "angle", "response", "octave"))
+            if batch_mode:
+                w, h = min(w, 500), min(h, 400)
+                imgs = np.stack([content(rng, w, h) for _ in range(int(rng.integers(9, 25)))])
+                img = imgs[0]
+                e.set_streams(int(rng.integers(1, 9)))
+                res = e.extract_batch(imgs)
+                ok = True
+                for i in range(len(imgs)):
+                    kr, dr = o.extract(imgs[i])
+                    kg, dg = res[i]
+                    ok = ok and len(kr) == len(kg) and np.array_equal(dr, dg) and all(
+                        np.array_equal(kr[f], kg[f]) for f in ("x", "y", "size", "angle", "response", "octave"))
+            else:
+                kr, dr = o.extract(img)
+                kg, dg = e(img)
+                ok = len(kr) == len(kg) and np.array_equal(dr, dg) and all(
+                    np.array_equal(kr[f], kg[f]) for f in ("x", "y", "size", "angle", "response", "octave"))
         except amd.OrbfeError as ex:
             if "does not fit in LDS" in str(ex):  # documented limit: per-level quota <= ~2890 keypoints
                 skipped += 1
