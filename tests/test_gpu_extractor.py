@@ -215,3 +215,44 @@ def test_noise_fullsize_stresses_cell_capacity(amd):
     img = np.zeros((480, 640), np.uint8)
     img[::2, ::2] = 255  # isolated bright pixels on a 2-px lattice: maximal NMS-survivor density
     _check_frame(amd, img, (1000, 1.2, 8, 20, 7))
+
+
+def test_full_size_device_batch_properties(amd):
+    """BASELINE configs[1] shape at batch scale (device-resident, 4 streams, asynchronous): size-independent
+    properties for every frame, and equality with the oracle-checked single-frame path for a sample."""
+    torch = pytest.importorskip("torch")
+    B, w, h = 96, 640, 480
+    imgs = np.stack(synth.render_sequence(500, B, w, h, step=1.5))
+    e = amd.ORBextractor(1000, 1.2, 8, 20, 7)
+    e.set_streams(4)
+    cap = e.max_keypoints()
+    dev = torch.device("cuda", 0)
+    d_img = torch.from_numpy(imgs).to(dev)
+    d_kp = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros((B,), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for _ in range(2):  # second pass: workspace reuse, asynchronous entry point
+        e.extract_batch_device(d_img.data_ptr(), B, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(), cap,
+                               d_n.data_ptr(), wait=False)
+    e.synchronize()
+    n = d_n.cpu().numpy()
+    kp = d_kp.cpu().numpy()
+    desc = d_desc.cpu().numpy()
+    sf = np.array(e.GetScaleFactors(), np.float32)
+    assert (n > 800).all() and (n <= cap).all()
+    for f in range(B):
+        k = kp[f, :n[f]]
+        octv = k[:, 5].view(np.int32)
+        assert (np.diff(octv) >= 0).all() and octv.min() >= 0 and octv.max() <= 7   # level-major output order
+        assert (k[:, 6].view(np.int32) == -1).all()                                  # class_id
+        assert (k[:, 0] >= 19 * 0.99).all() and (k[:, 0] < w).all() and (k[:, 1] >= 19 * 0.99).all() and (k[:, 1] < h).all()
+        assert np.array_equal(k[:, 2], np.floor(31 * sf[octv]))                      # size = (int)(31 * scale)
+        assert (k[:, 3] >= 0).all() and (k[:, 3] < 360).all()                        # fastAtan2 range
+        assert (k[:, 4] >= 7).all() and (k[:, 4] <= 255).all()                       # FAST response >= minThFAST
+    single = amd.ORBextractor(1000, 1.2, 8, 20, 7)
+    for f in (0, 1, 31, 32, 47, 64, 95):
+        ks, ds = single(imgs[f])
+        assert len(ks) == n[f]
+        assert np.array_equal(ds, desc[f, :n[f]])
+        assert np.array_equal(np.stack([ks["x"], ks["y"], ks["angle"], ks["response"]], 1), kp[f, :n[f]][:, [0, 1, 3, 4]])
