@@ -238,23 +238,42 @@ void launch_resize(hipStream_t s, LevelView src, LevelViewMut dst, const int32_t
   }
 }
 
-// level 0 = copy of the caller's image (the copyMakeBorder of :1231 without the dead border)
-__global__ __launch_bounds__(256) void k_copy2d(LevelView src, LevelViewMut dst) {
-  const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
-  const int y = blockIdx.y;
-  const int f = blockIdx.z;
-  if (x >= dst.w) return;
-  const uint8_t* S = src.base + (size_t)f * src.frameStride + (size_t)y * src.pitch;
-  uint32_t p = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++)
-    if (x + k < dst.w) p |= (uint32_t)S[x + k] << (8 * k);
-  *reinterpret_cast<uint32_t*>(dst.base + (size_t)f * dst.frameStride + (size_t)y * dst.pitch + x) = p;
+// level 0 = copy of the caller's image (the copyMakeBorder of :1231 without the dead border) into the
+// pitch-aligned slab; used when the caller's rows are not 4-byte aligned (e.g. KITTI's 1241-byte rows),
+// so that every later kernel reads aligned dwords.  A thread moves 16 bytes of one row: five aligned
+// source dwords -> v_alignbyte -> one 16-byte store; threads are numbered row-major over (row, chunk).
+__global__ __launch_bounds__(256) void k_copy2d(LevelView src, LevelViewMut dst, int chunks, uint32_t magic, int total) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int f = blockIdx.y;
+  if (gid >= total) return;
+  const int y = (int)__umulhi((uint32_t)gid, magic);  // gid / chunks
+  const int x = (gid - y * chunks) * 16;
+  const uint8_t* S = src.base + (size_t)f * src.frameStride + (size_t)y * src.pitch + x;
+  uint8_t* D = dst.base + (size_t)f * dst.frameStride + (size_t)y * dst.pitch + x;  // 16-byte aligned: pitch % 64 == 0
+  const int left = dst.w - x;  // bytes of this row still to copy (> 0)
+  uint4 o;
+  if (left >= 16 + 3) {  // the five dwords stay inside the source row
+    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(S) & 3);
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(S - mis);
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3], d4 = mis ? p[4] : 0u;
+    o.x = __builtin_amdgcn_alignbyte(d1, d0, mis);
+    o.y = __builtin_amdgcn_alignbyte(d2, d1, mis);
+    o.z = __builtin_amdgcn_alignbyte(d3, d2, mis);
+    o.w = __builtin_amdgcn_alignbyte(d4, d3, mis);
+  } else {  // row tail: bytes, zero beyond the row
+    uint32_t v[4] = {0u, 0u, 0u, 0u};
+    for (int k = 0; k < 16 && k < left; k++) v[k >> 2] |= (uint32_t)S[k] << (8 * (k & 3));
+    o = make_uint4(v[0], v[1], v[2], v[3]);
+  }
+  *reinterpret_cast<uint4*>(D) = o;
 }
 
 void launch_copy2d(hipStream_t s, LevelView src, LevelViewMut dst, int nFrames) {
-  dim3 grid((dst.w + 1023) / 1024, dst.h, nFrames);
-  hipLaunchKernelGGL(k_copy2d, grid, dim3(256), 0, s, src, dst);
+  if (dst.w <= 0 || dst.h <= 0 || nFrames <= 0) return;
+  const int chunks = (dst.w + 15) / 16;
+  const int total = chunks * dst.h;
+  const uint32_t magic = (uint32_t)((1ULL << 32) / (uint32_t)chunks) + 1u;  // exact for gid * chunks < 2^32
+  hipLaunchKernelGGL(k_copy2d, dim3((unsigned)((total + 255) / 256), nFrames), dim3(256), 0, s, src, dst, chunks, magic, total);
 }
 
 }  // namespace orbfe
