@@ -151,6 +151,8 @@ void free_outputs(orbfe_extractor* e) {
 
 int ensure_geometry(orbfe_extractor* e, int W, int H) {
   if (e->geom.W == W && e->geom.H == H && e->d_lvgeom) return ORBFE_OK;
+  if (W > 8191 || H > 8191)  // 13-bit coordinate fields (spatial slot keys of k_octree), 16-bit elsewhere
+    return fail(ORBFE_ERR_INVALID, "images larger than 8191 x 8191 are not supported");
   free_geometry(e);
   free_workspace(e);
   e->haveLast = false;

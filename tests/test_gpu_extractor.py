@@ -129,6 +129,8 @@ def test_empty_and_errors(amd):
     with pytest.raises(amd.OrbfeError) as ei:
         amd.ORBextractor(3000, 1.3, 1, 20, 7)(synth.render_frame(2, 320, 240))
     assert ei.value.code == -1 and "LDS" in str(ei.value)
+    with pytest.raises(amd.OrbfeError):  # coordinate fields are 13 bits wide
+        e(np.zeros((40, 8200), dtype=np.uint8))
 
 
 def test_tables_match_oracle(amd):
