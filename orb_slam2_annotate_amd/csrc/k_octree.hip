@@ -172,12 +172,29 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
     }
     __syncthreads();
     // B. speculative 4-way histogram of the candidates' keys (DivideNode :531-546)
+    int kbin[kRegCand];  // REG: child counter this candidate voted for in this pass (-1: its node is not split)
     if constexpr (REG) {
+      // four candidates at a time: their node flags and rectangles are requested together, so a pass
+      // is 4 x (one LDS round trip + 4 atomics) instead of 16 dependent round trips
 #pragma unroll
-      for (int j = 0; j < kRegCand; j++) {
-        const int p = (int)knode[j];
-        if (j * 256 + tid < n && inS[p])
-          atomicAdd(&child[4 * p + quadrant(rc[p], (int)(kxy[j] & 0xffffu), (int)(kxy[j] >> 16))], 1);
+      for (int j0 = 0; j0 < kRegCand; j0 += 4) {
+        uint8_t in4[4];
+        Rect r4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int p = (int)knode[j0 + u];
+          in4[u] = inS[p];
+          r4[u] = rc[p];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int j = j0 + u;
+          const int p = (int)knode[j];
+          int bin = -1;
+          if (j * 256 + tid < n && in4[u]) bin = 4 * p + quadrant(r4[u], (int)(kxy[j] & 0xffffu), (int)(kxy[j] >> 16));
+          kbin[j] = bin;
+          if (bin >= 0) atomicAdd(&child[bin], 1);
+        }
       }
     } else {
       for (int k = tid; k < n; k += 256) {
@@ -285,12 +302,23 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
     __syncthreads();
     // F. re-home the keys
     if constexpr (REG) {
+      // a split that the early break cancelled (inS cleared in C) keeps its node; the vote of pass B
+      // already names the child otherwise
 #pragma unroll
-      for (int j = 0; j < kRegCand; j++) {
-        const int p = (int)knode[j];
-        if (j * 256 + tid < n)
-          knode[j] = (uint32_t)(inS[p] ? child[4 * p + quadrant(rc[p], (int)(kxy[j] & 0xffffu), (int)(kxy[j] >> 16))]
-                                       : scanB[p]);
+      for (int j0 = 0; j0 < kRegCand; j0 += 4) {
+        uint8_t in4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) in4[u] = inS[knode[j0 + u]];
+        int v4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int j = j0 + u;
+          const int* srcp = (in4[u] && kbin[j] >= 0) ? &child[kbin[j]] : &scanB[knode[j]];
+          v4[u] = *srcp;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if ((j0 + u) * 256 + tid < n) knode[j0 + u] = (uint32_t)v4[u];
       }
     } else {
       for (int k = tid; k < n; k += 256) {
@@ -346,6 +374,7 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
   for (int p = tid; p < nKp; p += 256) {
     const uint32_t key = skey[p];
     int pos = 0;
+#pragma unroll 8
     for (int q = 0; q < nKp; q++) pos += skey[q] < key;  // keys are distinct (one keypoint per pixel)
     const Candidate c = cand[0xffffffu - ((unsigned)best[p] & 0xffffffu)];
     LevelKp o;
