@@ -221,16 +221,24 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
         for (int t = 0; t < 4; t++) { t0v[u][t] = 0; t1v[u][t] = 0; }
         if (s_out[j] < 0) continue;  // wave-uniform
         const float ca = s_cos[j], sb = s_sin[j];
-        const uint8_t* cb = reinterpret_cast<const uint8_t*>(myPatch + u * kPatchRows * kPatchDw) + 18 * 4 * kPatchDw + colOff[u];
+        const uint8_t* pbytes = reinterpret_cast<const uint8_t*>(s_patch);
+        // cvRound by the magic-number add: for |v| < 2^22, float(v + 1.5*2^23) has the bit pattern
+        // 0x4B400000 + RNE(v) (round-half-even, like cvRound; 1.5*2^23 is even).  Row and column are left
+        // biased and the bias of row*48 + col (0x4B400000 * 49 mod 2^32) is folded into the base offset.
+        constexpr float kMagic = 12582912.0f;
+        constexpr uint32_t kBias = 0x4B400000u * 49u;
+        const uint32_t baseK = (uint32_t)((wave * 2 + u) * kPatchRows * kPatchDw * 4 + 18 * 4 * kPatchDw + colOff[u]) - kBias;
         const f32x2 ba = {sb, ca}, ab = {ca, sb};
 #pragma unroll
         for (int t = 0; t < 4; t++) {
           const f32x2 p0 = {P[t].x, P[t].y}, p1 = {P[t].z, P[t].w};
           const f32x2 r0 = p0 * ba, c0 = p0 * ab, r1 = p1 * ba, c1 = p1 * ab;  // (x*b, y*a), (x*a, y*b)
-          const int rr0 = cv_round(__fadd_rn(r0.x, r0.y)), cc0 = cv_round(__fsub_rn(c0.x, c0.y));
-          const int rr1 = cv_round(__fadd_rn(r1.x, r1.y)), cc1 = cv_round(__fsub_rn(c1.x, c1.y));
-          t0v[u][t] = cb[rr0 * (4 * kPatchDw) + cc0];
-          t1v[u][t] = cb[rr1 * (4 * kPatchDw) + cc1];
+          const uint32_t ir0 = __float_as_uint(__fadd_rn(__fadd_rn(r0.x, r0.y), kMagic));
+          const uint32_t ic0 = __float_as_uint(__fadd_rn(__fsub_rn(c0.x, c0.y), kMagic));
+          const uint32_t ir1 = __float_as_uint(__fadd_rn(__fadd_rn(r1.x, r1.y), kMagic));
+          const uint32_t ic1 = __float_as_uint(__fadd_rn(__fsub_rn(c1.x, c1.y), kMagic));
+          t0v[u][t] = pbytes[baseK + ir0 * (4u * kPatchDw) + ic0];
+          t1v[u][t] = pbytes[baseK + ir1 * (4u * kPatchDw) + ic1];
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
