@@ -211,27 +211,30 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
         const int px = e & 255, py = e >> 8;
         const uint8_t* c = tb + (py + 3) * P + 4 + px;
         const int v = c[0];
-        int d[16];
+        // cornerScore on the raw ring values: min over an arc of (v - r) is v - max over the arc of r, so the
+        // sliding windows run on r itself and the centre enters twice at the end instead of 16 times up front:
+        //   S = max( v - min_k max9_k(r),  max_k min9_k(r) - v )
+        int r[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) d[k] = v - (int)c[kRingDx[k] + kRingDy[k] * P];
-        int lo3[16], hi3[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-          lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-          hi3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-        }
-        int lo9[16], hi9[16];
+        for (int k = 0; k < 16; k++) r[k] = (int)c[kRingDx[k] + kRingDy[k] * P];
+        int mx3[16], mn3[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-          lo9[k] = min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
-          hi9[k] = max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
+          mx3[k] = max3i(r[k], r[(k + 1) & 15], r[(k + 2) & 15]);
+          mn3[k] = min3i(r[k], r[(k + 1) & 15], r[(k + 2) & 15]);
         }
-        int sd = max3i(lo9[0], lo9[1], lo9[2]), sb = min3i(hi9[0], hi9[1], hi9[2]);
+        int mx9[16], mn9[16];
 #pragma unroll
-        for (int k = 3; k < 15; k += 2) { sd = max3i(sd, lo9[k], lo9[k + 1]); sb = min3i(sb, hi9[k], hi9[k + 1]); }
-        sd = max(sd, lo9[15]);
-        sb = min(sb, hi9[15]);
-        S = max(sd, -sb);
+        for (int k = 0; k < 16; k++) {
+          mx9[k] = max3i(mx3[k], mx3[(k + 3) & 15], mx3[(k + 6) & 15]);
+          mn9[k] = min3i(mn3[k], mn3[(k + 3) & 15], mn3[(k + 6) & 15]);
+        }
+        int darkest = min3i(mx9[0], mx9[1], mx9[2]), brightest = max3i(mn9[0], mn9[1], mn9[2]);
+#pragma unroll
+        for (int k = 3; k < 15; k += 2) { darkest = min3i(darkest, mx9[k], mx9[k + 1]); brightest = max3i(brightest, mn9[k], mn9[k + 1]); }
+        darkest = min(darkest, mx9[15]);
+        brightest = max(brightest, mn9[15]);
+        S = max(v - darkest, brightest - v);
         isCorner = S > tlo;
       }
       const unsigned long long bal = __ballot(isCorner);
