@@ -58,8 +58,8 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b)
 //      ADJACENT cardinal ring points (0,4,8,12), so a corner needs (c0|c8)&(c4|c12) in one
 //      polarity.  ~19 % of pixels pass; they are appended to an LDS work list IN RASTER ORDER
 //      (ballot prefix).
-//   B. exact cv::FAST response S-1 for the listed pixels, one pixel per lane (dense lanes); the
-//      list shrinks in place to the corners.
+//   B. exact cv::FAST response S-1 for the listed pixels, one pixel per lane (dense lanes), sliding
+//      min/max windows on the raw ring values; the list shrinks in place to the corners.
 //   C. cell-local 3x3 strict NMS of the corners (one lane per corner) + threshold classes.
 //   D. per-cell 20->7 fallback, then ordered compaction of the survivors = emission order.
 // Dynamic LDS: tile [tileRows][24 dw] | score [scoreRows][24 dw] | queue [queueLen] u16, sized by
