@@ -170,12 +170,11 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
             const s16x2 rE = as_s2(__builtin_amdgcn_perm(m2, m1, sel2(3 + st)));  // ring 4  (+3,0)
             const s16x2 rN = as_s2(__builtin_amdgcn_perm(up, up, sel2(st)));      // ring 8  (0,-3)
             const s16x2 rW = as_s2(__builtin_amdgcn_perm(m1, m0, sel2(1 + st)));  // ring 12 (-3,0)
-            // sign bit set <=> ring value x darker than v-t:  (t - v) + x < 0;  brighter than v+t: (v + t) - x < 0
-            // both axes hold a dark point <=> max(min(S,N), min(E,W)) < v-t; bright: min(max, max) > v+t
-            const s16x2 lo = T - c, hi = c + T;
+            // both axes hold a dark point <=> mD = max(min(S,N), min(E,W)) < v-t; bright: mB = min(max, max) > v+t;
+            // either <=> max(v - mD, mB - v) > t <=> sign bit of t - max(...)
             const s16x2 mD = pk_max(pk_min(rS, rN), pk_min(rE, rW));
             const s16x2 mB = pk_min(pk_max(rS, rN), pk_max(rE, rW));
-            const uint32_t p = as_u(lo + mD) | as_u(hi - mB);
+            const uint32_t p = as_u(T - pk_max(c - mD, mB - c));
             pass |= (((p >> 15) & 1u) | ((p >> 29) & 4u)) << (st + 4 * hh);
           }
         }
