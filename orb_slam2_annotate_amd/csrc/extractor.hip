@@ -507,7 +507,14 @@ extern "C" int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlev
         if (err == hipSuccess) err = hipEventCreate(&e->evB[r][u][i]);
       }
   float patF[1024];
-  for (int i = 0; i < 1024; i++) patF[i] = (float)kOrbBitPattern31[i];
+  // test i = (x0, y0, x1, y1) in the table; uploaded as (x0, x1, y0, y1) so that k_orient_desc rotates the
+  // two points of a test in one packed-fp32 operation per product
+  for (int i = 0; i < 256; i++) {
+    patF[4 * i + 0] = (float)kOrbBitPattern31[4 * i + 0];
+    patF[4 * i + 1] = (float)kOrbBitPattern31[4 * i + 2];
+    patF[4 * i + 2] = (float)kOrbBitPattern31[4 * i + 1];
+    patF[4 * i + 3] = (float)kOrbBitPattern31[4 * i + 3];
+  }
   uint8_t momTab[1024];
   build_moment_table(momTab);
   if (err == hipSuccess) err = hipMalloc((void**)&e->d_patternF, sizeof(patF));

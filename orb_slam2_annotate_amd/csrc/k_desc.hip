@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
   {
     float4 P[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) P[j] = patternF[lane + 64 * j];  // (x0,y0,x1,y1) of test lane+64j
+    for (int j = 0; j < 4; j++) P[j] = patternF[lane + 64 * j];  // (x0,x1,y0,y1) of test lane+64j
     // two keypoints per iteration.  Their blurred patches are staged in LDS with 16-byte requests
     // (3 lanes per row: 111 lanes = 2 instructions per keypoint, each patch line touched once) and
     // the 512 samples are LDS byte reads; sampling global memory directly cost one L1 line lookup
@@ -195,28 +195,30 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
     for (int j0 = wave * kKpPerWave3; j0 < wave * kKpPerWave3 + kKpPerWave3; j0 += 2) {
       int t0v[2][4], t1v[2][4];
       U4 stage[2][2];
-      int colOff[2];
+      int colOff[2], kout[2];  // per-keypoint values are wave-uniform: scalar registers, scalar branches
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const int j = j0 + u;
         colOff[u] = 0;
-#pragma unroll
-        for (int h = 0; h < 2; h++) stage[u][h] = U4{0u, 0u, 0u, 0u};
-        if (s_out[j] < 0) continue;  // wave-uniform
-        const LevelView bl = a.blur.lv[s_level[j]];
-        int ws = (s_x[j] - 18) & ~3;
+        kout[u] = __builtin_amdgcn_readfirstlane(s_out[j]);
+        if (kout[u] < 0) continue;
+        const int kl = __builtin_amdgcn_readfirstlane(s_level[j]);
+        const int kx = __builtin_amdgcn_readfirstlane(s_x[j]), ky = __builtin_amdgcn_readfirstlane(s_y[j]);
+        const LevelView bl = a.blur.lv[kl];
+        int ws = (kx - 18) & ~3;
         if (ws > bl.pitch - 4 * kPatchDw) ws = bl.pitch - 4 * kPatchDw;  // stay inside the row pitch
-        colOff[u] = s_x[j] - ws;
-        const uint8_t* pb = bl.base + (size_t)f * bl.frameStride + (size_t)(s_y[j] - 18) * bl.pitch + ws;
+        colOff[u] = kx - ws;
+        const uint8_t* pb = bl.base + (size_t)f * bl.frameStride + (size_t)(ky - 18) * bl.pitch + ws;  // scalar
 #pragma unroll
         for (int h = 0; h < 2; h++) {
           const int idx = lane + 64 * h;
           const int row = (idx * 43) >> 7, part = idx - 3 * row;  // idx / 3 for idx < 128
-          if (idx < 3 * kPatchRows) stage[u][h] = *reinterpret_cast<const U4*>(pb + (size_t)row * bl.pitch + 16 * part);
+          if (idx < 3 * kPatchRows) stage[u][h] = *reinterpret_cast<const U4*>(pb + (uint32_t)(row * bl.pitch + 16 * part));
         }
       }
 #pragma unroll
-      for (int u = 0; u < 2; u++)
+      for (int u = 0; u < 2; u++) {
+        if (kout[u] < 0) continue;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
           const int idx = lane + 64 * h;
@@ -224,15 +226,14 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
             *reinterpret_cast<uint4*>(&myPatch[u * kPatchRows * kPatchDw + 4 * idx]) =
                 make_uint4(stage[u][h].x, stage[u][h].y, stage[u][h].z, stage[u][h].w);
         }
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const int j = j0 + u;
-#pragma unroll
-        for (int t = 0; t < 4; t++) { t0v[u][t] = 0; t1v[u][t] = 0; }
-        if (s_out[j] < 0) continue;  // wave-uniform
+        if (kout[u] < 0) continue;
         const float ca = s_cos[j], sb = s_sin[j];
         const uint8_t* pbytes = reinterpret_cast<const uint8_t*>(s_patch);
         // cvRound by the magic-number add: for |v| < 2^22, float(v + 1.5*2^23) has the bit pattern
@@ -241,15 +242,16 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
         constexpr float kMagic = 12582912.0f;
         constexpr uint32_t kBias = 0x4B400000u * 49u;
         const uint32_t baseK = (uint32_t)((wave * 2 + u) * kPatchRows * kPatchDw * 4 + 18 * 4 * kPatchDw + colOff[u]) - kBias;
-        const f32x2 ba = {sb, ca}, ab = {ca, sb};
+        // both points of a test at once (packed fp32, no FMA): row = x*b + y*a, col = x*a - y*b
+        // (src/ORBextractor.cc:123-125 with a = cos, b = sin), P[t] = (x0, x1, y0, y1)
+        const f32x2 aa = {ca, ca}, bb = {sb, sb}, mm = {kMagic, kMagic};
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-          const f32x2 p0 = {P[t].x, P[t].y}, p1 = {P[t].z, P[t].w};
-          const f32x2 r0 = p0 * ba, c0 = p0 * ab, r1 = p1 * ba, c1 = p1 * ab;  // (x*b, y*a), (x*a, y*b)
-          const uint32_t ir0 = __float_as_uint(__fadd_rn(__fadd_rn(r0.x, r0.y), kMagic));
-          const uint32_t ic0 = __float_as_uint(__fadd_rn(__fsub_rn(c0.x, c0.y), kMagic));
-          const uint32_t ir1 = __float_as_uint(__fadd_rn(__fadd_rn(r1.x, r1.y), kMagic));
-          const uint32_t ic1 = __float_as_uint(__fadd_rn(__fsub_rn(c1.x, c1.y), kMagic));
+          const f32x2 X = {P[t].x, P[t].y}, Y = {P[t].z, P[t].w};
+          const f32x2 R = (X * bb + Y * aa) + mm;
+          const f32x2 Cc = (X * aa - Y * bb) + mm;
+          const uint32_t ir0 = __float_as_uint(R.x), ir1 = __float_as_uint(R.y);
+          const uint32_t ic0 = __float_as_uint(Cc.x), ic1 = __float_as_uint(Cc.y);
           t0v[u][t] = pbytes[baseK + ir0 * (4u * kPatchDw) + ic0];
           t1v[u][t] = pbytes[baseK + ir1 * (4u * kPatchDw) + ic1];
         }
@@ -259,8 +261,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const int j = j0 + u;
-        const int outIdx = s_out[j];
-        if (outIdx < 0) continue;  // wave-uniform
+        const int outIdx = kout[u];
+        if (outIdx < 0) continue;
         unsigned long long* dout = reinterpret_cast<unsigned long long*>(
             descOut + ((size_t)f * a.outCapacity + outIdx) * 32);
 #pragma unroll
