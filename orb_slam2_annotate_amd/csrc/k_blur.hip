@@ -75,10 +75,11 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
     const int ty0 = (int)(((uint32_t)tid * 3641u) >> 16), tj = tid - ty0 * kTDW;  // tid / 18 for tid < 252
     if (aligned && bx >= 4 && bx + kBW + 4 <= src.w && by >= 3 && by + kBH + 3 <= src.h) {
       // interior tile (block-uniform): no reflection, every dword is an aligned in-row load
-      const uint8_t* T = S + (size_t)(by - 3 + ty0) * src.pitch + (bx - 4) + 4 * tj;
+      const uint8_t* T0 = S + (size_t)(by - 3) * src.pitch + (bx - 4);     // block-uniform (scalar) tile origin
+      const uint32_t o0 = (uint32_t)ty0 * (uint32_t)src.pitch + 4u * (uint32_t)tj;  // 32-bit lane offset
 #pragma unroll
       for (int k = 0; k < 5; k++)
-        tin[(ty0 + 14 * k) * kTDW + tj] = *reinterpret_cast<const uint32_t*>(T + (size_t)(14 * k) * src.pitch);
+        tin[(ty0 + 14 * k) * kTDW + tj] = *reinterpret_cast<const uint32_t*>(T0 + (o0 + (uint32_t)(14 * k) * (uint32_t)src.pitch));
     } else {
       const int c = bx - 4 + 4 * tj;
       const bool inRow = (src.pitch & 3) == 0 && c >= 0 && c + 3 < src.w;
@@ -136,11 +137,15 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   }
   __syncthreads();
   // ---- 3. horizontal pass on u16 pairs: out[x] = (sum_i K[i] * v[x+4+i-3] + 2^15) >> 16 ----
+  // thread = (row mod 16, column group): the tile origin D is block-uniform (scalar), the thread keeps a
+  // 32-bit byte offset and an LDS pointer and steps both by 16 rows per iteration
   uint8_t* D = dst.base + (size_t)f * dst.frameStride + (size_t)by * dst.pitch + bx;
-  for (int i = tid; i < rowsValid * (kBW / 4); i += 256) {
-    const int row = i >> 4, gx = i & 15;
-    if (bx + 4 * gx >= dst.w) continue;
-    const uint2* vp = &vbuf[row * kTDW + gx];
+  const int gx = tid & 15;
+  uint32_t off = (uint32_t)(tid >> 4) * (uint32_t)dst.pitch + 4u * (uint32_t)gx;
+  const uint2* vp = &vbuf[(tid >> 4) * kTDW + gx];
+  const bool colIn = bx + 4 * gx < dst.w;
+  for (int row = tid >> 4; row < rowsValid; row += 16, off += 16u * (uint32_t)dst.pitch, vp += 16 * kTDW) {
+    if (!colIn) continue;
     const uint2 e0 = vp[0], e1 = vp[1], e2 = vp[2];
     // d_k = (v'[2k], v'[2k+1]) with v' indexed from tile column 4*gx
     const uint32_t d0 = e0.x, d1 = e0.y, d2 = e1.x, d3 = e1.y, d4 = e2.x, d5 = e2.y;
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
     // the rounded sums are < 2^24: byte 2 of each is the result; two v_perm gather them
     const uint32_t lo = __builtin_amdgcn_perm(o1, o0, 0x0c0c0602u);   // (o0.b2, o1.b2, 0, 0)
     const uint32_t hi = __builtin_amdgcn_perm(o3, o2, 0x06020c0cu);   // (0, 0, o2.b2, o3.b2)
-    *reinterpret_cast<uint32_t*>(D + (size_t)row * dst.pitch + 4 * gx) = lo | hi;
+    *reinterpret_cast<uint32_t*>(D + off) = lo | hi;
   }
 }
 
