@@ -80,6 +80,14 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
 #pragma unroll
       for (int k = 0; k < 5; k++)
         tin[(ty0 + 14 * k) * kTDW + tj] = *reinterpret_cast<const uint32_t*>(T0 + (o0 + (uint32_t)(14 * k) * (uint32_t)src.pitch));
+    } else if (aligned && bx >= 4 && bx + kBW + 4 <= src.w) {
+      // top / bottom tile away from the left and right edges: every dword is still an aligned in-row
+      // load, only the row index is reflected
+      const uint32_t c0 = (uint32_t)(bx - 4) + 4u * (uint32_t)tj;
+      for (int ty = ty0; ty < stageRows; ty += 14) {
+        const int sy = reflect101c(by - 3 + ty, src.h);
+        tin[ty * kTDW + tj] = *reinterpret_cast<const uint32_t*>(S + ((uint32_t)sy * (uint32_t)src.pitch + c0));
+      }
     } else {
       const int c = bx - 4 + 4 * tj;
       const bool inRow = (src.pitch & 3) == 0 && c >= 0 && c + 3 < src.w;
