@@ -296,11 +296,16 @@ void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d
   const int kpb = latencyForm ? 16 : 64;
   const int blocksPerFrame = (a.kpSlotsPerFrame + kpb - 1) / kpb;
   const unsigned total = (unsigned)blocksPerFrame * (unsigned)nFrames;
+  // Occupancy cap for the throughput form: 23 KB of unused dynamic LDS leave room for 4 workgroups per CU
+  // instead of 9.  All workgroups of a frame run on one XCD; with fewer frames in flight per XCD their
+  // patches stay in its 4 MB L2 (HBM fetch 1.17 -> 0.63 GB per 256 frames) -- same-box A/B over the
+  // whole pipeline: 291 k -> 303 k frames/s; 3 workgroups per CU measured the same, 2 and 5+ worse.
+  constexpr size_t kPad = 23 * 1024;
   if (latencyForm)
     hipLaunchKernelGGL(k_orient_desc<16>, dim3((total + 7u) / 8u * 8u), dim3(256), 0, s, a, d_levelKp, d_levelCount,
                        d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames);
   else
-    hipLaunchKernelGGL(k_orient_desc<64>, dim3((total + 7u) / 8u * 8u), dim3(256), 0, s, a, d_levelKp, d_levelCount,
+    hipLaunchKernelGGL(k_orient_desc<64>, dim3((total + 7u) / 8u * 8u), dim3(256), kPad, s, a, d_levelKp, d_levelCount,
                        d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames);
 }
 
