@@ -41,6 +41,7 @@ struct BlurBatch {
   LevelViewMut dst[kMaxLevels];
   int tilesX[kMaxLevels], tilesY[kMaxLevels];
   unsigned tileStart[kMaxLevels + 1];  // in units of (tile, frame) work items
+  uint32_t perFrameMagic[kMaxLevels], tilesXMagic[kMaxLevels];  // udiv_magic multipliers
   int nlevels, nFrames;
 };
 
@@ -61,9 +62,9 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   const int tilesX = bb.tilesX[l];
   const unsigned perFrame = (unsigned)tilesX * (unsigned)bb.tilesY[l];
   const unsigned w0 = work - bb.tileStart[l];
-  const int f = (int)(w0 / perFrame);
+  const int f = (int)udiv_magic(w0, perFrame, bb.perFrameMagic[l]);          // w0 / perFrame
   const unsigned rem = w0 - (unsigned)f * perFrame;
-  const int tyI = (int)(rem / (unsigned)tilesX);
+  const int tyI = (int)udiv_magic(rem, (uint32_t)tilesX, bb.tilesXMagic[l]);  // rem / tilesX
   const int bx = (int)(rem - (unsigned)tyI * (unsigned)tilesX) * kBW, by = tyI * kBH;
   const int rowsValid = dst.h - by < kBH ? dst.h - by : kBH;  // output rows of this tile inside the level
   const int rowBlocks = (rowsValid + 3) >> 2;                 // 4-row blocks the vertical pass computes
@@ -193,6 +194,9 @@ void launch_blur7_levels(hipStream_t s, const LevelView* src, const LevelViewMut
     bb.tilesX[l] = (dst[l].w + kBW - 1) / kBW;
     bb.tilesY[l] = (dst[l].h + kBH - 1) / kBH;
     bb.tileStart[l] = total;
+    const unsigned perFrame = (unsigned)bb.tilesX[l] * (unsigned)bb.tilesY[l];
+    bb.perFrameMagic[l] = udiv_magic_multiplier(perFrame);
+    bb.tilesXMagic[l] = udiv_magic_multiplier((uint32_t)bb.tilesX[l]);
     total += (unsigned)bb.tilesX[l] * (unsigned)bb.tilesY[l] * (unsigned)nFrames;
   }
   bb.tileStart[nlevels] = total;

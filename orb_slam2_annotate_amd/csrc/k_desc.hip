@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
                                                      float* __restrict__ kpOut,
                                                      uint8_t* __restrict__ descOut,
                                                      int32_t* __restrict__ nOut, int blocksPerFrame,
-                                                     int nFrames) {
+                                                     int nFrames, uint32_t blocksMagic) {
   __shared__ int s_m10[kKpPerBlock], s_m01[kKpPerBlock];
   __shared__ int s_x[kKpPerBlock], s_y[kKpPerBlock], s_level[kKpPerBlock], s_out[kKpPerBlock];
   __shared__ unsigned s_score[kKpPerBlock];
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
   const unsigned chunkW = gridDim.x >> 3;
   const unsigned work = (blockIdx.x & 7u) * chunkW + (blockIdx.x >> 3);
   if (work >= (unsigned)blocksPerFrame * (unsigned)nFrames) return;
-  const int f = (int)(work / (unsigned)blocksPerFrame);
+  const int f = (int)udiv_magic(work, (uint32_t)blocksPerFrame, blocksMagic);  // work / blocksPerFrame
   const int slot0 = (int)(work - (unsigned)f * (unsigned)blocksPerFrame) * kKpPerBlock;
   const int32_t* cnt = levelCount + (size_t)f * a.nlevels;
 
@@ -296,6 +296,7 @@ void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d
   const int kpb = latencyForm ? 16 : 64;
   const int blocksPerFrame = (a.kpSlotsPerFrame + kpb - 1) / kpb;
   const unsigned total = (unsigned)blocksPerFrame * (unsigned)nFrames;
+  const uint32_t blocksMagic = udiv_magic_multiplier((uint32_t)blocksPerFrame);
   // Occupancy cap for the throughput form: 23 KB of unused dynamic LDS leave room for 4 workgroups per CU
   // instead of 9.  All workgroups of a frame run on one XCD; with fewer frames in flight per XCD their
   // patches stay in its 4 MB L2 (HBM fetch 1.17 -> 0.63 GB per 256 frames) -- same-box A/B over the
@@ -303,10 +304,10 @@ void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d
   constexpr size_t kPad = 23 * 1024;
   if (latencyForm)
     hipLaunchKernelGGL(k_orient_desc<16>, dim3((total + 7u) / 8u * 8u), dim3(256), 0, s, a, d_levelKp, d_levelCount,
-                       d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames);
+                       d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic);
   else
     hipLaunchKernelGGL(k_orient_desc<64>, dim3((total + 7u) / 8u * 8u), dim3(256), kPad, s, a, d_levelKp, d_levelCount,
-                       d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames);
+                       d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic);
 }
 
 // Weight/mask bytes of a 16-pixel half row of the orientation disc, for every half-width d:

@@ -23,6 +23,12 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ s16x2 as_s2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
 __device__ __forceinline__ uint32_t as_u(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+// 65536 / d + 1 for d = 1..32 (exact i / d for i < 4096 by multiply-shift) -- a table instead of a
+// run-time division per workgroup
+__constant__ uint32_t kInv16[33] = {0,     65537, 32769, 21846, 16385, 13108, 10923, 9363, 8193, 7282, 6554,
+                                    5958,  5462,  5042,  4682,  4370,  4097,  3856,  3641, 3450, 3277, 3121,
+                                    2979,  2850,  2731,  2622,  2521,  2428,  2341,  2260, 2185, 2115, 2049};
+
 // wave64 inclusive scan in the DPP network (checked on gfx950 by tools/ubench/dpp_scan.hip)
 __device__ __forceinline__ int wave_incl_scan(int x) {
   x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
                                                    Candidate* __restrict__ slots,
                                                    int slotsPerFrame,
                                                    uint16_t* __restrict__ cellCount,
-                                                   int tileRows, int scoreRows) {
+                                                   int tileRows, int scoreRows, uint32_t cellsMagic) {
   extern __shared__ uint32_t lds[];
   uint32_t* tile = lds;                                   // pixels: origin (x0-4, y0-3)
   uint32_t* score = lds + tileRows * kPitchDw;            // FAST responses: origin (x0-4, y0-1)
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
   const unsigned chunk = gridDim.x >> 3;
   const unsigned work = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
   if (work >= (unsigned)nCells * (unsigned)nFrames) return;
-  const int f = (int)(work / (unsigned)nCells);
+  const int f = (int)udiv_magic(work, (uint32_t)nCells, cellsMagic);  // work / nCells
   const int cellId = (int)(work - (unsigned)f * (unsigned)nCells);
   const CellDesc cd = cells[cellId];
   const LevelView lv = pyr.lv[cd.level];
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
   const int ngx = (cw + 3) >> 2;          // 4-pixel groups per row
   const int tdw = ngx + 2;                // tile dwords per row
   // exact i / d for i < 4096 by multiply-shift (divisors <= 17)
-  const uint32_t invT = 65536u / (uint32_t)tdw + 1u;
+  const uint32_t invT = kInv16[tdw];
   const unsigned long long ltMask = (1ull << lane) - 1ull;
   constexpr int P = kPitchDw * 4;         // LDS row pitch in bytes
 
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
       const uint32_t a = (uint32_t)(addr0 & 3);     // same misalignment for every row
       const uint8_t* al = img - a;
       const int parts = (tdw + 3) >> 2;             // 16-byte pieces per tile row (<= 5)
-      const uint32_t invP = 65536u / (uint32_t)parts + 1u;
+      const uint32_t invP = kInv16[parts];
       // bytes of the row still inside the pitch, counted from `al`: never read beyond the level's rows
       const int rowBytes = lv.pitch - ((x0 - 4) - (int)a);
       for (int i = lane; i < th * parts; i += 64) {
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
     const s16x2 T = {(short)tlo, (short)tlo};
     const int ng8 = (cw + 7) >> 3;          // 8-pixel groups per row
     const int ngroups8 = ng8 * ch;
-    const uint32_t invG8 = 65536u / (uint32_t)ng8 + 1u;
+    const uint32_t invG8 = kInv16[ng8];
     for (int g0 = 0; g0 < ngroups8; g0 += 64) {
       const int g = g0 + lane;
       uint32_t pass = 0;
@@ -297,7 +303,8 @@ void launch_fast_cells(hipStream_t s, PyramidViews pyr, const CellDesc* d_cells,
   const int queueLen = (((maxCellW + 3) & ~3) * maxCellH + 1) & ~1;
   const size_t ldsBytes = (size_t)(tileRows + scoreRows) * kPitchDw * 4 + (size_t)queueLen * 2;
   hipLaunchKernelGGL(k_fast_cells, dim3((total + 7u) / 8u * 8u), dim3(64), ldsBytes, s, pyr, d_cells, nCells, nFrames,
-                     iniTh, minTh, d_slots, slotsPerFrame, d_cellCount, tileRows, scoreRows);
+                     iniTh, minTh, d_slots, slotsPerFrame, d_cellCount, tileRows, scoreRows,
+                     udiv_magic_multiplier((uint32_t)nCells));
 }
 
 // Ordered compaction: cells of a level in cell-row-major order, raster inside each cell.

@@ -7,6 +7,20 @@
 
 namespace orbfe {
 
+// n / d for a run-time invariant d with the host-built multiplier M = floor(2^32 / d): the estimate
+// umulhi(n, M) is q or q-1 for EVERY 32-bit n, one compare fixes it (block-uniform operands: scalar ALU).
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t udiv_magic(uint32_t n, uint32_t d, uint32_t M) {
+  uint32_t q = __umulhi(n, M);
+  if (n - q * d >= d) q++;
+  return q;
+}
+#endif
+inline uint32_t udiv_magic_multiplier(uint32_t d) {
+  return d <= 1 ? 0xffffffffu : (uint32_t)((1ULL << 32) / d);  // d = 1: umulhi gives n-1, the compare adds the 1
+}
+
+
 // A pyramid level of a batch of frames in HBM: frame f, row y starts at
 // base + f*frameStride + y*pitch.  Row-major u8, pitch is a multiple of 64 for owned levels.
 struct LevelView {
