@@ -384,27 +384,69 @@ bool frame_ok(const orbfe_frame_view* f) {
   return true;
 }
 
+// Pinned staging of the calling thread: every input array of a call is packed into it and travels in
+// ONE host-to-device copy, counts + candidate lists come back in ONE copy (13 + 2 small transfers of
+// ~7 us each were most of a call before).
+struct Staging {
+  uint8_t* h = nullptr;
+  size_t cap = 0;
+  ~Staging() { if (h) (void)hipHostFree(h); }
+};
+thread_local Staging t_staging;
+
+hipError_t staging_reserve(size_t bytes) {
+  if (bytes <= t_staging.cap) return hipSuccess;
+  if (t_staging.h) (void)hipHostFree(t_staging.h);
+  t_staging.h = nullptr;
+  t_staging.cap = 0;
+  const size_t want = bytes + bytes / 2 + (1u << 16);
+  hipError_t e = hipHostMalloc((void**)&t_staging.h, want, hipHostMallocDefault);
+  if (e == hipSuccess) t_staging.cap = want;
+  return e;
+}
+
 // Upload the frame + queries, build the grid, search every window; grows K until every list fits.
 int window_search(int device, const orbfe_frame_view* f, int nq, const float* qx, const float* qy, const float* qr,
                   const int32_t* qmin, const int32_t* qmax, const uint8_t* qactive, const float* qur,
                   const uint8_t* qdesc, int K0, WindowResult* res) {
   int K = K0 < 8 ? 8 : K0;
+  const size_t n = (size_t)f->n, q = (size_t)nq;
+  const bool withDesc = f->desc && qdesc;
+  const bool withUr = qur && f->u_right;
+  // packed input block: offsets (256-byte aligned) of every array inside it
+  size_t off = 0;
+  auto place = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t oX = place(n * 4), oY = place(n * 4), oOct = place(n * 4);
+  const size_t oUr = f->u_right ? place(n * 4) : 0, oDesc = withDesc ? place(n * 32) : 0;
+  const size_t oQx = place(q * 4), oQy = place(q * 4), oQr = place(q * 4), oQmin = place(q * 4), oQmax = place(q * 4);
+  const size_t oQact = qactive ? place(q) : 0, oQur = withUr ? place(q * 4) : 0, oQdesc = withDesc ? place(q * 32) : 0;
+  const size_t inBytes = off ? off : 256;
   for (;;) {
     Arena* ar;
-    const size_t n = (size_t)f->n, q = (size_t)nq;
-    size_t bytes = 4 * pad(n * 4) + pad(n * 32) + pad(n * 4) + pad(3073 * 4) + 6 * pad(q * 4) + pad(q) + pad(q * 32) +
-                   pad(q * 4) + pad(q * (size_t)K * 4);
-    MHIP(arena_begin(device, bytes, &ar));
+    const size_t outBytes = pad(q * 4) + pad(q * (size_t)K * 4);
+    MHIP(arena_begin(device, pad(inBytes) + pad(n * 4) + pad(3073 * 4) + outBytes + 1024, &ar));
+    MHIP(staging_reserve(inBytes > outBytes ? inBytes : outBytes));
+    uint8_t* h = t_staging.h;
+    if (n) {
+      std::memcpy(h + oX, f->x, n * 4); std::memcpy(h + oY, f->y, n * 4); std::memcpy(h + oOct, f->octave, n * 4);
+      if (f->u_right) std::memcpy(h + oUr, f->u_right, n * 4);
+      if (withDesc) std::memcpy(h + oDesc, f->desc, n * 32);
+    }
+    if (q) {
+      std::memcpy(h + oQx, qx, q * 4); std::memcpy(h + oQy, qy, q * 4); std::memcpy(h + oQr, qr, q * 4);
+      std::memcpy(h + oQmin, qmin, q * 4); std::memcpy(h + oQmax, qmax, q * 4);
+      if (qactive) std::memcpy(h + oQact, qactive, q);
+      if (withUr) std::memcpy(h + oQur, qur, q * 4);
+      if (withDesc) std::memcpy(h + oQdesc, qdesc, q * 32);
+    }
+    uint8_t* din = carve<uint8_t>(ar, inBytes);
+    MHIP(hipMemcpyAsync(din, h, inBytes, hipMemcpyHostToDevice, ar->stream));
     GridFrame g{};
-    float *dx, *dy, *dur = nullptr;
-    int32_t* doct;
-    uint8_t* ddesc = nullptr;
-    MHIP(up(ar, &dx, f->x, n));
-    MHIP(up(ar, &dy, f->y, n));
-    MHIP(up(ar, &doct, f->octave, n));
-    if (f->u_right) MHIP(up(ar, &dur, f->u_right, n));
-    if (f->desc && qdesc) MHIP(up(ar, &ddesc, f->desc, n * 32));
-    g.x = dx; g.y = dy; g.octave = doct; g.uRight = dur; g.desc = ddesc; g.n = f->n;
+    g.x = reinterpret_cast<const float*>(din + oX); g.y = reinterpret_cast<const float*>(din + oY);
+    g.octave = reinterpret_cast<const int32_t*>(din + oOct);
+    g.uRight = f->u_right ? reinterpret_cast<const float*>(din + oUr) : nullptr;
+    g.desc = withDesc ? din + oDesc : nullptr;
+    g.n = f->n;
     g.minX = f->min_x; g.minY = f->min_y;
     g.wInv = 64.0f / (f->max_x - f->min_x);  // src/Frame.cc:109-110 (FRAME_GRID_COLS / ROWS)
     g.hInv = 48.0f / (f->max_y - f->min_y);
@@ -413,31 +455,28 @@ int window_search(int device, const orbfe_frame_view* f, int nq, const float* qx
     launch_grid_build(ar->stream, g, dkey, dcell);
     MHIP(hipGetLastError());
     WindowQueries wq{};
-    float *dqx, *dqy, *dqr, *dqur = nullptr;
-    int32_t *dqmin, *dqmax;
-    uint8_t *dqact = nullptr, *dqdesc = nullptr;
-    MHIP(up(ar, &dqx, qx, q));
-    MHIP(up(ar, &dqy, qy, q));
-    MHIP(up(ar, &dqr, qr, q));
-    MHIP(up(ar, &dqmin, qmin, q));
-    MHIP(up(ar, &dqmax, qmax, q));
-    if (qactive) MHIP(up(ar, &dqact, qactive, q));
-    if (qur && f->u_right) MHIP(up(ar, &dqur, qur, q));
-    if (ddesc) MHIP(up(ar, &dqdesc, qdesc, q * 32));
-    wq.x = dqx; wq.y = dqy; wq.r = dqr; wq.minLevel = dqmin; wq.maxLevel = dqmax; wq.active = dqact; wq.ur = dqur;
-    wq.desc = dqdesc; wq.n = nq; wq.K = K;
-    int32_t* dcount = carve<int32_t>(ar, q ? q : 1);
-    uint32_t* dcand = carve<uint32_t>(ar, q * (size_t)K + 1);
+    wq.x = reinterpret_cast<const float*>(din + oQx); wq.y = reinterpret_cast<const float*>(din + oQy);
+    wq.r = reinterpret_cast<const float*>(din + oQr);
+    wq.minLevel = reinterpret_cast<const int32_t*>(din + oQmin); wq.maxLevel = reinterpret_cast<const int32_t*>(din + oQmax);
+    wq.active = qactive ? din + oQact : nullptr;
+    wq.ur = withUr ? reinterpret_cast<const float*>(din + oQur) : nullptr;
+    wq.desc = withDesc ? din + oQdesc : nullptr;
+    wq.n = nq; wq.K = K;
+    // counts and candidate lists are adjacent: one copy back
+    uint8_t* dout = carve<uint8_t>(ar, outBytes);
+    int32_t* dcount = reinterpret_cast<int32_t*>(dout);
+    uint32_t* dcand = reinterpret_cast<uint32_t*>(dout + pad(q * 4));
     launch_window_search(ar->stream, g, dkey, dcell, wq, dcount, dcand);
     MHIP(hipGetLastError());
     res->count.assign(q, 0);
     res->cand.resize(q * (size_t)K);
     res->K = K;
-    if (nq > 0) {
-      MHIP(hipMemcpyAsync(res->count.data(), dcount, q * 4, hipMemcpyDeviceToHost, ar->stream));
-      MHIP(hipMemcpyAsync(res->cand.data(), dcand, q * (size_t)K * 4, hipMemcpyDeviceToHost, ar->stream));
-    }
+    if (nq > 0) MHIP(hipMemcpyAsync(h, dout, pad(q * 4) + q * (size_t)K * 4, hipMemcpyDeviceToHost, ar->stream));
     MHIP(hipStreamSynchronize(ar->stream));
+    if (nq > 0) {
+      std::memcpy(res->count.data(), h, q * 4);
+      std::memcpy(res->cand.data(), h + pad(q * 4), q * (size_t)K * 4);
+    }
     int mx = 0;
     for (int i = 0; i < nq; i++) mx = res->count[i] > mx ? res->count[i] : mx;
     if (mx <= K) return ORBFE_OK;

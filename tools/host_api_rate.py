@@ -35,3 +35,26 @@ p = e.profile_get()
 e.profile(False)
 print("single frame with stage events: %.3f ms/call;" % (1e3 * dt),
       " ".join(f"{k}={v[0] / 200 * 1e3:.0f}us" for k, v in p.items()))
+
+# tracking-thread matcher calls (host arrays in, host arrays out): per-call latency
+import numpy as _np
+from orb_slam2_annotate_amd import FrameView, ORBmatcher
+_rng = _np.random.default_rng(0)
+_n = 1000
+_x = _rng.uniform(0, 640, _n).astype(_np.float32); _y = _rng.uniform(0, 480, _n).astype(_np.float32)
+_oct = _rng.integers(0, 8, _n).astype(_np.int32); _ang = _rng.uniform(0, 360, _n).astype(_np.float32)
+_desc = _rng.integers(0, 256, (_n, 32), dtype=_np.uint8)
+_F = FrameView(_x, _y, _oct, _desc, (0.0, 640.0, 0.0, 480.0), angle=_ang)
+_sf = (1.2 ** _np.arange(8)).astype(_np.float32)
+_src = _rng.integers(0, _n, _n)
+_u = (_x[_src] + _rng.normal(0, 3, _n)).astype(_np.float32); _v = (_y[_src] + _rng.normal(0, 3, _n)).astype(_np.float32)
+_valid = _np.ones(_n, _np.uint8)
+_m = ORBmatcher(0.9, True)
+for _name, _fn in (("SearchByProjection(Frame, LastFrame) th=15", lambda: _m.SearchByProjectionLastFrame(_F, _sf, _valid, _u, _v, _oct[_src], _ang[_src], _desc[_src], 15.0)),
+                   ("SearchByProjection(Frame, MapPoints) th=3", lambda: _m.SearchByProjection(_F, _sf, _valid, _oct[_src], _np.full(_n, 0.9995, _np.float32), _u, _v, _desc[_src], th=3.0)),
+                   ("GetFeaturesInArea x1000 r=15", lambda: _F.GetFeaturesInArea(_u, _v, _np.full(_n, 15.0, _np.float32)))):
+    _fn()
+    t0 = time.perf_counter()
+    for _ in range(100):
+        _fn()
+    print(f"{_name}: {1e3 * (time.perf_counter() - t0) / 100:.3f} ms/call (1000 features, 1000 queries, incl. the Python wrapper)")
