@@ -28,9 +28,14 @@ struct Arena {
   hipStream_t stream = nullptr;
   uint8_t* base = nullptr;
   size_t cap = 0, used = 0;
+  // pinned mirror of the uploaded part of the arena: up() only copies into it, flush() sends the whole
+  // dirty range in ONE host-to-device copy before the first kernel of the call
+  uint8_t* hmirror = nullptr;
+  size_t hcap = 0, dirtyLo = 0, dirtyHi = 0;
   ~Arena() {
     if (device >= 0) {
       (void)hipSetDevice(device);
+      if (hmirror) (void)hipHostFree(hmirror);
       if (base) (void)hipFree(base);
       if (stream) (void)hipStreamDestroy(stream);
     }
@@ -58,6 +63,7 @@ hipError_t arena_begin(int device, size_t bytes, Arena** out) {
     a.cap = want;
   }
   a.used = 0;
+  a.dirtyLo = a.dirtyHi = 0;
   *out = &a;
   return hipSuccess;
 }
@@ -73,7 +79,34 @@ template <typename T>
 hipError_t up(Arena* a, T** d, const T* h, size_t n) {
   *d = carve<T>(a, n ? n : 1);
   if (n == 0) return hipSuccess;
-  return hipMemcpyAsync(*d, h, n * sizeof(T), hipMemcpyHostToDevice, a->stream);
+  const size_t off = (size_t)(reinterpret_cast<uint8_t*>(*d) - a->base), bytes = n * sizeof(T);
+  if (off + bytes > a->hcap) {  // grow the mirror, keeping what earlier up() calls of this call put there
+    const size_t want = (off + bytes) + (off + bytes) / 2 + (1u << 16);
+    uint8_t* nh = nullptr;
+    hipError_t e = hipHostMalloc((void**)&nh, want, hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    if (a->hmirror) {
+      if (a->dirtyHi > a->dirtyLo) std::memcpy(nh + a->dirtyLo, a->hmirror + a->dirtyLo, a->dirtyHi - a->dirtyLo);
+      (void)hipHostFree(a->hmirror);
+    }
+    a->hmirror = nh;
+    a->hcap = want;
+  }
+  std::memcpy(a->hmirror + off, h, bytes);
+  if (a->dirtyHi == a->dirtyLo) { a->dirtyLo = off; a->dirtyHi = off + bytes; }
+  else {
+    if (off < a->dirtyLo) a->dirtyLo = off;
+    if (off + bytes > a->dirtyHi) a->dirtyHi = off + bytes;
+  }
+  return hipSuccess;
+}
+// one H2D copy for everything up() staged since arena_begin(); call before the first kernel launch
+hipError_t flush(Arena* a) {
+  if (a->dirtyHi == a->dirtyLo) return hipSuccess;
+  hipError_t e = hipMemcpyAsync(a->base + a->dirtyLo, a->hmirror + a->dirtyLo, a->dirtyHi - a->dirtyLo,
+                                hipMemcpyHostToDevice, a->stream);
+  a->dirtyLo = a->dirtyHi = 0;
+  return e;
 }
 
 // merge-walk of the two ascending node-id lists (the std::map iteration + lower_bound of
@@ -129,6 +162,7 @@ extern "C" int orbfe_descriptor_distance(int device, const uint8_t* a, const uin
   MHIP(up(ar, &da, a, (size_t)n * 32));
   MHIP(up(ar, &db, b, (size_t)n * 32));
   int32_t* dout = carve<int32_t>(ar, n);
+  MHIP(flush(ar));
   launch_hamming_pairs(ar->stream, da, db, n, dout);
   MHIP(hipGetLastError());
   MHIP(hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, ar->stream));
@@ -146,6 +180,7 @@ extern "C" int orbfe_hamming_matrix(int device, const uint8_t* d1, int n1, const
   MHIP(up(ar, &da, d1, (size_t)n1 * 32));
   MHIP(up(ar, &db, d2, (size_t)n2 * 32));
   int32_t* dout = carve<int32_t>(ar, (size_t)n1 * n2);
+  MHIP(flush(ar));
   launch_hamming_matrix(ar->stream, da, n1, db, n2, dout);
   MHIP(hipGetLastError());
   MHIP(hipMemcpyAsync(out, dout, (size_t)n1 * n2 * 4, hipMemcpyDeviceToHost, ar->stream));
@@ -196,6 +231,7 @@ static int bow_common(int device, const uint8_t* desc1, const uint8_t* has_mp1, 
   a.desc2 = dd2; a.hasMp2 = dm2; a.angle2 = da2; a.indices2 = di2;
   a.angleStride = 1;
   a.nnratio = nnratio; a.strictLow = kfkf; a.match = dmatch; a.bin = dbin;
+  MHIP(flush(ar));
   launch_search_by_bow(ar->stream, a, (int)pairs.size(), maxCnt2);
   launch_rot_prune(ar->stream, dmatch, dbin, nOut, check_ori, dcount);
   MHIP(hipGetLastError());
@@ -290,6 +326,7 @@ extern "C" int orbfe_search_for_triangulation(int device, const uint8_t* desc1, 
   a.desc2 = dd2; a.hasMp2 = dm2; a.x2 = dx2; a.y2 = dy2; a.angle2 = da2; a.octave2 = doc2; a.stereo2 = ds2;
   a.indices2 = di2; a.F12 = dF; a.ex = ex; a.ey = ey; a.scaleFactors2 = dsf; a.levelSigma2_2 = dsg;
   a.onlyStereo = only_stereo; a.match = dmatch; a.bin = dbin;
+  MHIP(flush(ar));
   launch_search_triangulation(ar->stream, a);
   launch_rot_prune(ar->stream, dmatch, dbin, n1, check_orientation, dcount);
   MHIP(hipGetLastError());
@@ -353,6 +390,7 @@ extern "C" int orbfe_compute_stereo_matches(orbfe_extractor* left, int frameL, o
     a.bandR = (int)std::ceil(2.0f * scL[nlL - 1]) + 2;
   }
   int32_t* dcount = carve<int32_t>(ar, 1);
+  MHIP(flush(ar));
   launch_stereo(ar->stream, a, dcount);
   MHIP(hipGetLastError());
   int32_t cnt = 0;
