@@ -118,3 +118,21 @@ def test_host_octree_edge_cases():
     sel = orc.distribute_octtree(xs, ys, np.full(len(xs), 20), 16, 624, 16, 464, 0)
     got = _octree_product(xs, ys, np.full(len(xs), 20), 16, 624, 16, 464, 0)
     assert len(got[0]) == len(sel) and np.array_equal(got[0], xs[sel] + 16)
+
+
+def test_udiv_magic_is_exact_for_all_32_bit_operands():
+    """csrc/kernels.h udiv_magic: q = umulhi(n, M) (+1 if n - q*d >= d) with M = floor(2^32/d) (2^32-1 for
+    d = 1) must equal n // d for every 32-bit n -- checked on the extremes and a random sample."""
+    rng = np.random.default_rng(0)
+    ds = np.concatenate([np.arange(1, 70), rng.integers(1, 1 << 16, 400), rng.integers(1, 1 << 32, 400),
+                         np.array([(1 << 32) - 1, (1 << 31), (1 << 31) + 1, 65535, 65536, 65537])]).astype(np.uint64)
+    for d in ds:
+        d = int(d)
+        M = 0xFFFFFFFF if d <= 1 else (1 << 32) // d
+        ns = np.concatenate([np.array([0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, (1 << 32) - 1, (1 << 32) - d,
+                                       ((1 << 32) - 1) // d * d, ((1 << 32) - 1) // d * d - 1], dtype=np.int64),
+                             rng.integers(0, 1 << 32, 300)])
+        ns = ns[(ns >= 0) & (ns < (1 << 32))].astype(np.uint64)
+        q = (ns * np.uint64(M)) >> np.uint64(32)
+        q = q + ((ns - q * np.uint64(d)) >= np.uint64(d)).astype(np.uint64)
+        assert np.array_equal(q, ns // np.uint64(d)), d
