@@ -79,6 +79,10 @@ int orbfe_extractor_get_features_per_level(const orbfe_extractor *e, int32_t *ou
 int orbfe_extractor_get_umax(const orbfe_extractor *e, int32_t *out16);
 /* Upper bound on keypoints one frame can return (quota + octree overshoot, Appendix A3). */
 int orbfe_extractor_max_keypoints(const orbfe_extractor *e);
+/* Exact output bound for a width x height image: sum over levels of max(quota + 3, 4 * nIni), where
+ * nIni = round(width' / height') roots start the octree (very wide, flat images can exceed the bound of
+ * orbfe_extractor_max_keypoints, which assumes nIni <= 16). */
+int orbfe_extractor_max_keypoints_for(const orbfe_extractor *e, int width, int height);
 
 /* Replaces ORBextractor::operator()(InputArray image, InputArray mask (ignored),
  * vector<KeyPoint>&, OutputArray descriptors)  (src/ORBextractor.cc:1119-1197).

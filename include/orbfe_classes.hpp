@@ -55,7 +55,8 @@ class ORBextractor {
   void operator()(const uint8_t* image, int width, int height, int stride, std::vector<KeyPoint>& keypoints,
                   std::vector<uint8_t>& descriptors) {
     if (!image || width <= 0 || height <= 0) return;
-    const int cap = orbfe_extractor_max_keypoints(h_);
+    int cap = orbfe_extractor_max_keypoints_for(h_, width, height);  // exact bound for this image size
+    if (cap < orbfe_extractor_max_keypoints(h_)) cap = orbfe_extractor_max_keypoints(h_);
     keypoints.resize(cap);
     descriptors.resize((size_t)cap * 32);
     int n = 0;

@@ -44,7 +44,7 @@ EXPORTS = [
     "orbfe_extractor_get_levels", "orbfe_extractor_get_scale_factor", "orbfe_extractor_get_scale_factors",
     "orbfe_extractor_get_inverse_scale_factors", "orbfe_extractor_get_scale_sigma_squares",
     "orbfe_extractor_get_inverse_scale_sigma_squares", "orbfe_extractor_get_features_per_level",
-    "orbfe_extractor_get_umax", "orbfe_extractor_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
+    "orbfe_extractor_get_umax", "orbfe_extractor_max_keypoints", "orbfe_extractor_max_keypoints_for", "orbfe_extract", "orbfe_extract_batch",
     "orbfe_extract_batch_device", "orbfe_extract_batch_device_async", "orbfe_extractor_synchronize", "orbfe_extractor_level_size", "orbfe_extractor_get_pyramid_level",
     "orbfe_extractor_pyramid_level_device", "orbfe_extractor_debug_candidates",
     "orbfe_extractor_debug_blurred_level", "orbfe_extractor_debug_host_octree", "orbfe_debug_octree_host", "orbfe_debug_geometry",
@@ -168,6 +168,7 @@ def load():
     L.orbfe_undistort_keypoints_batch_device.argtypes = [ci, vp, vp, ci, ci, vp, vp, ci, vp]
     L.orbfe_compute_image_bounds.argtypes = [ci, ci, ci, vp, vp, ci, vp]
     L.orbfe_stereo_from_rgbd.argtypes = [ci, vp, vp, vp, ci, vp, ci, ci, ci, cf, vp, vp]
+    L.orbfe_extractor_max_keypoints_for.argtypes = [vp, ci, ci]
     L.orbfe_debug_octree_host.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, ci]
     L.orbfe_debug_geometry.argtypes = [ci, cf, ci, ci, ci, ci, ci, vp, vp, vp, ci]
     L.orbfe_debug_resize_tables.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp]

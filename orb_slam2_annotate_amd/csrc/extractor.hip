@@ -591,6 +591,12 @@ extern "C" int orbfe_extractor_max_keypoints(const orbfe_extractor* e) {
   for (int l = 0; l < e->tab.nlevels; l++) n += (e->tab.quota[l] + 3 > 64 ? e->tab.quota[l] + 3 : 64);
   return n;
 }
+extern "C" int orbfe_extractor_max_keypoints_for(const orbfe_extractor* e, int width, int height) {
+  if (!e || width <= 0 || height <= 0) return 0;
+  FrameGeom g;  // the exact bound of the pipeline for this image size: per level max(quota + 3, 4 * nIni)
+  g.build(e->tab, width, height);
+  return g.totalKpCap;
+}
 extern "C" int orbfe_extractor_level_size(const orbfe_extractor* e, int width, int height, int level, int* w, int* h) {
   if (!e || !w || !h || level < 0 || level >= e->tab.nlevels) return fail(ORBFE_ERR_INVALID, "bad argument");
   const float s = e->tab.invScale[level];

@@ -17,7 +17,9 @@ namespace orbfe {
 
 namespace {
 // cell side bound: wCell = ceil(width/nCols) < 60, so py fits 6 bits and px 8 bits of a list entry
-constexpr int kPitchDw = 24;    // LDS row pitch in dwords (96 B): 4 rows x 8 groups hit 32 distinct banks
+// LDS row pitch in dwords is a template parameter of the kernel: 12 (cells up to 40 px wide: every VGA-class
+// level), 16 (up to 56) or 24 -- a 12-dword pitch needs 5.4 KB per cell instead of 8.9 KB, i.e. up to 29
+// instead of 17 resident wavefronts per CU (the kernel loses 30 % with 12 instead of 17).
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
@@ -70,6 +72,7 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b)
 //   D. per-cell 20->7 fallback, then ordered compaction of the survivors = emission order.
 // Dynamic LDS: tile [tileRows][24 dw] | score [scoreRows][24 dw] | queue [queueLen] u16, sized by
 // the largest cell of the frame geometry.
+template <int kPitchDw>
 __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
                                                    const CellDesc* __restrict__ cells,
                                                    int nCells, int nFrames, int iniTh, int minTh,
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
         o.y = __builtin_amdgcn_alignbyte(d[2], d[1], a);
         o.z = __builtin_amdgcn_alignbyte(d[3], d[2], a);
         o.w = __builtin_amdgcn_alignbyte(d[4], d[3], a);
-        *reinterpret_cast<uint4*>(&tile[ty * kPitchDw + 4 * part]) = o;  // pitch 24 dw >= 4*parts
+        *reinterpret_cast<uint4*>(&tile[ty * kPitchDw + 4 * part]) = o;  // pitch >= 4*parts (launch_fast_cells)
       }
     } else {  // caller-owned level 0 with an odd stride: byte loads
       for (int i = lane; i < th * tdw; i += 64) {
@@ -301,10 +304,20 @@ void launch_fast_cells(hipStream_t s, PyramidViews pyr, const CellDesc* d_cells,
   const unsigned total = (unsigned)nCells * (unsigned)nFrames;
   const int tileRows = maxCellH + 6, scoreRows = maxCellH + 2;
   const int queueLen = (((maxCellW + 3) & ~3) * maxCellH + 1) & ~1;
-  const size_t ldsBytes = (size_t)(tileRows + scoreRows) * kPitchDw * 4 + (size_t)queueLen * 2;
-  hipLaunchKernelGGL(k_fast_cells, dim3((total + 7u) / 8u * 8u), dim3(64), ldsBytes, s, pyr, d_cells, nCells, nFrames,
-                     iniTh, minTh, d_slots, slotsPerFrame, d_cellCount, tileRows, scoreRows,
-                     udiv_magic_multiplier((uint32_t)nCells));
+  // smallest pitch that holds a tile row (4 * ceil(tdw / 4) staged dwords, tdw = ceil(w/4) + 2) and a score row
+  const int tdwMax = ((maxCellW + 3) >> 2) + 2;
+  const int need = ((tdwMax + 3) >> 2) * 4;
+  const int pitch = (need <= 12 && maxCellW <= 40) ? 12 : (need <= 16 && maxCellW <= 56) ? 16 : 24;
+  const size_t ldsBytes = (size_t)(tileRows + scoreRows) * pitch * 4 + (size_t)queueLen * 2;
+  const dim3 grid((total + 7u) / 8u * 8u);
+  const uint32_t magic = udiv_magic_multiplier((uint32_t)nCells);
+#define ORBFE_LAUNCH_FAST(P)                                                                                     \
+  hipLaunchKernelGGL(k_fast_cells<P>, grid, dim3(64), ldsBytes, s, pyr, d_cells, nCells, nFrames, iniTh, minTh, \
+                     d_slots, slotsPerFrame, d_cellCount, tileRows, scoreRows, magic)
+  if (pitch == 12) ORBFE_LAUNCH_FAST(12);
+  else if (pitch == 16) ORBFE_LAUNCH_FAST(16);
+  else ORBFE_LAUNCH_FAST(24);
+#undef ORBFE_LAUNCH_FAST
 }
 
 // Ordered compaction: cells of a level in cell-row-major order, raster inside each cell.

@@ -62,7 +62,12 @@ class ORBextractor:
     def umax(self):
         return self._vec("orbfe_extractor_get_umax", np.int32, 16)
 
-    def max_keypoints(self) -> int:
+    def max_keypoints(self, width: int = 0, height: int = 0) -> int:
+        """Output bound; with an image size the exact bound for that size (very wide, flat images start the
+        octree with many roots and can exceed the size-independent figure)."""
+        if width > 0 and height > 0:
+            return max(self._L.orbfe_extractor_max_keypoints_for(self._h, int(width), int(height)),
+                       self._L.orbfe_extractor_max_keypoints(self._h))
         return self._L.orbfe_extractor_max_keypoints(self._h)
 
     def level_size(self, width, height, level):
@@ -81,7 +86,7 @@ class ORBextractor:
         if image.strides[1] != 1:
             image = np.ascontiguousarray(image)
         H, W = image.shape
-        cap = capacity or self.max_keypoints()
+        cap = capacity or self.max_keypoints(W, H)
         kps = np.zeros(cap, dtype=KP_DTYPE)
         desc = np.zeros((cap, 32), dtype=np.uint8)
         n = C.c_int(0)
@@ -94,7 +99,7 @@ class ORBextractor:
         """images: [B,H,W] uint8 (host).  Returns list of (keypoints, descriptors) per frame."""
         images = np.ascontiguousarray(images, dtype=np.uint8)
         B, H, W = images.shape
-        cap = capacity or self.max_keypoints()
+        cap = capacity or self.max_keypoints(W, H)
         kps = np.zeros((B, cap), dtype=KP_DTYPE)
         desc = np.zeros((B, cap, 32), dtype=np.uint8)
         n = np.zeros(B, dtype=np.int32)

@@ -187,6 +187,15 @@ def test_streams_and_async_give_identical_results(amd):
             _kp_equal(ref[f][0], res[f][0])
 
 
+def test_very_wide_image_starts_the_octree_with_many_roots(amd):
+    """813x77 at 3 levels: nIni = 17 roots per level, 4*nIni children can exceed the quota-based bound; the
+    wrappers size their buffers with orbfe_extractor_max_keypoints_for (found by tools/fuzz_parity.py)."""
+    img = synth.render_frame(7, 813, 77, n_shapes=120)
+    _check_frame(amd, img, (100, 1.1, 3, 30, 10))
+    e = amd.ORBextractor(100, 1.1, 3, 30, 10)
+    assert e.max_keypoints(813, 77) > e.max_keypoints()
+
+
 def test_large_batch_uses_the_throughput_kernels(amd):
     """Launches of more than 8 frames take the global-memory form of k_octree (the register form serves
     small launches); 1 stream = one 20-frame launch, 8 streams = sub-batches of 3."""
