@@ -19,5 +19,5 @@ for k in sorted(agg):
     if 'orbfe' not in k: continue
     steps=5
     mb=agg[k]*1024*2/steps/1e6
-    print(k.ljust(30),'fetch MB/step %8.1f'%mb,'us/step %7.1f'%(dur[k]/steps),'TB/s %.2f'%(mb/(dur[k]/steps)/1e6*1e6/1e6))
+    print(k.ljust(30),'fetch MB/step %8.1f'%mb,'us/step %7.1f'%(dur[k]/steps),'fetch TB/s %.2f'%(mb/(dur[k]/steps)))
 PY
