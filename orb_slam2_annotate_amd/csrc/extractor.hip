@@ -593,6 +593,7 @@ extern "C" int orbfe_extractor_max_keypoints(const orbfe_extractor* e) {
 }
 extern "C" int orbfe_extractor_max_keypoints_for(const orbfe_extractor* e, int width, int height) {
   if (!e || width <= 0 || height <= 0) return 0;
+  if (e->geom.W == width && e->geom.H == height && e->geom.totalKpCap > 0) return e->geom.totalKpCap;  // current geometry
   FrameGeom g;  // the exact bound of the pipeline for this image size: per level max(quota + 3, 4 * nIni)
   g.build(e->tab, width, height);
   return g.totalKpCap;
