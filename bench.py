@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="verify frame 0 of the batch against the oracle")
     ap.add_argument("--streams", type=int, default=4,
-                    help="sub-batch HIP streams per call in the timed region (1..4): the HBM-bound descriptor "
+                    help="sub-batch HIP streams per call in the timed region (1..8): the L2-bound descriptor "
                          "kernel of one sub-batch overlaps the VALU-bound FAST/blur kernels of the others")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for 1 rank")
     args = ap.parse_args()
