@@ -10,7 +10,8 @@
 //      row are skipped;
 //   3. HORIZONTAL pass on u16 pairs with v_dot2_u32_u16 (two taps per instruction, 32-bit
 //      accumulate), rounding, one 32-bit coalesced store per 4 pixels.
-// HBM-bound by design: every source byte is read once per tile (+ halo), every output once.
+// Every source byte is read once per tile (+ halo), every output written once; measured: 61 % VALU
+// issue, the rest is waiting for the tile's own staging loads.
 #include "kernels.h"
 
 namespace orbfe {

@@ -1,9 +1,11 @@
 // k_fast.hip -- the FAST grid stage of ComputeKeyPointsOctTree (src/ORBextractor.cc:846-896)
-// as ONE fused kernel: one 256-thread workgroup per (frame, grid cell) = per cv::FAST call
+// as ONE fused kernel: one wavefront (64-thread workgroup) per (frame, grid cell) = per cv::FAST call
 // of the reference.  The cell's pixels plus the 3-px ring halo are staged in LDS once
-// (coalesced row reads from HBM/L2), then
-//   A/B. every pixel gets the exact cv::FAST response (cornerScore<16>, S-1) in packed 16-bit
-//      arithmetic, two pixels per VALU lane-op; a pixel is a corner at threshold t iff S > t,
+// (16-byte requests from HBM/L2), then
+//   A. a cheap necessary test (two adjacent cardinal ring points) in packed 16-bit arithmetic builds an
+//      ordered work list of ~19 % of the pixels,
+//   B. the listed pixels get the exact cv::FAST response (cornerScore<16>, S-1); a pixel is a corner at
+//      threshold t iff S > t; the list is compacted to the corners,
 //   C. 3x3 strict non-max suppression restricted to the cell's detection rectangle
 //      (the reference's NMS never sees across a cell boundary),
 //   D. per-cell threshold fallback (:874-882): corners >= iniThFAST if any survive NMS,
@@ -11,6 +13,7 @@
 //      slot range (no atomics on HBM: output position is a pure function of the input).
 // Facts used: score = S-1 does not depend on the threshold, and a pixel kept by NMS at
 // threshold t is exactly a pixel with score >= t that beats all 8 neighbours' scores.
+// VALU-issue-bound; it wants resident waves, hence the small LDS footprint.
 #include "kernels.h"
 
 namespace orbfe {

@@ -1,8 +1,8 @@
 // k_pyramid.hip -- bilinear pyramid level (cv::resize INTER_LINEAR, src/ORBextractor.cc:1219).
-// Integer fixed-point, HBM-bound: every thread produces 4 horizontally adjacent output
-// pixels (one 32-bit store, coalesced 256 B per wave row); the four source taps per pixel
-// come from two rows ~1.2x denser than the output, i.e. they are served by L1/L2 lines the
-// neighbouring lanes touch as well.
+// Integer fixed-point with host-built coefficient tables.  k_resize_flat is the production kernel
+// (4 output columns x 8 output rows per thread, flat row-block-major thread numbering);
+// k_resize keeps the older strip form for inputs without packed tables, k_resize_generic serves
+// unaligned pitches and scale factors above 2, k_copy2d realigns caller-owned level-0 images.
 #include "kernels.h"
 
 namespace orbfe {
