@@ -51,6 +51,7 @@ def main():
     t0 = time.time()
     n = 0
     skipped = 0
+    last_report = t0
     while time.time() - t0 < seconds:
         w, h = int(rng.integers(64, 900)), int(rng.integers(64, 700))
         if rng.random() < 0.2:
@@ -92,6 +93,9 @@ def main():
             np.save(ROOT / "gpurun_out" / f"fuzz_fail_{seed}_{n}.npy", img)
             sys.exit(1)
         n += 1
+        if time.time() - last_report > 60:  # progress line (long runs must not look hung)
+            last_report = time.time()
+            print(f"  ... {n} cases so far", flush=True)
     print(f"fuzz_parity: {n} random cases bit-exact in {time.time() - t0:.0f} s (seed {seed}; {skipped} beyond the octree LDS limit skipped)")
 
 
