@@ -141,7 +141,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=2048, help="frames resident per GPU and processed per step")
+    ap.add_argument("--batch", type=int, default=4096, help="frames resident per GPU and processed per step")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="tum")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="verify frame 0 of the batch against the oracle")
