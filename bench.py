@@ -1,24 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py -- ORB extract(+match) frames/s on MI355X, one process per GPU.
+"""bench.py -- ORB extract+match frames/s on MI355X, one process per GPU.
 
-Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N>1 it
-is launched under torch.distributed.run with one rank per GPU.  A "step" is one pass of the hot
-path (ORBextractor::operator() for every frame of the rank's resident batch).  Frames are
-independent, so ranks share nothing: the only collectives are the barriers around the timed
-region and the max/sum reductions of the report (RCCL) -- weak scaling.
+Contract (task statement): `python bench.py --gpus N --steps K --warmup W`.  For N > 1 either the
+driver starts the ranks (torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE in the environment) or
+this script does it itself: with `--gpus N` and no WORLD_SIZE in the environment the parent spawns N
+fresh `python bench.py` children (one per GPU, RCCL rendezvous on 127.0.0.1) BEFORE anything touches
+the GPU, relays rank 0's JSON line and exits non-zero if any rank failed.
 
-Workloads (BASELINE.json configs):
-  tum   (default) configs[1]: 640x480 mono stream, nFeatures=1000, extract only
-  kitti           configs[2]: 1241x376 stereo, nFeatures=2000, extract L+R + ComputeStereoMatches
-  euroc           configs[3]: 752x480, nFeatures=1200, extract + SearchByBoW(t-1, t)
-Inputs are synthetic (no datasets offline), resident in HBM before the timed region starts.
+A "step" is one pass of the hot path over the rank's resident batch.  Frames / stereo pairs are
+independent, so ranks share nothing: the only collectives are the barriers around the timed region
+and the MAX(elapsed) / SUM(frames) reductions of the report (RCCL) -- weak scaling.
+
+Workloads (BASELINE.json configs), `--workload all` (default) runs the three of them:
+  kitti  (HEADLINE `value`) configs[2]: 1241x376 stereo, nFeatures=2000, ORBextractor::operator() on L and R
+         (src/ORBextractor.cc:1119-1197) + Frame::ComputeStereoMatches (src/Frame.cc:512-686)
+  tum    (secondary)        configs[1]: 640x480 mono stream, nFeatures=1000, extract only
+  euroc  (secondary)        configs[3]: 752x480, nFeatures=1200, extract + ComputeBoW + SearchByBoW(t-1, t)
+         (src/ORBmatcher.cc:185-325) with a synthetic k=10 L=2 vocabulary (ORBvoc.txt is not in the reference)
+  kitti_seq                 configs[4]: the KITTI 00-07 sequence lengths sharded over the ranks by shard.py's
+         `sequence` (one sequence per GPU) and `round_robin` (balanced) plans -- strong scaling, both reported
+Inputs are synthetic (no datasets offline), rendered before the GPU is touched and resident in HBM
+before the timed region starts.  Every workload is checked against the CPU oracle on >= 3 frames
+outside the timed region (keypoints, descriptors and match outputs bit-identical) on every run.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 from pathlib import Path
 
@@ -27,331 +40,723 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E (MI355X_MICROARCH.md)
+N_SIMD = 256 * 4
+# VALU issue ceiling, wave64 instructions/s chip-wide.  Guide: "v_fma_f32 (wave64): 2 cyc (SIMD-32)" at 2.4 GHz.
+# tools/ubench/valu_rate.hip (profiles/r02_valu_rate.txt) measures two classes on this part:
+#   v_add_u32 / v_xor_b32 / v_fma_f32           0.93-1.02 T/s with >= 2 waves per SIMD (2.4-2.7 cycles)
+#   v_perm_b32 / v_min3_i32 / v_bcnt / v_pk_*   0.58 T/s whatever the occupancy (4.2 cycles); a half EXEC mask
+#                                               changes neither class
+# No instruction issues faster than the first figure, so a fraction of VALU_PEAK is <= 1 by construction.
+VALU_PEAK = N_SIMD * 2.4e9 / 2
+VALU_MEASURED = {"fast_class(v_add_u32,v_xor_b32,v_fma_f32)": 1.017e12,
+                 "full_rate_class(v_perm_b32,v_min3_i32,v_bcnt_u32_b32,v_pk_min_i16)": 0.585e12}
+BCNT_PEAK = 0.585e12 * 64  # popcount-32 lane-ops/s: v_bcnt_u32_b32 measured at 0.585 T wave-instr/s x 64 lanes
 
 WORKLOADS = {
     "tum": dict(name="TUM fr1_xyz mono 640x480 nFeatures=1000 extract-only (synthetic frames)",
-                w=640, h=480, nfeatures=1000, ini=20, mn=7),
-    "kitti": dict(name="KITTI 00 stereo 1241x376 nFeatures=2000 extract L+R + ComputeStereoMatches "
-                       "(synthetic stereo pairs; frames/s counts stereo frames)",
-                  w=1241, h=376, nfeatures=2000, ini=20, mn=7, stereo=True, bf=386.1448, fx=718.856),
-    "euroc": dict(name="EuRoC MH_01 752x480 nFeatures=1200 extract + ComputeBoW + SearchByBoW(t-1,t) "
+                w=640, h=480, nfeatures=1000, ini=20, mn=7, batch=4096),
+    "kitti": dict(name="KITTI 00 stereo 1241x376 nFeatures=2000: extract L+R + ComputeStereoMatches "
+                       "(synthetic stereo pairs; frames/s counts STEREO frames = 2 images each)",
+                  w=1241, h=376, nfeatures=2000, ini=20, mn=7, stereo=True, bf=386.1448, fx=718.856, batch=512),
+    "euroc": dict(name="EuRoC MH_01 752x480 nFeatures=1200: extract + ComputeBoW + SearchByBoW(t-1,t) "
                        "(synthetic frames, synthetic k=10 L=2 vocabulary)",
-                  w=752, h=480, nfeatures=1200, ini=20, mn=7, bow=True),
+                  w=752, h=480, nfeatures=1200, ini=20, mn=7, bow=True, batch=2048),
+}
+GPU_STAGES = ["pyramid", "fast", "octree", "blur", "orient_desc", "match"]
+STAGE_KERNELS = {  # kernels (and launches per step) behind each timed stage
+    "pyramid": [("k_copy2d", 1), ("k_resize_flat", 7)], "fast": [("k_fast_cells", 1)],
+    "octree": [("k_gather_candidates", 1), ("k_octree", 1)], "blur": [("k_blur7", 1)],
+    "orient_desc": [("k_orient_desc", 1)],
+    "match": [("k_stereo_bucket", 1), ("k_stereo_match_batch", 1), ("k_stereo_median_cut", 1),
+              ("k_vocab_featvec", 1), ("k_search_by_bow_batch", 1)],
 }
 
 
-def level_pixels(ext, w, h):
-    return [ext.level_size(w, h, l) for l in range(ext.GetLevels())]
+# ------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` starts the N ranks itself (the parent never touches the GPU)
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
-def algorithmic_bytes(sizes, n_kp):
-    """per-frame algorithmic bytes, split by the kernel that moves them."""
+def launch_ranks(n: int) -> int:
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = b""
+    rc = 0
+    deadline = None
+    try:
+        out0 = procs[0].communicate()[0] or b""
+        deadline = time.time() + 120
+        for p in procs:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+    except subprocess.TimeoutExpired:
+        rc = 1
+    for p in procs:
+        if p.poll() is None:  # a rank that is still alive after rank 0 ended and the grace period: stop exactly it
+            p.kill()
+            rc = 1
+        elif p.returncode != 0:
+            rc = rc or p.returncode or 1
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic inputs (rendered in worker processes forked before any GPU use)
+# ------------------------------------------------------------------------------------------------
+def _render_task(t):
+    from orb_slam2_annotate_amd import synth
+    kind, seed, n, w, h = t
+    if kind == "stereo":
+        l, r = synth.render_stereo(seed, w, h)
+        return [l, r]
+    return synth.render_sequence(seed, n, w, h, step=1.5)
+
+
+def render_inputs(names, batches, rank):
+    """{workload: list of u8 frames}.  Mono streams: chunks of 64 consecutive frames of one scene (sequence id =
+    seed); stereo: one scene per pair, ordered L0,R0,L1,R1,..."""
+    tasks, owner = [], []
+    for nm in names:
+        wl, B = WORKLOADS[nm], batches[nm]
+        if wl.get("stereo"):
+            for i in range(B):
+                tasks.append(("stereo", 5000 + 100000 * rank + i, 1, wl["w"], wl["h"]))
+                owner.append(nm)
+        else:
+            for c in range(0, B, 64):
+                tasks.append(("seq", 1000 + 100000 * rank + c // 64 + (7000 if nm == "euroc" else 0), min(64, B - c),
+                              wl["w"], wl["h"]))
+                owner.append(nm)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    nproc = max(1, min(16, ncpu, len(tasks)))
+    if nproc > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(nproc) as pool:
+            res = pool.map(_render_task, tasks, chunksize=1)
+    else:
+        res = [_render_task(t) for t in tasks]
+    out = {nm: [] for nm in names}
+    for nm, fr in zip(owner, res):
+        out[nm].extend(fr)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# algorithmic bytes (SURVEY.md 8(d)) and committed PMC summaries
+# ------------------------------------------------------------------------------------------------
+def algorithmic_bytes(sizes, n_kp, wl, n_stereo=0.0):
+    """Per IMAGE, split by the stage that moves them; 'match' per FRAME (stereo pair / consecutive pair)."""
     P0 = sizes[0][0] * sizes[0][1]
     P = sum(a * b for a, b in sizes)
     last = sizes[-1][0] * sizes[-1][1]
     parts = {
         "pyramid": (P - P0) + (P - last),      # write levels 1..7 + read levels 0..6
         "fast": P,                             # read every level once for FAST
+        "octree": 0,                           # candidates only (<< P): latency-bound, no algorithmic bytes
         "blur": 2 * P,                         # read + write every level
         "orient_desc": n_kp * (749 + 512 + 28 + 32),
     }
     parts["extract_total"] = P0 + sum(parts.values())  # + read of the input frame
+    if wl.get("stereo"):  # 32(N+Nr) + 28(N+Nr) + 8N + matched*(121 + 11*121)
+        parts["match"] = 60 * 2 * n_kp + 8 * n_kp + n_stereo * (121 + 11 * 121)
+    elif wl.get("bow"):   # 32(na+nb) + 8 na (+ 4 bytes of node id per feature written and read back)
+        parts["match"] = 64 * n_kp + 8 * n_kp
+    else:
+        parts["match"] = 0
     return parts
 
 
-STAGE_KERNELS = {  # kernels (and launches per step) behind each timed stage
-    "pyramid": [("k_resize_flat", 7)], "fast": [("k_fast_cells", 1)],
-    "octree": [("k_gather_candidates", 1), ("k_octree", 1)], "blur": [("k_blur7", 1)],
-    "orient_desc": [("k_orient_desc", 1)],
-}
-
-
-def pmc_traffic(stage, workload, batch, frames_per_launch):
-    """HBM bytes per launch of the stage's kernels from the committed rocprofv3 --pmc summary
-    (profiles/*_traffic.json, produced by tools/collect_traffic.py, collected at `batch` frames per
-    launch and scaled to the frames one timed launch processes); None when no summary matches."""
+def _latest_profile(suffix, workload):
     best = None
-    for f in sorted((ROOT / "profiles").glob("*_traffic.json")):
+    for f in sorted((ROOT / "profiles").glob(f"*_{suffix}.json")):
         try:
             t = json.loads(f.read_text())
         except Exception:
             continue
         if t.get("workload") == workload:
             best = t
-    if best is None:
+            best["_file"] = f.name
+    return best
+
+
+def pmc_traffic(stage, workload, images_per_launch):
+    """HBM bytes per launch group of the stage's kernels from the committed rocprofv3 --pmc summary
+    (profiles/*_traffic.json, tools/collect_traffic.py), scaled to the images one timed launch processes."""
+    t = _latest_profile("traffic", workload)
+    if t is None:
         return None
-    tot = 0.0
+    tot, found = 0.0, False
     for k, n in STAGE_KERNELS[stage]:
-        if k not in best["kernels"]:
-            return None
-        tot += best["kernels"][k]["traffic_bytes_per_launch"] * n
-    return tot * frames_per_launch / best["batch"]
+        if k in t["kernels"]:
+            tot += t["kernels"][k]["traffic_bytes_per_launch"] * n
+            found = True
+    return tot * images_per_launch / t["batch"] if found else None
 
 
-VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4  # wave64 VALU instructions/s: 256 CUs x 4 SIMDs, 4 cycles per wave64 op
+def pmc_valu(workload):
+    return _latest_profile("valu", workload)
 
 
-def pmc_valu(stage, workload):
-    """VALU wave-instructions per frame of the stage's kernels from the committed SQ_INSTS_VALU summary
-    (profiles/*_valu.json, tools/collect_valu.py); None when no summary matches."""
-    best = None
-    for f in sorted((ROOT / "profiles").glob("*_valu.json")):
-        try:
-            t = json.loads(f.read_text())
-        except Exception:
-            continue
-        if t.get("workload") == workload:
-            best = t
-    if best is None:
-        return None, None
-    tot = 0.0
-    for k, _ in STAGE_KERNELS[stage]:
-        if k not in best["kernels"]:
-            return None, None
-        tot += best["kernels"][k]["valu_wave_instr_per_frame"]
-    return tot, best.get("total_valu_wave_instr_per_frame")
+# ------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle on the host cores (1 core; 2 threads L/R; all cores frame-parallel)
+# ------------------------------------------------------------------------------------------------
+class _CpuUnit:
+    """One unit of the workload's CPU path = one frame (tum, euroc) or one stereo frame (kitti)."""
+
+    def __init__(self, wlname, frames, voc_path=None):
+        sys.path.insert(0, str(ROOT / "tests"))
+        import oracle_lib as orc
+        self.orc, self.wl, self.name, self.frames = orc, WORKLOADS[wlname], wlname, frames
+        self.voc = orc.Vocabulary(voc_path) if voc_path else None
+        self.units = len(frames) // 2 if self.wl.get("stereo") else len(frames)
+        wl = self.wl
+        self.mbf = float(np.float32(wl.get("bf", 0)))
+        self.mb = float(np.float32(np.float32(wl.get("bf", 0)) / np.float32(wl.get("fx", 1))))
+
+    def new_oracle(self):
+        wl = self.wl
+        return self.orc.Oracle(wl["nfeatures"], 1.2, 8, wl["ini"], wl["mn"])
+
+    def run(self, o, i, state, pool=None):
+        wl, fr, orc = self.wl, self.frames, self.orc
+        i %= self.units
+        if wl.get("stereo"):
+            if pool is not None:  # left and right image in two threads, src/Frame.cc:78-81
+                fl = pool.submit(o[0].extract, fr[2 * i], None, True)
+                fr_ = pool.submit(o[1].extract, fr[2 * i + 1], None, True)
+                (kL, dL, pL), (kR, dR, pR) = fl.result(), fr_.result()
+                o0 = o[0]
+            else:
+                kL, dL, pL = o.extract(fr[2 * i], want_pyramid=True)
+                kR, dR, pR = o.extract(fr[2 * i + 1], want_pyramid=True)
+                o0 = o
+            o0.stereo(wl["w"], wl["h"], kL, dL, kR, dR, pL, pR, self.mbf, self.mb)
+        elif wl.get("bow"):
+            k, d = o.extract(fr[i])
+            fv = orc.FeatVec(self.voc.transform(d, 0)[3])
+            prev = state.get("prev")
+            if prev is not None and prev[0] == i - 1:
+                _, k0, d0, fv0 = prev
+                orc.search_by_bow(d0, np.ones(len(k0), np.uint8), k0["angle"], fv0, d, k["angle"], fv, 0.7, True)
+            state["prev"] = (i, k, d, fv)
+        else:
+            o.extract(fr[i])
 
 
-def cpu_baseline(frames, wl, seconds=12.0):
-    """The CPU oracle (a scalar C port of the reference path, oracle/orb_oracle.c) on 1 host core."""
-    sys.path.insert(0, str(ROOT / "tests"))
-    import oracle_lib as orc
-    o = orc.Oracle(wl["nfeatures"], 1.2, 8, wl["ini"], wl["mn"])
-    o.extract(frames[0])  # warm
-    t0 = time.perf_counter()
-    n = 0
+def _timed_loop(fn, seconds, min_units=3):
     per = []
+    t0 = time.perf_counter()
     while True:
         t1 = time.perf_counter()
-        o.extract(frames[n % len(frames)])
+        fn(len(per))
         per.append(time.perf_counter() - t1)
-        n += 1
-        if time.perf_counter() - t0 > seconds:
+        if time.perf_counter() - t0 > seconds and len(per) >= min_units:
             break
     dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit="frames/s", cores=1, kind="port",
-                sample=f"{n} synthetic {wl['w']}x{wl['h']} frames of the same workload, oracle/orb_oracle.c "
-                       f"(scalar C, gcc -O3), median {1e3 * float(np.median(per)):.2f} ms/frame",
-                stages_s=o.stage_times())
+    return dict(value=len(per) / dt, units=len(per), mean_ms=1e3 * float(np.mean(per)), median_ms=1e3 * float(np.median(per)))
+
+
+def cpu_baseline(wlname, frames, voc_path, seconds):
+    """The CPU oracle (oracle/orb_oracle.c, scalar C, gcc -O3) timed like the reference examples time Track
+    (steady wall clock around each unit, mean and median as Examples/Stereo/stereo_kitti.cc:113-122), in the three
+    threadings BASELINE.md 2 names.  `value` is the reference's own threading for the workload."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    u = _CpuUnit(wlname, frames, voc_path)
+    wl = u.wl
+    unit = "stereo frames/s" if wl.get("stereo") else "frames/s"
+    variants = {}
+    o = u.new_oracle()
+    st = {}
+    u.run(o, 0, st)  # warm
+    one = _timed_loop(lambda i: u.run(o, i, st), seconds)
+    one["cores"] = 1
+    one["stages_s"] = o.stage_times()
+    variants["one_core"] = one
+    if wl.get("stereo"):
+        o2 = (u.new_oracle(), u.new_oracle())
+        with ThreadPoolExecutor(2) as pool:
+            u.run(o2, 0, {}, pool)
+            two = _timed_loop(lambda i: u.run(o2, i, {}, pool), seconds * 0.6)
+        two["cores"] = 2
+        variants["two_threads_left_right"] = two
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    T = max(1, min(ncpu, u.units, 64))
+    counts, pers = [0] * T, [[] for _ in range(T)]
+    stop = threading.Event()
+    span = max(1, u.units // T)
+
+    def work(t):
+        ot, stt = u.new_oracle(), {}
+        i = 0
+        while not stop.is_set():
+            t1 = time.perf_counter()
+            u.run(ot, t * span + (i % span), stt)
+            pers[t].append(time.perf_counter() - t1)
+            i += 1
+        counts[t] = i
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+    t0 = time.perf_counter()
+    for x in th:
+        x.start()
+    time.sleep(seconds * 0.8)
+    stop.set()
+    for x in th:
+        x.join()
+    dt = time.perf_counter() - t0
+    allp = [p for ps in pers for p in ps]
+    variants["all_cores_frame_parallel"] = dict(value=sum(counts) / dt, units=sum(counts), cores=T, nproc=ncpu,
+                                                mean_ms=1e3 * float(np.mean(allp)), median_ms=1e3 * float(np.median(allp)))
+    ref = "two_threads_left_right" if wl.get("stereo") else "one_core"
+    what = {"tum": "ORBextractor::operator()", "kitti": "operator() on L and R + ComputeStereoMatches",
+            "euroc": "operator() + vocabulary transform + SearchByBoW(t-1,t)"}[wlname]
+    return dict(value=variants[ref]["value"], unit=unit, cores=variants[ref]["cores"], kind="port",
+                sample=f"{variants[ref]['units']} units of the same synthetic {wl['w']}x{wl['h']} workload ({what}) through "
+                       f"oracle/orb_oracle.c (scalar C port, gcc -O3); threading of the reference for this workload: {ref}",
+                mean_ms=variants[ref]["mean_ms"], median_ms=variants[ref]["median_ms"], variants=variants)
+
+
+# ------------------------------------------------------------------------------------------------
+# one GPU workload
+# ------------------------------------------------------------------------------------------------
+class GpuWorkload:
+    def __init__(self, name, frames, B, local_rank, torch, voc_path=None):
+        import orb_slam2_annotate_amd as amd
+        self.amd, self.torch, self.name = amd, torch, name
+        wl = self.wl = WORKLOADS[name]
+        self.W, self.H, self.B = wl["w"], wl["h"], B
+        self.stereo, self.bow = bool(wl.get("stereo")), bool(wl.get("bow"))
+        self.frames = frames
+        self.NI = NI = len(frames)
+        assert NI == (2 * B if self.stereo else B)
+        dev = self.dev = torch.device("cuda", local_rank)
+        self.ext = ext = amd.ORBextractor(wl["nfeatures"], 1.2, 8, wl["ini"], wl["mn"], device=local_rank)
+        self.cap = cap = ext.max_keypoints(self.W, self.H)
+        self.d_img = torch.from_numpy(np.stack(frames)).to(dev)
+        self.d_kp = torch.zeros((NI, cap, 7), dtype=torch.float32, device=dev)
+        self.d_desc = torch.zeros((NI, cap, 32), dtype=torch.uint8, device=dev)
+        self.d_n = torch.zeros((NI,), dtype=torch.int32, device=dev)
+        if self.stereo:
+            self.mbf = np.float32(wl["bf"])
+            self.mb = np.float32(self.mbf / np.float32(wl["fx"]))  # src/Frame.cc:114
+            self.d_u = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+            self.d_dep = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+            self.d_ns = torch.zeros((B,), dtype=torch.int32, device=dev)
+        if self.bow:
+            self.voc = amd.ORBVocabulary(device=local_rank)
+            assert self.voc.loadFromTextFile(voc_path)
+            self.d_match = torch.zeros((NI - 1, cap), dtype=torch.int32, device=dev)
+            self.d_nm = torch.zeros((NI - 1,), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+
+    def step(self, n_units=None):
+        """Enqueue one pass over the first n_units frames / stereo pairs (default: the whole batch); no host wait."""
+        n_units = self.B if n_units is None else n_units
+        ni = 2 * n_units if self.stereo else n_units
+        W, H, cap, ext = self.W, self.H, self.cap, self.ext
+        ext.extract_batch_device(self.d_img.data_ptr(), ni, W, H, W, W * H, self.d_kp.data_ptr(), self.d_desc.data_ptr(),
+                                 cap, self.d_n.data_ptr(), wait=False)
+        if self.stereo:
+            ext.stereo_match_batch_device(n_units, self.d_kp.data_ptr(), self.d_desc.data_ptr(), self.d_n.data_ptr(), cap,
+                                          float(self.mbf), float(self.mb), self.d_u.data_ptr(), self.d_dep.data_ptr(),
+                                          self.d_ns.data_ptr())
+        if self.bow:
+            self.voc.bow_match_consecutive_batch_device(ni, self.d_kp.data_ptr(), self.d_desc.data_ptr(),
+                                                        self.d_n.data_ptr(), cap, self.d_match.data_ptr(),
+                                                        self.d_nm.data_ptr(), nnratio=0.7, check_orientation=True,
+                                                        levelsup=0, extractor=ext)
+
+    def sync(self):
+        self.ext.synchronize()
+        self.torch.cuda.synchronize()
+
+    def check(self, voc_path):
+        """>= 3 frames of the resident batch against the CPU oracle (first, middle = another sub-batch, last);
+        returns the report and the oracle's DescriptorDistance call count per frame of the matching stage."""
+        sys.path.insert(0, str(ROOT / "tests"))
+        import oracle_lib as orc
+        wl, fr, NI, B = self.wl, self.frames, self.NI, self.B
+        o = orc.Oracle(wl["nfeatures"], 1.2, 8, wl["ini"], wl["mn"])
+        n = self.d_n.cpu().numpy()
+        units = sorted({0, B // 2, B - 1})
+        dist_calls, matched = [], []
+        vo = orc.Vocabulary(voc_path) if self.bow else None
+        for ui in units:
+            imgs = [2 * ui, 2 * ui + 1] if self.stereo else ([ui - 1, ui] if (self.bow and ui > 0) else [ui])
+            ref = []
+            for fi in imgs:
+                kr, dr, pr = o.extract(fr[fi], want_pyramid=True)
+                n0 = int(n[fi])
+                kg = self.d_kp[fi, :n0].cpu().numpy().view(np.uint8).reshape(n0, 28)
+                if n0 != len(kr) or not np.array_equal(kg, kr.view(np.uint8).reshape(-1, 28)):
+                    raise SystemExit(f"PARITY FAILURE ({self.name}): keypoints of image {fi} differ from the oracle")
+                if not np.array_equal(self.d_desc[fi, :n0].cpu().numpy(), dr):
+                    raise SystemExit(f"PARITY FAILURE ({self.name}): descriptors of image {fi} differ from the oracle")
+                ref.append((kr, dr, pr))
+            if self.stereo:
+                (kL, dL, pL), (kR, dR, pR) = ref
+                orc.distance_calls_reset()
+                u_ref, dep_ref = o.stereo(self.W, self.H, kL, dL, kR, dR, pL, pR, float(self.mbf), float(self.mb))
+                dist_calls.append(orc.distance_calls())
+                matched.append(int((u_ref >= 0).sum()))
+                if not (np.array_equal(self.d_u[ui, :len(kL)].cpu().numpy(), u_ref) and
+                        np.array_equal(self.d_dep[ui, :len(kL)].cpu().numpy(), dep_ref)):
+                    raise SystemExit(f"PARITY FAILURE ({self.name}): mvuRight/mvDepth of pair {ui} differ from the oracle")
+            if self.bow and ui > 0:
+                (k0, de0, _), (k1, de1, _) = ref
+                fv0, fv1 = orc.FeatVec(vo.transform(de0, 0)[3]), orc.FeatVec(vo.transform(de1, 0)[3])
+                orc.distance_calls_reset()
+                rn, rm = orc.search_by_bow(de0, np.ones(len(k0), np.uint8), k0["angle"], fv0, de1, k1["angle"], fv1, 0.7, True)
+                dist_calls.append(orc.distance_calls())
+                matched.append(int(rn))
+                if int(self.d_nm[ui - 1].item()) != rn or not np.array_equal(self.d_match[ui - 1, :len(k1)].cpu().numpy(), rm):
+                    raise SystemExit(f"PARITY FAILURE ({self.name}): SearchByBoW({ui - 1},{ui}) differs from the oracle")
+        rep = {"ok": True, "units_checked": units,
+               "compared": "keypoints (28-byte records) and descriptors bit-identical"
+                           + (", mvuRight / mvDepth identical" if self.stereo else "")
+                           + (", SearchByBoW match arrays identical" if self.bow else "")}
+        return rep, (float(np.mean(dist_calls)) if dist_calls else 0.0), (float(np.mean(matched)) if matched else 0.0)
+
+
+def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, use_dist, voc_path, batches):
+    wl = WORKLOADS[name]
+    B = batches[name]
+    g = GpuWorkload(name, frames, B, local_rank, torch, voc_path)
+    ext, NI = g.ext, g.NI
+    S = max(1, min(8, args.streams))
+
+    def barrier():
+        g.sync()
+        if use_dist:
+            dist.barrier()
+
+    # (1) warm-up on ONE stream, every stage bracketed by HIP events on its own stream: the exclusive
+    #     (un-shared) duration of every stage
+    ext.set_streams(1)
+    ext.profile(True)
+    n_warm = max(args.warmup, 1)
+    for _ in range(n_warm):
+        g.step()
+        g.sync()
+    warm = ext.profile_get()
+    excl = {s_: warm[s_][0] / n_warm for s_ in GPU_STAGES}
+    # (2) the timed configuration (S sub-batch streams), all stages still timed: the LIVE split -- which kernel
+    #     the GPU spends its time in when the sub-batches overlap; the dominant stage is the largest one here
+    ext.set_streams(S)
+    ext.profile(False)
+    g.step()
+    g.sync()
+    ext.profile(True)
+    n_live = 2
+    for _ in range(n_live):
+        g.step()
+    g.sync()
+    livep = ext.profile_get()
+    live = {s_: livep[s_][0] / n_live for s_ in GPU_STAGES}
+    dom = max(GPU_STAGES, key=lambda s_: live[s_])
+    # (3) timed region: K steps enqueued back to back; only the dominant stage keeps its events (one pair per
+    #     sub-batch launch, on that sub-batch's own stream)
+    ext.profile([dom])
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ext.profile_get()
+    ext.profile(False)
+
+    n_kp = float(g.d_n.float().mean().item())
+    n_st = float(g.d_ns.float().mean().item()) if g.stereo else 0.0
+    dt_max, total_units = reduce_report(dt, float(B * args.steps), torch, dist, use_dist, g.dev)
+    res = None
+    if rank == 0:
+        check, dist_per_unit, _ = g.check(voc_path)
+        sizes = [ext.level_size(g.W, g.H, l) for l in range(ext.GetLevels())]
+        alg = algorithmic_bytes(sizes, n_kp, wl, n_st)
+        ipu = NI / B  # images per unit (2 for stereo)
+        per_launch_units = {s_: (B if s_ == "match" else NI) for s_ in GPU_STAGES}  # exclusive launches: whole batch
+
+        def stage_bytes(s_, images):  # algorithmic bytes of a launch group of stage s_ over `images` images
+            return alg[s_] * (images / ipu if s_ == "match" else images)
+
+        value = total_units / dt_max
+        n_groups = max(prof[dom][1] / (1 if dom == "match" else sum(n for k, n in STAGE_KERNELS[dom] if k != "k_copy2d")), 1)
+        dom_ms = prof[dom][0] / n_groups
+        dom_imgs = prof[dom][2] / n_groups
+        ach = stage_bytes(dom, prof[dom][2]) / (prof[dom][0] * 1e-3) / 1e9 if prof[dom][0] > 0 else 0.0
+        stages = {}
+        for s_ in GPU_STAGES:
+            if excl[s_] <= 0:
+                continue
+            b = stage_bytes(s_, NI)
+            stages[s_] = {"ms_per_step_exclusive": excl[s_], "ms_per_step_live": live[s_],
+                          "algorithmic_bytes_per_step": b,
+                          "hbm_frac_exclusive": b / (excl[s_] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "hbm_frac_live": (b / (live[s_] * 1e-3) / 1e9 / HBM_PEAK_GBS) if live[s_] > 0 else None}
+        pipe_bytes = alg["extract_total"] * ipu + alg["match"]
+        roof = {
+            "bound": "hbm", "kernel": "+".join(k for k, _ in STAGE_KERNELS[dom] if k != "k_copy2d" or name == "kitti"),
+            "stage": dom, "dominant_by": "largest live (multi-stream) HIP-event time of a step",
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": pmc_traffic(dom, name, dom_imgs),
+            "algorithmic_bytes_per_launch_group": stage_bytes(dom, dom_imgs), "ms_per_launch_group": dom_ms,
+            "images_per_launch": dom_imgs, "launch_groups_timed": n_groups, "streams": S,
+            "stages": stages,
+            "pipeline": {"algorithmic_bytes_per_unit": pipe_bytes, "achieved": pipe_bytes * value / world / 1e9,
+                         "frac": pipe_bytes * value / world / 1e9 / HBM_PEAK_GBS,
+                         "sum_exclusive_ms": sum(excl.values()), "ms_per_step": 1e3 * dt_max / args.steps},
+        }
+        if (g.stereo or g.bow) and excl["match"] > 0:
+            pairs = dist_per_unit * B  # distance evaluations of one step (oracle count on the checked units x B)
+            roof["matching"] = {
+                "what": "256-bit Hamming distances of the matcher stage (the reference's DescriptorDistance calls, counted "
+                        "by the oracle on the checked units), alone on the GPU",
+                "distance_pairs_per_unit": dist_per_unit, "distance_pairs_per_s": pairs / (excl["match"] * 1e-3),
+                "popcount32_per_s": 8 * pairs / (excl["match"] * 1e-3), "peak": BCNT_PEAK, "unit": "popcount-32 lane-ops/s",
+                "frac": 8 * pairs / (excl["match"] * 1e-3) / BCNT_PEAK,
+                "note": "v_bcnt_u32_b32 peak measured by tools/ubench/valu_rate.hip (0.585 T wave-instr/s x 64 lanes); the "
+                        "stage is latency-bound (row buckets / node lists of a few dozen candidates per query), not popcount-bound"}
+        v = pmc_valu(name)
+        if v is not None:
+            tot = v.get("total_valu_wave_instr_per_image")
+            per = {}
+            for s_ in GPU_STAGES:
+                ks = [k for k, _ in STAGE_KERNELS[s_] if k in v["kernels"]]
+                if not ks or excl[s_] <= 0:
+                    continue
+                wi = sum(v["kernels"][k]["valu_wave_instr_per_image"] for k in ks) * NI
+                busy = [v["kernels"][k].get("valu_busy") for k in ks if v["kernels"][k].get("valu_busy") is not None]
+                per[s_] = {"wave_instr_per_step": wi, "frac_exclusive": wi / (excl[s_] * 1e-3) / VALU_PEAK,
+                           "valu_busy_pmc": (max(busy) if busy else None)}
+            roof["valu_issue"] = {
+                "peak": VALU_PEAK, "unit": "wave64 VALU instr/s", "measured_class_ceilings": VALU_MEASURED,
+                "source": v.get("_file"), "stages": per,
+                "pipeline_frac": (tot * NI * (value / world / B) / VALU_PEAK) if tot else None,
+                "note": "peak = 2 cycles per wave64 instruction per SIMD (guide); SQ_INSTS_VALU from the committed PMC "
+                        "pass; valu_busy_pmc = 4*SQ_ACTIVE_INST_VALU/(SIMDs*GRBM_GUI_ACTIVE) of the stage's busiest kernel"}
+            best_valu = max([p["frac_exclusive"] for p in per.values()] + [0.0])
+            if dom in per and per[dom]["frac_exclusive"] > stages.get(dom, {}).get("hbm_frac_exclusive", 0):
+                roof["bound_closest"] = "valu_issue"
+            else:
+                roof["bound_closest"] = "hbm"
+            roof["valu_issue"]["max_stage_frac"] = best_valu
+        res = {"workload": wl["name"], "key": name, "value": value,
+               "unit": "stereo frames/s" if g.stereo else "frames/s", "ms_per_step": 1e3 * dt_max / args.steps,
+               "units_per_gpu_per_step": B, "images_per_gpu_per_step": NI, "keypoints_per_image": n_kp,
+               "stereo_matches_per_frame": n_st if g.stereo else None, "roofline": roof, "parity_check": check}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(name, frames[: min(len(frames), 256)], voc_path, args.cpu_seconds)
+            res["vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
+        if args.e2e and hasattr(ext, "extract_batch_pipelined"):
+            res["e2e"] = e2e_rate(g, args)
+    del g
+    torch.cuda.empty_cache()
+    return res
+
+
+def e2e_rate(g, args):
+    """Host images in -> host keypoints/descriptors out (what ORBextractor::operator() is, :1119-1197) through the
+    pinned, double-buffered host-batch path; PCIe-inclusive, reported beside `value`, never as `value`."""
+    n = min(g.NI, 1024)
+    imgs = np.stack(g.frames[:n])
+    g.ext.extract_batch_pipelined(imgs[: min(n, 128)])  # warm: allocations, pinned staging
+    t0 = time.perf_counter()
+    out = g.ext.extract_batch_pipelined(imgs)
+    dt = time.perf_counter() - t0
+    return {"images_per_s": n / dt, "images": n, "what": "orbfe_extract_batch_pipelined: pageable host images -> pinned "
+            "staging -> H2D / compute / D2H overlapped on separate streams -> host keypoints + descriptors",
+            "keypoints_out": int(sum(len(k) for k, _ in out))}
+
+
+def reduce_report(dt, units, torch, dist, use_dist, dev):
+    if not use_dist:
+        return dt, units
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    n = torch.tensor([units], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(n, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(n.item())
+
+
+def run_kitti_seq(frames, args, rank, world, local_rank, torch, dist, use_dist, batches):
+    """configs[4]: the KITTI 00-07 sequences (lengths only -- the images are synthetic pairs cycled from the
+    rank's resident pool) dealt to the ranks by shard.py; one step = every rank runs its share once."""
+    from orb_slam2_annotate_amd import shard
+    B = batches["kitti"]
+    g = GpuWorkload("kitti", frames, B, local_rank, torch)
+    g.ext.set_streams(max(1, min(8, args.streams)))
+    lengths = [max(1, int(round(n * args.seq_scale))) for n in shard.KITTI_00_07]
+    out = {}
+    for mode in ("sequence", "round_robin"):
+        mine = shard.frames_of(shard.shard_sequences(lengths, world, mode)[rank])
+
+        def one_pass():
+            left = mine
+            while left > 0:
+                g.step(min(B, left))
+                left -= min(B, left)
+
+        for _ in range(max(args.warmup, 1)):
+            one_pass()
+        g.sync()
+        if use_dist:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_pass()
+        g.sync()
+        if use_dist:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        dt_max, total = reduce_report(dt, float(mine * args.steps), torch, dist, use_dist, g.dev)
+        out[mode] = {"value": total / dt_max, "ms_per_step": 1e3 * dt_max / args.steps, "stereo_frames_per_step": total / args.steps,
+                     "frames_of_rank0": mine}
+    check = g.check(None)[0] if rank == 0 else None
+    del g
+    return out, lengths, check
+
+
+# ------------------------------------------------------------------------------------------------
+def stub_worker(args, rank, world):
+    """The launcher / barrier / reduction protocol with a CPU stub step (tests/test_shard_gloo.py): no GPU."""
+    import torch
+    import torch.distributed as dist
+    use_dist = world > 1
+    if use_dist:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    units = 100 + rank
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (1 + rank))
+    if use_dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    dt_max, total = reduce_report(dt, float(units * args.steps), torch, dist, use_dist, torch.device("cpu"))
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": total / dt_max, "unit": "units/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps, "stub": True,
+                          "total_units": total}), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096, help="frames resident per GPU and processed per step")
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="tum")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=0, help="units (frames / stereo pairs) resident per GPU and processed "
+                    "per step; 0 = per-workload default (tum 4096, kitti 512, euroc 2048)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["all", "kitti_seq"], default="all")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--check", action="store_true", help="verify frame 0 of the batch against the oracle")
+    ap.add_argument("--cpu-seconds", type=float, default=5.0, help="CPU-baseline budget per variant and workload")
     ap.add_argument("--streams", type=int, default=4,
-                    help="sub-batch HIP streams per call in the timed region (1..8): the L2-bound descriptor "
-                         "kernel of one sub-batch overlaps the VALU-bound FAST/blur kernels of the others")
+                    help="sub-batch HIP streams per call in the timed region (1..8): the latency-bound kernels "
+                         "of one sub-batch overlap the VALU-bound ones of the others")
+    ap.add_argument("--e2e", action="store_true", help="add the host-in/host-out (PCIe-inclusive) rate of each workload")
+    ap.add_argument("--seq-scale", type=float, default=1.0, help="kitti_seq: scale factor on the sequence lengths")
+    ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for 1 rank")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))  # the parent only spawns, waits and relays: no torch, no HIP
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = args.gpus > 1 or world > 1 or args.force_dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if args.stub:
+        return stub_worker(args, rank, world)
+
+    names = ["kitti", "tum", "euroc"] if args.workload == "all" else (["kitti"] if args.workload == "kitti_seq" else [args.workload])
+    batches = {nm: (args.batch if args.batch > 0 else WORKLOADS[nm]["batch"]) for nm in names}
+    inputs = render_inputs(names, batches, rank)  # forks worker processes: before torch / HIP are initialised
+
+    import torch
+    import torch.distributed as dist
+    use_dist = world > 1 or args.force_dist
     if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
-    import orb_slam2_annotate_amd as amd
-    from orb_slam2_annotate_amd import synth
-
-    wl = WORKLOADS[args.workload]
-    W, H, B = wl["w"], wl["h"], args.batch
-    # each rank renders its own shard of the synthetic stream (sequence id = rank)
-    stereo = bool(wl.get("stereo"))
-    if stereo:  # B stereo frames = 2B images, ordered L0,R0,L1,R1,... through one extractor handle
-        pairs = [synth.render_stereo(5000 + 1000 * rank + i, W, H) for i in range(B)]
-        frames = [im for pr in pairs for im in pr]
-    else:
-        frames = synth.render_sequence(1000 + rank, B, W, H, step=1.5)
-    NI = len(frames)  # images resident per GPU
-    ext = amd.ORBextractor(wl["nfeatures"], 1.2, 8, wl["ini"], wl["mn"], device=local_rank)
-    cap = ext.max_keypoints()
-    d_img = torch.from_numpy(np.stack(frames)).to(dev)
-    d_kp = torch.zeros((NI, cap, 7), dtype=torch.float32, device=dev)
-    d_desc = torch.zeros((NI, cap, 32), dtype=torch.uint8, device=dev)
-    d_n = torch.zeros((NI,), dtype=torch.int32, device=dev)
-    if stereo:
-        mbf = np.float32(wl["bf"])
-        mb = np.float32(mbf / np.float32(wl["fx"]))  # src/Frame.cc:114
-        d_u = torch.zeros((B, cap), dtype=torch.float32, device=dev)
-        d_dep = torch.zeros((B, cap), dtype=torch.float32, device=dev)
-        d_ns = torch.zeros((B,), dtype=torch.int32, device=dev)
-    bow = bool(wl.get("bow"))
-    if bow:
-        import tempfile
+    voc_path = None
+    if "euroc" in names:
         from orb_slam2_annotate_amd.vocabulary import write_synthetic_vocabulary
-        vpath = os.path.join(tempfile.gettempdir(), f"orbfe_voc_{os.getpid()}.txt")
-        write_synthetic_vocabulary(vpath, k=10, L=2, seed=1)
-        voc = amd.ORBVocabulary(device=local_rank)
-        assert voc.loadFromTextFile(vpath)
-        os.unlink(vpath)
-        d_match = torch.zeros((NI - 1, cap), dtype=torch.int32, device=dev)
-        d_nm = torch.zeros((NI - 1,), dtype=torch.int32, device=dev)
-    torch.cuda.synchronize()
+        voc_path = os.path.join(tempfile.gettempdir(), f"orbfe_voc_{os.getpid()}.txt")
+        write_synthetic_vocabulary(voc_path, k=10, L=2, seed=1)
 
-    def step(wait=False):
-        ext.extract_batch_device(d_img.data_ptr(), NI, W, H, W, W * H, d_kp.data_ptr(), d_desc.data_ptr(), cap,
-                                 d_n.data_ptr(), wait=wait and not stereo and not bow)
-        if stereo:
-            ext.stereo_match_batch_device(B, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, float(mbf),
-                                          float(mb), d_u.data_ptr(), d_dep.data_ptr(), d_ns.data_ptr())
-            if wait:
-                ext.synchronize()
-        if bow:
-            ext.synchronize()  # the vocabulary handle runs on its own stream
-            voc.bow_match_consecutive_batch_device(NI, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap,
-                                                   d_match.data_ptr(), d_nm.data_ptr(), nnratio=0.7,
-                                                   check_orientation=True, levelsup=0)
-
-    def barrier():
-        ext.synchronize()
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-
-    # warmup on ONE stream, every stage timed with HIP events on the extractor's stream: finds the
-    # dominant kernel and gives its exclusive (un-shared) duration
-    gpu_stages = ["pyramid", "fast", "octree", "blur", "orient_desc"]
-    ext.set_streams(1)
-    ext.profile(True)
-    for _ in range(max(args.warmup, 1)):
-        step(wait=True)
-    warm = ext.profile_get()
-    n_warm = max(args.warmup, 1)
-    dom = max(gpu_stages, key=lambda s_: warm[s_][0])
-    # timed region: K steps enqueued back to back (each step = one pass of ORBextractor::operator()
-    # over the resident batch, split over `streams` sub-batch streams); only the dominant stage keeps
-    # its events: one pair per sub-batch launch, recorded on that sub-batch's own stream
-    ext.set_streams(max(1, min(8, args.streams)))
-    ext.profile(False)
-    step(wait=True)  # one untimed pass on the new stream split
-    ext.profile([dom])
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(wait=False)
-    barrier()
-    dt = time.perf_counter() - t0
-    prof = ext.profile_get()
-    ext.profile(False)
-
-    n_kp = float(d_n.float().mean().item())
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    frames_done = torch.tensor([float(B * args.steps)], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(frames_done, op=dist.ReduceOp.SUM)
-    dt_max = float(t.item())
-    total_frames = float(frames_done.item())
-
-    if args.check and rank == 0:
-        sys.path.insert(0, str(ROOT / "tests"))
-        import oracle_lib as orc
-        o = orc.Oracle(wl["nfeatures"], 1.2, 8, wl["ini"], wl["mn"])
-        for fi in sorted({0, NI // 2, NI - 1}):  # first, middle (second sub-batch) and last image
-            kr, dr = o.extract(frames[fi])
-            n0 = int(d_n[fi].item())
-            kg = d_kp[fi, :n0].cpu().numpy().view(np.uint8).reshape(n0, 28)
-            assert n0 == len(kr) and np.array_equal(kg, kr.view(np.uint8).reshape(-1, 28)), "keypoints differ from oracle"
-            assert np.array_equal(d_desc[fi, :n0].cpu().numpy(), dr), "descriptors differ from oracle"
-        if stereo:
-            kL, dL, pL = o.extract(frames[0], want_pyramid=True)
-            kR, dR, pR = o.extract(frames[1], want_pyramid=True)
-            u_ref, dep_ref = o.stereo(W, H, kL, dL, kR, dR, pL, pR, float(mbf), float(mb))
-            assert np.array_equal(d_u[0, :len(kL)].cpu().numpy(), u_ref), "mvuRight differs from oracle"
-            assert np.array_equal(d_dep[0, :len(kL)].cpu().numpy(), dep_ref), "mvDepth differs from oracle"
-        if bow:
-            vpath = os.path.join(tempfile.gettempdir(), f"orbfe_voc_chk_{os.getpid()}.txt")
-            write_synthetic_vocabulary(vpath, k=10, L=2, seed=1)
-            vo = orc.Vocabulary(vpath)
-            os.unlink(vpath)
-            k0, de0 = o.extract(frames[0])
-            k1, de1 = o.extract(frames[1])
-            _, _, _, nd0 = vo.transform(de0, 0)
-            _, _, _, nd1 = vo.transform(de1, 0)
-            rn, rm = orc.search_by_bow(de0, np.ones(len(k0), np.uint8), k0["angle"], orc.FeatVec(nd0), de1,
-                                       k1["angle"], orc.FeatVec(nd1), 0.7, True)
-            assert int(d_nm[0].item()) == rn and np.array_equal(d_match[0, :len(k1)].cpu().numpy(), rm), \
-                "SearchByBoW differs from oracle"
-
-    if rank == 0:
-        sizes = level_pixels(ext, W, H)
-        alg = algorithmic_bytes(sizes, n_kp)
-        alg["octree"] = 0
-        # dominant kernel = the stage with the largest event time; timed live in the timed region
-        # every sub-batch launch of the dominant stage is timed: prof[dom] = (ms, launches, frames) in total
-        n_groups = max(prof[dom][1] / sum(n for _, n in STAGE_KERNELS[dom]), 1)  # timed launches of the stage
-        dom_ms_per_group = prof[dom][0] / n_groups
-        dom_frames_per_group = prof[dom][2] / n_groups
-        ach = alg[dom] * prof[dom][2] / (prof[dom][0] * 1e-3) / 1e9 if prof[dom][0] > 0 else 0.0
-        imgs_per_frame = NI / B
-        value = total_frames / dt_max
-        out = {
-            "metric": "ORB extract frames/sec (bit-exact kp/desc vs CPU oracle)",
-            "value": value,
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt_max / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8",
-            "data": "synthetic",
-            "config": {"workload": wl["name"], "frames_per_gpu_per_step": B, "images_per_gpu_per_step": NI,
-                       "keypoints_per_frame": n_kp,
-                       "sharding": f"frames sharded one batch per GPU x{world}, no data-path collective"},
-            "roofline": {
-                "bound": "hbm", "kernel": "+".join(k for k, _ in STAGE_KERNELS[dom]), "stage": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(dom, args.workload, B, dom_frames_per_group),
-                "algorithmic_bytes_per_launch_group": alg[dom] * dom_frames_per_group,
-                "algorithmic_bytes_per_frame": alg[dom], "ms_per_launch_group": dom_ms_per_group,
-                "frames_per_launch": dom_frames_per_group, "launch_groups_timed": n_groups,
-                "pipeline": {"algorithmic_bytes_per_image": alg["extract_total"],
-                             "achieved": alg["extract_total"] * imgs_per_frame * value / world / 1e9,
-                             "frac": alg["extract_total"] * imgs_per_frame * value / world / 1e9 / HBM_PEAK_GBS},
-                "streams": max(1, min(8, args.streams)),
-                "exclusive": {  # the same stage alone on the GPU (single-stream warm-up passes)
-                    "ms_per_launch_group": warm[dom][0] / n_warm, "frames_per_launch": NI,
-                    "achieved": alg[dom] * NI / (warm[dom][0] / n_warm * 1e-3) / 1e9,
-                    "frac": alg[dom] * NI / (warm[dom][0] / n_warm * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                "stage_ms_per_step_exclusive": {s_: warm[s_][0] / n_warm for s_ in gpu_stages},
-            },
-        }
-        # what actually limits the dominant kernel (DESIGN.md 4): VALU issue, from the committed PMC summary
-        v_stage, v_total = pmc_valu(dom, args.workload)
-        if v_stage is not None:
-            excl_s = warm[dom][0] / n_warm * 1e-3
-            out["roofline"]["valu_issue"] = {
-                "wave_instr_per_frame": v_stage, "peak": VALU_ISSUE_PEAK, "unit": "wave64 VALU instr/s",
-                "achieved_exclusive": v_stage * NI / excl_s, "frac_exclusive": v_stage * NI / excl_s / VALU_ISSUE_PEAK,
-                "note": "peak = nominal rate of full wave64 instructions (4 cycles each); an instruction whose upper or "
-                        "lower half-wave is inactive issues in 2, so a divergent kernel can exceed it",
-                "pipeline_wave_instr_per_frame": v_total,
-                "pipeline_frac": (v_total * imgs_per_frame * value / world / VALU_ISSUE_PEAK) if v_total else None}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames, wl)
-            if stereo:
-                out["cpu_baseline"]["note"] = "extraction only (per image); stereo matching not included"
-        print(json.dumps(out))
+    if args.workload == "kitti_seq":
+        plans, lengths, check = run_kitti_seq(inputs["kitti"], args, rank, world, local_rank, torch, dist, use_dist, batches)
+        if rank == 0:
+            wl = WORKLOADS["kitti"]
+            print(json.dumps({
+                "metric": "ORB extract+match stereo frames/sec, KITTI 00-07 sharded over the GPUs (bit-exact vs CPU oracle on checked frames)",
+                "value": plans["sequence"]["value"], "unit": "stereo frames/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": plans["sequence"]["ms_per_step"], "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                "config": {"workload": "KITTI 00-07 (sequence lengths %s; synthetic 1241x376 stereo pairs cycled from a resident pool of %d), "
+                                       "nFeatures=2000, extract L+R + ComputeStereoMatches" % (lengths, batches["kitti"]),
+                           "sharding": "plan 'sequence': sequence s -> rank s mod N (configs[4]); no data-path collective",
+                           "per_image": wl["name"]},
+                "plans": plans, "parity_check": check}), flush=True)
+    else:
+        results = []
+        for nm in names:
+            r = run_gpu_workload(nm, inputs.pop(nm), args, rank, world, local_rank, torch, dist, use_dist, voc_path, batches)
+            results.append(r)
+        if rank == 0:
+            head = results[0]
+            out = {
+                "metric": "ORB extract+match frames/sec (kp/desc/matches bit-exact vs CPU oracle on the checked frames of every run)",
+                "value": head["value"], "unit": head["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "u8", "data": "synthetic",
+                "config": {"workload": head["workload"], "units_per_gpu_per_step": head["units_per_gpu_per_step"],
+                           "images_per_gpu_per_step": head["images_per_gpu_per_step"],
+                           "keypoints_per_image": head["keypoints_per_image"],
+                           "sharding": f"independent frames, one resident batch per GPU x{world}, no data-path collective"},
+                "roofline": head["roofline"], "parity_check": head["parity_check"],
+            }
+            for k in ("cpu_baseline", "vs_cpu_baseline", "e2e", "stereo_matches_per_frame"):
+                if head.get(k) is not None:
+                    out[k] = head[k]
+            if len(results) > 1:
+                out["secondary"] = results[1:]
+            print(json.dumps(out), flush=True)
+    if voc_path:
+        try:
+            os.unlink(voc_path)
+        except OSError:
+            pass
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -177,6 +177,7 @@ enum {
   ORBFE_STAGE_BLUR,
   ORBFE_STAGE_ORIENT_DESC,
   ORBFE_STAGE_D2H,
+  ORBFE_STAGE_MATCH, /* batched matcher enqueued on the handle's stream (stereo / consecutive-frame BoW) */
   ORBFE_STAGE_COUNT
 };
 int orbfe_extractor_profile(orbfe_extractor *e, int stage_mask);
@@ -307,6 +308,16 @@ int orbfe_bow_match_consecutive_batch_device(orbfe_vocabulary *v, int n_frames,
                                              int capacity, int levelsup, float nnratio,
                                              int check_orientation, int32_t *d_match,
                                              int32_t *d_nmatches);
+/* The same, enqueued on extractor e's stream behind every sub-batch of its last
+ * orbfe_extract_batch_device_async call (ordered on the device, no host wait); returns at once,
+ * orbfe_extractor_synchronize(e) waits.  The next extract call on e may be enqueued right away: its
+ * sub-batch streams wait for this matcher before they overwrite the keypoints it reads. */
+int orbfe_bow_match_consecutive_batch_device_async(orbfe_vocabulary *v, orbfe_extractor *e, int n_frames,
+                                                   const orbfe_keypoint *d_keypoints,
+                                                   const uint8_t *d_descriptors, const int32_t *d_n,
+                                                   int capacity, int levelsup, float nnratio,
+                                                   int check_orientation, int32_t *d_match,
+                                                   int32_t *d_nmatches);
 
 /* ------------------------------------------------------------------------- */
 /* Next to the path                                */

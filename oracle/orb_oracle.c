@@ -820,8 +820,14 @@ int orc_extract(orc_extractor *e, const uint8_t *img, int W, int H, int stride, 
 /* ------------------------------------------------------------------ */
 /* matcher: src/ORBmatcher.cc                                          */
 /* ------------------------------------------------------------------ */
+/* bench.py's matching roofline counts the reference's DescriptorDistance calls: per-thread tally */
+static __thread int64_t g_distance_calls = 0;
+void orc_distance_calls_reset(void) { g_distance_calls = 0; }
+int64_t orc_distance_calls(void) { return g_distance_calls; }
+
 int orc_descriptor_distance(const uint8_t *a, const uint8_t *b) { /* :1828-1844 */
   int dist = 0;
+  g_distance_calls++;
   for (int i = 0; i < 8; i++) {
     uint32_t pa, pb;
     memcpy(&pa, a + 4 * i, 4);

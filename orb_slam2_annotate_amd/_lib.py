@@ -17,7 +17,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
 assert KP_DTYPE.itemsize == 28
 
-STAGES = ["h2d", "pyramid", "fast", "octree", "blur", "orient_desc", "d2h"]
+STAGES = ["h2d", "pyramid", "fast", "octree", "blur", "orient_desc", "d2h", "match"]
 ORBFE_OK, ERR_INVALID, ERR_CAPACITY, ERR_HIP, ERR_NOMEM = 0, -1, -2, -3, -4
 
 
@@ -53,7 +53,7 @@ EXPORTS = [
     "orbfe_hamming_matrix", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",
     "orbfe_search_for_triangulation", "orbfe_compute_stereo_matches", "orbfe_stereo_match_batch_device", "orbfe_vocabulary_load_text", "orbfe_vocabulary_destroy",
     "orbfe_vocabulary_info", "orbfe_vocabulary_transform", "orbfe_vocabulary_featvec_batch_device",
-    "orbfe_bow_match_consecutive_batch_device", "orbfe_cvt_gray", "orbfe_cvt_gray_batch_device",
+    "orbfe_bow_match_consecutive_batch_device", "orbfe_bow_match_consecutive_batch_device_async", "orbfe_cvt_gray", "orbfe_cvt_gray_batch_device",
     "orbfe_distinctive_descriptors", "orbfe_features_in_area", "orbfe_search_by_projection",
     "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_keyframe",
     "orbfe_search_by_projection_sim3", "orbfe_search_for_initialization", "orbfe_fuse_search", "orbfe_search_by_sim3",
@@ -146,6 +146,7 @@ def load():
     L.orbfe_vocabulary_transform.argtypes = [vp, vp, ci, ci, vp, vp, vp]
     L.orbfe_vocabulary_featvec_batch_device.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp]
     L.orbfe_bow_match_consecutive_batch_device.argtypes = [vp, ci, vp, vp, vp, ci, ci, cf, ci, vp, vp]
+    L.orbfe_bow_match_consecutive_batch_device_async.argtypes = [vp, vp, ci, vp, vp, vp, ci, ci, cf, ci, vp, vp]
     L.orbfe_cvt_gray.argtypes = [ci, vp, ci, ci, ci, ci, ci, vp, ci]
     L.orbfe_cvt_gray_batch_device.argtypes = [ci, vp, ci, ci, ci, ci, cs, ci, ci, vp, ci, cs]
     L.orbfe_distinctive_descriptors.argtypes = [ci, vp, vp, ci, vp]

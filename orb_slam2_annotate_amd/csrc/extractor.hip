@@ -49,6 +49,14 @@ struct orbfe_extractor {
   static constexpr int kMaxStreams = 8;
   hipStream_t extra[kMaxStreams - 1] = {};   // sub-batch streams 1..7
   int nStreams = 1;                          // >1: sub-batches of one call run concurrently
+  // cross-stream ordering without host synchronisation: evChunkDone[i] marks the end of sub-batch i of the
+  // last extract call (consumers on `stream` wait for it); evConsumerDone marks the end of the last kernel
+  // on `stream` that READS the workspace / the caller's outputs of all sub-batches (batched stereo matcher),
+  // and every sub-batch stream of the next extract call waits for it before it overwrites them
+  hipEvent_t evChunkDone[kMaxStreams] = {};
+  hipEvent_t evConsumerDone = nullptr;
+  int chunksPending = 0;                     // sub-batch streams 1..chunksPending-1 carry an unrecorded-for-consumer event
+  bool consumerPending = false;
   int lastSplitFrames = -1, lastSplitStreams = -1;
   double stageFrames[ORBFE_STAGE_COUNT] = {};
   // stage timing: a ring of event pairs per stage so that asynchronous calls can stay in flight
@@ -461,10 +469,14 @@ int run_pipeline(orbfe_extractor* e, LevelView level0, int nFrames, orbfe_keypoi
     const int n = f0 + per <= nFrames ? per : nFrames - f0;
     if (n <= 0) break;
     hipStream_t s = i == 0 ? e->stream : e->extra[i - 1];
+    if (i > 0 && e->consumerPending) HIPCHK(hipStreamWaitEvent(s, e->evConsumerDone, 0));
     int rc = run_chunk(e, s, i, level0, f0, n, d_kp, d_desc, capacity, d_nOut, i == 0 ? &e->lastPyr : nullptr,
                        i == 0 ? &e->lastBlur : nullptr);
     if (rc) return rc;
+    if (i > 0) HIPCHK(hipEventRecord(e->evChunkDone[i], s));
   }
+  e->consumerPending = false;  // stream 0 is ordered behind the consumer by itself
+  e->chunksPending = S;
   e->lastFrames = nFrames;
   e->haveLast = true;
   return ORBFE_OK;
@@ -500,6 +512,9 @@ extern "C" int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlev
     int v = atoi(env);
     if (v >= 1 && v <= orbfe_extractor::kMaxStreams) e->nStreams = v;
   }
+  for (int i = 0; i < orbfe_extractor::kMaxStreams && err == hipSuccess; i++)
+    err = hipEventCreateWithFlags(&e->evChunkDone[i], hipEventDisableTiming);
+  if (err == hipSuccess) err = hipEventCreateWithFlags(&e->evConsumerDone, hipEventDisableTiming);
   for (int r = 0; r < orbfe_extractor::kEvRing; r++)
     for (int u = 0; u < orbfe_extractor::kEvSubs; u++)
       for (int i = 0; i < ORBFE_STAGE_COUNT && err == hipSuccess; i++) {
@@ -558,6 +573,9 @@ extern "C" void orbfe_extractor_destroy(orbfe_extractor* e) {
         if (e->evA[r][u][i]) (void)hipEventDestroy(e->evA[r][u][i]);
         if (e->evB[r][u][i]) (void)hipEventDestroy(e->evB[r][u][i]);
       }
+  for (int i = 0; i < orbfe_extractor::kMaxStreams; i++)
+    if (e->evChunkDone[i]) (void)hipEventDestroy(e->evChunkDone[i]);
+  if (e->evConsumerDone) (void)hipEventDestroy(e->evConsumerDone);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -810,7 +828,7 @@ extern "C" int orbfe_extractor_profile_get(orbfe_extractor* e, double* ms_out, i
   return ORBFE_OK;
 }
 extern "C" const char* orbfe_stage_name(int stage) {
-  static const char* names[ORBFE_STAGE_COUNT] = {"h2d", "pyramid", "fast", "octree", "blur", "orient_desc", "d2h"};
+  static const char* names[ORBFE_STAGE_COUNT] = {"h2d", "pyramid", "fast", "octree", "blur", "orient_desc", "d2h", "match"};
   return (stage >= 0 && stage < ORBFE_STAGE_COUNT) ? names[stage] : "?";
 }
 
@@ -893,6 +911,31 @@ extern "C" int orbfe_stereo_views_(orbfe_extractor* e, int frame, PyramidViews* 
   return ORBFE_OK;
 }
 
+// internal (vocabulary.hip): a consumer of the last extract call's outputs that runs on the handle's own
+// stream.  begin: stream 0 waits (on the device) for every sub-batch stream of that call and is returned;
+// end: marks the consumer's last kernel so that the next extract call's sub-batch streams wait for it.
+extern "C" int orbfe_extractor_consumer_begin_(orbfe_extractor* e, hipStream_t* s) {
+  if (!e || !s) return fail(ORBFE_ERR_INVALID, "NULL handle");
+  HIPCHK(hipSetDevice(e->device));
+  for (int i = 1; i < e->chunksPending; i++) HIPCHK(hipStreamWaitEvent(e->stream, e->evChunkDone[i], 0));
+  *s = e->stream;
+  if ((e->stageMask >> ORBFE_STAGE_MATCH) & 1u) {  // same ring slot as the extract call it follows, sub-batch 0
+    HIPCHK(hipEventRecord(e->evA[e->evSlot][0][ORBFE_STAGE_MATCH], e->stream));
+    e->evLaunches[e->evSlot][0][ORBFE_STAGE_MATCH] = 1;
+    e->evFrames[e->evSlot][0][ORBFE_STAGE_MATCH] = e->lastFrames;
+  }
+  return ORBFE_OK;
+}
+extern "C" int orbfe_extractor_consumer_end_(orbfe_extractor* e) {
+  if ((e->stageMask >> ORBFE_STAGE_MATCH) & 1u) {
+    HIPCHK(hipEventRecord(e->evB[e->evSlot][0][ORBFE_STAGE_MATCH], e->stream));
+    e->evUsed[e->evSlot][0][ORBFE_STAGE_MATCH] = true;
+  }
+  HIPCHK(hipEventRecord(e->evConsumerDone, e->stream));
+  e->consumerPending = true;
+  return ORBFE_OK;
+}
+
 // Debug: route DistributeOctTree through the host implementation (cross-check of k_octree).
 extern "C" int orbfe_extractor_debug_host_octree(orbfe_extractor* e, int enable) {
   if (!e) return fail(ORBFE_ERR_INVALID, "NULL handle");
@@ -923,7 +966,9 @@ extern "C" int orbfe_stereo_match_batch_device(orbfe_extractor* e, int n_pairs, 
     return fail(ORBFE_ERR_INVALID, "stereo_match_batch_device: the last extract call holds fewer than 2*n_pairs frames");
   if (capacity >= (1 << 20)) return fail(ORBFE_ERR_INVALID, "stereo_match_batch_device: capacity too large");
   HIPCHK(hipSetDevice(e->device));
-  if (e->nStreams > 1) { int rc = sync_all(e); if (rc) return rc; }  // all sub-batches must have landed
+  // every sub-batch of the extract call must have landed before the matcher reads its keypoints and
+  // pyramid: stream 0 waits for the other sub-batch streams ON THE DEVICE (no host synchronisation)
+  { hipStream_t s0; int rc = orbfe_extractor_consumer_begin_(e, &s0); if (rc) return rc; }
   const size_t need = (size_t)n_pairs * capacity;
   const int rows = e->lastPyr.lv[0].h;
   const size_t needRows = (size_t)n_pairs * (rows + 1);
@@ -958,6 +1003,9 @@ extern "C" int orbfe_stereo_match_batch_device(orbfe_extractor* e, int n_pairs, 
   b.sad = e->d_stereoSad;
   launch_stereo_batch(e->stream, a, b, n_pairs, d_n_stereo);
   HIPCHK(hipGetLastError());
+  // the next extract call's sub-batch streams overwrite the pyramid slabs and the caller's keypoint /
+  // descriptor / count buffers this matcher is still reading: they wait for this event (run_pipeline)
+  { int rc = orbfe_extractor_consumer_end_(e); if (rc) return rc; }
   return ORBFE_OK;  // asynchronous on the handle's stream: orbfe_extractor_synchronize() to wait
 }
 

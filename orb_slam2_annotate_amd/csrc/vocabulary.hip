@@ -44,6 +44,7 @@ struct orbfe_vocabulary {
   uint32_t* w_nodes = nullptr; int32_t* w_offsets = nullptr; uint32_t* w_indices = nullptr; int32_t* w_count = nullptr;
   int8_t* w_bin = nullptr;
   size_t wFrames = 0; int wCap = 0;
+  hipStream_t lastStream = nullptr;  // stream of the last batched call (its workspace may still be in use there)
 };
 
 namespace {
@@ -367,12 +368,15 @@ extern "C" int orbfe_vocabulary_featvec_batch_device(orbfe_vocabulary* v, const 
 // Tracking::TrackReferenceKeyFrame-style matching over a device-resident batch: for t = 1..n-1,
 // ComputeBoW of both frames then SearchByBoW(KF = frame t-1 with a MapPoint on every feature,
 // F = frame t)  (src/Tracking.cc:836-843, src/ORBmatcher.cc:185-325).
-extern "C" int orbfe_bow_match_consecutive_batch_device(orbfe_vocabulary* v, int n_frames,
-                                                        const orbfe_keypoint* d_keypoints,
-                                                        const uint8_t* d_descriptors, const int32_t* d_n,
-                                                        int capacity, int levelsup, float nnratio,
-                                                        int check_orientation, int32_t* d_match,
-                                                        int32_t* d_nmatches) {
+extern "C" int orbfe_extractor_consumer_begin_(orbfe_extractor* e, hipStream_t* s);
+extern "C" int orbfe_extractor_consumer_end_(orbfe_extractor* e);
+
+// e != NULL: enqueue on the extractor's stream, ordered behind every sub-batch of its last extract call, and
+// return without waiting (orbfe_extractor_synchronize() to wait); e == NULL: the vocabulary's own stream, waits.
+static int bow_match_consecutive(orbfe_vocabulary* v, orbfe_extractor* e, int n_frames,
+                                 const orbfe_keypoint* d_keypoints, const uint8_t* d_descriptors,
+                                 const int32_t* d_n, int capacity, int levelsup, float nnratio,
+                                 int check_orientation, int32_t* d_match, int32_t* d_nmatches) {
   if (!v || n_frames < 0 || capacity <= 0 || capacity > 65535 || !d_keypoints || !d_descriptors || !d_n || !d_match ||
       !d_nmatches)
     return vfail(ORBFE_ERR_INVALID, "bow_match_consecutive_batch_device: bad argument");
@@ -380,23 +384,56 @@ extern "C" int orbfe_bow_match_consecutive_batch_device(orbfe_vocabulary* v, int
   const int sortN = next_pow2(capacity);
   if ((size_t)sortN * 8 > 64 * 1024) return vfail(ORBFE_ERR_INVALID, "bow_match_consecutive_batch_device: capacity > 8192");
   VHIP(hipSetDevice(v->device));
+  if ((size_t)n_frames > v->wFrames || capacity > v->wCap) {
+    if (v->lastStream) VHIP(hipStreamSynchronize(v->lastStream));  // the workspace may still be in use there
+  }
   int rc = ensure_bow_workspace(v, n_frames, capacity);
   if (rc) return rc;
+  hipStream_t s = v->stream;
+  if (e) {
+    if ((rc = orbfe_extractor_consumer_begin_(e, &s))) return rc;
+    if (v->lastStream && v->lastStream != s) VHIP(hipStreamSynchronize(v->lastStream));
+  } else if (v->lastStream && v->lastStream != s) {
+    VHIP(hipStreamSynchronize(v->lastStream));
+  }
+  v->lastStream = s;
   FeatVecBatch fb = {};
   fb.desc = d_descriptors; fb.n = d_n; fb.capacity = capacity; fb.sortN = sortN;
   fb.fvNodes = v->w_nodes; fb.fvOffsets = v->w_offsets; fb.fvIndices = v->w_indices; fb.fvCount = v->w_count;
-  launch_vocab_featvec(v->stream, v->d, fb, n_frames, v->L - levelsup);
+  launch_vocab_featvec(s, v->d, fb, n_frames, v->L - levelsup);
   const int nPairs = n_frames - 1;
-  VHIP(hipMemsetAsync(d_match, 0xff, (size_t)nPairs * capacity * 4, v->stream));
-  VHIP(hipMemsetAsync(v->w_bin, 0, (size_t)nPairs * capacity, v->stream));
+  VHIP(hipMemsetAsync(d_match, 0xff, (size_t)nPairs * capacity * 4, s));
+  VHIP(hipMemsetAsync(v->w_bin, 0, (size_t)nPairs * capacity, s));
   BowBatch bb = {};
   bb.kp = reinterpret_cast<const float*>(d_keypoints); bb.desc = d_descriptors; bb.capacity = capacity;
   bb.fvNodes = v->w_nodes; bb.fvOffsets = v->w_offsets; bb.fvIndices = v->w_indices; bb.fvCount = v->w_count;
   bb.nnratio = nnratio; bb.match = d_match; bb.bin = v->w_bin;
-  launch_search_by_bow_batch(v->stream, bb, nPairs, check_orientation, d_nmatches);
+  launch_search_by_bow_batch(s, bb, nPairs, check_orientation, d_nmatches);
   VHIP(hipGetLastError());
-  VHIP(hipStreamSynchronize(v->stream));
+  if (e) return orbfe_extractor_consumer_end_(e);
+  VHIP(hipStreamSynchronize(s));
   return ORBFE_OK;
+}
+
+extern "C" int orbfe_bow_match_consecutive_batch_device(orbfe_vocabulary* v, int n_frames,
+                                                        const orbfe_keypoint* d_keypoints,
+                                                        const uint8_t* d_descriptors, const int32_t* d_n,
+                                                        int capacity, int levelsup, float nnratio,
+                                                        int check_orientation, int32_t* d_match,
+                                                        int32_t* d_nmatches) {
+  return bow_match_consecutive(v, nullptr, n_frames, d_keypoints, d_descriptors, d_n, capacity, levelsup, nnratio,
+                               check_orientation, d_match, d_nmatches);
+}
+
+extern "C" int orbfe_bow_match_consecutive_batch_device_async(orbfe_vocabulary* v, orbfe_extractor* e, int n_frames,
+                                                              const orbfe_keypoint* d_keypoints,
+                                                              const uint8_t* d_descriptors, const int32_t* d_n,
+                                                              int capacity, int levelsup, float nnratio,
+                                                              int check_orientation, int32_t* d_match,
+                                                              int32_t* d_nmatches) {
+  if (!e) return vfail(ORBFE_ERR_INVALID, "bow_match_consecutive_batch_device_async: NULL extractor");
+  return bow_match_consecutive(v, e, n_frames, d_keypoints, d_descriptors, d_n, capacity, levelsup, nnratio,
+                               check_orientation, d_match, d_nmatches);
 }
 
 // internal: device view for the batched BoW path (extractor.hip)

@@ -53,7 +53,17 @@ def lib():
         _lib.orc_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         _lib.orc_pattern.restype = C.POINTER(C.c_byte)
         _lib.orc_ic_angle.restype = C.c_float
+        _lib.orc_distance_calls.restype = C.c_int64
     return _lib
+
+
+def distance_calls_reset():
+    lib().orc_distance_calls_reset()
+
+
+def distance_calls() -> int:
+    """DescriptorDistance calls of this thread since the last reset (bench.py's matching roofline)."""
+    return int(lib().orc_distance_calls())
 
 
 def _p(a):

@@ -184,3 +184,47 @@ def test_stereo_batch_device_resident(amd):
             assert np.array_equal(u[: len(kL)], u_ref) and np.array_equal(d[: len(kL)], d_ref)
             assert (u[len(kL):] == -1).all()
             assert int(d_ns[p].item()) == int((u_ref >= 0).sum()) > 30
+
+
+def test_stereo_then_next_async_extract_does_not_race(amd):
+    """async extract(A) on 4 sub-batch streams, stereo(A), async extract(B != A) enqueued
+    right behind it without any host wait -- stereo(A) must still equal the oracle (the sub-batch streams
+    of extract(B) overwrite the pyramid slabs and keypoint buffers stereo(A) reads)."""
+    torch = pytest.importorskip("torch")
+    w, h, nf = 640, 240, 800
+    P = 8
+    pairsA = [synth.render_stereo(300 + p, w, h, n_shapes=300, max_disp=48) for p in range(P)]
+    pairsB = [synth.render_stereo(900 + p, w, h, n_shapes=200, max_disp=32) for p in range(P)]
+    imgsA = np.stack([im for pr in pairsA for im in pr])
+    imgsB = np.stack([im for pr in pairsB for im in pr])
+    e = amd.ORBextractor(nf, 1.2, 8, 20, 7)
+    e.set_streams(4)
+    cap = e.max_keypoints()
+    dev = torch.device("cuda", 0)
+    B = 2 * P
+    d_A, d_B = torch.from_numpy(imgsA).to(dev), torch.from_numpy(imgsB).to(dev)
+    d_kp = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros((B,), dtype=torch.int32, device=dev)
+    d_u = torch.zeros((2, P, cap), dtype=torch.float32, device=dev)
+    d_d = torch.zeros((2, P, cap), dtype=torch.float32, device=dev)
+    d_ns = torch.zeros((2, P), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    mbf = np.float32(120.0)
+    mb = np.float32(mbf / np.float32(400.0))
+    for rep in range(3):  # several back-to-back rounds keep all four streams busy
+        for k, d_img in enumerate((d_A, d_B)):
+            e.extract_batch_device(d_img.data_ptr(), B, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(), cap,
+                                   d_n.data_ptr(), wait=False)
+            e.stereo_match_batch_device(P, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, float(mbf),
+                                        float(mb), d_u[k].data_ptr(), d_d[k].data_ptr(), d_ns[k].data_ptr())
+    e.synchronize()
+    o = orc.Oracle(nf, 1.2, 8, 20, 7)
+    for k, imgs in enumerate((imgsA, imgsB)):
+        for p in range(P):
+            kL, dL, pL = o.extract(imgs[2 * p], want_pyramid=True)
+            kR, dR, pR = o.extract(imgs[2 * p + 1], want_pyramid=True)
+            u_ref, d_ref = o.stereo(w, h, kL, dL, kR, dR, pL, pR, float(mbf), float(mb))
+            assert np.array_equal(d_u[k, p, :len(kL)].cpu().numpy(), u_ref), (k, p)
+            assert np.array_equal(d_d[k, p, :len(kL)].cpu().numpy(), d_ref), (k, p)
+            assert int(d_ns[k, p].item()) == int((u_ref >= 0).sum())

@@ -73,3 +73,36 @@ def test_gloo_world2_barrier_and_reductions():
     for _, t, n in res:
         assert t == 2.0  # max over ranks
         assert n == float(sum(shard.KITTI_00_07))  # every frame counted exactly once
+
+
+def test_bench_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must spawn two ranks (fresh child
+    processes), run the barrier / MAX / SUM protocol (gloo here, a stub step: no GPU) and relay rank 0's single
+    JSON line with n_gpus = 2."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--stub", "--steps", "3"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3
+    assert out["total_units"] == 3 * (100 + 101)  # SUM over both ranks
+    assert out["ms_per_step"] >= 4.0  # MAX over ranks: rank 1 sleeps 4 ms per step
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    # an unknown workload makes every rank exit with an argparse error: the launcher must not report success
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--stub", "--workload", "nope"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0

@@ -139,3 +139,56 @@ def test_gpu_bow_batch_device_matches_oracle(tmp_path):
         assert np.array_equal(got, ref)
         total += ref_n
     assert total > 100
+
+
+@pytest.mark.gpu
+def test_gpu_euroc_composite_extract_then_search_by_bow(tmp_path):
+    """BASELINE.json configs[3] as one composite: 752x480 / 1200-feature extraction output of consecutive
+    frames -> ComputeBoW -> SearchByBoW(t-1, t), device-resident and asynchronous behind the extractor's
+    4 sub-batch streams, twice back to back (no host wait in between), against the oracle end to end."""
+    torch = pytest.importorskip("torch")
+    import orb_slam2_annotate_amd as amd
+    path = tmp_path / "voc.txt"
+    write_synthetic_vocabulary(path, k=10, L=2, seed=1)
+    vo = orc.Vocabulary(path)
+    voc = amd.ORBVocabulary()
+    assert voc.loadFromTextFile(path)
+    W, H, NF, B = 752, 480, 1200, 6
+    seqs = [np.stack(synth.render_sequence(s, B, W, H, step=1.5)) for s in (4100, 4200)]
+    e = amd.ORBextractor(NF, 1.2, 8, 20, 7)
+    e.set_streams(4)
+    cap = e.max_keypoints()
+    dev = torch.device("cuda", 0)
+    d_imgs = [torch.from_numpy(s).to(dev) for s in seqs]
+    d_kp = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros((B,), dtype=torch.int32, device=dev)
+    d_match = torch.zeros((2, B - 1, cap), dtype=torch.int32, device=dev)
+    d_nm = torch.zeros((2, B - 1), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for k in range(2):
+        e.extract_batch_device(d_imgs[k].data_ptr(), B, W, H, W, W * H, d_kp.data_ptr(), d_desc.data_ptr(), cap,
+                               d_n.data_ptr(), wait=False)
+        voc.bow_match_consecutive_batch_device(B, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap,
+                                               d_match[k].data_ptr(), d_nm[k].data_ptr(), nnratio=0.7,
+                                               check_orientation=True, levelsup=0, extractor=e)
+    e.synchronize()
+    o = orc.Oracle(NF, 1.2, 8, 20, 7)
+    for k in range(2):
+        ref = [o.extract(f) for f in seqs[k]]
+        fvs = [orc.FeatVec(vo.transform(d, 0)[3]) for _, d in ref]
+        total = 0
+        for t in range(1, B):
+            (k1, de1), (k2, de2) = ref[t - 1], ref[t]
+            rn, rm = orc.search_by_bow(de1, np.ones(len(k1), np.uint8), k1["angle"], fvs[t - 1], de2, k2["angle"],
+                                       fvs[t], 0.7, True)
+            assert int(d_nm[k, t - 1].item()) == rn, (k, t)
+            assert np.array_equal(d_match[k, t - 1, :len(k2)].cpu().numpy(), rm), (k, t)
+            total += rn
+        assert total > 200
+    # the last extract call left sequence 1 in the output buffers: bit-exact too
+    n = d_n.cpu().numpy()
+    for f in range(B):
+        kr, dr = o.extract(seqs[1][f])
+        assert n[f] == len(kr)
+        assert np.array_equal(d_desc[f, :n[f]].cpu().numpy(), dr)

@@ -1,19 +1,24 @@
 #!/usr/bin/env python3
-"""Turns a rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES pass of bench.py into profiles/<round>_valu.json:
-VALU wave-instructions per frame for every kernel (average per dispatch x dispatches per step / batch).
+"""Turns a rocprofv3 --pmc pass of bench.py (SQ_WAVES SQ_INSTS_VALU [SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE]) into
+profiles/<round>_<workload>_valu.json: VALU wave-instructions per IMAGE for every kernel (average per dispatch x
+dispatches per step / images per step) and, when the two extra counters are present, the hardware's own VALU
+utilisation VALUBusy = 4 * SQ_ACTIVE_INST_VALU / (SIMDs * GRBM_GUI_ACTIVE) (SQ_ACTIVE_INST_* count quad-cycles).
 
-    rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU --output-format csv -d gpurun_out/pmc_valu -- \
-        python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1 --batch 256
-    python3 tools/collect_valu.py gpurun_out/pmc_valu gpurun_out/r01_valu.json 256 tum
+    rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv \
+        -d gpurun_out/pmc_valu -- python3 bench.py --workload tum --steps 3 --warmup 1 --no-cpu-baseline --streams 1 --batch 256
+    python3 tools/collect_valu.py gpurun_out/pmc_valu gpurun_out/r02_tum_valu.json 256 tum
+(third argument: IMAGES per step -- 2 x --batch for the stereo workload)
 """
 import csv
 import glob
 import json
+import os
 import sys
 from collections import defaultdict
 from pathlib import Path
 
 LAUNCHES_PER_STEP = {"k_resize_flat": 7, "k_resize": 7}
+N_SIMD = 256 * 4
 
 
 def kname(full):
@@ -23,24 +28,33 @@ def kname(full):
 
 
 def main():
-    d, out, batch, workload = sys.argv[1:5]
+    d, out, images, workload = sys.argv[1:5]
     files = glob.glob(f"{d}/*/*counter_collection.csv")
     if not files:
         raise SystemExit(f"no counter_collection.csv under {d}")
     acc = defaultdict(lambda: defaultdict(list))
-    for r in csv.DictReader(open(max(files, key=lambda f: __import__('os').path.getmtime(f)))):
+    for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
         if "orbfe::" in r["Kernel_Name"]:
             acc[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    res = {"batch": int(batch), "workload": workload,
-           "unit": "VALU wave64 instructions (SQ_INSTS_VALU) per frame; issue peak = 256 CU x 4 SIMD x 2.4 GHz / 4 cycles",
+    res = {"batch": int(images), "workload": workload,
+           "unit": "VALU wave64 instructions (SQ_INSTS_VALU) per image; valu_busy = 4*SQ_ACTIVE_INST_VALU/(1024 SIMDs*GRBM_GUI_ACTIVE)",
            "kernels": {}}
     for k, c in sorted(acc.items()):
+        if not c["SQ_INSTS_VALU"]:
+            continue
         n = LAUNCHES_PER_STEP.get(k, 1)
         valu = sum(c["SQ_INSTS_VALU"]) / len(c["SQ_INSTS_VALU"]) * n
         waves = sum(c["SQ_WAVES"]) / len(c["SQ_WAVES"]) * n
-        res["kernels"][k] = {"dispatches_sampled": len(c["SQ_INSTS_VALU"]), "dispatches_per_step": n,
-                             "valu_per_wave": valu / waves, "valu_wave_instr_per_frame": valu / int(batch)}
-    res["total_valu_wave_instr_per_frame"] = sum(v["valu_wave_instr_per_frame"] for v in res["kernels"].values())
+        e = {"dispatches_sampled": len(c["SQ_INSTS_VALU"]), "dispatches_per_step": n,
+             "valu_per_wave": valu / max(waves, 1), "valu_wave_instr_per_image": valu / int(images)}
+        if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE"):
+            act = sum(c["SQ_ACTIVE_INST_VALU"]) / len(c["SQ_ACTIVE_INST_VALU"])
+            gui = sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"])
+            e["SQ_ACTIVE_INST_VALU"] = act
+            e["GRBM_GUI_ACTIVE"] = gui
+            e["valu_busy"] = 4.0 * act / (N_SIMD * gui) if gui > 0 else None
+        res["kernels"][k] = e
+    res["total_valu_wave_instr_per_image"] = sum(v["valu_wave_instr_per_image"] for v in res["kernels"].values())
     Path(out).write_text(json.dumps(res, indent=1) + "\n")
     print(json.dumps(res, indent=1))
 

@@ -1,25 +1,33 @@
 #!/bin/bash
 # Regenerates the judged profile artefacts of a round on the GPU box (run through gpurun):
-#   tools/profile_round.sh r01
-# -> gpurun_out/<tag>_{valu,traffic}.json (PMC summaries), <tag>_bench.json (bench.py line, which reads the
-#    two summaries), <tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats of the same bench command).
-# Copy the four files into profiles/.
+#   tools/profile_round.sh r02 [workloads...]          (default: kitti tum euroc)
+# per workload W -> gpurun_out/<tag>_W_{valu,traffic}.json (PMC summaries, separate passes) and
+#   <tag>_W_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --workload W`, the timed multi-stream run);
+# then <tag>_bench.json = the default bench.py line (all three workloads; reads the PMC summaries from profiles/).
+# Copy the files into profiles/.
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
+shift || true
+WLS=${@:-kitti tum euroc}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out
 mkdir -p $OUT
-rm -rf $OUT/${TAG}_pmc_valu $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_stats
-PMC_ARGS="--steps 3 --warmup 1 --no-cpu-baseline --streams 1 --batch 256"
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU --output-format csv -d $OUT/${TAG}_pmc_valu -- python3 bench.py $PMC_ARGS > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -- python3 bench.py $PMC_ARGS > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -- python3 bench.py $PMC_ARGS > /dev/null 2>&1
-python3 tools/collect_valu.py $OUT/${TAG}_pmc_valu $OUT/${TAG}_valu.json 256 tum > /dev/null
-python3 tools/collect_traffic.py $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_traffic.json 256 tum > /dev/null
-cp $OUT/${TAG}_valu.json $OUT/${TAG}_traffic.json profiles/   # bench.py reads the summaries from profiles/
+for W in $WLS; do
+  case $W in kitti) B=128; IMGS=256;; tum) B=256; IMGS=256;; euroc) B=256; IMGS=256;; esac
+  rm -rf $OUT/${TAG}_${W}_pmc_valu $OUT/${TAG}_${W}_pmc_fetch $OUT/${TAG}_${W}_pmc_write $OUT/${TAG}_${W}_stats
+  PMC_ARGS="--workload $W --steps 3 --warmup 1 --no-cpu-baseline --streams 1 --batch $B"
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_${W}_pmc_valu -- python3 bench.py $PMC_ARGS > /dev/null 2>$OUT/${TAG}_${W}_pmc_valu.err
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_${W}_pmc_fetch -- python3 bench.py $PMC_ARGS > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_${W}_pmc_write -- python3 bench.py $PMC_ARGS > /dev/null 2>&1
+  python3 tools/collect_valu.py $OUT/${TAG}_${W}_pmc_valu $OUT/${TAG}_${W}_valu.json $IMGS $W > /dev/null
+  python3 tools/collect_traffic.py $OUT/${TAG}_${W}_pmc_fetch $OUT/${TAG}_${W}_pmc_write $OUT/${TAG}_${W}_traffic.json $IMGS $W > /dev/null
+  cp $OUT/${TAG}_${W}_valu.json $OUT/${TAG}_${W}_traffic.json profiles/   # bench.py reads the summaries from profiles/
+  echo "pmc $W done"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_${W}_stats -- python3 bench.py --workload $W --no-cpu-baseline > $OUT/${TAG}_${W}_stats_bench.json 2>/dev/null
+  cp $OUT/${TAG}_${W}_stats/*/*kernel_stats.csv $OUT/${TAG}_${W}_kernel_stats.csv
+  echo "stats $W done"
+done
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-tail -c 600 $OUT/${TAG}_bench.json; echo
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 bench.py --no-cpu-baseline > /dev/null 2>&1
-cp $OUT/${TAG}_stats/*/*kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
+tail -c 400 $OUT/${TAG}_bench.json; echo
 echo done
