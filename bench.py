@@ -539,13 +539,14 @@ def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, u
                         "stage is latency-bound (row buckets / node lists of a few dozen candidates per query), not popcount-bound"}
         v = pmc_valu(name)
         if v is not None:
-            tot = v.get("total_valu_wave_instr_per_image")
+            key = "valu_wave_instr_per_image" if "total_valu_wave_instr_per_image" in v else "valu_wave_instr_per_frame"
+            tot = v.get("total_" + key)
             per = {}
             for s_ in GPU_STAGES:
                 ks = [k for k, _ in STAGE_KERNELS[s_] if k in v["kernels"]]
                 if not ks or excl[s_] <= 0:
                     continue
-                wi = sum(v["kernels"][k]["valu_wave_instr_per_image"] for k in ks) * NI
+                wi = sum(v["kernels"][k][key] for k in ks) * NI
                 busy = [v["kernels"][k].get("valu_busy") for k in ks if v["kernels"][k].get("valu_busy") is not None]
                 per[s_] = {"wave_instr_per_step": wi, "frac_exclusive": wi / (excl[s_] * 1e-3) / VALU_PEAK,
                            "valu_busy_pmc": (max(busy) if busy else None)}
