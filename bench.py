@@ -140,11 +140,7 @@ def render_inputs(names, batches, rank):
                 tasks.append(("seq", 1000 + 100000 * rank + c // 64 + (7000 if nm == "euroc" else 0), min(64, B - c),
                               wl["w"], wl["h"]))
                 owner.append(nm)
-    try:
-        ncpu = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncpu = os.cpu_count() or 1
-    nproc = max(1, min(16, ncpu, len(tasks)))
+    nproc = max(1, min(16, host_cores(), len(tasks)))
     if nproc > 1:
         import multiprocessing as mp
         with mp.get_context("fork").Pool(nproc) as pool:
@@ -259,6 +255,21 @@ class _CpuUnit:
             o.extract(fr[i])
 
 
+def host_cores():
+    """Cores this process may use: the affinity mask, capped by the cgroup CPU quota (a 1-GPU box share)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
 def _timed_loop(fn, seconds, min_units=3):
     per = []
     t0 = time.perf_counter()
@@ -296,10 +307,7 @@ def cpu_baseline(wlname, frames, voc_path, seconds):
             two = _timed_loop(lambda i: u.run(o2, i, {}, pool), seconds * 0.6)
         two["cores"] = 2
         variants["two_threads_left_right"] = two
-    try:
-        ncpu = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncpu = os.cpu_count() or 1
+    ncpu = host_cores()
     T = max(1, min(ncpu, u.units, 64))
     counts, pers = [0] * T, [[] for _ in range(T)]
     stop = threading.Event()

@@ -159,6 +159,10 @@ int orbfe_debug_resize_tables(int sw, int sh, int dw, int dh, int32_t *xofs, int
  * (D2H/H2D round trip) instead of the device kernel.  Off by default; results are identical. */
 int orbfe_extractor_debug_host_octree(orbfe_extractor *e, int enable);
 
+/* GaussianBlur fused into the FAST kernel (1) or run as its own launch (0, the default; $ORBFE_FUSED).  Results
+ * are identical; the fused form measured no faster and is kept as a parity-tested alternative. */
+int orbfe_extractor_set_fused(orbfe_extractor *e, int enable);
+
 /* A call's frames are split into n consecutive sub-batches that run concurrently on n HIP
  * streams with private workspace slices (1..8, default 2 or $ORBFE_STREAMS); results do not
  * depend on n.  Stage timing covers the kernels of sub-batch 0 (frames_out reports how many

@@ -3,12 +3,12 @@
 // Mirrors the reference's operator/plugin interface for the hot path with the same names,
 // argument meaning and error behaviour:
 //   ORB_SLAM2::ORBextractor  include/ORBextractor.h:46-114   (reference paths)
-//   ORB_SLAM2::ORBmatcher    include/ORBmatcher.h:38-118     (DescriptorDistance, SearchByBoW x2,
-//                                                            SearchForTriangulation)
+//   ORB_SLAM2::ORBmatcher    include/ORBmatcher.h:55-103     (all 11 methods + DescriptorDistance)
 //   Frame::ComputeStereoMatches  src/Frame.cc:512-686
-// cv::KeyPoint / cv::Mat are replaced by layout-compatible PODs so that tests and tools build
-// without OpenCV; include/ORBextractor.h and include/ORBmatcher.h of this repo wrap these
-// classes once more with the exact cv:: signatures when OpenCV is available.
+// cv::KeyPoint / cv::Mat / KeyFrame* / MapPoint* are replaced by layout-compatible PODs and flat arrays so
+// that tests and tools build without OpenCV.  include/ORBextractor.h (extractor) and include/ORBmatcher.h +
+// src/ORBmatcher_orbfe.cc (matcher) of this repo wrap these classes once more with the reference's exact
+// signatures for a build that has OpenCV and the reference's own headers; those two are not compiled here.
 #pragma once
 #include <cstdint>
 #include <cstring>
@@ -259,6 +259,119 @@ class ORBmatcher {
     check(orbfe_search_for_initialization(device_, &F1.c, &F2.c, prevX.data(), prevY.data(), windowSize, mfNNratio,
                                           mbCheckOrientation, vnMatches12.data(), &n),
           "SearchForInitialization");
+    return n;
+  }
+
+  // int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12,
+  //                            vector<pair<size_t,size_t>>& vMatchedPairs, const bool bOnlyStereo)
+  // (src/ORBmatcher.cc:754-928).  KF1 / KF2 carry mvKeysUn + mvuRight; hasMp = "GetMapPoint(idx) != NULL";
+  // F12 row-major 3x3; (ex, ey) = the epipole of :766-769; mvScaleFactors2 / mvLevelSigma2_2 of pKF2.
+  int SearchForTriangulation(const FrameArrays& KF1, const std::vector<uint8_t>& hasMp1, const FeatureVectorCSR& fv1,
+                             const FrameArrays& KF2, const std::vector<uint8_t>& hasMp2, const FeatureVectorCSR& fv2,
+                             const float F12[9], float ex, float ey, const std::vector<float>& mvScaleFactors2,
+                             const std::vector<float>& mvLevelSigma2_2, std::vector<std::pair<size_t, size_t> >& vMatchedPairs,
+                             bool bOnlyStereo) {
+    const int n1 = KF1.N(), n2 = KF2.N();
+    std::vector<uint8_t> st1(n1, 0), st2(n2, 0);  // bStereo1 = mvuRight[idx] >= 0 (:806, :830)
+    for (int i = 0; i < n1 && !KF1.uRight.empty(); i++) st1[i] = KF1.uRight[i] >= 0;
+    for (int i = 0; i < n2 && !KF2.uRight.empty(); i++) st2[i] = KF2.uRight[i] >= 0;
+    std::vector<int32_t> match12(n1 > 0 ? n1 : 1, -1);
+    const int rc = orbfe_search_for_triangulation(
+        device_, KF1.desc.data(), hasMp1.data(), KF1.x.data(), KF1.y.data(), KF1.angle.data(), st1.data(), n1, &fv1.c,
+        KF2.desc.data(), hasMp2.data(), KF2.x.data(), KF2.y.data(), KF2.angle.data(), KF2.octave.data(), st2.data(), n2,
+        &fv2.c, F12, ex, ey, mvScaleFactors2.data(), mvLevelSigma2_2.data(), (int)mvScaleFactors2.size(), bOnlyStereo,
+        mbCheckOrientation, match12.data());
+    check(rc, "SearchForTriangulation");
+    vMatchedPairs.clear();
+    vMatchedPairs.reserve(rc);
+    for (int i = 0; i < n1; i++)  // :920-925: ascending idx1
+      if (match12[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)match12[i]));
+    return rc;
+  }
+
+  // int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, const float th,
+  //                        const int ORBdist) (src/ORBmatcher.cc:1641-1775, relocalisation) after the caller's
+  // projection prologue (:1657-1700): valid[i] = pKF's map point i exists, is good, not in sAlreadyFound, projects
+  // inside the image and its distance range; level = PredictScale; kfAngle = pKF->mvKeysUn[i].angle;
+  // curHasMapPoint[i2] = CurrentFrame.mvpMapPoints[i2] != NULL (may be empty).  matchCur[i2] = index i or -1.
+  int SearchByProjection(const FrameArrays& CurrentFrame, const std::vector<float>& mvScaleFactors,
+                         const std::vector<uint8_t>& curHasMapPoint, const std::vector<uint8_t>& valid,
+                         const std::vector<float>& u, const std::vector<float>& v, const std::vector<int32_t>& level,
+                         const std::vector<float>& kfAngle, const std::vector<uint8_t>& mpDescriptors, float th,
+                         int ORBdist, std::vector<int32_t>& matchCur) {
+    matchCur.assign(CurrentFrame.N(), -1);
+    int32_t n = 0;
+    check(orbfe_search_by_projection_keyframe(device_, &CurrentFrame.c, mvScaleFactors.data(), (int)mvScaleFactors.size(),
+                                              curHasMapPoint.empty() ? nullptr : curHasMapPoint.data(), (int)valid.size(),
+                                              valid.data(), u.data(), v.data(), level.data(), kfAngle.data(),
+                                              mpDescriptors.data(), th, ORBdist, mbCheckOrientation, matchCur.data(), &n),
+          "SearchByProjection(Frame,KeyFrame)");
+    return n;
+  }
+
+  // int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints,
+  //                        vector<MapPoint*>& vpMatched, int th) (src/ORBmatcher.cc:335-449, loop closing) after the
+  // caller's Sim3 projection (:355-400): valid[i] = point i is good, not already in vpMatched, in front of the
+  // camera, inside the image, its distance range and viewing cone.  alreadyMatched[idx] = vpMatched[idx] != NULL
+  // (may be empty).  match[idx] = point newly matched to keypoint idx, or -1.
+  int SearchByProjection(const FrameArrays& KF, const std::vector<float>& mvScaleFactors,
+                         const std::vector<uint8_t>& alreadyMatched, const std::vector<uint8_t>& valid,
+                         const std::vector<float>& u, const std::vector<float>& v, const std::vector<int32_t>& level,
+                         const std::vector<uint8_t>& mpDescriptors, int th, std::vector<int32_t>& match) {
+    match.assign(KF.N(), -1);
+    int32_t n = 0;
+    check(orbfe_search_by_projection_sim3(device_, &KF.c, mvScaleFactors.data(), (int)mvScaleFactors.size(),
+                                          alreadyMatched.empty() ? nullptr : alreadyMatched.data(), (int)valid.size(),
+                                          valid.data(), u.data(), v.data(), level.data(), mpDescriptors.data(), (float)th,
+                                          match.data(), &n),
+          "SearchByProjection(KeyFrame,Scw)");
+    return n;
+  }
+
+  // The search inside int Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, const float th = 3.0)
+  // (src/ORBmatcher.cc:940-1110): per map point, after the caller's projection (:960-1020, valid / u / v / ur /
+  // PredictScale level), bestIdx[i] = the keypoint of pKF to fuse with, or -1.  Replace / AddObservation on a hit
+  // (:1088-1106) is map bookkeeping and stays with the caller.  ur is read for stereo keypoints only.
+  void Fuse(const FrameArrays& KF, const std::vector<float>& mvScaleFactors, const std::vector<float>& mvInvLevelSigma2,
+            const std::vector<uint8_t>& valid, const std::vector<float>& u, const std::vector<float>& v,
+            const std::vector<float>& ur, const std::vector<int32_t>& level, const std::vector<uint8_t>& mpDescriptors,
+            std::vector<int32_t>& bestIdx, float th = 3.0f) {
+    bestIdx.assign(valid.size(), -1);
+    check(orbfe_fuse_search(device_, &KF.c, mvScaleFactors.data(), mvInvLevelSigma2.data(), (int)mvScaleFactors.size(),
+                            (int)valid.size(), valid.data(), u.data(), v.data(), ur.empty() ? nullptr : ur.data(),
+                            level.data(), mpDescriptors.data(), th, 1, bestIdx.data()),
+          "Fuse");
+  }
+  // The search inside int Fuse(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints, float th,
+  //                            vector<MapPoint*>& vpReplacePoint) (src/ORBmatcher.cc:1112-1249): no chi2 gate.
+  void Fuse(const FrameArrays& KF, const std::vector<float>& mvScaleFactors, const std::vector<uint8_t>& valid,
+            const std::vector<float>& u, const std::vector<float>& v, const std::vector<int32_t>& level,
+            const std::vector<uint8_t>& mpDescriptors, float th, std::vector<int32_t>& bestIdx) {
+    bestIdx.assign(valid.size(), -1);
+    check(orbfe_fuse_search(device_, &KF.c, mvScaleFactors.data(), nullptr, (int)mvScaleFactors.size(),
+                            (int)valid.size(), valid.data(), u.data(), v.data(), nullptr, level.data(),
+                            mpDescriptors.data(), th, 0, bestIdx.data()),
+          "Fuse(Scw)");
+  }
+
+  // int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12, const float& s12,
+  //                  const cv::Mat& R12, const cv::Mat& t12, const float th) (src/ORBmatcher.cc:1251-1482) after the
+  // caller's two projection loops: valid1[i1] = map point of KF1 keypoint i1 is good, not matched yet, projects
+  // into KF2 (u1, v1) inside the image and its distance range, level1 = PredictScale(pKF2), desc1 = its
+  // descriptor; the "2" arrays are the KF2 -> KF1 direction.  match12[i1] = i2 for mutually consistent pairs.
+  int SearchBySim3(const FrameArrays& KF1, const FrameArrays& KF2, const std::vector<float>& mvScaleFactors1,
+                   const std::vector<float>& mvScaleFactors2, const std::vector<uint8_t>& valid1,
+                   const std::vector<float>& u1, const std::vector<float>& v1, const std::vector<int32_t>& level1,
+                   const std::vector<uint8_t>& desc1, const std::vector<uint8_t>& valid2, const std::vector<float>& u2,
+                   const std::vector<float>& v2, const std::vector<int32_t>& level2, const std::vector<uint8_t>& desc2,
+                   float th, std::vector<int32_t>& match12) {
+    match12.assign(KF1.N(), -1);
+    int32_t n = 0;
+    check(orbfe_search_by_sim3(device_, &KF1.c, &KF2.c, mvScaleFactors1.data(), mvScaleFactors2.data(),
+                               (int)mvScaleFactors1.size(), valid1.data(), u1.data(), v1.data(), level1.data(),
+                               desc1.data(), valid2.data(), u2.data(), v2.data(), level2.data(), desc2.data(), th,
+                               match12.data(), &n),
+          "SearchBySim3");
     return n;
   }
 

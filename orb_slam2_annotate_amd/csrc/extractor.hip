@@ -69,6 +69,11 @@ struct orbfe_extractor {
   int evSlot = 0;
   unsigned stageMask = 0;
   bool hostOctree = false;  // debug cross-check only (orbfe_extractor_debug_host_octree)
+  // GaussianBlur inside the FAST kernel (k_fast_cells<.., true>) instead of the separate k_blur7 launch.  Measured
+  // (r02, same box, 4096 VGA frames): fused 8.41 ms vs 5.28 + 3.26 ms for the two launches, pipeline 285.9 k vs
+  // 291.8 k frames/s -- FAST already runs at the VALU issue ceiling, so the blur's instructions cost their full price
+  // inside it; off by default, selectable ($ORBFE_FUSED=1 / orbfe_extractor_set_fused) and parity-tested
+  bool fused = false;
   int octreeMaxL = 0;
   double stageMs[ORBFE_STAGE_COUNT] = {};
   int64_t stageLaunches[ORBFE_STAGE_COUNT] = {};
@@ -345,7 +350,8 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
               PyramidViews* blurOut) {
   const FrameGeom& g = e->geom;
   const size_t F = (size_t)f0;
-  const int nCells = (int)g.cells.size();
+  const int nCells = g.nFastCells;
+  const bool fused = e->fused && g.fusedBlur;
   PyramidViews pyr = {}, blur = {}, pyr0 = {}, blur0 = {};
   pyr.nlevels = blur.nlevels = pyr0.nlevels = blur0.nlevels = g.nlevels;
   pyr0.lv[0] = level0;
@@ -395,12 +401,12 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
       dsts[l] = LevelViewMut{const_cast<uint8_t*>(blur.lv[l].base), g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
     launch_blur7_levels(s, pyr.lv, dsts, g.nlevels, nFrames);
   };
-  const bool blurFirst = (sub & 1) != 0;  // measured +1.7 % frames/s (A/B on one box, 4 runs each)
+  const bool blurFirst = !fused && (sub & 1) != 0;  // measured +1.7 % frames/s (A/B on one box, 4 runs each)
   if (blurFirst) do_blur();
-  {  // FAST grid stage, :846-896 (timed alone: the dominant kernel of the pipeline)
+  {  // FAST grid stage, :846-896; fused: the same wavefronts also write the blurred level (:1169-1175)
     StageTimer t(e, ORBFE_STAGE_FAST, 1, nFrames, sub, s);
     launch_fast_cells(s, pyr, e->d_cells, nCells, nFrames, e->tab.iniThFAST, e->tab.minThFAST, slots,
-                      g.totalSlots, cellCount, g.maxCellW, g.maxCellH);
+                      g.totalSlots, cellCount, g.maxCellW, g.maxCellH, fused ? &blur : nullptr, (int)g.cells.size());
   }
   if (!e->hostOctree) {  // candidate ordering + DistributeOctTree, :566-808, one workgroup per (frame, level)
     StageTimer t(e, ORBFE_STAGE_OCTREE, 2, nFrames, sub, s);
@@ -424,7 +430,7 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
     int rc = run_host_octree(e, nFrames);  // single-stream debug path: f0 == 0
     if (rc) return rc;
   }
-  if (!blurFirst) do_blur();
+  if (!blurFirst && !fused) do_blur();
 
   {  // computeOrientation + computeDescriptors + output records
     StageTimer t(e, ORBFE_STAGE_ORIENT_DESC, 1, nFrames, sub, s);
@@ -508,6 +514,7 @@ extern "C" int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlev
   hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
   for (int i = 0; i < orbfe_extractor::kMaxStreams - 1 && err == hipSuccess; i++)
     err = hipStreamCreateWithFlags(&e->extra[i], hipStreamNonBlocking);
+  if (const char* env = getenv("ORBFE_FUSED")) e->fused = atoi(env) != 0;
   if (const char* env = getenv("ORBFE_STREAMS")) {
     int v = atoi(env);
     if (v >= 1 && v <= orbfe_extractor::kMaxStreams) e->nStreams = v;
@@ -943,6 +950,16 @@ extern "C" int orbfe_extractor_debug_host_octree(orbfe_extractor* e, int enable)
   return ORBFE_OK;
 }
 
+// GaussianBlur inside the FAST kernel (default) or as the separate k_blur7 launch (A/B and cross-check).
+extern "C" int orbfe_extractor_set_fused(orbfe_extractor* e, int enable) {
+  if (!e) return fail(ORBFE_ERR_INVALID, "NULL handle");
+  HIPCHK(hipSetDevice(e->device));
+  int rc = sync_all(e);
+  if (rc) return rc;
+  e->fused = enable != 0;
+  return ORBFE_OK;
+}
+
 // Number of sub-batch streams one call is split over (1..4; default 1, or $ORBFE_STREAMS).
 extern "C" int orbfe_extractor_set_streams(orbfe_extractor* e, int n) {
   if (!e || n < 1 || n > orbfe_extractor::kMaxStreams) return fail(ORBFE_ERR_INVALID, "set_streams: 1..8");
@@ -1050,11 +1067,11 @@ extern "C" int orbfe_debug_geometry(int nfeatures, float scaleFactor, int nlevel
     for (int k = 0; k < 9; k++) levels9[l * 9 + k] = row[k];
   }
   if (cells5)
-    for (int i = 0; i < (int)g.cells.size() && i < cell_cap; i++) {
+    for (int i = 0; i < g.nFastCells && i < cell_cap; i++) {
       const CellDesc& c = g.cells[i];
       cells5[i * 5 + 0] = c.level; cells5[i * 5 + 1] = c.x0; cells5[i * 5 + 2] = c.y0; cells5[i * 5 + 3] = c.w; cells5[i * 5 + 4] = c.h;
     }
-  return (int)g.cells.size();
+  return g.nFastCells;
 }
 
 // cv::resize coefficient tables (xofs, alpha pairs, yofs, beta pairs) the resize kernel uses.

@@ -14,6 +14,14 @@
 // Facts used: score = S-1 does not depend on the threshold, and a pixel kept by NMS at
 // threshold t is exactly a pixel with score >= t that beats all 8 neighbours' scores.
 // VALU-issue-bound; it wants resident waves, hence the small LDS footprint.
+//
+// Fused form (kBlur): the staged tile is exactly the +-3 neighbourhood cv::GaussianBlur(7x7) needs for the
+// cell's detection rectangle, so after D the same wavefront writes the BLURRED rectangle (phase E, the
+// arithmetic of k_blur.hip: packed-u16 vertical pass, v_dot2 horizontal pass) -- the level is read from HBM
+// once for FAST and blur together, and the blur's load latency hides behind the FAST work of the other
+// resident waves.  The detection rectangles tile [19, w-19) x [19, h-19); the 19-px frame around them is
+// covered by blur-only cells (no FAST phases, reflect-101 staging) appended to the cell table by
+// FrameGeom::build, so one launch writes the whole blurred level.
 #include "kernels.h"
 
 namespace orbfe {
@@ -54,6 +62,21 @@ constexpr int kRingDy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2,
 
 // v_perm_b32 selector that builds the packed u16 pair (byte[o], byte[o+2]) of the 8 bytes {hi,lo}
 constexpr uint32_t sel2(int o) { return (uint32_t)o | 0x0c00u | ((uint32_t)(o + 2) << 16) | 0x0c000000u; }
+
+// ---- blur arithmetic shared with k_blur.hip ----
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ uint32_t as_uu(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t dot2(uint32_t a, uint32_t k, uint32_t c) {
+  return __builtin_amdgcn_udot2(as_u2(a), as_u2(k), c, false);
+}
+constexpr uint32_t pk(uint32_t lo, uint32_t hi) { return lo | (hi << 16); }
+__device__ __forceinline__ int reflect101f(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  return i < 0 ? 0 : (i >= n ? n - 1 : i);  // clamp only matters for never-used tile cells
+}
+struct __attribute__((packed, aligned(1))) U1u { uint32_t x; };  // 4-byte store at any byte address
 }  // namespace
 
 // 32-bit 3-input forms for the per-pixel exact score (one pixel per lane)
@@ -75,14 +98,15 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b)
 //   D. per-cell 20->7 fallback, then ordered compaction of the survivors = emission order.
 // Dynamic LDS: tile [tileRows][24 dw] | score [scoreRows][24 dw] | queue [queueLen] u16, sized by
 // the largest cell of the frame geometry.
-template <int kPitchDw>
+template <int kPitchDw, bool kBlur>
 __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
                                                    const CellDesc* __restrict__ cells,
                                                    int nCells, int nFrames, int iniTh, int minTh,
                                                    Candidate* __restrict__ slots,
                                                    int slotsPerFrame,
                                                    uint16_t* __restrict__ cellCount,
-                                                   int tileRows, int scoreRows, uint32_t cellsMagic) {
+                                                   int tileRows, int scoreRows, uint32_t cellsMagic,
+                                                   PyramidViews blurOut, int nFastCells) {
   extern __shared__ uint32_t lds[];
   uint32_t* tile = lds;                                   // pixels: origin (x0-4, y0-3)
   uint32_t* score = lds + tileRows * kPitchDw;            // FAST responses: origin (x0-4, y0-1)
@@ -109,49 +133,67 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
   constexpr int P = kPitchDw * 4;         // LDS row pitch in bytes
 
   // ---- stage the tile: rows y0-3 .. y0+ch+2, bytes x0-4 .. x0+4*ngx+3 (inside the level) ----
+  const bool blurOnly = kBlur && (cd.flags & kCellBlurOnly) != 0;
   {
-    const uint8_t* img = lv.base + (size_t)f * lv.frameStride + (size_t)(y0 - 3) * lv.pitch + (x0 - 4);
+    const uint8_t* lvb = lv.base + (size_t)f * lv.frameStride;
     const int th = ch + 6;
-    const uintptr_t addr0 = reinterpret_cast<uintptr_t>(img);
-    if ((lv.pitch & 3) == 0) {
-      // a lane moves 16 bytes: (row, part) -> 5 aligned source dwords -> 4 byte-shifted tile dwords
-      const uint32_t a = (uint32_t)(addr0 & 3);     // same misalignment for every row
-      const uint8_t* al = img - a;
-      const int parts = (tdw + 3) >> 2;             // 16-byte pieces per tile row (<= 5)
-      const uint32_t invP = kInv16[parts];
-      // bytes of the row still inside the pitch, counted from `al`: never read beyond the level's rows
-      const int rowBytes = lv.pitch - ((x0 - 4) - (int)a);
-      for (int i = lane; i < th * parts; i += 64) {
-        const int ty = (int)(((uint32_t)i * invP) >> 16), part = i - ty * parts;
-        const uint32_t* row = reinterpret_cast<const uint32_t*>(al + (uint32_t)ty * (uint32_t)lv.pitch) + 4 * part;
-        uint32_t d[5];
-        if (16 * part + 20 <= rowBytes) {
-          const U4 q = *reinterpret_cast<const U4*>(row);
-          d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
-          d[4] = a ? row[4] : 0u;
-        } else {
-#pragma unroll
-          for (int k = 0; k < 5; k++) d[k] = (16 * part + 4 * k + 4 <= rowBytes) ? row[k] : 0u;
-        }
-        uint4 o;
-        o.x = __builtin_amdgcn_alignbyte(d[1], d[0], a);
-        o.y = __builtin_amdgcn_alignbyte(d[2], d[1], a);
-        o.z = __builtin_amdgcn_alignbyte(d[3], d[2], a);
-        o.w = __builtin_amdgcn_alignbyte(d[4], d[3], a);
-        *reinterpret_cast<uint4*>(&tile[ty * kPitchDw + 4 * part]) = o;  // pitch >= 4*parts (launch_fast_cells)
-      }
-    } else {  // caller-owned level 0 with an odd stride: byte loads
+    if (kBlur && (cd.flags & kCellColReflect)) {
+      // frame cell whose columns leave the level: bytes with BORDER_REFLECT_101 in both directions
       for (int i = lane; i < th * tdw; i += 64) {
         const int ty = (int)(((uint32_t)i * invT) >> 16), tx = i - ty * tdw;
-        const uint8_t* p = img + (size_t)ty * lv.pitch + 4 * tx;
-        tile[ty * kPitchDw + tx] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+        const uint8_t* row = lvb + (size_t)reflect101f(y0 - 3 + ty, lv.h) * lv.pitch;
+        const int c = x0 - 4 + 4 * tx;
+        tile[ty * kPitchDw + tx] = (uint32_t)row[reflect101f(c, lv.w)] | ((uint32_t)row[reflect101f(c + 1, lv.w)] << 8) |
+                                   ((uint32_t)row[reflect101f(c + 2, lv.w)] << 16) | ((uint32_t)row[reflect101f(c + 3, lv.w)] << 24);
+      }
+    } else {
+      const bool rr = kBlur && (cd.flags & kCellRowReflect) != 0;  // frame cell at the top / bottom: reflected row index
+      const uintptr_t addr0 = reinterpret_cast<uintptr_t>(lvb) + (uintptr_t)(x0 - 4);  // row-independent part
+      if ((lv.pitch & 3) == 0) {
+        // a lane moves 16 bytes: (row, part) -> 5 aligned source dwords -> 4 byte-shifted tile dwords
+        const uint32_t a = (uint32_t)(addr0 & 3);     // same misalignment for every row
+        const uint8_t* al = lvb + (x0 - 4) - a;
+        const int parts = (tdw + 3) >> 2;             // 16-byte pieces per tile row (<= 5)
+        const uint32_t invP = kInv16[parts];
+        // bytes of the row still inside the pitch, counted from `al`: never read beyond the level's rows
+        const int rowBytes = lv.pitch - ((x0 - 4) - (int)a);
+        for (int i = lane; i < th * parts; i += 64) {
+          const int ty = (int)(((uint32_t)i * invP) >> 16), part = i - ty * parts;
+          const int sy = rr ? reflect101f(y0 - 3 + ty, lv.h) : y0 - 3 + ty;
+          const uint32_t* row = reinterpret_cast<const uint32_t*>(al + (uint32_t)sy * (uint32_t)lv.pitch) + 4 * part;
+          uint32_t d[5];
+          if (16 * part + 20 <= rowBytes) {
+            const U4 q = *reinterpret_cast<const U4*>(row);
+            d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+            d[4] = a ? row[4] : 0u;
+          } else {
+#pragma unroll
+            for (int k = 0; k < 5; k++) d[k] = (16 * part + 4 * k + 4 <= rowBytes) ? row[k] : 0u;
+          }
+          uint4 o;
+          o.x = __builtin_amdgcn_alignbyte(d[1], d[0], a);
+          o.y = __builtin_amdgcn_alignbyte(d[2], d[1], a);
+          o.z = __builtin_amdgcn_alignbyte(d[3], d[2], a);
+          o.w = __builtin_amdgcn_alignbyte(d[4], d[3], a);
+          *reinterpret_cast<uint4*>(&tile[ty * kPitchDw + 4 * part]) = o;  // pitch >= 4*parts (launch_fast_cells)
+        }
+      } else {  // caller-owned level 0 with an odd stride: byte loads
+        for (int i = lane; i < th * tdw; i += 64) {
+          const int ty = (int)(((uint32_t)i * invT) >> 16), tx = i - ty * tdw;
+          const int sy = rr ? reflect101f(y0 - 3 + ty, lv.h) : y0 - 3 + ty;
+          const uint8_t* p = lvb + (size_t)sy * lv.pitch + (x0 - 4) + 4 * tx;
+          tile[ty * kPitchDw + tx] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+        }
       }
     }
-    uint4* sz = reinterpret_cast<uint4*>(score);  // row pitch 96 B: (ch+2)*6 aligned 16-byte stores
-    for (int i = lane; i < (ch + 2) * (kPitchDw / 4); i += 64) sz[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (!blurOnly) {
+      uint4* sz = reinterpret_cast<uint4*>(score);  // row pitch 96 B: (ch+2)*6 aligned 16-byte stores
+      for (int i = lane; i < (ch + 2) * (kPitchDw / 4); i += 64) sz[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
   }
   __syncthreads();
 
+  if (!blurOnly) {  // wave-uniform: the FAST phases A-D of a detection cell
   // ---- A: cardinal-pair test at the lower threshold; ordered work list.  A lane owns 8 adjacent
   //      pixels (two tile dwords); list positions come from a DPP inclusive scan of the lane counts ----
   int nq = 0;  // wave-uniform
@@ -295,31 +337,127 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
       out[o] = cnd;
     }
   }
-  if (lane == 0) cellCount[(size_t)f * nCells + cellId] = (uint16_t)run;
+  if (lane == 0) cellCount[(size_t)f * nFastCells + cellId] = (uint16_t)run;
+  }  // !blurOnly
+
+  if (kBlur) {
+    // ---- E: GaussianBlur 7x7 of the cell's own rectangle from the staged tile (arithmetic of k_blur.hip:
+    //      [18,34,48,56,48,34,18]/256 twice, one rounding (x + 2^15) >> 16).  The vertical sums reuse the
+    //      score + queue area, which is dead after D ----
+    __syncthreads();
+    uint2* vbuf = reinterpret_cast<uint2*>(score);  // [4*rowBlocks][tdw] entries of 4 u16
+    const int rowBlocks = (ch + 3) >> 2;
+    for (int i = lane; i < rowBlocks * tdw; i += 64) {
+      const int rb = (int)(((uint32_t)i * invT) >> 16), tj = i - rb * tdw;
+      const uint32_t* tp = &tile[(4 * rb) * kPitchDw + tj];
+      u16x2 te[10], to[10];  // even bytes (0,2) and odd bytes (1,3) of each source dword
+#pragma unroll
+      for (int j = 0; j < 10; j++) {
+        const uint32_t r = tp[j * kPitchDw];   // rows past the tile (last, partial block): in-bounds garbage, never stored
+        te[j] = as_u2(r & 0x00ff00ffu);
+        to[j] = as_u2(__builtin_amdgcn_perm(r, r, 0x0c030c01u));
+      }
+      const u16x2 k18 = {18, 18}, k34 = {34, 34}, k48 = {48, 48}, k56 = {56, 56};
+      uint2* vo = &vbuf[(4 * rb) * tdw + tj];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        u16x2 a = (te[r] + te[r + 6]) * k18;
+        a = (te[r + 1] + te[r + 5]) * k34 + a;
+        a = (te[r + 2] + te[r + 4]) * k48 + a;
+        const uint32_t A = as_uu(te[r + 3] * k56 + a);   // (v0, v2)
+        u16x2 b = (to[r] + to[r + 6]) * k18;
+        b = (to[r + 1] + to[r + 5]) * k34 + b;
+        b = (to[r + 2] + to[r + 4]) * k48 + b;
+        const uint32_t B = as_uu(to[r + 3] * k56 + b);   // (v1, v3)
+        uint2 o;
+        o.x = __builtin_amdgcn_perm(B, A, 0x05040100u);  // (v0, v1)
+        o.y = __builtin_amdgcn_perm(B, A, 0x07060302u);  // (v2, v3)
+        vo[r * tdw] = o;
+      }
+    }
+    __syncthreads();
+    const LevelView bv = blurOut.lv[cd.level];
+    uint8_t* D = const_cast<uint8_t*>(bv.base) + (size_t)f * bv.frameStride + (size_t)y0 * bv.pitch + x0;
+    const uint32_t invN = kInv16[ngx];
+    for (int i = lane; i < ch * ngx; i += 64) {
+      const int r = (int)(((uint32_t)i * invN) >> 16), g = i - r * ngx;
+      const uint2* vp = &vbuf[r * tdw + g];
+      const uint2 e0 = vp[0], e1 = vp[1], e2 = vp[2];
+      // d_k = (v'[2k], v'[2k+1]) with v' indexed from tile column 4*g; output pixel j of the group = tile column 4*g+4+j
+      const uint32_t d0 = e0.x, d1 = e0.y, d2 = e1.x, d3 = e1.y, d4 = e2.x, d5 = e2.y;
+      const uint32_t R = 1u << 15;
+      uint32_t o0 = dot2(d0, pk(0, 18), R);   // taps v'1..v'7
+      o0 = dot2(d1, pk(34, 48), o0);
+      o0 = dot2(d2, pk(56, 48), o0);
+      o0 = dot2(d3, pk(34, 18), o0);
+      uint32_t o1 = dot2(d1, pk(18, 34), R);  // taps v'2..v'8
+      o1 = dot2(d2, pk(48, 56), o1);
+      o1 = dot2(d3, pk(48, 34), o1);
+      o1 = dot2(d4, pk(18, 0), o1);
+      uint32_t o2 = dot2(d1, pk(0, 18), R);   // taps v'3..v'9
+      o2 = dot2(d2, pk(34, 48), o2);
+      o2 = dot2(d3, pk(56, 48), o2);
+      o2 = dot2(d4, pk(34, 18), o2);
+      uint32_t o3 = dot2(d2, pk(18, 34), R);  // taps v'4..v'10
+      o3 = dot2(d3, pk(48, 56), o3);
+      o3 = dot2(d4, pk(48, 34), o3);
+      o3 = dot2(d5, pk(18, 0), o3);
+      // the rounded sums are < 2^24: byte 2 of each is the result; two v_perm gather them
+      const uint32_t lo = __builtin_amdgcn_perm(o1, o0, 0x0c0c0602u);   // (o0.b2, o1.b2, 0, 0)
+      const uint32_t hi = __builtin_amdgcn_perm(o3, o2, 0x06020c0cu);   // (0, 0, o2.b2, o3.b2)
+      const uint32_t v = lo | hi;
+      uint8_t* d = D + (uint32_t)r * (uint32_t)bv.pitch + 4u * (uint32_t)g;
+      const int valid = cw - 4 * g;
+      if (valid >= 4) {
+        U1u st = {v};
+        *reinterpret_cast<U1u*>(d) = st;  // one dword store at whatever byte alignment x0 has
+      } else {  // the rectangle's last, partial group: bytes (the next cell owns the rest of the dword)
+        d[0] = (uint8_t)v;
+        if (valid > 1) d[1] = (uint8_t)(v >> 8);
+        if (valid > 2) d[2] = (uint8_t)(v >> 16);
+      }
+    }
+  }
 }
 
 void launch_fast_cells(hipStream_t s, PyramidViews pyr, const CellDesc* d_cells, int nCells,
                        int nFrames, int iniTh, int minTh, Candidate* d_slots, int slotsPerFrame,
-                       uint16_t* d_cellCount, int maxCellW, int maxCellH) {
-  if (nCells <= 0 || nFrames <= 0) return;
+                       uint16_t* d_cellCount, int maxCellW, int maxCellH, const PyramidViews* blurOut,
+                       int nCellsAll) {
+  // blurOut != NULL: the fused FAST+blur form over all nCellsAll cells (FAST cells first, then blur-only frame
+  // cells); NULL: FAST only over the nCells detection cells
+  const int nWork = blurOut ? nCellsAll : nCells;
+  if (nWork <= 0 || nFrames <= 0) return;
   iniTh = iniTh < 0 ? 0 : (iniTh > 255 ? 255 : iniTh);  // cv::FAST clamps the threshold
   minTh = minTh < 0 ? 0 : (minTh > 255 ? 255 : minTh);
-  const unsigned total = (unsigned)nCells * (unsigned)nFrames;
+  const unsigned total = (unsigned)nWork * (unsigned)nFrames;
   const int tileRows = maxCellH + 6, scoreRows = maxCellH + 2;
   const int queueLen = (((maxCellW + 3) & ~3) * maxCellH + 1) & ~1;
   // smallest pitch that holds a tile row (4 * ceil(tdw / 4) staged dwords, tdw = ceil(w/4) + 2) and a score row
   const int tdwMax = ((maxCellW + 3) >> 2) + 2;
   const int need = ((tdwMax + 3) >> 2) * 4;
   const int pitch = (need <= 12 && maxCellW <= 40) ? 12 : (need <= 16 && maxCellW <= 56) ? 16 : 24;
-  const size_t ldsBytes = (size_t)(tileRows + scoreRows) * pitch * 4 + (size_t)queueLen * 2;
+  size_t work2 = (size_t)scoreRows * pitch * 4 + (size_t)queueLen * 2;  // score + queue
+  if (blurOut) {  // phase E keeps the vertical sums there: 4*ceil(h/4) rows of tdw 8-byte entries
+    const size_t vb = (size_t)((maxCellH + 3) & ~3) * tdwMax * 8;
+    if (vb > work2) work2 = vb;
+  }
+  const size_t ldsBytes = (size_t)tileRows * pitch * 4 + work2;
   const dim3 grid((total + 7u) / 8u * 8u);
-  const uint32_t magic = udiv_magic_multiplier((uint32_t)nCells);
-#define ORBFE_LAUNCH_FAST(P)                                                                                     \
-  hipLaunchKernelGGL(k_fast_cells<P>, grid, dim3(64), ldsBytes, s, pyr, d_cells, nCells, nFrames, iniTh, minTh, \
-                     d_slots, slotsPerFrame, d_cellCount, tileRows, scoreRows, magic)
-  if (pitch == 12) ORBFE_LAUNCH_FAST(12);
-  else if (pitch == 16) ORBFE_LAUNCH_FAST(16);
-  else ORBFE_LAUNCH_FAST(24);
+  const uint32_t magic = udiv_magic_multiplier((uint32_t)nWork);
+  PyramidViews bo = blurOut ? *blurOut : PyramidViews{};
+#define ORBFE_LAUNCH_FAST(P, B)                                                                                     \
+  hipLaunchKernelGGL((k_fast_cells<P, B>), grid, dim3(64), ldsBytes, s, pyr, d_cells, nWork, nFrames, iniTh, minTh, \
+                     d_slots, slotsPerFrame, d_cellCount, tileRows, scoreRows, magic, bo, nCells)
+  if (blurOut) {
+    if (pitch == 12) ORBFE_LAUNCH_FAST(12, true);
+    else if (pitch == 16) ORBFE_LAUNCH_FAST(16, true);
+    else ORBFE_LAUNCH_FAST(24, true);
+  } else {
+    if (pitch == 12) ORBFE_LAUNCH_FAST(12, false);
+    else if (pitch == 16) ORBFE_LAUNCH_FAST(16, false);
+    else ORBFE_LAUNCH_FAST(24, false);
+  }
 #undef ORBFE_LAUNCH_FAST
 }
 

@@ -169,7 +169,7 @@ void FrameGeom::build(const ExtractorTables& t, int W_, int H_) {
           c.y0 = (int16_t)y0;
           c.w = (int16_t)(x1 - x0 + 1);
           c.h = (int16_t)(y1 - y0 + 1);
-          c.pad = 0;
+          c.flags = 0;
           c.slotBase = slots;
           // strict 3x3 NMS keeps no two 8-adjacent pixels -> at most ceil(w/2)*ceil(h/2)
           slots += ((c.w + 1) / 2) * ((c.h + 1) / 2);
@@ -199,6 +199,57 @@ void FrameGeom::build(const ExtractorTables& t, int W_, int H_) {
   pyrBytes = off;
   totalSlots = slots;
   totalKpCap = kps;
+  // ---- blur-only frame cells (fused FAST+blur kernel): per level, the level rectangle minus the bounding box
+  //      of its detection rectangles, cut into strips of cells no larger than 32 x 32 ----
+  nFastCells = (int)cells.size();
+  fusedBlur = true;
+  std::vector<CellDesc> frame;
+  for (int l = 0; l < nlevels; l++) {
+    const LevelGeom& g = lv[l];
+    if (g.w <= 0 || g.h <= 0) continue;
+    int bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;  // bounding box of the FAST rectangles; empty when the level has none
+    long long area = 0;
+    for (int c = g.cellStart; c < g.cellStart + g.nCells; c++) {
+      const CellDesc& cd = cells[c];
+      if (area == 0) { bx0 = cd.x0; bx1 = cd.x0 + cd.w; by0 = cd.y0; by1 = cd.y0 + cd.h; }
+      if (cd.x0 < bx0) bx0 = cd.x0;
+      if (cd.x0 + cd.w > bx1) bx1 = cd.x0 + cd.w;
+      if (cd.y0 < by0) by0 = cd.y0;
+      if (cd.y0 + cd.h > by1) by1 = cd.y0 + cd.h;
+      area += (long long)cd.w * cd.h;
+    }
+    // the reference's grid tiles its bounding box exactly (sub-images overlap by 6 px, detection rims by 0);
+    // if a geometry ever does not, the unfused kernels are used instead
+    if (area != (long long)(bx1 - bx0) * (by1 - by0)) fusedBlur = false;
+    auto add_rect = [&](int rx0, int ry0, int rx1, int ry1) {
+      for (int y = ry0; y < ry1; y += 32)
+        for (int x = rx0; x < rx1; x += 32) {
+          CellDesc c;
+          c.level = (int16_t)l;
+          c.x0 = (int16_t)x;
+          c.y0 = (int16_t)y;
+          c.w = (int16_t)(rx1 - x < 32 ? rx1 - x : 32);
+          c.h = (int16_t)(ry1 - y < 32 ? ry1 - y : 32);
+          c.flags = (int16_t)kCellBlurOnly;
+          if (c.y0 - 3 < 0 || c.y0 + c.h + 2 >= g.h) c.flags |= kCellRowReflect;
+          // the staging loads whole dwords x0-4 .. x0+4*ceil(w/4)+3: every column the blur reads must be in the level
+          if (c.x0 - 3 < 0 || c.x0 + c.w + 2 >= g.w) c.flags |= kCellColReflect;
+          c.slotBase = 0;
+          frame.push_back(c);
+          if (c.w > maxCellW) maxCellW = c.w;
+          if (c.h > maxCellH) maxCellH = c.h;
+        }
+    };
+    if (area == 0) {
+      add_rect(0, 0, g.w, g.h);
+    } else {
+      add_rect(0, 0, g.w, by0);       // top strip
+      add_rect(0, by1, g.w, g.h);     // bottom strip
+      add_rect(0, by0, bx0, by1);     // left strip
+      add_rect(bx1, by0, g.w, by1);   // right strip
+    }
+  }
+  cells.insert(cells.end(), frame.begin(), frame.end());
 }
 
 }  // namespace orbfe

@@ -28,9 +28,13 @@ struct ExtractorTables {
 struct CellDesc {
   int16_t level;
   int16_t x0, y0, w, h;
-  int16_t pad;
+  int16_t flags;     // kCell* bits; 0 for a FAST cell
   int32_t slotBase;  // first candidate slot of this cell inside the per-frame slot array
 };
+// Blur-only cells of the fused FAST+blur kernel: the frame of the level that no detection rectangle covers.
+constexpr int kCellBlurOnly = 1;    // no FAST phases
+constexpr int kCellRowReflect = 2;  // tile rows leave [0, h): BORDER_REFLECT_101 on the row index
+constexpr int kCellColReflect = 4;  // tile columns leave [0, w): byte-wise staging with reflected columns
 
 struct LevelGeom {
   int w, h, pitch;
@@ -55,7 +59,9 @@ struct ResizeTables {  // cv::resize INTER_LINEAR fixed-point coefficients (leve
 struct FrameGeom {
   int W = 0, H = 0, nlevels = 0;
   LevelGeom lv[kMaxLevels] = {};
-  std::vector<CellDesc> cells;
+  std::vector<CellDesc> cells;  // FAST cells of all levels (level-major), then the blur-only frame cells
+  int nFastCells = 0;           // length of the FAST prefix of `cells`
+  bool fusedBlur = false;       // the FAST rectangles + frame cells tile every level exactly: fused kernel usable
   ResizeTables rz[kMaxLevels];
   uint32_t pyrBytes = 0;   // bytes of levels 1..n-1 (+ level 0 when owned) per frame
   int totalSlots = 0;      // candidate slots per frame

@@ -182,6 +182,10 @@ class ORBextractor:
     def set_streams(self, n: int):
         check(self._L.orbfe_extractor_set_streams(self._h, int(n)))
 
+    def set_fused(self, enable: bool):
+        """GaussianBlur inside the FAST kernel (default) or as its own launch; identical results."""
+        check(self._L.orbfe_extractor_set_fused(self._h, int(bool(enable))))
+
 
 def resize_linear(src: np.ndarray, dw: int, dh: int, device: int = 0) -> np.ndarray:
     src = np.ascontiguousarray(src, dtype=np.uint8)

@@ -267,3 +267,51 @@ def test_full_size_device_batch_properties(amd):
         assert len(ks) == n[f]
         assert np.array_equal(ds, desc[f, :n[f]])
         assert np.array_equal(np.stack([ks["x"], ks["y"], ks["angle"], ks["response"]], 1), kp[f, :n[f]][:, [0, 1, 3, 4]])
+
+
+@pytest.mark.parametrize("shape,params", [((640, 480), (1000, 1.2, 8, 20, 7)), ((1241, 376), (2000, 1.2, 8, 20, 7)),
+                                          ((752, 480), (1200, 1.2, 8, 20, 7)), ((333, 217), (500, 1.2, 8, 20, 7)),
+                                          ((97, 81), (300, 1.2, 8, 20, 7)), ((200, 64), (200, 1.5, 4, 20, 7))])
+def test_fused_and_separate_blur_agree_with_the_oracle(amd, shape, params):
+    """The blur runs inside the FAST kernel by default (detection cells + blur-only frame cells with
+    reflect-101 staging); the separate k_blur7 launch stays selectable.  Both must give the oracle's blurred
+    levels (every byte of every level, including the 19-px frame and levels too small for any FAST cell)
+    and identical keypoints / descriptors."""
+    w, h = shape
+    nf, sf, nl, ini, mn = params
+    for seed, img in ((1, synth.render_frame(40, w, h)), (2, synth.adversarial("noise", w, h, seed=9))):
+        o = orc.Oracle(nf, sf, nl, ini, mn)
+        kr, dr, pyr = o.extract(img, want_pyramid=True)
+        levels = o.split_pyramid(pyr, w, h)
+        for fused in (True, False):
+            e = amd.ORBextractor(nf, sf, nl, ini, mn)
+            e.set_fused(fused)
+            kps, desc = e(img)
+            for l, ref in enumerate(levels):
+                got = e.debug_blurred_level(l)
+                assert np.array_equal(orc.gaussian_blur7(ref), got), f"blur level {l} fused={fused} seed={seed}"
+            _kp_equal(kr, kps)
+            assert np.array_equal(dr, desc)
+    # batch of frames on several streams, strided caller-owned input (odd pitch = byte staging of level 0)
+    torch = pytest.importorskip("torch")
+    B = 5
+    frames = np.stack([synth.render_frame(60 + i, w, h) for i in range(B)])
+    dev = torch.device("cuda", 0)
+    stride = w + 3
+    buf = torch.zeros((B, h, stride), dtype=torch.uint8, device=dev)
+    buf[:, :, :w] = torch.from_numpy(frames).to(dev)
+    e = amd.ORBextractor(nf, sf, nl, ini, mn)
+    e.set_streams(2)
+    cap = e.max_keypoints(w, h)
+    d_kp = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros((B,), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    e.extract_batch_device(buf.data_ptr(), B, w, h, stride, stride * h, d_kp.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr())
+    o = orc.Oracle(nf, sf, nl, ini, mn)
+    for f in range(B):
+        kr, dr = o.extract(frames[f])
+        n = int(d_n[f].item())
+        assert n == len(kr)
+        assert np.array_equal(d_kp[f, :n].cpu().numpy().view(np.uint8).reshape(n, 28), kr.view(np.uint8).reshape(-1, 28))
+        assert np.array_equal(d_desc[f, :n].cpu().numpy(), dr)
