@@ -66,6 +66,49 @@ int main(int argc, char** argv) {
                 (unsigned long long)fnv(mc.data(), mc.size() * 4),
                 (unsigned long long)fnv(area32.data(), area32.size() * 4), area.size());
   }
+  // the remaining ORBmatcher searches through the C++ layer (LocalMapping / LoopClosing / relocalisation callers):
+  // inputs derived from the two frames by fixed formulas the Python test repeats for the oracle
+  {
+    const std::vector<float> sf = eL.GetScaleFactors(), sig2 = eL.GetScaleSigmaSquares(), isig2 = eL.GetInverseScaleSigmaSquares();
+    std::vector<float> urL(kL.size()), urR(kR.size());
+    for (size_t i = 0; i < kL.size(); i++) urL[i] = (i % 5 == 0) ? kL[i].x - 3.0f : -1.0f;   // some stereo keypoints
+    for (size_t i = 0; i < kR.size(); i++) urR[i] = (i % 7 == 0) ? kR[i].x - 2.0f : -1.0f;
+    FrameArrays K1(kL, dL, 0.0f, (float)W, 0.0f, (float)H, urL), K2(kR, dR, 0.0f, (float)W, 0.0f, (float)H, urR);
+    FrameArrays M2(kR, dR, 0.0f, (float)W, 0.0f, (float)H);  // monocular view of the right frame
+    std::vector<uint8_t> has1(kL.size()), has2(kR.size());
+    for (size_t i = 0; i < kL.size(); i++) has1[i] = i % 3 == 0;
+    for (size_t i = 0; i < kR.size(); i++) has2[i] = i % 4 == 0;
+    std::map<unsigned, std::vector<unsigned> > fm1, fm2;  // DBoW2::FeatureVector stand-in: node = f(descriptor)
+    for (size_t i = 0; i < kL.size(); i++) fm1[(unsigned)((dL[32 * i] ^ dL[32 * i + 7]) % 37) * 5u + 2u].push_back((unsigned)i);
+    for (size_t i = 0; i < kR.size(); i++) fm2[(unsigned)((dR[32 * i] ^ dR[32 * i + 7]) % 37) * 5u + 2u].push_back((unsigned)i);
+    FeatureVectorCSR fv1(fm1), fv2(fm2);
+    const float F12[9] = {0, 0, 0, 0, 0, -1, 0, 1, 0};  // rectified pair: epipolar lines are image rows
+    std::vector<std::pair<size_t, size_t> > pairs;
+    ORBmatcher tri(0.6f, false);
+    const int nTri = tri.SearchForTriangulation(K1, has1, fv1, K2, has2, fv2, F12, 1000.0f, 100.0f, sf, sig2, pairs, false);
+    std::vector<int32_t> flat;
+    for (auto& pr : pairs) { flat.push_back((int32_t)pr.first); flat.push_back((int32_t)pr.second); }
+    std::vector<std::pair<size_t, size_t> > pairsS;
+    const int nTriS = tri.SearchForTriangulation(K1, has1, fv1, K2, has2, fv2, F12, 1000.0f, 100.0f, sf, sig2, pairsS, true);
+    // relocalisation / loop-closing / fuse / Sim3 searches: the left frame's keypoints play the projected map points
+    std::vector<uint8_t> valid(kL.size(), 1), validR(kR.size(), 1), none;
+    std::vector<float> u(kL.size()), v(kL.size()), u2(kR.size()), v2(kR.size()), urp(kL.size(), -1.0f);
+    std::vector<int32_t> lev(kL.size()), lev2(kR.size());
+    for (size_t i = 0; i < kL.size(); i++) { u[i] = kL[i].x - 2.0f; v[i] = kL[i].y; lev[i] = kL[i].octave; valid[i] = i % 11 != 0; }
+    for (size_t i = 0; i < kR.size(); i++) { u2[i] = kR[i].x + 2.0f; v2[i] = kR[i].y; lev2[i] = kR[i].octave; }
+    ORBmatcher m(0.9f, true);
+    std::vector<int32_t> mReloc, mSim, bestA, bestB, m12;
+    const int nReloc = m.SearchByProjection(M2, sf, none, valid, u, v, lev, K1.angle, dL, 12.0f, 100, mReloc);
+    const int nSim = m.SearchByProjection(M2, sf, none, valid, u, v, lev, dL, 10, mSim);
+    m.Fuse(M2, sf, isig2, valid, u, v, urp, lev, dL, bestA, 12.0f);
+    m.Fuse(M2, sf, valid, u, v, lev, dL, 12.0f, bestB);
+    const int nS3 = m.SearchBySim3(K1, K2, sf, sf, valid, u, v, lev, dL, validR, u2, v2, lev2, dR, 12.0f, m12);
+    std::printf("ntri=%d tri=%016llx ntris=%d nreloc=%d reloc=%016llx nsim=%d sim=%016llx fusea=%016llx fuseb=%016llx ns3=%d s3=%016llx\n",
+                nTri, (unsigned long long)fnv(flat.data(), flat.size() * 4), nTriS, nReloc,
+                (unsigned long long)fnv(mReloc.data(), mReloc.size() * 4), nSim,
+                (unsigned long long)fnv(mSim.data(), mSim.size() * 4), (unsigned long long)fnv(bestA.data(), bestA.size() * 4),
+                (unsigned long long)fnv(bestB.data(), bestB.size() * 4), nS3, (unsigned long long)fnv(m12.data(), m12.size() * 4));
+  }
   // empty image: silent return, outputs untouched
   std::vector<KeyPoint> k0(3);
   std::vector<uint8_t> d0(96);
