@@ -159,6 +159,19 @@ int orbfe_debug_resize_tables(int sw, int sh, int dw, int dh, int32_t *xofs, int
  * (D2H/H2D round trip) instead of the device kernel.  Off by default; results are identical. */
 int orbfe_extractor_debug_host_octree(orbfe_extractor *e, int enable);
 
+/* Which cv::GaussianBlur(7x7, sigma 2) arithmetic the extractor reproduces.  The reference does not pin its OpenCV
+ * (CMakeLists.txt:33-39 accepts 2.4.3 and 3.x, README.md:74 names 2.4.11 / 3.2) and the 8-bit path changed:
+ *   ORBFE_BLUR_CV4        (0, default; $ORBFE_BLUR_SPEC) OpenCV >= 3.4.1 / 4.x: taps 18 34 48 56 48 34 18 (/256),
+ *                          (x + 2^15) >> 16;
+ *   ORBFE_BLUR_CV2_SCALAR (1) OpenCV 2.4.x / 3.0-3.3 without SIMD: taps 18 34 49 55 49 34 18 (each rounded on its own,
+ *                          sum 257), saturate((x + 2^15) >> 16);
+ *   ORBFE_BLUR_CV2_SSE2   (2) the same versions on x86 with SSE2: round-half-to-even on the first width & ~3 columns
+ *                          (float column pass + cvtps2dq), the scalar form on the last width & 3.
+ * All three are restated from OpenCV's published sources and unverifiable in this image; the CPU
+ * oracle implements the same three and the GPU equals it for each. */
+enum { ORBFE_BLUR_CV4 = 0, ORBFE_BLUR_CV2_SCALAR = 1, ORBFE_BLUR_CV2_SSE2 = 2 };
+int orbfe_extractor_set_blur_spec(orbfe_extractor *e, int spec);
+
 /* GaussianBlur fused into the FAST kernel (1) or run as its own launch (0, the default; $ORBFE_FUSED).  Results
  * are identical; the fused form measured no faster and is kept as a parity-tested alternative. */
 int orbfe_extractor_set_fused(orbfe_extractor *e, int enable);
@@ -193,6 +206,8 @@ const char *orbfe_stage_name(int stage);
 /* Standalone primitives on host buffers (tests of the individual kernels). */
 int orbfe_resize_linear(int device, const uint8_t *src, int sw, int sh, int sstride, uint8_t *dst,
                         int dw, int dh, int dstride);
+int orbfe_gaussian_blur7_spec(int device, int spec, const uint8_t *src, int w, int h, int sstride, uint8_t *dst,
+                             int dstride);
 int orbfe_gaussian_blur7(int device, const uint8_t *src, int w, int h, int sstride, uint8_t *dst,
                          int dstride);
 

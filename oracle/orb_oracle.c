@@ -219,11 +219,25 @@ static int reflect101(int i, int n) {
   return i;
 }
 
-void orc_gaussian_blur7(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride) {
-  static const int K[7] = {18, 34, 48, 56, 48, 34, 18};
+/* cv::GaussianBlur(src, dst, Size(7,7), 2, 2, BORDER_REFLECT_101) on CV_8UC1 (src/ORBextractor.cc:1175), in the three
+ * arithmetic variants the unpinned OpenCV version allows (see include/orbfe.h ORBFE_BLUR_*; all restated from OpenCV's
+ * published sources, none verifiable here):
+ *   spec 0  OpenCV >= 3.4.1 / 4.x fixed-point path (smooth.cpp, ufixedpoint16): bit-exact kernel 18 34 48 56 48 34 18,
+ *           which sums to 256, first pass exact in 8.8, (x + 2^15) >> 16 after the second;
+ *   spec 1  OpenCV 2.4.x / 3.0-3.3, filter.cpp without SIMD: getGaussianKernel(7, 2) in float converted tap by tap
+ *           with convertTo(CV_32S, 256) -> 18 34 49 55 49 34 18 (sum 257), column pass FixedPtCastEx<int, uchar>(16):
+ *           saturate_cast<uchar>((x + 2^15) >> 16);
+ *   spec 2  the same versions with SSE2 (SymmColumnVec_32s8u): for x < width - width % 4 the column pass converts the
+ *           row sums to float, multiplies by tap / 2^16, accumulates in float (centre tap first, then the symmetric
+ *           pairs outward) and converts with cvtps2dq = round-half-to-EVEN, then packs with unsigned saturation; the
+ *           remaining width % 4 columns go through the scalar spec-1 code. */
+void orc_gaussian_blur7_spec(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride, int spec) {
+  static const int K0[7] = {18, 34, 48, 56, 48, 34, 18};
+  static const int K1[7] = {18, 34, 49, 55, 49, 34, 18};
+  const int *K = spec == 0 ? K0 : K1;
   uint16_t *hs = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)w * h);
   uint8_t *row = (uint8_t *)malloc((size_t)w + 6);
-  for (int y = 0; y < h; y++) { /* horizontal pass into 8.8 fixed point (<= 65280) */
+  for (int y = 0; y < h; y++) { /* horizontal pass into 8.8 fixed point (<= 255 * 257 = 65535) */
     const uint8_t *S = src + (size_t)y * sstride;
     memcpy(row + 3, S, w);
     for (int i = 1; i <= 3; i++) { row[3 - i] = S[reflect101(-i, w)]; row[3 + w - 1 + i] = S[reflect101(w - 1 + i, w)]; }
@@ -233,18 +247,32 @@ void orc_gaussian_blur7(const uint8_t *src, int w, int h, int sstride, uint8_t *
       H[x] = (uint16_t)(K[0] * (r[0] + r[6]) + K[1] * (r[1] + r[5]) + K[2] * (r[2] + r[4]) + K[3] * r[3]);
     }
   }
-  for (int y = 0; y < h; y++) { /* vertical pass, 16.16 -> u8 with round-half-up */
+  const int simd_cols = spec == 2 ? w - (w % 4) : 0;
+  const float kf[4] = {(float)K[3] * (1.f / 65536.f), (float)K[2] * (1.f / 65536.f), (float)K[1] * (1.f / 65536.f),
+                       (float)K[0] * (1.f / 65536.f)}; /* kernel.convertTo(CV_32F, 1./(1 << 16)): centre, +-1, +-2, +-3 */
+  for (int y = 0; y < h; y++) { /* vertical pass, 16.16 -> u8 */
     const uint16_t *r[7];
     for (int j = 0; j < 7; j++) r[j] = hs + (size_t)reflect101(y + j - 3, h) * w;
     uint8_t *D = dst + (size_t)y * dstride;
     for (int x = 0; x < w; x++) {
+      if (x < simd_cols) { /* float column pass, no FMA (-ffp-contract=off), default rounding mode */
+        float s0 = (float)(int)r[3][x] * kf[0] + 0.f;
+        for (int k = 1; k <= 3; k++) s0 = s0 + (float)((int)r[3 + k][x] + (int)r[3 - k][x]) * kf[k];
+        long v = lrintf(s0); /* cvtps2dq */
+        D[x] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); /* packs + packus */
+        continue;
+      }
       uint32_t acc = (uint32_t)K[0] * ((uint32_t)r[0][x] + r[6][x]) + (uint32_t)K[1] * ((uint32_t)r[1][x] + r[5][x]) +
                      (uint32_t)K[2] * ((uint32_t)r[2][x] + r[4][x]) + (uint32_t)K[3] * r[3][x];
-      D[x] = (uint8_t)((acc + (1u << 15)) >> 16);
+      const uint32_t v = (acc + (1u << 15)) >> 16;
+      D[x] = (uint8_t)(v > 255 ? 255 : v); /* saturate_cast: only reachable with the 257-sum taps */
     }
   }
   free(row);
   free(hs);
+}
+void orc_gaussian_blur7(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride) {
+  orc_gaussian_blur7_spec(src, w, h, sstride, dst, dstride, 0);
 }
 
 /* ------------------------------------------------------------------ */
@@ -796,7 +824,7 @@ int orc_extract(orc_extractor *e, const uint8_t *img, int W, int H, int stride, 
     if (ln[l] == 0) continue;
     double ta = now_s();
     uint8_t *blur = (uint8_t *)malloc((size_t)lw[l] * lh[l]);
-    orc_gaussian_blur7(lev[l], lw[l], lh[l], lw[l], blur, lw[l]);
+    orc_gaussian_blur7_spec(lev[l], lw[l], lh[l], lw[l], blur, lw[l], e->blur_spec);
     double tb = now_s();
     e->t_blur += tb - ta;
     for (int i = 0; i < ln[l]; i++) {

@@ -50,6 +50,7 @@ typedef struct orc_extractor {
   int umax[16];
   /* per-stage wall-clock accumulators (seconds), filled by orc_extract */
   double t_pyramid, t_fast, t_octree, t_orient, t_blur, t_desc;
+  int blur_spec; /* 0 (default) / 1 / 2: GaussianBlur arithmetic variant, see orc_gaussian_blur7_spec */
 } orc_extractor;
 
 /* ---- arithmetic primitives (canonical spec) ---- */
@@ -67,6 +68,7 @@ void orc_resize_linear(const uint8_t *src, int sw, int sh, int sstride, uint8_t 
                        int dh, int dstride);
 /* cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101), src/ORBextractor.cc:1175 */
 void orc_gaussian_blur7(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride);
+void orc_gaussian_blur7_spec(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride, int spec);
 /* cv::FAST(sub-image, thr, nonmax=true) -> keypoints relative to the sub-image.
  * Returns count; writes up to cap (x,y,score) triples. */
 int orc_fast_nms(const uint8_t *img, int w, int h, int stride, int threshold, int *xs, int *ys,

@@ -74,6 +74,7 @@ struct orbfe_extractor {
   // 291.8 k frames/s -- FAST already runs at the VALU issue ceiling, so the blur's instructions cost their full price
   // inside it; off by default, selectable ($ORBFE_FUSED=1 / orbfe_extractor_set_fused) and parity-tested
   bool fused = false;
+  int blurSpec = kBlurSpecCv4;  // GaussianBlur arithmetic, orbfe_extractor_set_blur_spec / $ORBFE_BLUR_SPEC
   int octreeMaxL = 0;
   double stageMs[ORBFE_STAGE_COUNT] = {};
   int64_t stageLaunches[ORBFE_STAGE_COUNT] = {};
@@ -101,6 +102,8 @@ struct orbfe_extractor {
   int32_t* d_cellPrefix = nullptr;
   int32_t* d_candCount = nullptr;
   uint16_t* d_nodeOf = nullptr;
+  uint8_t* d_octreeWork = nullptr;  // node lists of k_octree_global (only when they do not fit in LDS)
+  size_t octreeWorkStride = 0;
   float* d_scaleTab = nullptr;     // mvScaleFactor[16] + mvInvScaleFactor[16]
   int32_t* d_stereoSad = nullptr;  // scratch of the batched stereo matcher
   int32_t* d_stereoRowStart = nullptr;
@@ -153,7 +156,8 @@ void free_geometry(orbfe_extractor* e) {
 void free_workspace(orbfe_extractor* e) {
   dfree(&e->d_pyr); dfree(&e->d_blur); dfree(&e->d_slots); dfree(&e->d_cand);
   dfree(&e->d_cellCount); dfree(&e->d_cellPrefix); dfree(&e->d_candCount); dfree(&e->d_nodeOf);
-  dfree(&e->d_levelKp); dfree(&e->d_levelCount);
+  dfree(&e->d_levelKp); dfree(&e->d_levelCount); dfree(&e->d_octreeWork);
+  e->octreeWorkStride = 0;
   e->capFrames = 0;
 }
 void free_outputs(orbfe_extractor* e) {
@@ -182,9 +186,9 @@ int ensure_geometry(orbfe_extractor* e, int W, int H) {
     if (g.lv[l].slotCount >= (1 << 24)) return fail(ORBFE_ERR_INVALID, "level too large for the octree kernel");
   }
   maxL = (maxL + 3) & ~3;
-  if (octree_lds_bytes(maxL) > 150 * 1024)
-    return fail(ORBFE_ERR_INVALID, "nfeatures too large: octree node list does not fit in LDS");
-  e->octreeMaxL = maxL;
+  if (maxL > 65532)  // 16-bit node positions (nodeOf, order, rank)
+    return fail(ORBFE_ERR_INVALID, "nfeatures too large: more than 65532 keypoints on one pyramid level");
+  e->octreeMaxL = maxL;  // octree_lds_bytes(maxL) > kOctreeLdsLimit: node lists in global memory (ensure_workspace)
   int rc;
   if ((rc = dalloc(&e->d_cells, g.cells.size()))) return rc;
   if (!g.cells.empty()) HIPCHK(hipMemcpy(e->d_cells, g.cells.data(), g.cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
@@ -226,6 +230,10 @@ int ensure_workspace(orbfe_extractor* e, int nFrames) {
   if ((rc = dalloc(&e->d_nodeOf, B * (size_t)g.totalSlots))) return rc;
   if ((rc = dalloc(&e->d_levelKp, B * (size_t)g.totalKpCap))) return rc;
   if ((rc = dalloc(&e->d_levelCount, B * (size_t)g.nlevels))) return rc;
+  if (octree_lds_bytes(e->octreeMaxL) > kOctreeLdsLimit) {
+    e->octreeWorkStride = (octree_lds_bytes(e->octreeMaxL) + 255) & ~(size_t)255;
+    if ((rc = dalloc(&e->d_octreeWork, B * (size_t)g.nlevels * e->octreeWorkStride))) return rc;
+  }
   e->capFrames = nFrames;
   return ORBFE_OK;
 }
@@ -351,7 +359,7 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
   const FrameGeom& g = e->geom;
   const size_t F = (size_t)f0;
   const int nCells = g.nFastCells;
-  const bool fused = e->fused && g.fusedBlur;
+  const bool fused = e->fused && g.fusedBlur && e->blurSpec == kBlurSpecCv4;  // the fused phase E implements spec 0 only
   PyramidViews pyr = {}, blur = {}, pyr0 = {}, blur0 = {};
   pyr.nlevels = blur.nlevels = pyr0.nlevels = blur0.nlevels = g.nlevels;
   pyr0.lv[0] = level0;
@@ -399,7 +407,7 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
     LevelViewMut dsts[kMaxLevels];
     for (int l = 0; l < g.nlevels; l++)
       dsts[l] = LevelViewMut{const_cast<uint8_t*>(blur.lv[l].base), g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
-    launch_blur7_levels(s, pyr.lv, dsts, g.nlevels, nFrames);
+    launch_blur7_levels(s, pyr.lv, dsts, g.nlevels, nFrames, e->blurSpec);
   };
   const bool blurFirst = !fused && (sub & 1) != 0;  // measured +1.7 % frames/s (A/B on one box, 4 runs each)
   if (blurFirst) do_blur();
@@ -423,6 +431,8 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
     oa.levelCount = levelCount;
     oa.kpSlotsPerFrame = g.totalKpCap;
     oa.maxL = e->octreeMaxL;
+    oa.work = e->d_octreeWork ? e->d_octreeWork + F * (size_t)g.nlevels * e->octreeWorkStride : nullptr;
+    oa.workStride = e->octreeWorkStride;
     HIPCHK(launch_octree(s, oa, g.nlevels, nFrames));
   } else {
     launch_gather_candidates(s, e->d_cells, e->d_lvgeom, g.nlevels, nFrames, slots, g.totalSlots, cellCount,
@@ -515,6 +525,10 @@ extern "C" int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlev
   for (int i = 0; i < orbfe_extractor::kMaxStreams - 1 && err == hipSuccess; i++)
     err = hipStreamCreateWithFlags(&e->extra[i], hipStreamNonBlocking);
   if (const char* env = getenv("ORBFE_FUSED")) e->fused = atoi(env) != 0;
+  if (const char* env = getenv("ORBFE_BLUR_SPEC")) {
+    const int v = atoi(env);
+    if (v >= 0 && v <= 2) e->blurSpec = v;
+  }
   if (const char* env = getenv("ORBFE_STREAMS")) {
     int v = atoi(env);
     if (v >= 1 && v <= orbfe_extractor::kMaxStreams) e->nStreams = v;
@@ -882,8 +896,12 @@ extern "C" int orbfe_resize_linear(int device, const uint8_t* src, int sw, int s
   return ORBFE_OK;
 }
 
+extern "C" int orbfe_gaussian_blur7_spec(int device, int spec, const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
 extern "C" int orbfe_gaussian_blur7(int device, const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride) {
-  if (!src || !dst || w <= 0 || h <= 0 || sstride < w || dstride < w) return fail(ORBFE_ERR_INVALID, "blur: bad argument");
+  return orbfe_gaussian_blur7_spec(device, kBlurSpecCv4, src, w, h, sstride, dst, dstride);
+}
+extern "C" int orbfe_gaussian_blur7_spec(int device, int spec, const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride) {
+  if (!src || !dst || w <= 0 || h <= 0 || sstride < w || dstride < w || spec < 0 || spec > 2) return fail(ORBFE_ERR_INVALID, "blur: bad argument");
   HIPCHK(hipSetDevice(device));
   const int p = (w + 63) & ~63;
   uint8_t *d_src = nullptr, *d_dst = nullptr;
@@ -892,7 +910,7 @@ extern "C" int orbfe_gaussian_blur7(int device, const uint8_t* src, int w, int h
   if ((rc = dalloc(&d_dst, (size_t)p * h))) { dfree(&d_src); return rc; }
   hipError_t err = hipMemcpy2D(d_src, p, src, sstride, w, h, hipMemcpyHostToDevice);
   if (err == hipSuccess) {
-    launch_blur7(nullptr, LevelView{d_src, 0, p, w, h}, LevelViewMut{d_dst, 0, p, w, h}, 1);
+    launch_blur7(nullptr, LevelView{d_src, 0, p, w, h}, LevelViewMut{d_dst, 0, p, w, h}, 1, spec);
     err = hipGetLastError();
   }
   if (err == hipSuccess) err = hipDeviceSynchronize();
@@ -947,6 +965,16 @@ extern "C" int orbfe_extractor_consumer_end_(orbfe_extractor* e) {
 extern "C" int orbfe_extractor_debug_host_octree(orbfe_extractor* e, int enable) {
   if (!e) return fail(ORBFE_ERR_INVALID, "NULL handle");
   e->hostOctree = enable != 0;
+  return ORBFE_OK;
+}
+
+// Which OpenCV's GaussianBlur arithmetic the extractor reproduces (include/orbfe.h, ORBFE_BLUR_*).
+extern "C" int orbfe_extractor_set_blur_spec(orbfe_extractor* e, int spec) {
+  if (!e || spec < 0 || spec > 2) return fail(ORBFE_ERR_INVALID, "set_blur_spec: 0 (OpenCV >= 3.4.1/4.x), 1 (2.4/3.x scalar) or 2 (2.4/3.x SSE2)");
+  HIPCHK(hipSetDevice(e->device));
+  int rc = sync_all(e);
+  if (rc) return rc;
+  e->blurSpec = spec;
   return ORBFE_OK;
 }
 

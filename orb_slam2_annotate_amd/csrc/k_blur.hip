@@ -1,7 +1,15 @@
 // k_blur.hip -- cv::GaussianBlur(7x7, sigma=2, BORDER_REFLECT_101) on a u8 level
-// (the `workingMat` of src/ORBextractor.cc:1169-1175), OpenCV's bit-exact fixed-point path:
-// separable kernel [18,34,48,56,48,34,18]/256, first pass exact in 8.8, second pass in 16.16,
-// one rounding (x + 2^15) >> 16.  Both passes are exact integer sums, so their order is free:
+// (the `workingMat` of src/ORBextractor.cc:1169-1175).  The arithmetic is a SPEC (orb_spec.h, kBlurSpec*),
+// selectable per extractor because the reference does not pin its OpenCV version:
+//   SPEC 0 (default)  OpenCV >= 3.4.1 / 4.x bit-exact fixed-point path: separable kernel
+//                     [18,34,48,56,48,34,18]/256 (sums to 256), one rounding (x + 2^15) >> 16;
+//   SPEC 1            OpenCV 2.4.x / 3.0-3.3 generic C++ path: every tap rounded on its own,
+//                     [18,34,49,55,49,34,18]/256 (sums to 257), saturate_cast<uchar>((x + 2^15) >> 16);
+//   SPEC 2            the same versions built with SSE2 (x86 desktop builds): the column pass of the first
+//                     width & ~3 columns runs in float and ends in cvtps2dq, i.e. round-half-to-EVEN of x / 2^16
+//                     (the float sums are exact below 256), the last width & 3 columns take the SPEC 1 form.
+// First pass exact in 8.8 (255 * 257 = 65535 still fits the packed u16), second pass in 16.16.
+// Both passes are exact integer sums, so their order is free:
 //   1. a 64x64 output tile stages (64+6) x (64+8) source bytes in LDS as aligned dwords
 //      (reflect-101 resolved while loading);
 //   2. VERTICAL pass, packed 16-bit: a thread takes 4 adjacent columns of 4 rows (the byte -> u16
@@ -46,7 +54,9 @@ struct BlurBatch {
   int nlevels, nFrames;
 };
 
+template <int SPEC>
 __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
+  constexpr uint32_t K0 = 18, K1 = 34, K2 = SPEC == 0 ? 48 : 49, K3 = SPEC == 0 ? 56 : 55;
   __shared__ uint32_t tin[kTH * kTDW];             // source bytes
   __shared__ uint2 vbuf[kBH * kTDW];               // vertical sums, 4 u16 per entry
   const int tid = threadIdx.x;
@@ -127,7 +137,8 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
       te[j] = as_u2(r & 0x00ff00ffu);
       to[j] = as_u2(__builtin_amdgcn_perm(r, r, 0x0c030c01u));
     }
-    const u16x2 k18 = {18, 18}, k34 = {34, 34}, k48 = {48, 48}, k56 = {56, 56};
+    const u16x2 k18 = {(unsigned short)K0, (unsigned short)K0}, k34 = {(unsigned short)K1, (unsigned short)K1},
+                k48 = {(unsigned short)K2, (unsigned short)K2}, k56 = {(unsigned short)K3, (unsigned short)K3};
     uint2* vo = &vbuf[(4 * rb) * kTDW + tj];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -159,23 +170,33 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
     const uint2 e0 = vp[0], e1 = vp[1], e2 = vp[2];
     // d_k = (v'[2k], v'[2k+1]) with v' indexed from tile column 4*gx
     const uint32_t d0 = e0.x, d1 = e0.y, d2 = e1.x, d3 = e1.y, d4 = e2.x, d5 = e2.y;
-    const uint32_t R = 1u << 15;
-    uint32_t o0 = dot2(d0, pk(0, 18), R);   // taps v'1..v'7
-    o0 = dot2(d1, pk(34, 48), o0);
-    o0 = dot2(d2, pk(56, 48), o0);
-    o0 = dot2(d3, pk(34, 18), o0);
-    uint32_t o1 = dot2(d1, pk(18, 34), R);  // taps v'2..v'8
-    o1 = dot2(d2, pk(48, 56), o1);
-    o1 = dot2(d3, pk(48, 34), o1);
-    o1 = dot2(d4, pk(18, 0), o1);
-    uint32_t o2 = dot2(d1, pk(0, 18), R);   // taps v'3..v'9
-    o2 = dot2(d2, pk(34, 48), o2);
-    o2 = dot2(d3, pk(56, 48), o2);
-    o2 = dot2(d4, pk(34, 18), o2);
-    uint32_t o3 = dot2(d2, pk(18, 34), R);  // taps v'4..v'10
-    o3 = dot2(d3, pk(48, 56), o3);
-    o3 = dot2(d4, pk(48, 34), o3);
-    o3 = dot2(d5, pk(18, 0), o3);
+    // SPEC 2, SIMD columns: no bias here, round-half-even below
+    const bool simdCols = SPEC == 2 && bx + 4 * gx < (dst.w & ~3);
+    const uint32_t R = (SPEC == 2 && simdCols) ? 0u : (1u << 15);
+    uint32_t o0 = dot2(d0, pk(0, K0), R);   // taps v'1..v'7
+    o0 = dot2(d1, pk(K1, K2), o0);
+    o0 = dot2(d2, pk(K3, K2), o0);
+    o0 = dot2(d3, pk(K1, K0), o0);
+    uint32_t o1 = dot2(d1, pk(K0, K1), R);  // taps v'2..v'8
+    o1 = dot2(d2, pk(K2, K3), o1);
+    o1 = dot2(d3, pk(K2, K1), o1);
+    o1 = dot2(d4, pk(K0, 0), o1);
+    uint32_t o2 = dot2(d1, pk(0, K0), R);   // taps v'3..v'9
+    o2 = dot2(d2, pk(K1, K2), o2);
+    o2 = dot2(d3, pk(K3, K2), o2);
+    o2 = dot2(d4, pk(K1, K0), o2);
+    uint32_t o3 = dot2(d2, pk(K0, K1), R);  // taps v'4..v'10
+    o3 = dot2(d3, pk(K2, K3), o3);
+    o3 = dot2(d4, pk(K2, K1), o3);
+    o3 = dot2(d5, pk(K0, 0), o3);
+    if (SPEC != 0) {
+      if (SPEC == 2 && simdCols) {  // round-half-to-even of x / 2^16: + 0x7fff + (bit 16 of x)
+        o0 += 0x7fffu + ((o0 >> 16) & 1u); o1 += 0x7fffu + ((o1 >> 16) & 1u);
+        o2 += 0x7fffu + ((o2 >> 16) & 1u); o3 += 0x7fffu + ((o3 >> 16) & 1u);
+      }
+      // the taps sum to 257: 255 * 257 * 257 + 2^15 reaches 257 << 16 -- saturate_cast<uchar>
+      o0 = min(o0, 0xffffffu); o1 = min(o1, 0xffffffu); o2 = min(o2, 0xffffffu); o3 = min(o3, 0xffffffu);
+    }
     // the rounded sums are < 2^24: byte 2 of each is the result; two v_perm gather them
     const uint32_t lo = __builtin_amdgcn_perm(o1, o0, 0x0c0c0602u);   // (o0.b2, o1.b2, 0, 0)
     const uint32_t hi = __builtin_amdgcn_perm(o3, o2, 0x06020c0cu);   // (0, 0, o2.b2, o3.b2)
@@ -183,7 +204,7 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   }
 }
 
-void launch_blur7_levels(hipStream_t s, const LevelView* src, const LevelViewMut* dst, int nlevels, int nFrames) {
+void launch_blur7_levels(hipStream_t s, const LevelView* src, const LevelViewMut* dst, int nlevels, int nFrames, int spec) {
   if (nlevels <= 0 || nFrames <= 0) return;
   BlurBatch bb = {};
   bb.nlevels = nlevels;
@@ -202,12 +223,15 @@ void launch_blur7_levels(hipStream_t s, const LevelView* src, const LevelViewMut
   }
   bb.tileStart[nlevels] = total;
   if (total == 0) return;
-  hipLaunchKernelGGL(k_blur7, dim3((total + 7u) / 8u * 8u), dim3(256), 0, s, bb);
+  const dim3 grid((total + 7u) / 8u * 8u);
+  if (spec == kBlurSpecCv2Scalar) hipLaunchKernelGGL(k_blur7<1>, grid, dim3(256), 0, s, bb);
+  else if (spec == kBlurSpecCv2Sse2) hipLaunchKernelGGL(k_blur7<2>, grid, dim3(256), 0, s, bb);
+  else hipLaunchKernelGGL(k_blur7<0>, grid, dim3(256), 0, s, bb);
 }
 
-void launch_blur7(hipStream_t s, LevelView src, LevelViewMut dst, int nFrames) {
+void launch_blur7(hipStream_t s, LevelView src, LevelViewMut dst, int nFrames, int spec) {
   if (dst.w <= 0 || dst.h <= 0) return;
-  launch_blur7_levels(s, &src, &dst, 1, nFrames);
+  launch_blur7_levels(s, &src, &dst, 1, nFrames, spec);
 }
 
 }  // namespace orbfe

@@ -407,6 +407,17 @@ __global__ __launch_bounds__(256) void k_octree_reg(OctreeArgs a) {
   else octree_body<false>(a, smem, waveTot, sh);
 }
 
+// Third build: the node list does not fit in LDS (a level asked for more than ~2 890 keypoints, e.g. 3000 features
+// on a 1-level pyramid): the same generation passes with the per-workgroup arrays in a global-memory slab.  Every
+// array access becomes a flat load / store / atomic and __syncthreads() orders them inside the workgroup -- slow
+// next to the LDS form, but it is the rare configuration and it stays on the device (no CPU path).
+__global__ __launch_bounds__(256) void k_octree_global(OctreeArgs a) {
+  __shared__ int waveTot[4];
+  __shared__ int sh[4];
+  uint8_t* slab = a.work + ((size_t)blockIdx.y * a.nlevels + blockIdx.x) * a.workStride;
+  octree_body<false>(a, slab, waveTot, sh);
+}
+
 size_t octree_lds_bytes(int maxL) {
   // 2 rect (8) + 2 cnt (4) + child (16) + scanA (4) + scanB (4) + order (2) + rankOf (2) + inS (1)
   return (size_t)maxL * (2 * 8 + 2 * 4 + 16 + 4 + 4 + 2 + 2 + 1) + 64;
@@ -415,6 +426,11 @@ size_t octree_lds_bytes(int maxL) {
 hipError_t launch_octree(hipStream_t s, const OctreeArgs& a, int nlevels, int nFrames) {
   if (nFrames <= 0) return hipSuccess;
   const size_t lds = octree_lds_bytes(a.maxL);
+  if (lds > kOctreeLdsLimit) {  // node list in global memory
+    if (!a.work || a.workStride < lds) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_octree_global, dim3(nlevels, nFrames), dim3(256), 0, s, a);
+    return hipSuccess;
+  }
   const bool latencyForm = nFrames <= 8;  // too few workgroups to fill the GPU anyway
   static thread_local size_t configured[2] = {0, 0};
   const void* fn = latencyForm ? reinterpret_cast<const void*>(k_octree_reg) : reinterpret_cast<const void*>(k_octree);

@@ -83,14 +83,18 @@ struct OctreeArgs {
   LevelKp* levelKp;           // out, [frame][kpStart(level) + i]
   int32_t* levelCount;        // out, [frame][level]
   int kpSlotsPerFrame;
-  int maxL;                   // LDS node capacity (>= every level's kpCap and nIni, multiple of 4)
+  int maxL;                   // node capacity (>= every level's kpCap and nIni, multiple of 4)
+  uint8_t* work;              // global-memory node lists, one slab of workStride bytes per (frame, level);
+  size_t workStride;          //   only read when octree_lds_bytes(maxL) > kOctreeLdsLimit
 };
+constexpr size_t kOctreeLdsLimit = 150 * 1024;  // beyond it the node list lives in global memory (k_octree_global)
 size_t octree_lds_bytes(int maxL);
 hipError_t launch_octree(hipStream_t s, const OctreeArgs& a, int nlevels, int nFrames);
 
 // ---- blur (GaussianBlur 7x7 sigma 2 reflect-101, :1169-1175) ----
-void launch_blur7(hipStream_t s, LevelView src, LevelViewMut dst, int nFrames);
-void launch_blur7_levels(hipStream_t s, const LevelView* src, const LevelViewMut* dst, int nlevels, int nFrames);
+void launch_blur7(hipStream_t s, LevelView src, LevelViewMut dst, int nFrames, int spec = kBlurSpecCv4);
+void launch_blur7_levels(hipStream_t s, const LevelView* src, const LevelViewMut* dst, int nlevels, int nFrames,
+                         int spec = kBlurSpecCv4);
 
 // ---- orientation + descriptor + final keypoint record (:78-152, :905-916, :1187-1195) ----
 struct OrientDescArgs {

@@ -16,6 +16,10 @@ constexpr int kPatchSize = 31;      // src/ORBextractor.cc:71
 constexpr int kHalfPatch = 15;      // :72
 constexpr int kEdgeThreshold = 19;  // :73
 constexpr int kMinBorder = kEdgeThreshold - 3;  // 16, :823
+// cv::GaussianBlur(7x7, sigma 2) arithmetic variants (k_blur.hip; include/orbfe.h ORBFE_BLUR_*)
+constexpr int kBlurSpecCv4 = 0;        // OpenCV >= 3.4.1 / 4.x bit-exact fixed point, taps 18 34 48 56
+constexpr int kBlurSpecCv2Scalar = 1;  // OpenCV 2.4.x / 3.0-3.3 generic C++ path, taps 18 34 49 55, round half up
+constexpr int kBlurSpecCv2Sse2 = 2;    // the same with the SSE2 column pass: round half to even on the first w & ~3 columns
 
 // cvRound(float): round half to even (SSE cvtss2si semantics), used at :82,118,124-125.
 ORB_HD int cv_round(float v) {

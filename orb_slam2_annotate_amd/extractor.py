@@ -182,6 +182,11 @@ class ORBextractor:
     def set_streams(self, n: int):
         check(self._L.orbfe_extractor_set_streams(self._h, int(n)))
 
+    def set_blur_spec(self, spec: int):
+        """0: OpenCV >= 3.4.1/4.x GaussianBlur arithmetic (default); 1: OpenCV 2.4/3.0-3.3 scalar path;
+        2: the same with the SSE2 column pass (include/orbfe.h ORBFE_BLUR_*)."""
+        check(self._L.orbfe_extractor_set_blur_spec(self._h, int(spec)))
+
     def set_fused(self, enable: bool):
         """GaussianBlur inside the FAST kernel (default) or as its own launch; identical results."""
         check(self._L.orbfe_extractor_set_fused(self._h, int(bool(enable))))
@@ -195,9 +200,9 @@ def resize_linear(src: np.ndarray, dw: int, dh: int, device: int = 0) -> np.ndar
     return dst
 
 
-def gaussian_blur7(src: np.ndarray, device: int = 0) -> np.ndarray:
+def gaussian_blur7(src: np.ndarray, device: int = 0, spec: int = 0) -> np.ndarray:
     src = np.ascontiguousarray(src, dtype=np.uint8)
     h, w = src.shape
     dst = np.zeros_like(src)
-    check(_lib.load().orbfe_gaussian_blur7(device, ptr(src), w, h, w, ptr(dst), w))
+    check(_lib.load().orbfe_gaussian_blur7_spec(device, int(spec), ptr(src), w, h, w, ptr(dst), w))
     return dst

@@ -24,7 +24,7 @@ class OrcExtractor(C.Structure):
                 ("mvLevelSigma2", C.c_float * MAX_LEVELS), ("mvInvLevelSigma2", C.c_float * MAX_LEVELS),
                 ("mnFeaturesPerLevel", C.c_int * MAX_LEVELS), ("umax", C.c_int * 16),
                 ("t_pyramid", C.c_double), ("t_fast", C.c_double), ("t_octree", C.c_double),
-                ("t_orient", C.c_double), ("t_blur", C.c_double), ("t_desc", C.c_double)]
+                ("t_orient", C.c_double), ("t_blur", C.c_double), ("t_desc", C.c_double), ("blur_spec", C.c_int)]
 
 
 class OrcFeatVec(C.Structure):
@@ -73,11 +73,12 @@ def _p(a):
 class Oracle:
     """Mirror of ORB_SLAM2::ORBextractor on the CPU oracle."""
 
-    def __init__(self, nfeatures=1000, scale=1.2, nlevels=8, ini=20, minth=7):
+    def __init__(self, nfeatures=1000, scale=1.2, nlevels=8, ini=20, minth=7, blur_spec=0):
         self.L = lib()
         self.e = OrcExtractor()
         self.L.orc_extractor_init(C.byref(self.e), int(nfeatures), C.c_float(scale), int(nlevels),
                                   int(ini), int(minth))
+        self.e.blur_spec = int(blur_spec)  # GaussianBlur arithmetic variant (orc_gaussian_blur7_spec)
         self.nlevels = self.e.nlevels
 
     # tables
@@ -159,11 +160,11 @@ def resize_linear(src, dw, dh):
     return dst
 
 
-def gaussian_blur7(src):
+def gaussian_blur7(src, spec=0):
     src = np.ascontiguousarray(src, dtype=np.uint8)
     h, w = src.shape
     dst = np.zeros_like(src)
-    lib().orc_gaussian_blur7(_p(src), w, h, w, _p(dst), w)
+    lib().orc_gaussian_blur7_spec(_p(src), w, h, w, _p(dst), w, int(spec))
     return dst
 
 

@@ -188,3 +188,50 @@ def test_bow_two_min_and_triangulation_last_wins():
                                         np.ones(3, np.uint8), orc.FeatVec(np.zeros(3, np.uint32)), F, 0.0, 0.0,
                                         np.ones(8, np.float32), np.ones(8, np.float32), False, False)
     assert n == 1 and m[0] == 2
+
+
+def test_blur_spec_variants_known_answers():
+    """The three GaussianBlur arithmetic variants (OpenCV is unpinned in the reference):
+    facts that follow from the published definitions alone."""
+    # getGaussianKernel(7, 2): exp(-x^2/8) normalised; times 256 and rounded tap by tap -> 18 34 49 55 (sum 257)
+    g = np.exp(-(np.arange(-3, 4) ** 2) / 8.0)
+    g /= g.sum()
+    assert list(np.rint(g * 256).astype(int)) == [18, 34, 49, 55, 49, 34, 18]
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    b0, b1, b2 = (orc.gaussian_blur7(img, s) for s in (0, 1, 2))
+    # a constant image: spec 0 (taps sum to 256) reproduces it; the 257-sum taps give round(c * 257^2 / 65536), saturated
+    for c in (0, 1, 100, 200, 254, 255):
+        k = np.full((20, 24), c, np.uint8)
+        assert (orc.gaussian_blur7(k, 0) == c).all()
+        want = min(255, (c * 257 * 257 + 32768) >> 16)
+        assert (orc.gaussian_blur7(k, 1) == want).all()
+        assert (orc.gaussian_blur7(k, 2) == want).all()  # no exact .5 ties for these values
+    # spec 2 differs from spec 1 only where the 16.16 sum is an exact tie (x mod 2^16 == 2^15) with an even floor, and
+    # never on the last width % 4 columns; spec 0 and spec 1 differ by at most 1 grey level on an image below saturation
+    assert np.array_equal(b1[:, 53 - 53 % 4:], b2[:, 53 - 53 % 4:])
+    assert np.abs(b1.astype(int) - b2.astype(int)).max() <= 1
+    assert np.abs(b0.astype(int) - b1.astype(int)).max() <= 2
+    # an engineered exact tie: a 7x7 neighbourhood whose weighted sum is k * 65536 + 32768
+    # (all pixels p: sum = p * 257^2 = p * 66049 -> p = 64: 4227136 = 64 * 65536 + 32832, not a tie; so search one)
+    K = np.array([18, 34, 49, 55, 49, 34, 18])
+    W = np.outer(K, K)
+    patch = np.random.default_rng(1).integers(0, 200, (7, 7))
+    patch[0, 0] = patch[3, 3] = patch[0, 1] = 0
+    base = int((W * patch).sum())
+    a, b, c = np.meshgrid(np.arange(256), np.arange(256), np.arange(256), indexing="ij")
+    tot = base + W[0, 0] * a + W[3, 3] * b + W[0, 1] * c
+    hit = np.argwhere((tot % 65536 == 32768) & ((tot >> 16) % 2 == 0))  # exact tie with an EVEN floor: the two roundings differ
+    assert len(hit) > 0
+    patch[0, 0], patch[3, 3], patch[0, 1] = hit[0]
+    big = np.zeros((7, 8), np.uint8)  # width 8: column 3 is a SIMD column of spec 2
+    big[:, :7] = patch
+    x = int((W * patch).sum())
+    assert x % 65536 == 32768
+    assert orc.gaussian_blur7(big, 1)[3, 3] == (x >> 16) + 1   # round half up
+    assert orc.gaussian_blur7(big, 2)[3, 3] == (x >> 16)       # round half to even (floor is even)
+    big7 = np.ascontiguousarray(big[:, :7])                    # width 7: column 3 is in the scalar tail (7 - 7 % 4 = 4 > 3: still SIMD)
+    assert orc.gaussian_blur7(big7, 2)[3, 3] == (x >> 16)
+    # width 3 has no SIMD columns at all (3 - 3 % 4 = 0): spec 2 must equal spec 1 everywhere
+    tiny = np.random.default_rng(2).integers(0, 256, (9, 3), dtype=np.uint8)
+    assert np.array_equal(orc.gaussian_blur7(tiny, 1), orc.gaussian_blur7(tiny, 2))
