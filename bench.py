@@ -577,7 +577,7 @@ def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, u
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(name, frames[: min(len(frames), 256)], voc_path, args.cpu_seconds)
             res["vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
-        if args.e2e and hasattr(ext, "extract_batch_pipelined"):
+        if not args.no_e2e:
             res["e2e"] = e2e_rate(g, args)
     del g
     torch.cuda.empty_cache()
@@ -585,17 +585,34 @@ def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, u
 
 
 def e2e_rate(g, args):
-    """Host images in -> host keypoints/descriptors out (what ORBextractor::operator() is, :1119-1197) through the
-    pinned, double-buffered host-batch path; PCIe-inclusive, reported beside `value`, never as `value`."""
-    n = min(g.NI, 1024)
-    imgs = np.stack(g.frames[:n])
-    g.ext.extract_batch_pipelined(imgs[: min(n, 128)])  # warm: allocations, pinned staging
+    """Host images in -> host keypoints/descriptors out (what ORBextractor::operator() is, :1119-1197) through
+    orbfe_extract_batch_pipelined: pinned host buffers, chunked H2D / kernels / D2H overlapped on separate streams.
+    PCIe-inclusive, reported beside `value`, never as `value`; extraction only (the matchers take device arrays)."""
+    n = min(g.NI, 2048)
+    ext = g.ext
+    ext.set_streams(2)
+    img, kps, desc, cnt = ext.pinned_buffers(n, g.H, g.W, g.cap)
+    np.copyto(img, np.stack(g.frames[:n]))
+    ext.extract_pinned(args.e2e_chunk)  # warm: device slabs, copy streams
+    reps = 3
     t0 = time.perf_counter()
-    out = g.ext.extract_batch_pipelined(imgs)
-    dt = time.perf_counter() - t0
-    return {"images_per_s": n / dt, "images": n, "what": "orbfe_extract_batch_pipelined: pageable host images -> pinned "
-            "staging -> H2D / compute / D2H overlapped on separate streams -> host keypoints + descriptors",
-            "keypoints_out": int(sum(len(k) for k, _ in out))}
+    for _ in range(reps):
+        ext.extract_pinned(args.e2e_chunk)
+    dt = (time.perf_counter() - t0) / reps
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_lib as orc
+    o = orc.Oracle(g.wl["nfeatures"], 1.2, 8, g.wl["ini"], g.wl["mn"])
+    for fi in sorted({0, n // 2 + 1, n - 1}):  # parity of the pipelined path too (first / middle / last chunk)
+        kr, dr = o.extract(g.frames[fi])
+        if int(cnt[fi]) != len(kr) or not np.array_equal(kps[fi, :len(kr)].view(np.uint8), kr.view(np.uint8)) or \
+                not np.array_equal(desc[fi, :len(kr)], dr):
+            raise SystemExit(f"PARITY FAILURE ({g.name}): pipelined host path, image {fi}")
+    bytes_in = n * g.W * g.H
+    bytes_out = n * g.cap * (28 + 32) + 4 * n
+    return {"images_per_s": n / dt, "images": n, "chunk_frames": args.e2e_chunk or 256, "ms": 1e3 * dt,
+            "pcie_GBps": {"h2d": bytes_in / dt / 1e9, "d2h": bytes_out / dt / 1e9},
+            "what": "orbfe_extract_batch_pipelined: pinned host images -> H2D / kernels / D2H overlapped on separate streams -> "
+                    "host keypoints + descriptors (whole capacity-sized output blocks come back); oracle-checked on 3 images"}
 
 
 def reduce_report(dt, units, torch, dist, use_dist, dev):
@@ -686,7 +703,8 @@ def main():
     ap.add_argument("--streams", type=int, default=4,
                     help="sub-batch HIP streams per call in the timed region (1..8): the latency-bound kernels "
                          "of one sub-batch overlap the VALU-bound ones of the others")
-    ap.add_argument("--e2e", action="store_true", help="add the host-in/host-out (PCIe-inclusive) rate of each workload")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-in/host-out (PCIe-inclusive) rate of each workload")
+    ap.add_argument("--e2e-chunk", type=int, default=0, help="frames per chunk of the pipelined host path (0 = 256)")
     ap.add_argument("--seq-scale", type=float, default=1.0, help="kitti_seq: scale factor on the sequence lengths")
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for 1 rank")

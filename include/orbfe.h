@@ -102,6 +102,19 @@ int orbfe_extract_batch(orbfe_extractor *e, const uint8_t *images, int n_frames,
                         int height, int stride, size_t frame_stride, orbfe_keypoint *keypoints,
                         uint8_t *descriptors, int capacity, int *n_out);
 
+/* Pinned (page-locked) host memory for the buffers of orbfe_extract_batch_pipelined. */
+int orbfe_host_alloc(void **p, size_t bytes);
+void orbfe_host_free(void *p);
+
+/* operator() for a host batch, end to end and pipelined: the batch is cut into chunks of chunk_frames (0 = 256); the
+ * H2D copy of chunk k+1, the kernels of chunk k and the D2H copy of chunk k-1 overlap on separate HIP streams (two
+ * input slabs / output blocks in HBM, ordered by events, no host wait inside the loop).  Output layout as
+ * orbfe_extract_batch (frame f at keypoints + f*capacity, descriptors + f*capacity*32; rows past n_out[f] are
+ * unspecified).  Buffers from orbfe_host_alloc move at PCIe speed; other memory is page-locked for the call. */
+int orbfe_extract_batch_pipelined(orbfe_extractor *e, const uint8_t *images, int n_frames, int width, int height,
+                                  int stride, size_t frame_stride, orbfe_keypoint *keypoints,
+                                  uint8_t *descriptors, int capacity, int *n_out, int chunk_frames);
+
 /* Same, but `d_images`, `d_keypoints`, `d_descriptors`, `d_n_out` are DEVICE pointers
  * (HBM-resident in, HBM-resident out; nothing crosses PCIe except per-batch control words).
  * The call returns after the work is complete on the handle's stream. */

@@ -45,7 +45,7 @@ EXPORTS = [
     "orbfe_extractor_get_inverse_scale_factors", "orbfe_extractor_get_scale_sigma_squares",
     "orbfe_extractor_get_inverse_scale_sigma_squares", "orbfe_extractor_get_features_per_level",
     "orbfe_extractor_get_umax", "orbfe_extractor_max_keypoints", "orbfe_extractor_max_keypoints_for", "orbfe_extract", "orbfe_extract_batch",
-    "orbfe_extract_batch_device", "orbfe_extract_batch_device_async", "orbfe_extractor_synchronize", "orbfe_extractor_level_size", "orbfe_extractor_get_pyramid_level",
+    "orbfe_extract_batch_device", "orbfe_extract_batch_device_async", "orbfe_extract_batch_pipelined", "orbfe_host_alloc", "orbfe_host_free", "orbfe_extractor_synchronize", "orbfe_extractor_level_size", "orbfe_extractor_get_pyramid_level",
     "orbfe_extractor_pyramid_level_device", "orbfe_extractor_debug_candidates",
     "orbfe_extractor_debug_blurred_level", "orbfe_extractor_debug_host_octree", "orbfe_debug_octree_host", "orbfe_debug_geometry",
     "orbfe_debug_resize_tables", "orbfe_extractor_set_streams", "orbfe_extractor_set_fused", "orbfe_extractor_set_blur_spec", "orbfe_gaussian_blur7_spec", "orbfe_extractor_profile", "orbfe_extractor_profile_get",
@@ -116,6 +116,10 @@ def load():
     L.orbfe_extract.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, vp]
     L.orbfe_extract_batch.argtypes = [vp, vp, ci, ci, ci, ci, cs, vp, vp, ci, vp]
     L.orbfe_extract_batch_device.argtypes = [vp, vp, ci, ci, ci, ci, cs, vp, vp, ci, vp]
+    L.orbfe_extract_batch_pipelined.argtypes = [vp, vp, ci, ci, ci, ci, cs, vp, vp, ci, vp, ci]
+    L.orbfe_host_alloc.argtypes = [C.POINTER(vp), cs]
+    L.orbfe_host_free.argtypes = [vp]
+    L.orbfe_host_free.restype = None
     L.orbfe_extract_batch_device_async.argtypes = [vp, vp, ci, ci, ci, ci, cs, vp, vp, ci, vp]
     L.orbfe_extractor_synchronize.argtypes = [vp]
     L.orbfe_extractor_level_size.argtypes = [vp, ci, ci, ci, vp, vp]

@@ -122,6 +122,13 @@ struct orbfe_extractor {
   uint8_t* h_outStage = nullptr;  // pinned
   size_t outStageBytes = 0;
   int outCap = 0;
+  // pinned-host pipelined path (orbfe_extract_batch_pipelined): two input slabs + two output blocks in HBM,
+  // one copy stream per direction, events per slot
+  hipStream_t sH2D = nullptr, sD2H = nullptr;
+  uint8_t* d_pipeIn[2] = {nullptr, nullptr};
+  uint8_t* d_pipeOut[2] = {nullptr, nullptr};
+  size_t pipeInBytes = 0, pipeOutBytes = 0;
+  hipEvent_t evIn[2] = {}, evComp[2] = {}, evOutDone[2] = {};
   // host staging
   std::vector<int32_t> h_candCount, h_levelCount;
   std::vector<Candidate> h_cand;
@@ -467,7 +474,7 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
 // its own slice of the workspace: the VALU-bound kernels (FAST, blur) of one sub-batch overlap the
 // gather/latency-bound ones (orientation+descriptor, octree, resize) of the other.
 int run_pipeline(orbfe_extractor* e, LevelView level0, int nFrames, orbfe_keypoint* d_kp,
-                 uint8_t* d_desc, int capacity, int32_t* d_nOut) {
+                 uint8_t* d_desc, int capacity, int32_t* d_nOut, const hipEvent_t* waitFor = nullptr, int nWait = 0) {
   int S = e->hostOctree ? 1 : e->nStreams;
   if (S > nFrames) S = nFrames;
   if (S < 1) S = 1;
@@ -486,6 +493,7 @@ int run_pipeline(orbfe_extractor* e, LevelView level0, int nFrames, orbfe_keypoi
     if (n <= 0) break;
     hipStream_t s = i == 0 ? e->stream : e->extra[i - 1];
     if (i > 0 && e->consumerPending) HIPCHK(hipStreamWaitEvent(s, e->evConsumerDone, 0));
+    for (int k = 0; k < nWait; k++) HIPCHK(hipStreamWaitEvent(s, waitFor[k], 0));  // e.g. the H2D copy of this chunk
     int rc = run_chunk(e, s, i, level0, f0, n, d_kp, d_desc, capacity, d_nOut, i == 0 ? &e->lastPyr : nullptr,
                        i == 0 ? &e->lastBlur : nullptr);
     if (rc) return rc;
@@ -581,6 +589,15 @@ extern "C" void orbfe_extractor_destroy(orbfe_extractor* e) {
   free_workspace(e);
   free_outputs(e);
   if (e->h_outStage) (void)hipHostFree(e->h_outStage);
+  for (int i = 0; i < 2; i++) {
+    dfree(&e->d_pipeIn[i]);
+    dfree(&e->d_pipeOut[i]);
+    if (e->evIn[i]) (void)hipEventDestroy(e->evIn[i]);
+    if (e->evComp[i]) (void)hipEventDestroy(e->evComp[i]);
+    if (e->evOutDone[i]) (void)hipEventDestroy(e->evOutDone[i]);
+  }
+  if (e->sH2D) { (void)hipStreamSynchronize(e->sH2D); (void)hipStreamDestroy(e->sH2D); }
+  if (e->sD2H) { (void)hipStreamSynchronize(e->sD2H); (void)hipStreamDestroy(e->sD2H); }
   dfree(&e->d_patternF);
   dfree(&e->d_stereoSad);
   dfree(&e->d_scaleTab);
@@ -764,6 +781,150 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* images, in
     if (overflow) return fail(ORBFE_ERR_CAPACITY, "keypoint capacity too small");
   }
   resolve_stage_times(e);
+  return ORBFE_OK;
+}
+
+// ---- pinned host memory + the pipelined host-batch path (end-to-end form of operator()) ----
+extern "C" int orbfe_host_alloc(void** p, size_t bytes) {
+  if (!p) return fail(ORBFE_ERR_INVALID, "host_alloc: NULL argument");
+  *p = nullptr;
+  HIPCHK(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault));
+  return ORBFE_OK;
+}
+extern "C" void orbfe_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
+namespace {
+// page-locks [p, p+bytes) for the duration of a call when the caller did not allocate it with orbfe_host_alloc
+struct ScopedPin {
+  void* p = nullptr;
+  int pin(const void* ptr, size_t bytes) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, ptr) == hipSuccess && at.type != hipMemoryTypeUnregistered) return ORBFE_OK;  // already pinned
+    (void)hipGetLastError();
+    if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return ORBFE_OK;  // pageable memory still works (the runtime stages it), only slower
+    }
+    p = const_cast<void*>(ptr);
+    return ORBFE_OK;
+  }
+  ~ScopedPin() { if (p) (void)hipHostUnregister(p); }
+};
+}  // namespace
+
+// ORBextractor::operator() for a host batch, end to end: images in host memory -> keypoints and descriptors in host
+// memory (src/ORBextractor.cc:1119-1197 per frame).  The batch is cut into chunks; the H2D copy of chunk k+1, the
+// kernels of chunk k and the D2H copy of chunk k-1 run at the same time on three sets of streams (two input slabs and
+// two output blocks in HBM, ordered by events; no host wait inside the loop).  Outputs use the layout of
+// orbfe_extract_batch: frame f at keypoints + f*capacity, descriptors + f*capacity*32; rows past n_out[f] are
+// unspecified.  Host buffers from orbfe_host_alloc (pinned) transfer at PCIe speed; others are page-locked for the
+// duration of the call.
+extern "C" int orbfe_extract_batch_pipelined(orbfe_extractor* e, const uint8_t* images, int n_frames, int width, int height,
+                                             int stride, size_t frame_stride, orbfe_keypoint* keypoints,
+                                             uint8_t* descriptors, int capacity, int* n_out, int chunk_frames) {
+  if (!e || !n_out || n_frames < 0) return fail(ORBFE_ERR_INVALID, "extract_batch_pipelined: bad argument");
+  for (int f = 0; f < n_frames; f++) n_out[f] = 0;
+  if (n_frames == 0) return ORBFE_OK;
+  if (!images || width <= 0 || height <= 0) return ORBFE_OK;  // empty image: silent return (:1122)
+  if (!keypoints || !descriptors || capacity <= 0 || stride < width || frame_stride < (size_t)stride * (height - 1) + width)
+    return fail(ORBFE_ERR_INVALID, "extract_batch_pipelined: bad buffers");
+  HIPCHK(hipSetDevice(e->device));
+  int rc;
+  if ((rc = sync_all(e))) return rc;
+  if ((rc = ensure_geometry(e, width, height))) return rc;
+  int C = chunk_frames > 0 ? chunk_frames : 256;
+  if (C > n_frames) C = n_frames;
+  if ((rc = ensure_workspace(e, C))) return rc;
+  if (!e->sH2D) {
+    HIPCHK(hipStreamCreateWithFlags(&e->sH2D, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&e->sD2H, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+      HIPCHK(hipEventCreateWithFlags(&e->evIn[i], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&e->evComp[i], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&e->evOutDone[i], hipEventDisableTiming));
+    }
+  }
+  const int pitch = (width + 63) & ~63;
+  const size_t inBytes = (size_t)C * pitch * height;
+  const size_t kpB = ((size_t)C * capacity * sizeof(orbfe_keypoint) + 255) & ~(size_t)255;
+  const size_t deB = ((size_t)C * capacity * 32 + 255) & ~(size_t)255;
+  const size_t outBytes = kpB + deB + (size_t)C * 4;
+  if (inBytes > e->pipeInBytes || outBytes > e->pipeOutBytes) {
+    HIPCHK(hipStreamSynchronize(e->sH2D));
+    HIPCHK(hipStreamSynchronize(e->sD2H));
+    for (int i = 0; i < 2; i++) {
+      if ((rc = dalloc(&e->d_pipeIn[i], inBytes))) return rc;
+      if ((rc = dalloc(&e->d_pipeOut[i], outBytes))) return rc;
+    }
+    e->pipeInBytes = inBytes;
+    e->pipeOutBytes = outBytes;
+  }
+  ScopedPin pinIn, pinKp, pinDesc;
+  pinIn.pin(images, frame_stride * (size_t)(n_frames - 1) + (size_t)stride * (height - 1) + width);
+  pinKp.pin(keypoints, (size_t)n_frames * capacity * sizeof(orbfe_keypoint));
+  pinDesc.pin(descriptors, (size_t)n_frames * capacity * 32);
+  int32_t* h_cnt = nullptr;  // counts come back through a small pinned block of their own
+  HIPCHK(hipHostMalloc((void**)&h_cnt, sizeof(int32_t) * (size_t)n_frames, hipHostMallocDefault));
+  const bool tight = frame_stride == (size_t)stride * height;  // whole chunk = one 2-D copy of C*height rows
+  const int nChunks = (n_frames + C - 1) / C;
+  int status = ORBFE_OK;
+  for (int k = 0; k < nChunks && status == ORBFE_OK; k++) {
+    const int slot = k & 1;
+    const int f0 = k * C, n = f0 + C <= n_frames ? C : n_frames - f0;
+    auto H = [&](hipError_t err) { if (err != hipSuccess && status == ORBFE_OK) status = fail(ORBFE_ERR_HIP, hipGetErrorString(err)); };
+    // input slab `slot` is free once the kernels of chunk k-2 are done
+    if (k >= 2) H(hipStreamWaitEvent(e->sH2D, e->evComp[slot], 0));
+    if (tight && stride == pitch) {  // rows are already at the device pitch: one linear copy
+      H(hipMemcpyAsync(e->d_pipeIn[slot], images + (size_t)f0 * frame_stride, (size_t)n * pitch * height, hipMemcpyHostToDevice,
+                       e->sH2D));
+    } else if (tight) {
+      H(hipMemcpy2DAsync(e->d_pipeIn[slot], pitch, images + (size_t)f0 * frame_stride, stride, width, (size_t)height * n,
+                         hipMemcpyHostToDevice, e->sH2D));
+    } else {
+      for (int f = 0; f < n; f++)
+        H(hipMemcpy2DAsync(e->d_pipeIn[slot] + (size_t)f * pitch * height, pitch, images + (size_t)(f0 + f) * frame_stride, stride,
+                           width, height, hipMemcpyHostToDevice, e->sH2D));
+    }
+    H(hipEventRecord(e->evIn[slot], e->sH2D));
+    // kernels: wait for the upload, and for the D2H of chunk k-2 before its output block is overwritten
+    hipEvent_t waits[2] = {e->evIn[slot], e->evOutDone[slot]};
+    orbfe_keypoint* d_kp = reinterpret_cast<orbfe_keypoint*>(e->d_pipeOut[slot]);
+    uint8_t* d_de = e->d_pipeOut[slot] + kpB;
+    int32_t* d_n = reinterpret_cast<int32_t*>(e->d_pipeOut[slot] + kpB + deB);
+    next_event_slot(e);
+    LevelView l0{e->d_pipeIn[slot], (size_t)pitch * height, pitch, width, height};
+    if (status == ORBFE_OK) {
+      rc = run_pipeline(e, l0, n, d_kp, d_de, capacity, d_n, waits, k >= 2 ? 2 : 1);
+      if (rc) { status = rc; break; }
+    }
+    for (int i = 1; i < e->chunksPending; i++) H(hipStreamWaitEvent(e->stream, e->evChunkDone[i], 0));  // join the sub-batches
+    H(hipEventRecord(e->evComp[slot], e->stream));
+    // results of this chunk straight into the caller's arrays
+    H(hipStreamWaitEvent(e->sD2H, e->evComp[slot], 0));
+    H(hipMemcpyAsync(keypoints + (size_t)f0 * capacity, d_kp, (size_t)n * capacity * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost, e->sD2H));
+    H(hipMemcpyAsync(descriptors + (size_t)f0 * capacity * 32, d_de, (size_t)n * capacity * 32, hipMemcpyDeviceToHost, e->sD2H));
+    H(hipMemcpyAsync(h_cnt + f0, d_n, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, e->sD2H));
+    H(hipEventRecord(e->evOutDone[slot], e->sD2H));
+  }
+  hipError_t e1 = hipStreamSynchronize(e->sD2H);
+  int rc2 = sync_all(e);
+  hipError_t e2 = hipStreamSynchronize(e->sH2D);
+  bool overflow = false;
+  if (status == ORBFE_OK && e1 == hipSuccess && e2 == hipSuccess && rc2 == ORBFE_OK)
+    for (int f = 0; f < n_frames; f++) {
+      int n = h_cnt[f];
+      if (n > capacity) { overflow = true; n = capacity; }
+      n_out[f] = n;
+    }
+  (void)hipHostFree(h_cnt);
+  resolve_stage_times(e);
+  if (status != ORBFE_OK) return status;
+  if (e1 != hipSuccess) return fail(ORBFE_ERR_HIP, hipGetErrorString(e1));
+  if (e2 != hipSuccess) return fail(ORBFE_ERR_HIP, hipGetErrorString(e2));
+  if (rc2) return rc2;
+  if (overflow) return fail(ORBFE_ERR_CAPACITY, "keypoint capacity too small");
   return ORBFE_OK;
 }
 

@@ -27,6 +27,8 @@ class ORBextractor:
         self._last_shape = None
 
     def __del__(self):
+        if getattr(self, "_pin_ptrs", None):
+            self._free_pinned()
         h = getattr(self, "_h", None)
         if h:
             self._L.orbfe_extractor_destroy(h)
@@ -106,6 +108,52 @@ class ORBextractor:
         check(self._L.orbfe_extract_batch(self._h, ptr(images), B, W, H, W, W * H, ptr(kps), ptr(desc), cap,
                                           ptr(n)))
         self._last_shape = (B, H, W)
+        return [(kps[f, : n[f]].copy(), desc[f, : n[f]].copy()) for f in range(B)]
+
+    # ---- end to end: host images in, host keypoints / descriptors out, copies overlapped with the kernels ----
+    def pinned_buffers(self, n_frames: int, height: int, width: int, capacity: int | None = None):
+        """(images[B,H,W] u8, keypoints[B,cap] KP_DTYPE, descriptors[B,cap,32] u8, n[B] i32) as numpy views of
+        PINNED host memory owned by this extractor (orbfe_host_alloc); fill `images`, call extract_pinned()."""
+        cap = capacity or self.max_keypoints(width, height)
+        key = (n_frames, height, width, cap)
+        if getattr(self, "_pin_key", None) != key:
+            self._free_pinned()
+            sizes = [n_frames * height * width, n_frames * cap * KP_DTYPE.itemsize, n_frames * cap * 32, n_frames * 4]
+            self._pin_ptrs = []
+            for nb in sizes:
+                p = C.c_void_p()
+                check(self._L.orbfe_host_alloc(C.byref(p), nb))
+                self._pin_ptrs.append((p, nb))
+            mk = lambda i, dt, shape: np.frombuffer((C.c_uint8 * self._pin_ptrs[i][1]).from_address(self._pin_ptrs[i][0].value),
+                                                    dtype=dt).reshape(shape)
+            self._pin = (mk(0, np.uint8, (n_frames, height, width)), mk(1, KP_DTYPE, (n_frames, cap)),
+                         mk(2, np.uint8, (n_frames, cap, 32)), mk(3, np.int32, (n_frames,)))
+            self._pin_key = key
+        return self._pin
+
+    def _free_pinned(self):
+        for p, _ in getattr(self, "_pin_ptrs", []):
+            self._L.orbfe_host_free(p)
+        self._pin_ptrs, self._pin, self._pin_key = [], None, None
+
+    def extract_pinned(self, chunk_frames: int = 0):
+        """orbfe_extract_batch_pipelined over the pinned buffers: chunked H2D / kernels / D2H on separate streams."""
+        img, kps, desc, n = self._pin
+        B, H, W = img.shape
+        cap = kps.shape[1]
+        check(self._L.orbfe_extract_batch_pipelined(self._h, ptr(img), B, W, H, W, W * H, ptr(kps), ptr(desc), cap, ptr(n),
+                                                    int(chunk_frames)))
+        self._last_shape = (min(B, chunk_frames or 256), H, W)
+        return kps, desc, n
+
+    def extract_batch_pipelined(self, images: np.ndarray, chunk_frames: int = 0, capacity: int | None = None):
+        """images [B,H,W] uint8 in ordinary host memory -> list of (keypoints, descriptors): staged through the
+        extractor's pinned buffers, then the pipelined path."""
+        images = np.asarray(images, dtype=np.uint8)
+        B, H, W = images.shape
+        img, kps, desc, n = self.pinned_buffers(B, H, W, capacity)
+        np.copyto(img, images)
+        self.extract_pinned(chunk_frames)
         return [(kps[f, : n[f]].copy(), desc[f, : n[f]].copy()) for f in range(B)]
 
     def extract_batch_device(self, d_images: int, n_frames: int, width: int, height: int, stride: int,

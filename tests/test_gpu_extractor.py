@@ -364,3 +364,48 @@ def test_blur_spec_variants_match_the_oracle(amd, spec):
     d0 = orc.Oracle(1000, 1.2, 8, 20, 7).extract(img)[1]
     ds = orc.Oracle(1000, 1.2, 8, 20, 7, blur_spec=spec).extract(img)[1]
     assert d0.shape == ds.shape and not np.array_equal(d0, ds)
+
+
+def test_pipelined_host_batch_equals_oracle(amd):
+    """orbfe_extract_batch_pipelined: chunks of the host batch move H2D / through the kernels / D2H on separate streams.
+    Several chunks + a short tail, 1 and 3 sub-batch streams, pinned and ordinary (page-locked for the call) buffers,
+    an odd width with a non-tight row stride."""
+    import ctypes as C
+    from orb_slam2_annotate_amd import _lib
+    B, W, H = 21, 333, 217
+    frames = np.stack([synth.render_frame(500 + i, W, H) for i in range(B)])
+    o = orc.Oracle(500, 1.2, 8, 20, 7)
+    ref = [o.extract(f) for f in frames]
+    for streams, chunk in ((1, 8), (3, 5)):
+        e = amd.ORBextractor(500, 1.2, 8, 20, 7)
+        e.set_streams(streams)
+        out = e.extract_batch_pipelined(frames, chunk_frames=chunk)  # through the extractor's pinned buffers
+        for (kr, dr), (kg, dg) in zip(ref, out):
+            _kp_equal(kr, kg)
+            assert np.array_equal(dr, dg)
+        # twice in a row on the same handle (slabs and events are reused)
+        out = e.extract_batch_pipelined(frames[::-1].copy(), chunk_frames=chunk)
+        for (kr, dr), (kg, dg) in zip(ref[::-1], out):
+            _kp_equal(kr, kg)
+            assert np.array_equal(dr, dg)
+    # ordinary numpy memory + a padded row stride straight into the C entry point
+    e = amd.ORBextractor(500, 1.2, 8, 20, 7)
+    L = _lib.load()
+    stride = W + 11
+    padded = np.zeros((B, H, stride), np.uint8)
+    padded[:, :, :W] = frames
+    cap = e.max_keypoints(W, H)
+    kps = np.zeros((B, cap), dtype=_lib.KP_DTYPE)
+    desc = np.zeros((B, cap, 32), np.uint8)
+    n = np.zeros(B, np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = L.orbfe_extract_batch_pipelined(e._h, p(padded), B, W, H, stride, stride * H, p(kps), p(desc), cap, p(n), 4)
+    assert rc == 0
+    for f, (kr, dr) in enumerate(ref):
+        assert n[f] == len(kr)
+        _kp_equal(kr, kps[f, :n[f]])
+        assert np.array_equal(dr, desc[f, :n[f]])
+    # capacity too small is reported, empty batch is fine
+    rc = L.orbfe_extract_batch_pipelined(e._h, p(padded), B, W, H, stride, stride * H, p(kps), p(desc), 10, p(n), 4)
+    assert rc == -2
+    assert L.orbfe_extract_batch_pipelined(e._h, p(padded), 0, W, H, stride, stride * H, p(kps), p(desc), cap, p(n), 4) == 0
