@@ -471,6 +471,7 @@ def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, u
     # (2) the timed configuration (S sub-batch streams), all stages still timed: the LIVE split -- which kernel
     #     the GPU spends its time in when the sub-batches overlap; the dominant stage is the largest one here
     ext.set_streams(S)
+    ext.set_schedule(args.schedule == "lanes")
     ext.profile(False)
     g.step()
     g.sync()
@@ -529,7 +530,7 @@ def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, u
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": pmc_traffic(dom, name, dom_imgs),
             "algorithmic_bytes_per_launch_group": stage_bytes(dom, dom_imgs), "ms_per_launch_group": dom_ms,
-            "images_per_launch": dom_imgs, "launch_groups_timed": n_groups, "streams": S,
+            "images_per_launch": dom_imgs, "launch_groups_timed": n_groups, "streams": S, "schedule": args.schedule,
             "stages": stages,
             "pipeline": {"algorithmic_bytes_per_unit": pipe_bytes, "achieved": pipe_bytes * value / world / 1e9,
                          "frac": pipe_bytes * value / world / 1e9 / HBM_PEAK_GBS,
@@ -632,6 +633,7 @@ def run_kitti_seq(frames, args, rank, world, local_rank, torch, dist, use_dist, 
     B = batches["kitti"]
     g = GpuWorkload("kitti", frames, B, local_rank, torch)
     g.ext.set_streams(max(1, min(8, args.streams)))
+    g.ext.set_schedule(args.schedule == "lanes")
     lengths = [max(1, int(round(n * args.seq_scale))) for n in shard.KITTI_00_07]
     out = {}
     for mode in ("sequence", "round_robin"):
@@ -703,6 +705,8 @@ def main():
     ap.add_argument("--streams", type=int, default=4,
                     help="sub-batch HIP streams per call in the timed region (1..8): the latency-bound kernels "
                          "of one sub-batch overlap the VALU-bound ones of the others")
+    ap.add_argument("--schedule", choices=["streams", "lanes"], default="streams",
+                    help="sub-batches on independent streams, or as the three-lane software pipeline (pyramid | FAST+blur | tail)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-in/host-out (PCIe-inclusive) rate of each workload")
     ap.add_argument("--e2e-chunk", type=int, default=0, help="frames per chunk of the pipelined host path (0 = 256)")
     ap.add_argument("--seq-scale", type=float, default=1.0, help="kitti_seq: scale factor on the sequence lengths")

@@ -172,6 +172,12 @@ int orbfe_debug_resize_tables(int sw, int sh, int dw, int dh, int32_t *xofs, int
  * (D2H/H2D round trip) instead of the device kernel.  Off by default; results are identical. */
 int orbfe_extractor_debug_host_octree(orbfe_extractor *e, int enable);
 
+/* How the sub-batches of a device-batch call (orbfe_extractor_set_streams) are scheduled: 0 = one independent HIP
+ * stream per sub-batch; 1 ($ORBFE_LANES) = three lanes shared by all sub-batches -- pyramid | FAST + blur |
+ * gather + octree + orientation/descriptors -- ordered by events into a software pipeline, so that exactly one
+ * VALU-bound kernel runs beside the latency-bound ones at any time.  Results are identical. */
+int orbfe_extractor_set_schedule(orbfe_extractor *e, int lanes);
+
 /* Which cv::GaussianBlur(7x7, sigma 2) arithmetic the extractor reproduces.  The reference does not pin its OpenCV
  * (CMakeLists.txt:33-39 accepts 2.4.3 and 3.x, README.md:74 names 2.4.11 / 3.2) and the 8-bit path changed:
  *   ORBFE_BLUR_CV4        (0, default; $ORBFE_BLUR_SPEC) OpenCV >= 3.4.1 / 4.x: taps 18 34 48 56 48 34 18 (/256),

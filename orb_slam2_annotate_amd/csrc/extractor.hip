@@ -53,6 +53,15 @@ struct orbfe_extractor {
   // last extract call (consumers on `stream` wait for it); evConsumerDone marks the end of the last kernel
   // on `stream` that READS the workspace / the caller's outputs of all sub-batches (batched stereo matcher),
   // and every sub-batch stream of the next extract call waits for it before it overwrites them
+  // lane schedule (laneMode): every sub-batch uses the same three streams -- P = extra[0] (pyramid), V = extra[1]
+  // (FAST, blur: the VALU-bound kernels), T = stream (gather, octree, orientation + descriptors: the latency-bound
+  // tail) -- so the sub-batches form a software pipeline: while V works on sub-batch k, P already builds the pyramid
+  // of k+1 and T finishes k-1.  One VALU-bound kernel is in flight at any time instead of whatever the phases of
+  // independent sub-batch streams happen to overlap.  evPyr/evFast/evBlur order the lanes inside a sub-batch,
+  // evTail[k] (end of sub-batch k on T) holds back the next call's pyramid of the same workspace slice.
+  bool laneMode = false;
+  hipEvent_t evPyr[kMaxStreams] = {}, evFast[kMaxStreams] = {}, evBlur[kMaxStreams] = {}, evTail[kMaxStreams] = {};
+  bool tailPending[kMaxStreams] = {};
   hipEvent_t evChunkDone[kMaxStreams] = {};
   hipEvent_t evConsumerDone = nullptr;
   int chunksPending = 0;                     // sub-batch streams 1..chunksPending-1 carry an unrecorded-for-consumer event
@@ -362,7 +371,11 @@ int run_host_octree(orbfe_extractor* e, int nFrames) {
 // level0: view of the call's input frames in HBM (frame 0 of the call).
 int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int f0, int nFrames,
               orbfe_keypoint* d_kp, uint8_t* d_desc, int capacity, int32_t* d_nOut, PyramidViews* pyrOut,
-              PyramidViews* blurOut) {
+              PyramidViews* blurOut, hipStream_t sV = nullptr, hipStream_t sT = nullptr) {
+  // lanes: pyramid on s (= P), FAST + blur on sV, gather / octree / orientation + descriptors on sT; one stream
+  // for everything when sV is NULL
+  const bool lanes = sV != nullptr;
+  if (!lanes) { sV = s; sT = s; }
   const FrameGeom& g = e->geom;
   const size_t F = (size_t)f0;
   const int nCells = g.nFastCells;
@@ -409,23 +422,33 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
   // GaussianBlur of every level, :1169-1175 -- the levels are independent: one launch.  It only needs
   // the pyramid, so odd sub-batches run it BEFORE the FAST stage: neighbouring streams are then in
   // different phases (VALU-bound blur/FAST next to latency-bound octree/descriptors) instead of in step.
+  if (lanes) {
+    HIPCHK(hipEventRecord(e->evPyr[sub], s));
+    HIPCHK(hipStreamWaitEvent(sV, e->evPyr[sub], 0));
+  }
   auto do_blur = [&]() {
-    StageTimer t(e, ORBFE_STAGE_BLUR, 1, nFrames, sub, s);
+    StageTimer t(e, ORBFE_STAGE_BLUR, 1, nFrames, sub, sV);
     LevelViewMut dsts[kMaxLevels];
     for (int l = 0; l < g.nlevels; l++)
       dsts[l] = LevelViewMut{const_cast<uint8_t*>(blur.lv[l].base), g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
-    launch_blur7_levels(s, pyr.lv, dsts, g.nlevels, nFrames, e->blurSpec);
+    launch_blur7_levels(sV, pyr.lv, dsts, g.nlevels, nFrames, e->blurSpec);
   };
-  const bool blurFirst = !fused && (sub & 1) != 0;  // measured +1.7 % frames/s (A/B on one box, 4 runs each)
+  const bool blurFirst = !lanes && !fused && (sub & 1) != 0;  // measured +1.7 % frames/s (A/B on one box, 4 runs each)
   if (blurFirst) do_blur();
   {  // FAST grid stage, :846-896; fused: the same wavefronts also write the blurred level (:1169-1175)
-    StageTimer t(e, ORBFE_STAGE_FAST, 1, nFrames, sub, s);
-    launch_fast_cells(s, pyr, e->d_cells, nCells, nFrames, e->tab.iniThFAST, e->tab.minThFAST, slots,
+    StageTimer t(e, ORBFE_STAGE_FAST, 1, nFrames, sub, sV);
+    launch_fast_cells(sV, pyr, e->d_cells, nCells, nFrames, e->tab.iniThFAST, e->tab.minThFAST, slots,
                       g.totalSlots, cellCount, g.maxCellW, g.maxCellH, fused ? &blur : nullptr, (int)g.cells.size());
   }
+  if (lanes) {  // the tail lane starts on the candidates while the VALU lane goes on with the blur
+    HIPCHK(hipEventRecord(e->evFast[sub], sV));
+    HIPCHK(hipStreamWaitEvent(sT, e->evFast[sub], 0));
+    if (!fused) do_blur();
+    HIPCHK(hipEventRecord(e->evBlur[sub], sV));
+  }
   if (!e->hostOctree) {  // candidate ordering + DistributeOctTree, :566-808, one workgroup per (frame, level)
-    StageTimer t(e, ORBFE_STAGE_OCTREE, 2, nFrames, sub, s);
-    launch_gather_candidates(s, e->d_cells, e->d_lvgeom, g.nlevels, nFrames, slots, g.totalSlots, cellCount,
+    StageTimer t(e, ORBFE_STAGE_OCTREE, 2, nFrames, sub, sT);
+    launch_gather_candidates(sT, e->d_cells, e->d_lvgeom, g.nlevels, nFrames, slots, g.totalSlots, cellCount,
                              nCells, cand, candCount, cellPrefix);
     OctreeArgs oa = {};
     oa.cand = cand;
@@ -440,17 +463,18 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
     oa.maxL = e->octreeMaxL;
     oa.work = e->d_octreeWork ? e->d_octreeWork + F * (size_t)g.nlevels * e->octreeWorkStride : nullptr;
     oa.workStride = e->octreeWorkStride;
-    HIPCHK(launch_octree(s, oa, g.nlevels, nFrames));
+    HIPCHK(launch_octree(sT, oa, g.nlevels, nFrames));
   } else {
     launch_gather_candidates(s, e->d_cells, e->d_lvgeom, g.nlevels, nFrames, slots, g.totalSlots, cellCount,
                              nCells, cand, candCount, cellPrefix);
     int rc = run_host_octree(e, nFrames);  // single-stream debug path: f0 == 0
     if (rc) return rc;
   }
-  if (!blurFirst && !fused) do_blur();
+  if (!lanes && !blurFirst && !fused) do_blur();
+  if (lanes) HIPCHK(hipStreamWaitEvent(sT, e->evBlur[sub], 0));
 
   {  // computeOrientation + computeDescriptors + output records
-    StageTimer t(e, ORBFE_STAGE_ORIENT_DESC, 1, nFrames, sub, s);
+    StageTimer t(e, ORBFE_STAGE_ORIENT_DESC, 1, nFrames, sub, sT);
     OrientDescArgs a = {};
     a.pyr = pyr;
     a.blur = blur;
@@ -463,8 +487,12 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
       a.scale[l] = e->tab.scale[l];
       a.kpSize[l] = (float)(int)(kPatchSize * e->tab.scale[l]);  // :905
     }
-    launch_orient_desc(s, a, levelKp, levelCount, e->d_patternF, e->d_momentTab, e->d_umax, nFrames,
+    launch_orient_desc(sT, a, levelKp, levelCount, e->d_patternF, e->d_momentTab, e->d_umax, nFrames,
                        d_kp + F * capacity, d_desc + F * (size_t)capacity * 32, d_nOut + F);
+  }
+  if (lanes) {
+    HIPCHK(hipEventRecord(e->evTail[sub], sT));
+    e->tailPending[sub] = true;
   }
   HIPCHK(hipGetLastError());
   return ORBFE_OK;
@@ -478,15 +506,40 @@ int run_pipeline(orbfe_extractor* e, LevelView level0, int nFrames, orbfe_keypoi
   int S = e->hostOctree ? 1 : e->nStreams;
   if (S > nFrames) S = nFrames;
   if (S < 1) S = 1;
-  if (e->lastSplitFrames != nFrames || e->lastSplitStreams != S) {
+  if (e->lastSplitFrames != nFrames || e->lastSplitStreams != (e->laneMode ? -S : S)) {
     // a different split maps frames to different streams: drain everything first
     HIPCHK(hipStreamSynchronize(e->stream));
     for (int i = 0; i < orbfe_extractor::kMaxStreams - 1; i++)
       if (e->extra[i]) HIPCHK(hipStreamSynchronize(e->extra[i]));
     e->lastSplitFrames = nFrames;
-    e->lastSplitStreams = S;
+    e->lastSplitStreams = e->laneMode ? -S : S;
   }
   const int per = (nFrames + S - 1) / S;
+  const bool lanes = e->laneMode && !e->hostOctree && S >= 2;
+  if (lanes) {
+    hipStream_t sP = e->extra[0], sV = e->extra[1], sT = e->stream;
+    if (e->consumerPending) HIPCHK(hipStreamWaitEvent(sP, e->evConsumerDone, 0));  // a matcher still reads the last pyramid
+    for (int k = 0; k < nWait; k++) {  // e.g. the H2D copy of this chunk (read by P, V and T), the D2H of its output block (T)
+      HIPCHK(hipStreamWaitEvent(sP, waitFor[k], 0));
+      HIPCHK(hipStreamWaitEvent(sT, waitFor[k], 0));
+    }
+    for (int i = 0; i < S; i++) {
+      const int f0 = i * per;
+      const int n = f0 + per <= nFrames ? per : nFrames - f0;
+      if (n <= 0) break;
+      // slice i of the workspace is free once the previous call's tail lane has finished with it
+      if (e->tailPending[i]) HIPCHK(hipStreamWaitEvent(sP, e->evTail[i], 0));
+      int rc = run_chunk(e, sP, i, level0, f0, n, d_kp, d_desc, capacity, d_nOut, i == 0 ? &e->lastPyr : nullptr,
+                         i == 0 ? &e->lastBlur : nullptr, sV, sT);
+      if (rc) return rc;
+    }
+    e->consumerPending = false;
+    e->chunksPending = 1;  // every sub-batch ends on `stream`: consumers there are ordered behind all of them
+    e->lastFrames = nFrames;
+    e->haveLast = true;
+    return ORBFE_OK;
+  }
+  for (int i = 0; i < orbfe_extractor::kMaxStreams; i++) e->tailPending[i] = false;  // (drained above if the mode changed)
   for (int i = 0; i < S; i++) {
     const int f0 = i * per;
     const int n = f0 + per <= nFrames ? per : nFrames - f0;
@@ -532,6 +585,7 @@ extern "C" int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlev
   hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
   for (int i = 0; i < orbfe_extractor::kMaxStreams - 1 && err == hipSuccess; i++)
     err = hipStreamCreateWithFlags(&e->extra[i], hipStreamNonBlocking);
+  if (const char* env = getenv("ORBFE_LANES")) e->laneMode = atoi(env) != 0;
   if (const char* env = getenv("ORBFE_FUSED")) e->fused = atoi(env) != 0;
   if (const char* env = getenv("ORBFE_BLUR_SPEC")) {
     const int v = atoi(env);
@@ -541,8 +595,13 @@ extern "C" int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlev
     int v = atoi(env);
     if (v >= 1 && v <= orbfe_extractor::kMaxStreams) e->nStreams = v;
   }
-  for (int i = 0; i < orbfe_extractor::kMaxStreams && err == hipSuccess; i++)
+  for (int i = 0; i < orbfe_extractor::kMaxStreams && err == hipSuccess; i++) {
     err = hipEventCreateWithFlags(&e->evChunkDone[i], hipEventDisableTiming);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->evPyr[i], hipEventDisableTiming);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->evFast[i], hipEventDisableTiming);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->evBlur[i], hipEventDisableTiming);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->evTail[i], hipEventDisableTiming);
+  }
   if (err == hipSuccess) err = hipEventCreateWithFlags(&e->evConsumerDone, hipEventDisableTiming);
   for (int r = 0; r < orbfe_extractor::kEvRing; r++)
     for (int u = 0; u < orbfe_extractor::kEvSubs; u++)
@@ -611,8 +670,13 @@ extern "C" void orbfe_extractor_destroy(orbfe_extractor* e) {
         if (e->evA[r][u][i]) (void)hipEventDestroy(e->evA[r][u][i]);
         if (e->evB[r][u][i]) (void)hipEventDestroy(e->evB[r][u][i]);
       }
-  for (int i = 0; i < orbfe_extractor::kMaxStreams; i++)
+  for (int i = 0; i < orbfe_extractor::kMaxStreams; i++) {
     if (e->evChunkDone[i]) (void)hipEventDestroy(e->evChunkDone[i]);
+    if (e->evPyr[i]) (void)hipEventDestroy(e->evPyr[i]);
+    if (e->evFast[i]) (void)hipEventDestroy(e->evFast[i]);
+    if (e->evBlur[i]) (void)hipEventDestroy(e->evBlur[i]);
+    if (e->evTail[i]) (void)hipEventDestroy(e->evTail[i]);
+  }
   if (e->evConsumerDone) (void)hipEventDestroy(e->evConsumerDone);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -846,7 +910,12 @@ extern "C" int orbfe_extract_batch_pipelined(orbfe_extractor* e, const uint8_t* 
       HIPCHK(hipEventCreateWithFlags(&e->evOutDone[i], hipEventDisableTiming));
     }
   }
-  const int pitch = (width + 63) & ~63;
+  // device input slab: tightly packed host frames are uploaded as they are (ONE linear copy per chunk, row pitch =
+  // the caller's stride; an odd pitch is repacked on the device by run_chunk) -- a 2-D copy of 1241-byte rows
+  // degenerates into one DMA descriptor per row and ran at 0.1 GB/s; only batches with gaps between the frames
+  // take the per-frame 2-D form into a 64-byte pitch
+  const bool tight = frame_stride == (size_t)stride * height;
+  const int pitch = tight ? stride : (width + 63) & ~63;
   const size_t inBytes = (size_t)C * pitch * height;
   const size_t kpB = ((size_t)C * capacity * sizeof(orbfe_keypoint) + 255) & ~(size_t)255;
   const size_t deB = ((size_t)C * capacity * 32 + 255) & ~(size_t)255;
@@ -867,7 +936,6 @@ extern "C" int orbfe_extract_batch_pipelined(orbfe_extractor* e, const uint8_t* 
   pinDesc.pin(descriptors, (size_t)n_frames * capacity * 32);
   int32_t* h_cnt = nullptr;  // counts come back through a small pinned block of their own
   HIPCHK(hipHostMalloc((void**)&h_cnt, sizeof(int32_t) * (size_t)n_frames, hipHostMallocDefault));
-  const bool tight = frame_stride == (size_t)stride * height;  // whole chunk = one 2-D copy of C*height rows
   const int nChunks = (n_frames + C - 1) / C;
   int status = ORBFE_OK;
   for (int k = 0; k < nChunks && status == ORBFE_OK; k++) {
@@ -876,12 +944,10 @@ extern "C" int orbfe_extract_batch_pipelined(orbfe_extractor* e, const uint8_t* 
     auto H = [&](hipError_t err) { if (err != hipSuccess && status == ORBFE_OK) status = fail(ORBFE_ERR_HIP, hipGetErrorString(err)); };
     // input slab `slot` is free once the kernels of chunk k-2 are done
     if (k >= 2) H(hipStreamWaitEvent(e->sH2D, e->evComp[slot], 0));
-    if (tight && stride == pitch) {  // rows are already at the device pitch: one linear copy
-      H(hipMemcpyAsync(e->d_pipeIn[slot], images + (size_t)f0 * frame_stride, (size_t)n * pitch * height, hipMemcpyHostToDevice,
-                       e->sH2D));
-    } else if (tight) {
-      H(hipMemcpy2DAsync(e->d_pipeIn[slot], pitch, images + (size_t)f0 * frame_stride, stride, width, (size_t)height * n,
-                         hipMemcpyHostToDevice, e->sH2D));
+    if (tight) {
+      // (up to the last pixel of the chunk's last frame: the caller's array may end there)
+      H(hipMemcpyAsync(e->d_pipeIn[slot], images + (size_t)f0 * frame_stride,
+                       (size_t)(n - 1) * frame_stride + (size_t)(height - 1) * stride + width, hipMemcpyHostToDevice, e->sH2D));
     } else {
       for (int f = 0; f < n; f++)
         H(hipMemcpy2DAsync(e->d_pipeIn[slot] + (size_t)f * pitch * height, pitch, images + (size_t)(f0 + f) * frame_stride, stride,
@@ -1146,6 +1212,17 @@ extern "C" int orbfe_extractor_set_fused(orbfe_extractor* e, int enable) {
   int rc = sync_all(e);
   if (rc) return rc;
   e->fused = enable != 0;
+  return ORBFE_OK;
+}
+
+// Schedule of the sub-batches of a call: 0 = one independent stream per sub-batch, 1 = three lanes shared by all
+// sub-batches (pyramid | FAST + blur | gather + octree + orientation/descriptors) as a software pipeline.
+extern "C" int orbfe_extractor_set_schedule(orbfe_extractor* e, int lanes) {
+  if (!e) return fail(ORBFE_ERR_INVALID, "NULL handle");
+  HIPCHK(hipSetDevice(e->device));
+  int rc = sync_all(e);
+  if (rc) return rc;
+  e->laneMode = lanes != 0;
   return ORBFE_OK;
 }
 

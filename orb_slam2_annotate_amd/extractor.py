@@ -230,6 +230,10 @@ class ORBextractor:
     def set_streams(self, n: int):
         check(self._L.orbfe_extractor_set_streams(self._h, int(n)))
 
+    def set_schedule(self, lanes: bool):
+        """Sub-batches on independent streams (False) or as a three-lane software pipeline (True); same results."""
+        check(self._L.orbfe_extractor_set_schedule(self._h, int(bool(lanes))))
+
     def set_blur_spec(self, spec: int):
         """0: OpenCV >= 3.4.1/4.x GaussianBlur arithmetic (default); 1: OpenCV 2.4/3.0-3.3 scalar path;
         2: the same with the SSE2 column pass (include/orbfe.h ORBFE_BLUR_*)."""

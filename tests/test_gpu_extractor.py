@@ -409,3 +409,62 @@ def test_pipelined_host_batch_equals_oracle(amd):
     rc = L.orbfe_extract_batch_pipelined(e._h, p(padded), B, W, H, stride, stride * H, p(kps), p(desc), 10, p(n), 4)
     assert rc == -2
     assert L.orbfe_extract_batch_pipelined(e._h, p(padded), 0, W, H, stride, stride * H, p(kps), p(desc), cap, p(n), 4) == 0
+
+
+@pytest.mark.parametrize("subs", [2, 4, 8])
+def test_lane_schedule_equals_oracle_across_back_to_back_calls(amd, subs):
+    """The three-lane software pipeline (pyramid | FAST + blur | octree + descriptors on three shared streams):
+    several asynchronous calls on DIFFERENT inputs enqueued back to back -- every workspace slice is reused while
+    the previous call's tail lane may still read it -- with the batched stereo matcher in between; all results
+    must equal the oracle."""
+    torch = pytest.importorskip("torch")
+    w, h, nf, P = 480, 200, 600, 9
+    sets = [[synth.render_stereo(700 + 50 * s + p, w, h, n_shapes=250, max_disp=40) for p in range(P)] for s in range(3)]
+    imgs = [np.stack([im for pr in st for im in pr]) for st in sets]
+    dev = torch.device("cuda", 0)
+    B = 2 * P
+    d_img = [torch.from_numpy(x).to(dev) for x in imgs]
+    e = amd.ORBextractor(nf, 1.2, 8, 20, 7)
+    e.set_streams(subs)
+    e.set_schedule(True)
+    cap = e.max_keypoints(w, h)
+    d_kp = [torch.zeros((B, cap, 7), dtype=torch.float32, device=dev) for _ in range(3)]
+    d_desc = [torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev) for _ in range(3)]
+    d_n = [torch.zeros((B,), dtype=torch.int32, device=dev) for _ in range(3)]
+    d_u = torch.zeros((3, P, cap), dtype=torch.float32, device=dev)
+    d_d = torch.zeros((3, P, cap), dtype=torch.float32, device=dev)
+    d_ns = torch.zeros((3, P), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    mbf = np.float32(100.0)
+    mb = np.float32(mbf / np.float32(350.0))
+    for rep in range(2):
+        for s in range(3):
+            e.extract_batch_device(d_img[s].data_ptr(), B, w, h, w, w * h, d_kp[s].data_ptr(), d_desc[s].data_ptr(), cap,
+                                   d_n[s].data_ptr(), wait=False)
+            e.stereo_match_batch_device(P, d_kp[s].data_ptr(), d_desc[s].data_ptr(), d_n[s].data_ptr(), cap, float(mbf),
+                                        float(mb), d_u[s].data_ptr(), d_d[s].data_ptr(), d_ns[s].data_ptr())
+    e.synchronize()
+    o = orc.Oracle(nf, 1.2, 8, 20, 7)
+    for s in range(3):
+        n = d_n[s].cpu().numpy()
+        for p in range(P):
+            kL, dL, pL = o.extract(imgs[s][2 * p], want_pyramid=True)
+            kR, dR, pR = o.extract(imgs[s][2 * p + 1], want_pyramid=True)
+            for fi, (kr, dr) in ((2 * p, (kL, dL)), (2 * p + 1, (kR, dR))):
+                assert n[fi] == len(kr), (s, fi)
+                assert np.array_equal(d_kp[s][fi, :n[fi]].cpu().numpy().view(np.uint8).reshape(-1, 28), kr.view(np.uint8).reshape(-1, 28))
+                assert np.array_equal(d_desc[s][fi, :n[fi]].cpu().numpy(), dr)
+            u_ref, d_ref = o.stereo(w, h, kL, dL, kR, dR, pL, pR, float(mbf), float(mb))
+            assert np.array_equal(d_u[s, p, :len(kL)].cpu().numpy(), u_ref), (s, p)
+            assert np.array_equal(d_d[s, p, :len(kL)].cpu().numpy(), d_ref), (s, p)
+    # switching the schedule back on the same handle, and the host-batch paths under the lane schedule
+    frames = imgs[0][:7]
+    ref = [o.extract(f) for f in frames]
+    for out in (e.extract_batch(frames), e.extract_batch_pipelined(frames, chunk_frames=3)):
+        for (kr, dr), (kg, dg) in zip(ref, out):
+            _kp_equal(kr, kg)
+            assert np.array_equal(dr, dg)
+    e.set_schedule(False)
+    for (kr, dr), (kg, dg) in zip(ref, e.extract_batch(frames)):
+        _kp_equal(kr, kg)
+        assert np.array_equal(dr, dg)
