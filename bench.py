@@ -125,7 +125,7 @@ def _render_task(t):
     return synth.render_sequence(seed, n, w, h, step=1.5)
 
 
-def render_inputs(names, batches, rank):
+def render_inputs(names, batches, rank, procs=0):
     """{workload: list of u8 frames}.  Mono streams: chunks of 64 consecutive frames of one scene (sequence id =
     seed); stereo: one scene per pair, ordered L0,R0,L1,R1,..."""
     tasks, owner = [], []
@@ -141,6 +141,12 @@ def render_inputs(names, batches, rank):
                               wl["w"], wl["h"]))
                 owner.append(nm)
     nproc = max(1, min(16, host_cores(), len(tasks)))
+    # a profiler that preloads itself has initialised the GPU runtime before main(): never fork from such a process
+    # (rocprofv3 --pmc does; plain --kernel-trace --stats does not, and tools/profile_round.sh asks for the pool there)
+    if procs > 0:
+        nproc = min(procs, max(1, len(tasks)))
+    elif "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith("ROCPROF") for k in os.environ):
+        nproc = 1
     if nproc > 1:
         import multiprocessing as mp
         with mp.get_context("fork").Pool(nproc) as pool:
@@ -707,6 +713,8 @@ def main():
                          "of one sub-batch overlap the VALU-bound ones of the others")
     ap.add_argument("--schedule", choices=["streams", "lanes"], default="streams",
                     help="sub-batches on independent streams, or as the three-lane software pipeline (pyramid | FAST+blur | tail)")
+    ap.add_argument("--render-procs", type=int, default=0, help="processes rendering the synthetic inputs (0 = auto; 1 = in "
+                    "this process, which a run under a GPU-initialising profiler needs)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-in/host-out (PCIe-inclusive) rate of each workload")
     ap.add_argument("--e2e-chunk", type=int, default=0, help="frames per chunk of the pipelined host path (0 = 256)")
     ap.add_argument("--seq-scale", type=float, default=1.0, help="kitti_seq: scale factor on the sequence lengths")
@@ -728,7 +736,7 @@ def main():
 
     names = ["kitti", "tum", "euroc"] if args.workload == "all" else (["kitti"] if args.workload == "kitti_seq" else [args.workload])
     batches = {nm: (args.batch if args.batch > 0 else WORKLOADS[nm]["batch"]) for nm in names}
-    inputs = render_inputs(names, batches, rank)  # forks worker processes: before torch / HIP are initialised
+    inputs = render_inputs(names, batches, rank, args.render_procs)  # forks worker processes: before torch / HIP are initialised
 
     import torch
     import torch.distributed as dist

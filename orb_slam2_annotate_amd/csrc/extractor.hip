@@ -67,6 +67,8 @@ struct orbfe_extractor {
   int chunksPending = 0;                     // sub-batch streams 1..chunksPending-1 carry an unrecorded-for-consumer event
   bool consumerPending = false;
   int lastSplitFrames = -1, lastSplitStreams = -1;
+  int lastPer = 0, lastS = 1;     // frames per sub-batch and sub-batch count of the last run_pipeline call
+  bool lastLanes = false;
   double stageFrames[ORBFE_STAGE_COUNT] = {};
   // stage timing: a ring of event pairs per stage so that asynchronous calls can stay in flight
   static constexpr int kEvRing = 16;
@@ -516,6 +518,9 @@ int run_pipeline(orbfe_extractor* e, LevelView level0, int nFrames, orbfe_keypoi
   }
   const int per = (nFrames + S - 1) / S;
   const bool lanes = e->laneMode && !e->hostOctree && S >= 2;
+  e->lastPer = per;
+  e->lastS = S;
+  e->lastLanes = lanes;
   if (lanes) {
     hipStream_t sP = e->extra[0], sV = e->extra[1], sT = e->stream;
     if (e->consumerPending) HIPCHK(hipStreamWaitEvent(sP, e->evConsumerDone, 0));  // a matcher still reads the last pyramid
@@ -1249,14 +1254,12 @@ extern "C" int orbfe_stereo_match_batch_device(orbfe_extractor* e, int n_pairs, 
     return fail(ORBFE_ERR_INVALID, "stereo_match_batch_device: the last extract call holds fewer than 2*n_pairs frames");
   if (capacity >= (1 << 20)) return fail(ORBFE_ERR_INVALID, "stereo_match_batch_device: capacity too large");
   HIPCHK(hipSetDevice(e->device));
-  // every sub-batch of the extract call must have landed before the matcher reads its keypoints and
-  // pyramid: stream 0 waits for the other sub-batch streams ON THE DEVICE (no host synchronisation)
-  { hipStream_t s0; int rc = orbfe_extractor_consumer_begin_(e, &s0); if (rc) return rc; }
   const size_t need = (size_t)n_pairs * capacity;
   const int rows = e->lastPyr.lv[0].h;
   const size_t needRows = (size_t)n_pairs * (rows + 1);
   if (need > e->stereoSadCap || needRows > e->stereoRowCap) {
-    HIPCHK(hipStreamSynchronize(e->stream));
+    int rcs = sync_all(e);
+    if (rcs) return rcs;
     int rc = dalloc(&e->d_stereoSad, need);
     if (!rc) rc = dalloc(&e->d_stereoSorted, need);
     if (!rc) rc = dalloc(&e->d_stereoRowStart, needRows);
@@ -1284,12 +1287,52 @@ extern "C" int orbfe_stereo_match_batch_device(orbfe_extractor* e, int n_pairs, 
   b.uRight = d_uRight;
   b.depth = d_depth;
   b.sad = e->d_stereoSad;
-  launch_stereo_batch(e->stream, a, b, n_pairs, d_n_stereo);
+  // pairs [p0, p0+np) on stream st: every operand moved to the first pair by pointer arithmetic
+  auto launch_range = [&](hipStream_t st, int p0, int np, int sub) {
+    StereoArgs aa = a;
+    StereoBatch bb = b;
+    for (int l = 0; l < aa.pyrL.nlevels; l++) {
+      aa.pyrL.lv[l].base += (size_t)(2 * p0) * aa.pyrL.lv[l].frameStride;
+      aa.pyrR.lv[l].base += (size_t)(2 * p0) * aa.pyrR.lv[l].frameStride;
+    }
+    if (aa.rowStart) { aa.rowStart += (size_t)p0 * (rows + 1); aa.sortedIdx += (size_t)p0 * capacity; }
+    bb.kp += (size_t)(2 * p0) * capacity * 7;
+    bb.desc += (size_t)(2 * p0) * capacity * 32;
+    bb.n += 2 * p0;
+    bb.uRight += (size_t)p0 * capacity;
+    bb.depth += (size_t)p0 * capacity;
+    bb.sad += (size_t)p0 * capacity;
+    StageTimer t(e, ORBFE_STAGE_MATCH, 1, 2 * np, sub, st);
+    launch_stereo_batch(st, aa, bb, np, d_n_stereo + p0);
+  };
+  const int S = e->lastS, per = e->lastPer;
+  if (!e->lastLanes && S > 1 && (per & 1) == 0 && 2 * n_pairs == e->lastFrames) {
+    // The pairs of a sub-batch are matched on that sub-batch's own stream, right behind its extraction: no join of
+    // the sub-batch streams, and the (latency-bound) matcher of one sub-batch overlaps the kernels of the others.
+    // The next extract call's sub-batch i is enqueued on the same stream, i.e. behind this matcher, by itself.
+    for (int i = 0; i < S; i++) {
+      const int f0 = i * per;
+      const int n = f0 + per <= e->lastFrames ? per : e->lastFrames - f0;
+      if (n <= 0) break;
+      launch_range(i == 0 ? e->stream : e->extra[i - 1], f0 / 2, n / 2, i);
+      if (i > 0) HIPCHK(hipEventRecord(e->evChunkDone[i], e->extra[i - 1]));  // "sub-batch i done" now includes its matcher
+    }
+    HIPCHK(hipGetLastError());
+    return ORBFE_OK;
+  }
+  // one launch on stream 0 behind all sub-batches (joined ON THE DEVICE, no host synchronisation)
+  { hipStream_t s0; int rc = orbfe_extractor_consumer_begin_(e, &s0); if (rc) return rc; }
+  {
+    const unsigned keep = e->stageMask;
+    e->stageMask &= ~(1u << ORBFE_STAGE_MATCH);  // consumer_begin_/end_ time this form
+    launch_range(e->stream, 0, n_pairs, 0);
+    e->stageMask = keep;
+  }
   HIPCHK(hipGetLastError());
   // the next extract call's sub-batch streams overwrite the pyramid slabs and the caller's keypoint /
   // descriptor / count buffers this matcher is still reading: they wait for this event (run_pipeline)
   { int rc = orbfe_extractor_consumer_end_(e); if (rc) return rc; }
-  return ORBFE_OK;  // asynchronous on the handle's stream: orbfe_extractor_synchronize() to wait
+  return ORBFE_OK;  // asynchronous on the handle's streams: orbfe_extractor_synchronize() to wait
 }
 
 // ---- host-logic debug entry points (no GPU needed; CPU tests compare them with the oracle) ----
