@@ -570,7 +570,7 @@ def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, u
                 "source": v.get("_file"), "stages": per,
                 "pipeline_frac": (tot * NI * (value / world / B) / VALU_PEAK) if tot else None,
                 "note": "peak = 2 cycles per wave64 instruction per SIMD (guide); SQ_INSTS_VALU from the committed PMC "
-                        "pass; valu_busy_pmc = 4*SQ_ACTIVE_INST_VALU/(SIMDs*GRBM_GUI_ACTIVE) of the stage's busiest kernel"}
+                        "pass; valu_busy_pmc = 4*SQ_ACTIVE_INST_VALU/(SIMDs*GRBM_GUI_ACTIVE/8 XCDs) of the stage's busiest kernel: the hardware's own VALU utilisation"}
             best_valu = max([p["frac_exclusive"] for p in per.values()] + [0.0])
             if dom in per and per[dom]["frac_exclusive"] > stages.get(dom, {}).get("hbm_frac_exclusive", 0):
                 roof["bound_closest"] = "valu_issue"

@@ -124,7 +124,6 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
   const CellDesc cd = cells[cellId];
   const LevelView lv = pyr.lv[cd.level];
   const int cw = cd.w, ch = cd.h, x0 = cd.x0, y0 = cd.y0;
-  const int tlo = iniTh < minTh ? iniTh : minTh;
   const int ngx = (cw + 3) >> 2;          // 4-pixel groups per row
   const int tdw = ngx + 2;                // tile dwords per row
   // exact i / d for i < 4096 by multiply-shift (divisors <= 17)
@@ -194,11 +193,18 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
   __syncthreads();
 
   if (!blurOnly) {  // wave-uniform: the FAST phases A-D of a detection cell
-  // ---- A: cardinal-pair test at the lower threshold; ordered work list.  A lane owns 8 adjacent
+  // The reference calls cv::FAST(cell, iniThFAST) and only if that returns nothing cv::FAST(cell, minThFAST)
+  // (:874-882).  A cell is one wavefront, so the same order costs nothing here: phases A-C run at iniThFAST
+  // first -- its pre-test passes far fewer pixels than the one at minThFAST (7 is inside the image noise) -- and
+  // the wave-uniform fallback repeats them at minThFAST for the cells that kept no corner.
+  int nc = 0;      // wave-uniform: corners in the list after phase B
+  int tcur = iniTh;
+  for (int attempt = 0; attempt < 2; attempt++) {
+  // ---- A: cardinal-pair test at the current threshold; ordered work list.  A lane owns 8 adjacent
   //      pixels (two tile dwords); list positions come from a DPP inclusive scan of the lane counts ----
   int nq = 0;  // wave-uniform
   {
-    const s16x2 T = {(short)tlo, (short)tlo};
+    const s16x2 T = {(short)tcur, (short)tcur};
     const int ng8 = (cw + 7) >> 3;          // 8-pixel groups per row
     const int ngroups8 = ng8 * ch;
     const uint32_t invG8 = kInv16[ng8];
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
 
   // ---- B: exact response of the listed pixels (cornerScore<16>: S-1, corner iff S > t); the list is
   //      compacted in place to the corners (order kept: a pass writes no further than it has read) ----
-  int nc = 0;  // wave-uniform
+  nc = 0;
   {
     const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
     uint8_t* sbytes = reinterpret_cast<uint8_t*>(score);
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
         darkest = min(darkest, mx9[15]);
         brightest = max(brightest, mn9[15]);
         S = max(v - darkest, brightest - v);
-        isCorner = S > tlo;
+        isCorner = S > tcur;
       }
       const unsigned long long bal = __ballot(isCorner);
       if (isCorner) {
@@ -300,27 +306,29 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
   }
   __syncthreads();
 
-  // ---- C: cell-local 3x3 strict NMS, one lane per corner; classes in bits 14 (>= minThFAST)
-  //      and 15 (>= iniThFAST) of the list entry ----
+  // ---- C: cell-local 3x3 strict NMS, one lane per corner; survivors get bit 15 of the list entry.  Every listed
+  //      corner has S > tcur, i.e. response S-1 >= tcur: what cv::FAST(cell, tcur) keeps after NMS ----
   const uint8_t* sbytes = reinterpret_cast<const uint8_t*>(score);
-  int anyHigh = 0;
+  int anyKept = 0;
   for (int q = lane; q < nc; q += 64) {
     const int e = queue[q];
     const uint8_t* c = sbytes + ((e >> 8) + 1) * P + 4 + (e & 255);
     const int v = c[0];
     const int nb = max3i(max3i(c[-P - 1], c[-P], c[-P + 1]), max3i(c[-1], c[1], c[P - 1]), max(c[P], c[P + 1]));
-    int flags = 0;
-    if (v > nb) flags = ((v >= minTh) << 14) | ((v >= iniTh) << 15);
-    queue[q] = (uint16_t)(e | flags);
-    anyHigh |= flags >> 15;
+    const int keep = v > nb;
+    queue[q] = (uint16_t)(e | (keep << 15));
+    anyKept |= keep;
   }
-  // per-cell threshold fallback (:874-882): corners >= iniThFAST if any survived NMS, else >= minThFAST
-  const int useHigh = __ballot(anyHigh) != 0ull;
+  const int found = __ballot(anyKept) != 0ull;
   __syncthreads();
+  if (found || attempt == 1) break;
+  tcur = minTh;  // :880: nothing survived at iniThFAST
+  }  // attempt
 
   // ---- D: ordered compaction of the survivors (the list is in raster order, :884-893) ----
   Candidate* out = slots + (size_t)f * slotsPerFrame + cd.slotBase;
-  const int bit = useHigh ? 0x8000 : 0x4000;
+  const int bit = 0x8000;
+  const uint8_t* sbytes = reinterpret_cast<const uint8_t*>(score);
   int run = 0;  // wave-uniform
   for (int q0 = 0; q0 < nc; q0 += 64) {
     const int q = q0 + lane;

@@ -2,7 +2,7 @@
 """Turns a rocprofv3 --pmc pass of bench.py (SQ_WAVES SQ_INSTS_VALU [SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE]) into
 profiles/<round>_<workload>_valu.json: VALU wave-instructions per IMAGE for every kernel (average per dispatch x
 dispatches per step / images per step) and, when the two extra counters are present, the hardware's own VALU
-utilisation VALUBusy = 4 * SQ_ACTIVE_INST_VALU / (SIMDs * GRBM_GUI_ACTIVE) (SQ_ACTIVE_INST_* count quad-cycles).
+utilisation VALUBusy = 4 * SQ_ACTIVE_INST_VALU / (SIMDs * GRBM_GUI_ACTIVE / 8 XCDs) (SQ_ACTIVE_INST_* count quad-cycles).
 
     rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv \
         -d gpurun_out/pmc_valu -- python3 bench.py --workload tum --steps 3 --warmup 1 --no-cpu-baseline --streams 1 --batch 256
@@ -19,6 +19,8 @@ from pathlib import Path
 
 LAUNCHES_PER_STEP = {"k_resize_flat": 7, "k_resize": 7}
 N_SIMD = 256 * 4
+N_XCD = 8  # rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs (checked against HIP-event times: k_blur7 at 256
+           # frames counts 3.90 M = 8 x 488 k cycles = 8 x 0.203 ms at 2.4 GHz, its event time); the SQ counters are chip sums
 
 
 def kname(full):
@@ -37,7 +39,7 @@ def main():
         if "orbfe::" in r["Kernel_Name"]:
             acc[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     res = {"batch": int(images), "workload": workload,
-           "unit": "VALU wave64 instructions (SQ_INSTS_VALU) per image; valu_busy = 4*SQ_ACTIVE_INST_VALU/(1024 SIMDs*GRBM_GUI_ACTIVE)",
+           "unit": "VALU wave64 instructions (SQ_INSTS_VALU) per image; valu_busy = 4*SQ_ACTIVE_INST_VALU/(1024 SIMDs*GRBM_GUI_ACTIVE/8)",
            "kernels": {}}
     for k, c in sorted(acc.items()):
         if not c["SQ_INSTS_VALU"]:
@@ -52,7 +54,7 @@ def main():
             gui = sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"])
             e["SQ_ACTIVE_INST_VALU"] = act
             e["GRBM_GUI_ACTIVE"] = gui
-            e["valu_busy"] = 4.0 * act / (N_SIMD * gui) if gui > 0 else None
+            e["valu_busy"] = 4.0 * act / (N_SIMD * gui / N_XCD) if gui > 0 else None
         res["kernels"][k] = e
     res["total_valu_wave_instr_per_image"] = sum(v["valu_wave_instr_per_image"] for v in res["kernels"].values())
     Path(out).write_text(json.dumps(res, indent=1) + "\n")

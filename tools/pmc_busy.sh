@@ -1,5 +1,6 @@
 #!/bin/bash
 # Per-kernel utilisation of the shared execution resources (exclusive, 1 stream): VALU issue, LDS array, memory wait.
+# GRBM_GUI_ACTIVE comes summed over the 8 XCDs (see tools/collect_valu.py), hence the /8 in the busy fractions.
 #   tools/pmc_busy.sh tum 256      -> gpurun_out/pmc_busy_<workload>.txt
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
@@ -27,9 +28,9 @@ with open(out + ".txt", "w") as f:
     for k in sorted(agg):
         gui_a, gui_b, gui_c = m(k, "a:GRBM_GUI_ACTIVE"), m(k, "b:GRBM_GUI_ACTIVE"), m(k, "c:GRBM_GUI_ACTIVE")
         line = (f"{k:22s} disp {len(agg[k]['a:SQ_WAVES']):3d} cyc {gui_a:11.0f} waves {m(k,'a:SQ_WAVES'):9.0f} "
-                f"VALU/wave {m(k,'a:SQ_INSTS_VALU')/m(k,'a:SQ_WAVES'):7.1f} valu_busy {4*m(k,'a:SQ_ACTIVE_INST_VALU')/(1024*gui_a):.3f} "
-                f"| LDS/wave {m(k,'b:SQ_INSTS_LDS')/m(k,'a:SQ_WAVES'):6.1f} lds_busy {m(k,'b:SQ_LDS_IDX_ACTIVE')/(256*gui_b):.3f} "
-                f"lds_conflict {m(k,'b:SQ_LDS_BANK_CONFLICT')/(256*gui_b):.3f} inst_lds_busy {4*m(k,'b:SQ_ACTIVE_INST_LDS')/(1024*gui_b):.3f} "
+                f"VALU/wave {m(k,'a:SQ_INSTS_VALU')/m(k,'a:SQ_WAVES'):7.1f} valu_busy {4*m(k,'a:SQ_ACTIVE_INST_VALU')/(1024*gui_a/8):.3f} "
+                f"| LDS/wave {m(k,'b:SQ_INSTS_LDS')/m(k,'a:SQ_WAVES'):6.1f} lds_busy {m(k,'b:SQ_LDS_IDX_ACTIVE')/(256*gui_b/8):.3f} "
+                f"lds_conflict {m(k,'b:SQ_LDS_BANK_CONFLICT')/(256*gui_b/8):.3f} inst_lds_busy {4*m(k,'b:SQ_ACTIVE_INST_LDS')/(1024*gui_b/8):.3f} "
                 f"| SALU/wave {m(k,'c:SQ_INSTS_SALU')/m(k,'a:SQ_WAVES'):6.1f} VMEM/wave {(m(k,'c:SQ_INSTS_VMEM_RD')+m(k,'c:SQ_INSTS_VMEM_WR'))/m(k,'a:SQ_WAVES'):5.1f} "
                 f"wait_inst/wavecyc {m(k,'c:SQ_WAIT_INST_ANY')/m(k,'c:SQ_WAVE_CYCLES'):.3f}")
         print(line); f.write(line + "\n")
