@@ -59,15 +59,22 @@ def main():
         params = (int(rng.choice([100, 500, 1000, 2000, 3000])), float(rng.choice([1.1, 1.2, 1.3, 1.5])),
                   int(rng.integers(1, 9)), int(rng.choice([20, 30, 12, 7])), int(rng.choice([7, 5, 10, 3])))
         img = content(rng, w, h)
+        # round-2 knobs: GaussianBlur arithmetic variant, blur fused into the FAST kernel, lane schedule, host path
+        spec = int(rng.choice([0, 0, 1, 2]))
+        fused, lanes, piped = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        knobs = dict(spec=spec, fused=fused, lanes=lanes, pipelined=piped)
         try:
-            o = orc.Oracle(*params)
+            o = orc.Oracle(*params, blur_spec=spec)
             e = amd.ORBextractor(*params)
+            e.set_blur_spec(spec)
+            e.set_fused(fused)
             if batch_mode:
                 w, h = min(w, 500), min(h, 400)
                 imgs = np.stack([content(rng, w, h) for _ in range(int(rng.integers(9, 25)))])
                 img = imgs[0]
                 e.set_streams(int(rng.integers(1, 9)))
-                res = e.extract_batch(imgs)
+                e.set_schedule(lanes)
+                res = e.extract_batch_pipelined(imgs, chunk_frames=int(rng.integers(1, 12))) if piped else e.extract_batch(imgs)
                 ok = True
                 for i in range(len(imgs)):
                     kr, dr = o.extract(imgs[i])
@@ -80,23 +87,20 @@ def main():
                 ok = len(kr) == len(kg) and np.array_equal(dr, dg) and all(
                     np.array_equal(kr[f], kg[f]) for f in ("x", "y", "size", "angle", "response", "octave"))
         except amd.OrbfeError as ex:
-            if "does not fit in LDS" in str(ex):  # documented limit: per-level quota <= ~2890 keypoints
-                skipped += 1
-                continue
             print("EXCEPTION", ex)
             ok = False
         except Exception as ex:  # noqa: BLE001
             print("EXCEPTION", type(ex).__name__, ex)
             ok = False
         if not ok:
-            print(f"MISMATCH seed={seed} case={n} size={w}x{h} params={params}")
+            print(f"MISMATCH seed={seed} case={n} size={w}x{h} params={params} knobs={knobs}")
             np.save(ROOT / "gpurun_out" / f"fuzz_fail_{seed}_{n}.npy", img)
             sys.exit(1)
         n += 1
         if time.time() - last_report > 60:  # progress line (long runs must not look hung)
             last_report = time.time()
             print(f"  ... {n} cases so far", flush=True)
-    print(f"fuzz_parity: {n} random cases bit-exact in {time.time() - t0:.0f} s (seed {seed}; {skipped} beyond the octree LDS limit skipped)")
+    print(f"fuzz_parity: {n} random cases bit-exact in {time.time() - t0:.0f} s (seed {seed}; blur specs 0/1/2, fused / separate blur, stream / lane schedule, direct / pipelined host path drawn at random)")
 
 
 if __name__ == "__main__":
