@@ -125,9 +125,28 @@ def _render_task(t):
     return synth.render_sequence(seed, n, w, h, step=1.5)
 
 
-def render_inputs(names, batches, rank, procs=0):
+def render_inputs(names, batches, rank, procs=0, cache=None):
     """{workload: list of u8 frames}.  Mono streams: chunks of 64 consecutive frames of one scene (sequence id =
-    seed); stereo: one scene per pair, ordered L0,R0,L1,R1,..."""
+    seed); stereo: one scene per pair, ordered L0,R0,L1,R1,...  `cache`: directory holding the rendered batches
+    as .npy (written on first use) -- the profiler passes of tools/profile_round.sh reuse what the plain run rendered."""
+    out, todo = {}, []
+    for nm in names:
+        f = Path(cache) / f"{nm}_{batches[nm]}_{rank}.npy" if cache else None
+        if f is not None and f.exists():
+            out[nm] = list(np.load(f))
+        else:
+            todo.append(nm)
+    if todo:
+        rendered = _render(todo, batches, rank, procs)
+        for nm in todo:
+            out[nm] = rendered[nm]
+            if cache:
+                Path(cache).mkdir(parents=True, exist_ok=True)
+                np.save(Path(cache) / f"{nm}_{batches[nm]}_{rank}.npy", np.stack(rendered[nm]))
+    return out
+
+
+def _render(names, batches, rank, procs=0):
     tasks, owner = [], []
     for nm in names:
         wl, B = WORKLOADS[nm], batches[nm]
@@ -715,6 +734,7 @@ def main():
                     help="sub-batches on independent streams, or as the three-lane software pipeline (pyramid | FAST+blur | tail)")
     ap.add_argument("--render-procs", type=int, default=0, help="processes rendering the synthetic inputs (0 = auto; 1 = in "
                     "this process, which a run under a GPU-initialising profiler needs)")
+    ap.add_argument("--input-cache", default=None, help="directory for the rendered synthetic batches (.npy), reused when present")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-in/host-out (PCIe-inclusive) rate of each workload")
     ap.add_argument("--e2e-chunk", type=int, default=0, help="frames per chunk of the pipelined host path (0 = 256)")
     ap.add_argument("--seq-scale", type=float, default=1.0, help="kitti_seq: scale factor on the sequence lengths")
@@ -736,7 +756,7 @@ def main():
 
     names = ["kitti", "tum", "euroc"] if args.workload == "all" else (["kitti"] if args.workload == "kitti_seq" else [args.workload])
     batches = {nm: (args.batch if args.batch > 0 else WORKLOADS[nm]["batch"]) for nm in names}
-    inputs = render_inputs(names, batches, rank, args.render_procs)  # forks worker processes: before torch / HIP are initialised
+    inputs = render_inputs(names, batches, rank, args.render_procs, args.input_cache)  # may fork workers: before torch / HIP
 
     import torch
     import torch.distributed as dist

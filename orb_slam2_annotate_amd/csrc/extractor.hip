@@ -85,6 +85,7 @@ struct orbfe_extractor {
   // 291.8 k frames/s -- FAST already runs at the VALU issue ceiling, so the blur's instructions cost their full price
   // inside it; off by default, selectable ($ORBFE_FUSED=1 / orbfe_extractor_set_fused) and parity-tested
   bool fused = false;
+  bool copyUnaligned = false;  // debug: repack caller-owned frames with an odd stride first (round-1 behaviour)
   int blurSpec = kBlurSpecCv4;  // GaussianBlur arithmetic, orbfe_extractor_set_blur_spec / $ORBFE_BLUR_SPEC
   int octreeMaxL = 0;
   double stageMs[ORBFE_STAGE_COUNT] = {};
@@ -393,9 +394,11 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
     blur.lv[l] = blur0.lv[l];
     blur.lv[l].base += F * blur0.lv[l].frameStride;
   }
-  if ((level0.pitch & 3) || (level0.frameStride & 3) || (reinterpret_cast<uintptr_t>(level0.base) & 3)) {
-    // caller-owned frames that are not dword-aligned (e.g. a tight 1241-byte stride): one copy into
-    // the handle's own 64-B pitched level-0 slab keeps every later kernel on its aligned fast path
+  if (e->copyUnaligned && ((level0.pitch & 3) || (level0.frameStride & 3) || (reinterpret_cast<uintptr_t>(level0.base) & 3))) {
+    // caller-owned frames that are not dword-aligned (e.g. a tight 1241-byte stride).  Round 1 copied them into the
+    // handle's own 64-B pitched level-0 slab first (an extra read + write of every input pixel); since round 2 the
+    // four consumers of level 0 (resize, FAST, blur, orientation) read byte-aligned requests in place and the copy
+    // is only kept behind $ORBFE_COPY_UNALIGNED=1 as a cross-check
     LevelView own{e->d_pyr + g.lv[0].off, g.pyrBytes, g.lv[0].pitch, g.lv[0].w, g.lv[0].h};
     LevelView src = level0;
     src.base += F * level0.frameStride;
@@ -590,6 +593,7 @@ extern "C" int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlev
   hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
   for (int i = 0; i < orbfe_extractor::kMaxStreams - 1 && err == hipSuccess; i++)
     err = hipStreamCreateWithFlags(&e->extra[i], hipStreamNonBlocking);
+  if (const char* env = getenv("ORBFE_COPY_UNALIGNED")) e->copyUnaligned = atoi(env) != 0;
   if (const char* env = getenv("ORBFE_LANES")) e->laneMode = atoi(env) != 0;
   if (const char* env = getenv("ORBFE_FUSED")) e->fused = atoi(env) != 0;
   if (const char* env = getenv("ORBFE_BLUR_SPEC")) {

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
       }
     } else {
       const int c = bx - 4 + 4 * tj;
-      const bool inRow = (src.pitch & 3) == 0 && c >= 0 && c + 3 < src.w;
+      const bool inRow = c >= 0 && c + 3 < src.w;
       int cx[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) cx[k] = reflect101c(c + k, src.w);
@@ -111,12 +111,10 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
         const uint8_t* row = S + (size_t)sy * src.pitch;
         uint32_t v;
         if (inRow) {
-          const uintptr_t ad = reinterpret_cast<uintptr_t>(row + c);
-          const uint32_t a = (uint32_t)(ad & 3);
-          const uint32_t* p = reinterpret_cast<const uint32_t*>(ad - a);
-          const uint32_t lo = p[0];
-          const uint32_t hi = a ? p[1] : 0u;  // stays inside the row: c+3 < w <= pitch
-          v = __builtin_amdgcn_alignbyte(hi, lo, a);
+          // one dword at whatever byte address the row and column give (odd caller strides included):
+          // global_load_dword takes unaligned addresses on gfx950 (profiles/r02_unaligned.txt)
+          struct __attribute__((packed, aligned(1))) U1u { uint32_t x; };
+          v = reinterpret_cast<const U1u*>(row + c)->x;
         } else {
           v = (uint32_t)row[cx[0]] | ((uint32_t)row[cx[1]] << 8) | ((uint32_t)row[cx[2]] << 16) | ((uint32_t)row[cx[3]] << 24);
         }

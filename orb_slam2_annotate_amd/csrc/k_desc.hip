@@ -137,9 +137,11 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
               dw[u][0] = q.x; dw[u][1] = q.y; dw[u][2] = q.z; dw[u][3] = q.w;
               dw[u][4] = mis[u] ? al[4] : 0u;
             } else {
-#pragma unroll
-              for (int k = 0; k < 4; k++)
-                dw[u][k] = (uint32_t)p[4 * k] | ((uint32_t)p[4 * k + 1] << 8) | ((uint32_t)p[4 * k + 2] << 16) | ((uint32_t)p[4 * k + 3] << 24);
+              // caller-owned level 0 at an odd stride: one byte-aligned 16-byte request (columns x-15 .. x+16 are
+              // inside the row for every keypoint: 19 <= x <= w-20), mis stays 0
+              struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };
+              const U4u q = *reinterpret_cast<const U4u*>(p);
+              dw[u][0] = q.x; dw[u][1] = q.y; dw[u][2] = q.z; dw[u][3] = q.w;
             }
           }
         }

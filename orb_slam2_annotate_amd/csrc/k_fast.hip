@@ -77,6 +77,7 @@ __device__ __forceinline__ int reflect101f(int i, int n) {
   return i < 0 ? 0 : (i >= n ? n - 1 : i);  // clamp only matters for never-used tile cells
 }
 struct __attribute__((packed, aligned(1))) U1u { uint32_t x; };  // 4-byte store at any byte address
+struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };  // 16-byte load at any byte address
 }  // namespace
 
 // 32-bit 3-input forms for the per-pixel exact score (one pixel per lane)
@@ -176,12 +177,33 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
           o.w = __builtin_amdgcn_alignbyte(d[4], d[3], a);
           *reinterpret_cast<uint4*>(&tile[ty * kPitchDw + 4 * part]) = o;  // pitch >= 4*parts (launch_fast_cells)
         }
-      } else {  // caller-owned level 0 with an odd stride: byte loads
-        for (int i = lane; i < th * tdw; i += 64) {
-          const int ty = (int)(((uint32_t)i * invT) >> 16), tx = i - ty * tdw;
+      } else {
+        // caller-owned level 0 whose rows are not dword-aligned (e.g. KITTI's tight 1241-byte stride): the same
+        // (row, part) lanes issue ONE byte-aligned 16-byte request each (global_load_dwordx4 takes any address on
+        // gfx950 at full bandwidth, profiles/r02_unaligned.txt) and need no byte shifting at all
+        const int parts = (tdw + 3) >> 2;
+        const uint32_t invP = kInv16[parts];
+        const int rowBytes = lv.pitch - (x0 - 4);  // bytes from the tile's first column to the end of the row
+        for (int i = lane; i < th * parts; i += 64) {
+          const int ty = (int)(((uint32_t)i * invP) >> 16), part = i - ty * parts;
           const int sy = rr ? reflect101f(y0 - 3 + ty, lv.h) : y0 - 3 + ty;
-          const uint8_t* p = lvb + (size_t)sy * lv.pitch + (x0 - 4) + 4 * tx;
-          tile[ty * kPitchDw + tx] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+          const uint8_t* p = lvb + (size_t)sy * lv.pitch + (x0 - 4) + 16 * part;
+          uint4 o;
+          if (16 * part + 16 <= rowBytes) {
+            const U4u q = *reinterpret_cast<const U4u*>(p);
+            o = make_uint4(q.x, q.y, q.z, q.w);
+          } else {  // the last piece of a right-edge cell: stay inside the row (and the caller's buffer)
+            uint32_t d[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              d[k] = 0;
+#pragma unroll
+              for (int b = 0; b < 4; b++)
+                if (16 * part + 4 * k + b < rowBytes) d[k] |= (uint32_t)p[4 * k + b] << (8 * b);
+            }
+            o = make_uint4(d[0], d[1], d[2], d[3]);
+          }
+          *reinterpret_cast<uint4*>(&tile[ty * kPitchDw + 4 * part]) = o;
         }
       }
     }

@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelViewMut dst,
 // interpolated source row is reused by the next output row when the whole wave agrees (scalar
 // branch, no per-lane control flow); (b*h)>>16 is one v_mul_hi_u32 against b<<16.
 constexpr int kFlatRows = 8;
+template <bool UNALIGNED>
 __global__ __launch_bounds__(256) void k_resize_flat(LevelView src, LevelViewMut dst,
                                                      const uint4* __restrict__ colrec,
                                                      const uint4* __restrict__ rowrec, int ngx,
@@ -128,9 +129,13 @@ __global__ __launch_bounds__(256) void k_resize_flat(LevelView src, LevelViewMut
 #pragma unroll
   for (int r = 0; r < kFlatRows; r++) rr[r] = rowrec[dy0 + r < dst.h ? dy0 + r : dst.h - 1];
   const uint32_t sel[4] = {s4.x, s4.y, s4.z, s4.w}, al[4] = {a4.x, a4.y, a4.z, a4.w};
+  // UNALIGNED: the source rows start at arbitrary byte addresses (a caller-owned level 0 with an odd stride): the
+  // 8-byte window is read with two byte-aligned dword loads (fine on gfx950, profiles/r02_unaligned.txt), no third
+  // load and no byte shift; otherwise the window is cut out of aligned dwords by v_alignbyte
   const uint8_t* S = src.base + (size_t)f * src.frameStride + sxb;
-  const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(S) & 3);
+  const uint32_t mis = UNALIGNED ? 0u : (uint32_t)(reinterpret_cast<uintptr_t>(S) & 3);
   S -= mis;
+  struct __attribute__((packed, aligned(1))) U1u { uint32_t x; };
   // Output row r blends source rows (rr[r].x, rr[r].y); at pyramid scales rr[r].x is usually
   // rr[r-1].y.  When that holds for every lane of the wave (a scalar condition: the lanes of a wave
   // share their rows except where a wave straddles two row blocks) the interpolated row is reused
@@ -143,11 +148,21 @@ __global__ __launch_bounds__(256) void k_resize_flat(LevelView src, LevelViewMut
 #pragma unroll
   for (int r = 0; r < kFlatRows; r++) {
     if (!reuse[r]) {
-      const uint32_t* pa = reinterpret_cast<const uint32_t*>(S + (size_t)rr[r].x * src.pitch);
-      w[2 * r][0] = pa[0]; w[2 * r][1] = pa[1]; w[2 * r][2] = mis ? pa[2] : 0u;
+      const uint8_t* qa = S + (size_t)rr[r].x * src.pitch;
+      if (UNALIGNED) {
+        w[2 * r][0] = reinterpret_cast<const U1u*>(qa)->x; w[2 * r][1] = reinterpret_cast<const U1u*>(qa + 4)->x; w[2 * r][2] = 0u;
+      } else {
+        const uint32_t* pa = reinterpret_cast<const uint32_t*>(qa);
+        w[2 * r][0] = pa[0]; w[2 * r][1] = pa[1]; w[2 * r][2] = mis ? pa[2] : 0u;
+      }
     }
-    const uint32_t* pb = reinterpret_cast<const uint32_t*>(S + (size_t)rr[r].y * src.pitch);
-    w[2 * r + 1][0] = pb[0]; w[2 * r + 1][1] = pb[1]; w[2 * r + 1][2] = mis ? pb[2] : 0u;
+    const uint8_t* qb = S + (size_t)rr[r].y * src.pitch;
+    if (UNALIGNED) {
+      w[2 * r + 1][0] = reinterpret_cast<const U1u*>(qb)->x; w[2 * r + 1][1] = reinterpret_cast<const U1u*>(qb + 4)->x; w[2 * r + 1][2] = 0u;
+    } else {
+      const uint32_t* pb = reinterpret_cast<const uint32_t*>(qb);
+      w[2 * r + 1][0] = pb[0]; w[2 * r + 1][1] = pb[1]; w[2 * r + 1][2] = mis ? pb[2] : 0u;
+    }
   }
   uint8_t* D = dst.base + (size_t)f * dst.frameStride + 4 * gx;
   uint32_t hA[4], hB[4] = {0u, 0u, 0u, 0u};
@@ -221,14 +236,20 @@ __global__ __launch_bounds__(256) void k_resize_generic(LevelView src, LevelView
 void launch_resize(hipStream_t s, LevelView src, LevelViewMut dst, const int32_t* d_xofs,
                    const int16_t* d_alpha, const int32_t* d_yofs, const int16_t* d_beta,
                    const uint32_t* d_colrec, const uint32_t* d_rowrec, int nFrames) {
-  const bool fast = (src.pitch & 3) == 0 && src.w >= 8 && (long long)src.w <= 2LL * dst.w;
+  const bool aligned = (src.pitch & 3) == 0 && (src.frameStride & 3) == 0 && (reinterpret_cast<uintptr_t>(src.base) & 3) == 0;
+  const bool shape = src.w >= 8 && (long long)src.w <= 2LL * dst.w;
+  const bool fast = aligned && shape;
   const int ngx = (dst.w + 3) / 4;
   const long long total = (long long)ngx * ((dst.h + kFlatRows - 1) / kFlatRows);
-  if (fast && d_colrec && d_rowrec && total * ngx < (1LL << 32) && total > 0) {
+  if (shape && d_colrec && d_rowrec && total * ngx < (1LL << 32) && total > 0) {
     const uint32_t magic = (uint32_t)((1ULL << 32) / (uint32_t)ngx) + 1u;
-    hipLaunchKernelGGL(k_resize_flat, dim3((unsigned)((total + 255) / 256), nFrames), dim3(256), 0, s, src, dst,
-                       reinterpret_cast<const uint4*>(d_colrec), reinterpret_cast<const uint4*>(d_rowrec), ngx, magic,
-                       (int)total);
+    const dim3 grid((unsigned)((total + 255) / 256), nFrames);
+    if (aligned)
+      hipLaunchKernelGGL(k_resize_flat<false>, grid, dim3(256), 0, s, src, dst, reinterpret_cast<const uint4*>(d_colrec),
+                         reinterpret_cast<const uint4*>(d_rowrec), ngx, magic, (int)total);
+    else  // caller-owned level 0 at an odd stride: byte-aligned dword loads
+      hipLaunchKernelGGL(k_resize_flat<true>, grid, dim3(256), 0, s, src, dst, reinterpret_cast<const uint4*>(d_colrec),
+                         reinterpret_cast<const uint4*>(d_rowrec), ngx, magic, (int)total);
   } else if (fast) {
     dim3 grid((dst.w + 255) / 256, (dst.h + 4 * kRowsPerThread - 1) / (4 * kRowsPerThread), nFrames);
     hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, src, dst, d_xofs, d_alpha, d_yofs, d_beta);

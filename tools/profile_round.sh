@@ -13,10 +13,17 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out
 mkdir -p $OUT
+CACHE=/tmp/orbfe_inputs_$$
+for W in $WLS; do  # render every batch once, unprofiled (a profiled process must not fork the renderer pool)
+  case $W in kitti) B=64;; *) B=256;; esac
+  python3 bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --batch $B --input-cache $CACHE > /dev/null 2>&1
+  python3 bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --input-cache $CACHE > /dev/null 2>&1
+  echo "inputs $W rendered"
+done
 for W in $WLS; do
   case $W in kitti) B=64; IMGS=128;; tum) B=256; IMGS=256;; euroc) B=256; IMGS=256;; esac
   rm -rf $OUT/${TAG}_${W}_pmc_valu $OUT/${TAG}_${W}_pmc_fetch $OUT/${TAG}_${W}_pmc_write $OUT/${TAG}_${W}_stats
-  PMC_ARGS="--workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --render-procs 1 --streams 1 --batch $B"
+  PMC_ARGS="--workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --render-procs 1 --input-cache $CACHE --streams 1 --batch $B"
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_${W}_pmc_valu -- python3 bench.py $PMC_ARGS > /dev/null 2>$OUT/${TAG}_${W}_pmc_valu.err
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_${W}_pmc_fetch -- python3 bench.py $PMC_ARGS > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_${W}_pmc_write -- python3 bench.py $PMC_ARGS > /dev/null 2>&1
@@ -24,10 +31,11 @@ for W in $WLS; do
   python3 tools/collect_traffic.py $OUT/${TAG}_${W}_pmc_fetch $OUT/${TAG}_${W}_pmc_write $OUT/${TAG}_${W}_traffic.json $IMGS $W > /dev/null
   cp $OUT/${TAG}_${W}_valu.json $OUT/${TAG}_${W}_traffic.json profiles/   # bench.py reads the summaries from profiles/
   echo "pmc $W done"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_${W}_stats -- python3 bench.py --workload $W --no-cpu-baseline --no-e2e --render-procs 16 > $OUT/${TAG}_${W}_stats_bench.json 2>/dev/null
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_${W}_stats -- python3 bench.py --workload $W --no-cpu-baseline --no-e2e --render-procs 1 --input-cache $CACHE > $OUT/${TAG}_${W}_stats_bench.json 2>/dev/null
   cp $OUT/${TAG}_${W}_stats/*/*kernel_stats.csv $OUT/${TAG}_${W}_kernel_stats.csv
   echo "stats $W done"
 done
-python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+python3 bench.py --input-cache $CACHE > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+rm -rf $CACHE
 tail -c 400 $OUT/${TAG}_bench.json; echo
 echo done
