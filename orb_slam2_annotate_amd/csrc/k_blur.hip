@@ -81,24 +81,27 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   const int rowBlocks = (rowsValid + 3) >> 2;                 // 4-row blocks the vertical pass computes
   const int stageRows = 4 * rowBlocks + 6;                    // <= kTH
   const uint8_t* S = src.base + (size_t)f * src.frameStride;
-  const bool aligned = (src.pitch & 3) == 0 && (reinterpret_cast<uintptr_t>(S) & 3) == 0;
+  // every staging load is ONE dword at whatever byte address the level and the tile give: global_load_dword takes
+  // unaligned addresses on gfx950 (profiles/r02_unaligned.txt), so a caller-owned level 0 with an odd stride
+  // (KITTI: 1241) runs the same paths as the handle's own 64-byte pitched levels
+  struct __attribute__((packed, aligned(1))) U1u { uint32_t x; };
   // ---- 1. stage: thread (ty0, tj) = (tid / 18, tid % 18) walks down the tile 14 rows at a time ----
   if (tid < 14 * kTDW) {
     const int ty0 = (int)(((uint32_t)tid * 3641u) >> 16), tj = tid - ty0 * kTDW;  // tid / 18 for tid < 252
-    if (aligned && bx >= 4 && bx + kBW + 4 <= src.w && by >= 3 && by + kBH + 3 <= src.h) {
+    if (bx >= 4 && bx + kBW + 4 <= src.w && by >= 3 && by + kBH + 3 <= src.h) {
       // interior tile (block-uniform): no reflection, every dword is an aligned in-row load
       const uint8_t* T0 = S + (size_t)(by - 3) * src.pitch + (bx - 4);     // block-uniform (scalar) tile origin
       const uint32_t o0 = (uint32_t)ty0 * (uint32_t)src.pitch + 4u * (uint32_t)tj;  // 32-bit lane offset
 #pragma unroll
       for (int k = 0; k < 5; k++)
-        tin[(ty0 + 14 * k) * kTDW + tj] = *reinterpret_cast<const uint32_t*>(T0 + (o0 + (uint32_t)(14 * k) * (uint32_t)src.pitch));
-    } else if (aligned && bx >= 4 && bx + kBW + 4 <= src.w) {
+        tin[(ty0 + 14 * k) * kTDW + tj] = reinterpret_cast<const U1u*>(T0 + (o0 + (uint32_t)(14 * k) * (uint32_t)src.pitch))->x;
+    } else if (bx >= 4 && bx + kBW + 4 <= src.w) {
       // top / bottom tile away from the left and right edges: every dword is still an aligned in-row
       // load, only the row index is reflected
       const uint32_t c0 = (uint32_t)(bx - 4) + 4u * (uint32_t)tj;
       for (int ty = ty0; ty < stageRows; ty += 14) {
         const int sy = reflect101c(by - 3 + ty, src.h);
-        tin[ty * kTDW + tj] = *reinterpret_cast<const uint32_t*>(S + ((uint32_t)sy * (uint32_t)src.pitch + c0));
+        tin[ty * kTDW + tj] = reinterpret_cast<const U1u*>(S + ((uint32_t)sy * (uint32_t)src.pitch + c0))->x;
       }
     } else {
       const int c = bx - 4 + 4 * tj;
@@ -113,7 +116,6 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
         if (inRow) {
           // one dword at whatever byte address the row and column give (odd caller strides included):
           // global_load_dword takes unaligned addresses on gfx950 (profiles/r02_unaligned.txt)
-          struct __attribute__((packed, aligned(1))) U1u { uint32_t x; };
           v = reinterpret_cast<const U1u*>(row + c)->x;
         } else {
           v = (uint32_t)row[cx[0]] | ((uint32_t)row[cx[1]] << 8) | ((uint32_t)row[cx[2]] << 16) | ((uint32_t)row[cx[3]] << 24);

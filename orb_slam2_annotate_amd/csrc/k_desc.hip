@@ -38,7 +38,9 @@ __device__ __forceinline__ int wave_sum(int x) {
 
 // kKpPerBlock = 64 for throughput (16 keypoints per wavefront, 16 workgroups per VGA frame), 16 for
 // launches of a few frames (4 per wavefront, 4x the workgroups: the serial chain per wave is 4x shorter).
-template <int kKpPerBlock>
+// kUM / kUD: keypoints whose row loads (moments) / patch loads (descriptors) a wave keeps in flight at once (4 / 2;
+// 8 / 4 measured no faster, see launch_orient_desc).
+template <int kKpPerBlock, int kUM, int kUD>
 __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
                                                      const LevelKp* __restrict__ levelKp,
                                                      const int32_t* __restrict__ levelCount,
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
   __shared__ int s_x[kKpPerBlock], s_y[kKpPerBlock], s_level[kKpPerBlock], s_out[kKpPerBlock];
   __shared__ unsigned s_score[kKpPerBlock];
   __shared__ float s_angle[kKpPerBlock], s_cos[kKpPerBlock], s_sin[kKpPerBlock];
-  __shared__ __attribute__((aligned(16))) uint32_t s_patch[4 * 2 * kPatchRows * kPatchDw];  // per wave: 2 patches
+  __shared__ __attribute__((aligned(16))) uint32_t s_patch[4 * kUD * kPatchRows * kPatchDw];  // per wave: kUD patches
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware work mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, so block
@@ -111,12 +113,12 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
     // 16 keypoints per wave, 4 at a time: the 4 x 5 row loads are issued back to back so one
     // memory latency covers four keypoints (the kernel is latency-bound, not VALU-bound)
     constexpr int kKpPerWave = kKpPerBlock / 4;
-    for (int j0 = wave * kKpPerWave; j0 < wave * kKpPerWave + kKpPerWave; j0 += 4) {
-      uint32_t dw[4][5];
-      uint32_t mis[4];
-      int kout[4];  // per-keypoint values are wave-uniform: kept in scalar registers (readfirstlane)
+    for (int j0 = wave * kKpPerWave; j0 < wave * kKpPerWave + kKpPerWave; j0 += kUM) {
+      uint32_t dw[kUM][5];
+      uint32_t mis[kUM];
+      int kout[kUM];  // per-keypoint values are wave-uniform: kept in scalar registers (readfirstlane)
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < kUM; u++) {
         const int j = j0 + u;
         mis[u] = 0;
 #pragma unroll
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < kUM; u++) {
         const int j = j0 + u;
         if (kout[u] < 0) continue;  // scalar branch
         const uint32_t q0 = __builtin_amdgcn_alignbyte(dw[u][1], dw[u][0], mis[u]);
@@ -192,14 +194,14 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
     // (3 lanes per row: 111 lanes = 2 instructions per keypoint, each patch line touched once) and
     // the 512 samples are LDS byte reads; sampling global memory directly cost one L1 line lookup
     // per lane per sample (8 x 64 per keypoint) and was the slowest part of the kernel.
-    uint32_t* myPatch = &s_patch[wave * 2 * kPatchRows * kPatchDw];
+    uint32_t* myPatch = &s_patch[wave * kUD * kPatchRows * kPatchDw];
     constexpr int kKpPerWave3 = kKpPerBlock / 4;
-    for (int j0 = wave * kKpPerWave3; j0 < wave * kKpPerWave3 + kKpPerWave3; j0 += 2) {
-      int t0v[2][4], t1v[2][4];
-      U4 stage[2][2];
-      int colOff[2], kout[2];  // per-keypoint values are wave-uniform: scalar registers, scalar branches
+    for (int j0 = wave * kKpPerWave3; j0 < wave * kKpPerWave3 + kKpPerWave3; j0 += kUD) {
+      int t0v[kUD][4], t1v[kUD][4];
+      U4 stage[kUD][2];
+      int colOff[kUD], kout[kUD];  // per-keypoint values are wave-uniform: scalar registers, scalar branches
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
+      for (int u = 0; u < kUD; u++) {
         const int j = j0 + u;
         colOff[u] = 0;
         kout[u] = __builtin_amdgcn_readfirstlane(s_out[j]);
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
         }
       }
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
+      for (int u = 0; u < kUD; u++) {
         if (kout[u] < 0) continue;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
+      for (int u = 0; u < kUD; u++) {
         const int j = j0 + u;
         if (kout[u] < 0) continue;
         const float ca = s_cos[j], sb = s_sin[j];
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
         // biased and the bias of row*48 + col (0x4B400000 * 49 mod 2^32) is folded into the base offset.
         constexpr float kMagic = 12582912.0f;
         constexpr uint32_t kBias = 0x4B400000u * 49u;
-        const uint32_t baseK = (uint32_t)((wave * 2 + u) * kPatchRows * kPatchDw * 4 + 18 * 4 * kPatchDw + colOff[u]) - kBias;
+        const uint32_t baseK = (uint32_t)((wave * kUD + u) * kPatchRows * kPatchDw * 4 + 18 * 4 * kPatchDw + colOff[u]) - kBias;
         // both points of a test at once (packed fp32, no FMA): row = x*b + y*a, col = x*a - y*b
         // (src/ORBextractor.cc:123-125 with a = cos, b = sin), P[t] = (x0, x1, y0, y1)
         const f32x2 aa = {ca, ca}, bb = {sb, sb}, mm = {kMagic, kMagic};
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
+      for (int u = 0; u < kUD; u++) {
         const int j = j0 + u;
         const int outIdx = kout[u];
         if (outIdx < 0) continue;
@@ -304,11 +306,14 @@ void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d
   // patches stay in its 4 MB L2 (HBM fetch 1.17 -> 0.63 GB per 256 frames) -- same-box A/B over the
   // whole pipeline: 291 k -> 303 k frames/s; 3 workgroups per CU measured the same, 2 and 5+ worse.
   constexpr size_t kPad = 23 * 1024;
+  // Round 2 measured the wider form <64, 8, 4> (twice the row / patch loads in flight per wave, 106 VGPRs, same 4
+  // workgroups per CU): stage 3.36 vs 3.38 ms per 4096 VGA frames, pipeline unchanged -- the kernel is not short of
+  // memory-level parallelism (its L2 misses are 3.1 MB per frame = 3.7 TB/s), so <64, 4, 2> stays.
   if (latencyForm)
-    hipLaunchKernelGGL(k_orient_desc<16>, dim3((total + 7u) / 8u * 8u), dim3(256), 0, s, a, d_levelKp, d_levelCount,
+    hipLaunchKernelGGL((k_orient_desc<16, 4, 2>), dim3((total + 7u) / 8u * 8u), dim3(256), 0, s, a, d_levelKp, d_levelCount,
                        d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic);
   else
-    hipLaunchKernelGGL(k_orient_desc<64>, dim3((total + 7u) / 8u * 8u), dim3(256), kPad, s, a, d_levelKp, d_levelCount,
+    hipLaunchKernelGGL((k_orient_desc<64, 4, 2>), dim3((total + 7u) / 8u * 8u), dim3(256), kPad, s, a, d_levelKp, d_levelCount,
                        d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic);
 }
 
