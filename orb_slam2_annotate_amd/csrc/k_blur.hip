@@ -224,9 +224,10 @@ void launch_blur7_levels(hipStream_t s, const LevelView* src, const LevelViewMut
   bb.tileStart[nlevels] = total;
   if (total == 0) return;
   const dim3 grid((total + 7u) / 8u * 8u);
-  if (spec == kBlurSpecCv2Scalar) hipLaunchKernelGGL(k_blur7<1>, grid, dim3(256), 0, s, bb);
-  else if (spec == kBlurSpecCv2Sse2) hipLaunchKernelGGL(k_blur7<2>, grid, dim3(256), 0, s, bb);
-  else hipLaunchKernelGGL(k_blur7<0>, grid, dim3(256), 0, s, bb);
+  static const size_t pad = occupancy_pad_bytes("BLUR", 0);
+  if (spec == kBlurSpecCv2Scalar) hipLaunchKernelGGL(k_blur7<1>, grid, dim3(256), pad, s, bb);
+  else if (spec == kBlurSpecCv2Sse2) hipLaunchKernelGGL(k_blur7<2>, grid, dim3(256), pad, s, bb);
+  else hipLaunchKernelGGL(k_blur7<0>, grid, dim3(256), pad, s, bb);
 }
 
 void launch_blur7(hipStream_t s, LevelView src, LevelViewMut dst, int nFrames, int spec) {

@@ -305,7 +305,7 @@ void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d
   // instead of 9.  All workgroups of a frame run on one XCD; with fewer frames in flight per XCD their
   // patches stay in its 4 MB L2 (HBM fetch 1.17 -> 0.63 GB per 256 frames) -- same-box A/B over the
   // whole pipeline: 291 k -> 303 k frames/s; 3 workgroups per CU measured the same, 2 and 5+ worse.
-  constexpr size_t kPad = 23 * 1024;
+  static const size_t kPad = occupancy_pad_bytes("ORIENT", 23);
   // Round 2 measured the wider form <64, 8, 4> (twice the row / patch loads in flight per wave, 106 VGPRs, same 4
   // workgroups per CU): stage 3.36 vs 3.38 ms per 4096 VGA frames, pipeline unchanged -- the kernel is not short of
   // memory-level parallelism (its L2 misses are 3.1 MB per frame = 3.7 TB/s), so <64, 4, 2> stays.

@@ -425,13 +425,15 @@ size_t octree_lds_bytes(int maxL) {
 
 hipError_t launch_octree(hipStream_t s, const OctreeArgs& a, int nlevels, int nFrames) {
   if (nFrames <= 0) return hipSuccess;
-  const size_t lds = octree_lds_bytes(a.maxL);
+  size_t lds = octree_lds_bytes(a.maxL);
   if (lds > kOctreeLdsLimit) {  // node list in global memory
     if (!a.work || a.workStride < lds) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_octree_global, dim3(nlevels, nFrames), dim3(256), 0, s, a);
     return hipSuccess;
   }
   const bool latencyForm = nFrames <= 8;  // too few workgroups to fill the GPU anyway
+  static const size_t pad = occupancy_pad_bytes("OCTREE", 0);
+  if (!latencyForm && lds + pad <= 64 * 1024) lds += pad;
   static thread_local size_t configured[2] = {0, 0};
   const void* fn = latencyForm ? reinterpret_cast<const void*>(k_octree_reg) : reinterpret_cast<const void*>(k_octree);
   if (lds > 64 * 1024 && lds > configured[latencyForm]) {

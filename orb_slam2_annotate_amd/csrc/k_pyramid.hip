@@ -3,9 +3,22 @@
 // (4 output columns x 8 output rows per thread, flat row-block-major thread numbering);
 // k_resize keeps the older strip form for inputs without packed tables, k_resize_generic serves
 // unaligned pitches and scale factors above 2, k_copy2d realigns caller-owned level-0 images.
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
 #include "kernels.h"
 
 namespace orbfe {
+
+size_t occupancy_pad_bytes(const char* name, int default_kb) {
+  const std::string key = std::string("ORBFE_PAD_") + name;
+  const char* env = getenv(key.c_str());
+  int kb = env ? atoi(env) : default_kb;
+  if (kb < 0) kb = 0;
+  if (kb > 60) kb = 60;  // stays below the 64 KB default limit of dynamic LDS
+  return (size_t)kb * 1024;
+}
 
 namespace {
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -244,11 +257,12 @@ void launch_resize(hipStream_t s, LevelView src, LevelViewMut dst, const int32_t
   if (shape && d_colrec && d_rowrec && total * ngx < (1LL << 32) && total > 0) {
     const uint32_t magic = (uint32_t)((1ULL << 32) / (uint32_t)ngx) + 1u;
     const dim3 grid((unsigned)((total + 255) / 256), nFrames);
+    static const size_t pad = occupancy_pad_bytes("RESIZE", 0);
     if (aligned)
-      hipLaunchKernelGGL(k_resize_flat<false>, grid, dim3(256), 0, s, src, dst, reinterpret_cast<const uint4*>(d_colrec),
+      hipLaunchKernelGGL(k_resize_flat<false>, grid, dim3(256), pad, s, src, dst, reinterpret_cast<const uint4*>(d_colrec),
                          reinterpret_cast<const uint4*>(d_rowrec), ngx, magic, (int)total);
     else  // caller-owned level 0 at an odd stride: byte-aligned dword loads
-      hipLaunchKernelGGL(k_resize_flat<true>, grid, dim3(256), 0, s, src, dst, reinterpret_cast<const uint4*>(d_colrec),
+      hipLaunchKernelGGL(k_resize_flat<true>, grid, dim3(256), pad, s, src, dst, reinterpret_cast<const uint4*>(d_colrec),
                          reinterpret_cast<const uint4*>(d_rowrec), ngx, magic, (int)total);
   } else if (fast) {
     dim3 grid((dst.w + 255) / 256, (dst.h + 4 * kRowsPerThread - 1) / (4 * kRowsPerThread), nFrames);

@@ -21,6 +21,11 @@ inline uint32_t udiv_magic_multiplier(uint32_t d) {
 }
 
 
+// Occupancy caps for the latency-bound kernels: unused dynamic LDS per workgroup, in KB, so that at
+// most 160 / (own + pad) workgroups of the kernel are resident on a CU and the VALU-bound kernels of the other
+// sub-batch streams keep wave slots.  Defaults are the measured optimum; $ORBFE_PAD_<NAME> overrides (A/B sweeps).
+size_t occupancy_pad_bytes(const char* name, int default_kb);
+
 // A pyramid level of a batch of frames in HBM: frame f, row y starts at
 // base + f*frameStride + y*pitch.  Row-major u8, pitch is a multiple of 64 for owned levels.
 struct LevelView {
