@@ -63,6 +63,7 @@ WORKLOADS = {
                        "(synthetic frames, synthetic k=10 L=2 vocabulary)",
                   w=752, h=480, nfeatures=1200, ini=20, mn=7, bow=True, batch=2048),
 }
+SINGLE_SCENE = False  # --single-scene: the round-1 synthetic input (sparser; for continuity with profiles/history/r01_bench.json)
 GPU_STAGES = ["pyramid", "fast", "octree", "blur", "orient_desc", "match"]
 STAGE_KERNELS = {  # kernels (and launches per step) behind each timed stage
     "pyramid": [("k_copy2d", 1), ("k_resize_flat", 7)], "fast": [("k_fast_cells", 1)],
@@ -150,7 +151,10 @@ def _render(names, batches, rank, procs=0):
     tasks, owner = [], []
     for nm in names:
         wl, B = WORKLOADS[nm], batches[nm]
-        if wl.get("stereo"):
+        if SINGLE_SCENE and not wl.get("stereo"):  # round-1 style input: ONE scene for the whole mono batch
+            tasks.append(("seq", 1000 + rank, B, wl["w"], wl["h"]))
+            owner.append(nm)
+        elif wl.get("stereo"):
             for i in range(B):
                 tasks.append(("stereo", 5000 + 100000 * rank + i, 1, wl["w"], wl["h"]))
                 owner.append(nm)
@@ -734,6 +738,8 @@ def main():
                     help="sub-batches on independent streams, or as the three-lane software pipeline (pyramid | FAST+blur | tail)")
     ap.add_argument("--render-procs", type=int, default=0, help="processes rendering the synthetic inputs (0 = auto; 1 = in "
                     "this process, which a run under a GPU-initialising profiler needs)")
+    ap.add_argument("--single-scene", action="store_true", help="mono workloads: render ONE scene for the whole batch, the "
+                    "round-1 input (sparser than the default 64-scene batches); for continuity with the round-1 line")
     ap.add_argument("--input-cache", default=None, help="directory for the rendered synthetic batches (.npy), reused when present")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-in/host-out (PCIe-inclusive) rate of each workload")
     ap.add_argument("--e2e-chunk", type=int, default=0, help="frames per chunk of the pipelined host path (0 = 256)")
@@ -756,7 +762,9 @@ def main():
 
     names = ["kitti", "tum", "euroc"] if args.workload == "all" else (["kitti"] if args.workload == "kitti_seq" else [args.workload])
     batches = {nm: (args.batch if args.batch > 0 else WORKLOADS[nm]["batch"]) for nm in names}
-    inputs = render_inputs(names, batches, rank, args.render_procs, args.input_cache)  # may fork workers: before torch / HIP
+    global SINGLE_SCENE
+    SINGLE_SCENE = args.single_scene
+    inputs = render_inputs(names, batches, rank, args.render_procs, None if args.single_scene else args.input_cache)  # may fork workers: before torch / HIP
 
     import torch
     import torch.distributed as dist
@@ -799,7 +807,7 @@ def main():
                 "value": head["value"], "unit": head["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "u8", "data": "synthetic",
-                "config": {"workload": head["workload"], "units_per_gpu_per_step": head["units_per_gpu_per_step"],
+                "config": {"workload": head["workload"] + (" [single-scene round-1 input]" if args.single_scene else ""), "units_per_gpu_per_step": head["units_per_gpu_per_step"],
                            "images_per_gpu_per_step": head["images_per_gpu_per_step"],
                            "keypoints_per_image": head["keypoints_per_image"],
                            "sharding": f"independent frames, one resident batch per GPU x{world}, no data-path collective"},
