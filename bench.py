@@ -724,7 +724,7 @@ def stub_worker(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0, help="units (frames / stereo pairs) resident per GPU and processed "
                     "per step; 0 = per-workload default (tum 4096, kitti 512, euroc 2048)")

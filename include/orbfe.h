@@ -172,6 +172,13 @@ int orbfe_debug_resize_tables(int sw, int sh, int dw, int dh, int32_t *xofs, int
  * (D2H/H2D round trip) instead of the device kernel.  Off by default; results are identical. */
 int orbfe_extractor_debug_host_octree(orbfe_extractor *e, int enable);
 
+/* Order of the two FAST thresholds inside the grid-stage kernel (src/ORBextractor.cc:874-882): 1 = iniThFAST first and
+ * minThFAST only for the cells that found nothing (the reference's own order; fastest on textured images), 2 = one
+ * attempt at the lower threshold that classifies for both (fastest when most cells fall back: sparse, low-contrast
+ * images), 0 = auto (default; $ORBFE_FAST_MODE=auto|high|low): per call, from the fallback rate the last finished
+ * launch measured.  The results are identical in every mode. */
+int orbfe_extractor_set_fast_mode(orbfe_extractor *e, int mode);
+
 /* How the sub-batches of a device-batch call (orbfe_extractor_set_streams) are scheduled: 0 = one independent HIP
  * stream per sub-batch; 1 ($ORBFE_LANES) = three lanes shared by all sub-batches -- pyramid | FAST + blur |
  * gather + octree + orientation/descriptors -- ordered by events into a software pipeline, so that exactly one

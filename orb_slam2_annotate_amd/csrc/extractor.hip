@@ -85,6 +85,15 @@ struct orbfe_extractor {
   // 291.8 k frames/s -- FAST already runs at the VALU issue ceiling, so the blur's instructions cost their full price
   // inside it; off by default, selectable ($ORBFE_FUSED=1 / orbfe_extractor_set_fused) and parity-tested
   bool fused = false;
+  // FAST threshold order (k_fast_cells<.., kLowFirst>): 0 = auto (picked per call from the fallback rate the last
+  // finished launch measured), 1 = iniThFAST first + per-cell fallback, 2 = one attempt at the lower threshold
+  int fastMode = 0;
+  bool fastLowFirst = false;                 // current choice in auto mode
+  unsigned int* d_fastStat = nullptr;        // per sub-batch: cells that needed minThFAST
+  unsigned int* h_fastStat = nullptr;        // pinned copy
+  hipEvent_t evStat[kMaxStreams] = {};
+  bool statPending[kMaxStreams] = {};
+  double statCells[kMaxStreams] = {};
   bool copyUnaligned = false;  // debug: repack caller-owned frames with an odd stride first (round-1 behaviour)
   int blurSpec = kBlurSpecCv4;  // GaussianBlur arithmetic, orbfe_extractor_set_blur_spec / $ORBFE_BLUR_SPEC
   int octreeMaxL = 0;
@@ -441,9 +450,35 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
   const bool blurFirst = !lanes && !fused && (sub & 1) != 0;  // measured +1.7 % frames/s (A/B on one box, 4 runs each)
   if (blurFirst) do_blur();
   {  // FAST grid stage, :846-896; fused: the same wavefronts also write the blurred level (:1169-1175)
-    StageTimer t(e, ORBFE_STAGE_FAST, 1, nFrames, sub, sV);
-    launch_fast_cells(sV, pyr, e->d_cells, nCells, nFrames, e->tab.iniThFAST, e->tab.minThFAST, slots,
-                      g.totalSlots, cellCount, g.maxCellW, g.maxCellH, fused ? &blur : nullptr, (int)g.cells.size());
+    // threshold order: results are identical either way; auto follows the fallback rate of the launches that have
+    // finished (hysteresis 0.40 / 0.50), so the choice lags the content by a call or two -- speed only
+    if (e->fastMode == 0) {
+      for (int i = 0; i < orbfe_extractor::kMaxStreams; i++)
+        if (e->statPending[i] && hipEventQuery(e->evStat[i]) == hipSuccess) {
+          e->statPending[i] = false;
+          const double rate = e->statCells[i] > 0 ? (double)e->h_fastStat[i] / e->statCells[i] : 0.0;
+          if (rate > 0.50) e->fastLowFirst = true;
+          else if (rate < 0.40) e->fastLowFirst = false;
+        }
+      (void)hipGetLastError();  // hipEventQuery's hipErrorNotReady is not an error
+    }
+    const bool lowFirst = e->fastMode == 2 || (e->fastMode == 0 && e->fastLowFirst);
+    unsigned int* stat = nullptr;
+    if (e->fastMode == 0 && sub >= 0 && sub < orbfe_extractor::kMaxStreams && !e->statPending[sub]) {
+      stat = e->d_fastStat + sub;
+      HIPCHK(hipMemsetAsync(stat, 0, sizeof(unsigned int), sV));
+    }
+    {
+      StageTimer t(e, ORBFE_STAGE_FAST, 1, nFrames, sub, sV);
+      launch_fast_cells(sV, pyr, e->d_cells, nCells, nFrames, e->tab.iniThFAST, e->tab.minThFAST, slots, g.totalSlots,
+                        cellCount, g.maxCellW, g.maxCellH, fused ? &blur : nullptr, (int)g.cells.size(), lowFirst, stat);
+    }
+    if (stat) {
+      HIPCHK(hipMemcpyAsync(e->h_fastStat + sub, stat, sizeof(unsigned int), hipMemcpyDeviceToHost, sV));
+      HIPCHK(hipEventRecord(e->evStat[sub], sV));
+      e->statPending[sub] = true;
+      e->statCells[sub] = (double)nCells * nFrames;
+    }
   }
   if (lanes) {  // the tail lane starts on the candidates while the VALU lane goes on with the blur
     HIPCHK(hipEventRecord(e->evFast[sub], sV));
@@ -594,6 +629,13 @@ extern "C" int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlev
   for (int i = 0; i < orbfe_extractor::kMaxStreams - 1 && err == hipSuccess; i++)
     err = hipStreamCreateWithFlags(&e->extra[i], hipStreamNonBlocking);
   if (const char* env = getenv("ORBFE_COPY_UNALIGNED")) e->copyUnaligned = atoi(env) != 0;
+  if (const char* env = getenv("ORBFE_FAST_MODE")) {
+    const std::string v(env);
+    e->fastMode = v == "high" ? 1 : (v == "low" ? 2 : 0);
+  }
+  if (err == hipSuccess) err = hipMalloc((void**)&e->d_fastStat, sizeof(unsigned int) * orbfe_extractor::kMaxStreams);
+  if (err == hipSuccess) err = hipHostMalloc((void**)&e->h_fastStat, sizeof(unsigned int) * orbfe_extractor::kMaxStreams, hipHostMallocDefault);
+  for (int i = 0; i < orbfe_extractor::kMaxStreams && err == hipSuccess; i++) err = hipEventCreateWithFlags(&e->evStat[i], hipEventDisableTiming);
   if (const char* env = getenv("ORBFE_LANES")) e->laneMode = atoi(env) != 0;
   if (const char* env = getenv("ORBFE_FUSED")) e->fused = atoi(env) != 0;
   if (const char* env = getenv("ORBFE_BLUR_SPEC")) {
@@ -657,6 +699,10 @@ extern "C" void orbfe_extractor_destroy(orbfe_extractor* e) {
   free_workspace(e);
   free_outputs(e);
   if (e->h_outStage) (void)hipHostFree(e->h_outStage);
+  if (e->h_fastStat) (void)hipHostFree(e->h_fastStat);
+  dfree(&e->d_fastStat);
+  for (int i = 0; i < orbfe_extractor::kMaxStreams; i++)
+    if (e->evStat[i]) (void)hipEventDestroy(e->evStat[i]);
   for (int i = 0; i < 2; i++) {
     dfree(&e->d_pipeIn[i]);
     dfree(&e->d_pipeOut[i]);
@@ -776,6 +822,10 @@ extern "C" int orbfe_extract_batch_device(orbfe_extractor* e, const uint8_t* d_i
   return orbfe_extractor_synchronize(e);
 }
 
+extern "C" int orbfe_extract_batch_pipelined(orbfe_extractor* e, const uint8_t* images, int n_frames, int width, int height,
+                                             int stride, size_t frame_stride, orbfe_keypoint* keypoints,
+                                             uint8_t* descriptors, int capacity, int* n_out, int chunk_frames);
+
 extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* images, int n_frames, int width,
                                    int height, int stride, size_t frame_stride,
                                    orbfe_keypoint* keypoints, uint8_t* descriptors, int capacity,
@@ -786,6 +836,11 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* images, in
   if (!images || width <= 0 || height <= 0) return ORBFE_OK;  // empty image: silent return (:1122)
   if (!keypoints || !descriptors || capacity <= 0 || stride < width)
     return fail(ORBFE_ERR_INVALID, "extract_batch: bad output buffers");
+  if (n_frames > 16 && !e->hostOctree && frame_stride >= (size_t)stride * (height - 1) + width)
+    // a real batch: chunked H2D / kernels / D2H overlapped on separate streams (the buffers are page-locked for the
+    // call when they are not pinned already) instead of upload-all, compute, download-all
+    return orbfe_extract_batch_pipelined(e, images, n_frames, width, height, stride, frame_stride, keypoints, descriptors,
+                                         capacity, n_out, 0);
   HIPCHK(hipSetDevice(e->device));
   int rc;
   if ((rc = sync_all(e))) return rc;  // an earlier asynchronous call may still use the workspace
@@ -1201,6 +1256,17 @@ extern "C" int orbfe_extractor_consumer_end_(orbfe_extractor* e) {
 extern "C" int orbfe_extractor_debug_host_octree(orbfe_extractor* e, int enable) {
   if (!e) return fail(ORBFE_ERR_INVALID, "NULL handle");
   e->hostOctree = enable != 0;
+  return ORBFE_OK;
+}
+
+// FAST threshold order: 0 = auto, 1 = iniThFAST first with per-cell fallback, 2 = one attempt at the lower threshold.
+extern "C" int orbfe_extractor_set_fast_mode(orbfe_extractor* e, int mode) {
+  if (!e || mode < 0 || mode > 2) return fail(ORBFE_ERR_INVALID, "set_fast_mode: 0 (auto), 1 (high first) or 2 (low first)");
+  HIPCHK(hipSetDevice(e->device));
+  int rc = sync_all(e);
+  if (rc) return rc;
+  e->fastMode = mode;
+  for (int i = 0; i < orbfe_extractor::kMaxStreams; i++) e->statPending[i] = false;
   return ORBFE_OK;
 }
 

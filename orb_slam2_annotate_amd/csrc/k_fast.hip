@@ -99,7 +99,12 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b)
 //   D. per-cell 20->7 fallback, then ordered compaction of the survivors = emission order.
 // Dynamic LDS: tile [tileRows][24 dw] | score [scoreRows][24 dw] | queue [queueLen] u16, sized by
 // the largest cell of the frame geometry.
-template <int kPitchDw, bool kBlur>
+// kLowFirst: ONE attempt at min(iniThFAST, minThFAST) that classifies the survivors for both thresholds (round 1's
+// form) instead of iniThFAST first + per-cell fallback.  Same results; which is faster depends on the image: on
+// textured frames few cells need the fallback and the first form lists far fewer pixels for the exact score (-15 %);
+// on sparse, low-contrast frames most cells fall back and pay the pre-test twice (+12 %).  The extractor picks per
+// call from the fallback rate the previous call measured (fallbackStat; extractor.hip).
+template <int kPitchDw, bool kBlur, bool kLowFirst>
 __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
                                                    const CellDesc* __restrict__ cells,
                                                    int nCells, int nFrames, int iniTh, int minTh,
@@ -107,7 +112,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
                                                    int slotsPerFrame,
                                                    uint16_t* __restrict__ cellCount,
                                                    int tileRows, int scoreRows, uint32_t cellsMagic,
-                                                   PyramidViews blurOut, int nFastCells) {
+                                                   PyramidViews blurOut, int nFastCells,
+                                                   unsigned int* __restrict__ fallbackStat) {
   extern __shared__ uint32_t lds[];
   uint32_t* tile = lds;                                   // pixels: origin (x0-4, y0-3)
   uint32_t* score = lds + tileRows * kPitchDw;            // FAST responses: origin (x0-4, y0-1)
@@ -220,7 +226,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
   // first -- its pre-test passes far fewer pixels than the one at minThFAST (7 is inside the image noise) -- and
   // the wave-uniform fallback repeats them at minThFAST for the cells that kept no corner.
   int nc = 0;      // wave-uniform: corners in the list after phase B
-  int tcur = iniTh;
+  int tcur = kLowFirst ? (iniTh < minTh ? iniTh : minTh) : iniTh;
+  int useHigh = 1, fellBack = 0;  // wave-uniform
   for (int attempt = 0; attempt < 2; attempt++) {
   // ---- A: cardinal-pair test at the current threshold; ordered work list.  A lane owns 8 adjacent
   //      pixels (two tile dwords); list positions come from a DPP inclusive scan of the lane counts ----
@@ -328,8 +335,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
   }
   __syncthreads();
 
-  // ---- C: cell-local 3x3 strict NMS, one lane per corner; survivors get bit 15 of the list entry.  Every listed
-  //      corner has S > tcur, i.e. response S-1 >= tcur: what cv::FAST(cell, tcur) keeps after NMS ----
+  // ---- C: cell-local 3x3 strict NMS, one lane per corner.  Two-attempt form: survivors get bit 15 of the list entry
+  //      (every listed corner has S > tcur, i.e. response S-1 >= tcur: what cv::FAST(cell, tcur) keeps after NMS).
+  //      kLowFirst: classes in bits 14 (>= minThFAST) and 15 (>= iniThFAST), the fallback is decided afterwards ----
   const uint8_t* sbytes = reinterpret_cast<const uint8_t*>(score);
   int anyKept = 0;
   for (int q = lane; q < nc; q += 64) {
@@ -337,19 +345,28 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
     const uint8_t* c = sbytes + ((e >> 8) + 1) * P + 4 + (e & 255);
     const int v = c[0];
     const int nb = max3i(max3i(c[-P - 1], c[-P], c[-P + 1]), max3i(c[-1], c[1], c[P - 1]), max(c[P], c[P + 1]));
-    const int keep = v > nb;
-    queue[q] = (uint16_t)(e | (keep << 15));
-    anyKept |= keep;
+    int flags;
+    if (kLowFirst) flags = v > nb ? (((v >= minTh) << 14) | ((v >= iniTh) << 15)) : 0;
+    else flags = (v > nb) << 15;
+    queue[q] = (uint16_t)(e | flags);
+    anyKept |= flags >> 15;
   }
   const int found = __ballot(anyKept) != 0ull;
   __syncthreads();
+  if (kLowFirst) {  // per-cell threshold fallback (:874-882): corners >= iniThFAST if any survived NMS, else >= minThFAST
+    useHigh = found;
+    fellBack = !found;
+    break;
+  }
   if (found || attempt == 1) break;
   tcur = minTh;  // :880: nothing survived at iniThFAST
+  fellBack = 1;
   }  // attempt
+  if (fallbackStat && fellBack && lane == 0) atomicAdd(fallbackStat, 1u);  // cells that needed minThFAST (scheduling hint only)
 
   // ---- D: ordered compaction of the survivors (the list is in raster order, :884-893) ----
   Candidate* out = slots + (size_t)f * slotsPerFrame + cd.slotBase;
-  const int bit = 0x8000;
+  const int bit = (kLowFirst && !useHigh) ? 0x4000 : 0x8000;
   const uint8_t* sbytes = reinterpret_cast<const uint8_t*>(score);
   int run = 0;  // wave-uniform
   for (int q0 = 0; q0 < nc; q0 += 64) {
@@ -453,7 +470,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
 void launch_fast_cells(hipStream_t s, PyramidViews pyr, const CellDesc* d_cells, int nCells,
                        int nFrames, int iniTh, int minTh, Candidate* d_slots, int slotsPerFrame,
                        uint16_t* d_cellCount, int maxCellW, int maxCellH, const PyramidViews* blurOut,
-                       int nCellsAll) {
+                       int nCellsAll, bool lowFirst, unsigned int* d_fallbackStat) {
   // blurOut != NULL: the fused FAST+blur form over all nCellsAll cells (FAST cells first, then blur-only frame
   // cells); NULL: FAST only over the nCells detection cells
   const int nWork = blurOut ? nCellsAll : nCells;
@@ -476,18 +493,23 @@ void launch_fast_cells(hipStream_t s, PyramidViews pyr, const CellDesc* d_cells,
   const dim3 grid((total + 7u) / 8u * 8u);
   const uint32_t magic = udiv_magic_multiplier((uint32_t)nWork);
   PyramidViews bo = blurOut ? *blurOut : PyramidViews{};
-#define ORBFE_LAUNCH_FAST(P, B)                                                                                     \
-  hipLaunchKernelGGL((k_fast_cells<P, B>), grid, dim3(64), ldsBytes, s, pyr, d_cells, nWork, nFrames, iniTh, minTh, \
-                     d_slots, slotsPerFrame, d_cellCount, tileRows, scoreRows, magic, bo, nCells)
+#define ORBFE_LAUNCH_FAST(P, B, L)                                                                                     \
+  hipLaunchKernelGGL((k_fast_cells<P, B, L>), grid, dim3(64), ldsBytes, s, pyr, d_cells, nWork, nFrames, iniTh, minTh, \
+                     d_slots, slotsPerFrame, d_cellCount, tileRows, scoreRows, magic, bo, nCells, d_fallbackStat)
+#define ORBFE_LAUNCH_FAST_P(B, L)            \
+  do {                                       \
+    if (pitch == 12) ORBFE_LAUNCH_FAST(12, B, L);      \
+    else if (pitch == 16) ORBFE_LAUNCH_FAST(16, B, L); \
+    else ORBFE_LAUNCH_FAST(24, B, L);                  \
+  } while (0)
   if (blurOut) {
-    if (pitch == 12) ORBFE_LAUNCH_FAST(12, true);
-    else if (pitch == 16) ORBFE_LAUNCH_FAST(16, true);
-    else ORBFE_LAUNCH_FAST(24, true);
+    if (lowFirst) ORBFE_LAUNCH_FAST_P(true, true);
+    else ORBFE_LAUNCH_FAST_P(true, false);
   } else {
-    if (pitch == 12) ORBFE_LAUNCH_FAST(12, false);
-    else if (pitch == 16) ORBFE_LAUNCH_FAST(16, false);
-    else ORBFE_LAUNCH_FAST(24, false);
+    if (lowFirst) ORBFE_LAUNCH_FAST_P(false, true);
+    else ORBFE_LAUNCH_FAST_P(false, false);
   }
+#undef ORBFE_LAUNCH_FAST_P
 #undef ORBFE_LAUNCH_FAST
 }
 

@@ -70,7 +70,7 @@ void launch_copy2d(hipStream_t s, LevelView src, LevelViewMut dst, int nFrames);
 void launch_fast_cells(hipStream_t s, PyramidViews pyr, const CellDesc* d_cells, int nCells,
                        int nFrames, int iniTh, int minTh, Candidate* d_slots, int slotsPerFrame,
                        uint16_t* d_cellCount, int maxCellW, int maxCellH, const PyramidViews* blurOut = nullptr,
-                       int nCellsAll = 0);
+                       int nCellsAll = 0, bool lowFirst = false, unsigned int* d_fallbackStat = nullptr);
 // ordered compaction of the per-cell slots of each (frame, level) into d_cand
 void launch_gather_candidates(hipStream_t s, const CellDesc* d_cells, const LevelGeom* d_lv,
                               int nlevels, int nFrames, const Candidate* d_slots,

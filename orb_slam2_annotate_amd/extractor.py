@@ -234,6 +234,11 @@ class ORBextractor:
         """Sub-batches on independent streams (False) or as a three-lane software pipeline (True); same results."""
         check(self._L.orbfe_extractor_set_schedule(self._h, int(bool(lanes))))
 
+    def set_fast_mode(self, mode):
+        """FAST threshold order: 'auto' (default), 'high' (iniThFAST first, per-cell fallback) or 'low' (one attempt
+        at the lower threshold); identical results, different speed depending on the image content."""
+        check(self._L.orbfe_extractor_set_fast_mode(self._h, {"auto": 0, "high": 1, "low": 2}.get(mode, mode)))
+
     def set_blur_spec(self, spec: int):
         """0: OpenCV >= 3.4.1/4.x GaussianBlur arithmetic (default); 1: OpenCV 2.4/3.0-3.3 scalar path;
         2: the same with the SSE2 column pass (include/orbfe.h ORBFE_BLUR_*)."""

@@ -468,3 +468,59 @@ def test_lane_schedule_equals_oracle_across_back_to_back_calls(amd, subs):
     for (kr, dr), (kg, dg) in zip(ref, e.extract_batch(frames)):
         _kp_equal(kr, kg)
         assert np.array_equal(dr, dg)
+
+
+@pytest.mark.parametrize("mode", ["high", "low", "auto"])
+def test_fast_threshold_order_modes_are_equivalent(amd, mode):
+    """iniThFAST first with per-cell fallback, one attempt at the lower threshold, or the automatic choice: the grid
+    stage must emit the reference's candidates either way -- textured frames (few fallbacks), low-contrast frames (most
+    cells fall back), frames where nothing passes, reversed thresholds (iniTh < minTh), and a batch whose content
+    flips from call to call so that the automatic mode really switches."""
+    low = np.clip(synth.render_frame(3, 640, 480).astype(np.int32) // 6 + 100, 0, 255).astype(np.uint8)  # contrast / 6
+    y, x = np.mgrid[0:240, 0:320]
+    ramp = ((x * 0.3 + y * 0.2) % 256).astype(np.uint8)
+    for img, params in ((synth.render_frame(5, 640, 480), (1000, 1.2, 8, 20, 7)), (low, (1000, 1.2, 8, 20, 7)),
+                        (ramp, (500, 1.2, 6, 20, 7)), (synth.render_frame(6, 320, 240), (500, 1.2, 8, 7, 20)),
+                        (synth.render_frame(7, 320, 240), (500, 1.2, 8, 12, 12))):
+        nf, sf, nl, ini, mn = params
+        o = orc.Oracle(*params)
+        kr, dr, pyr = o.extract(img, want_pyramid=True)
+        e = amd.ORBextractor(*params)
+        e.set_fast_mode(mode)
+        kps, desc = e(img)
+        h, w = img.shape
+        for l, ref in enumerate(o.split_pyramid(pyr, w, h)):
+            xr, yr, rr = orc.grid_candidates(o, ref)
+            xg, yg, rg = e.debug_candidates(l)
+            assert np.array_equal(xr, xg) and np.array_equal(yr, yg) and np.array_equal(rr, rg), f"candidates level {l}"
+        _kp_equal(kr, kps)
+        assert np.array_equal(dr, desc)
+    # alternating content on one handle, asynchronous device batches (auto mode reads the statistic of finished launches)
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    tex = np.stack([synth.render_frame(20 + i, 640, 480) for i in range(6)])
+    flat = np.stack([np.clip(f.astype(np.int32) // 8 + 90, 0, 255).astype(np.uint8) for f in tex])
+    e = amd.ORBextractor(1000, 1.2, 8, 20, 7)
+    e.set_fast_mode(mode)
+    e.set_streams(2)
+    cap = e.max_keypoints(640, 480)
+    o = orc.Oracle(1000, 1.2, 8, 20, 7)
+    bufs = []
+    for rep in range(3):
+        for imgs in (tex, flat):
+            d_img = torch.from_numpy(imgs).to(dev)
+            d_kp = torch.zeros((6, cap, 7), dtype=torch.float32, device=dev)
+            d_desc = torch.zeros((6, cap, 32), dtype=torch.uint8, device=dev)
+            d_n = torch.zeros((6,), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            e.extract_batch_device(d_img.data_ptr(), 6, 640, 480, 640, 640 * 480, d_kp.data_ptr(), d_desc.data_ptr(), cap,
+                                   d_n.data_ptr(), wait=False)
+            bufs.append((imgs, d_img, d_kp, d_desc, d_n))
+    e.synchronize()
+    refs = {id(tex): [o.extract(f) for f in tex], id(flat): [o.extract(f) for f in flat]}
+    for imgs, _, d_kp, d_desc, d_n in bufs:
+        for f, (kr, dr) in enumerate(refs[id(imgs)]):
+            n = int(d_n[f].item())
+            assert n == len(kr)
+            assert np.array_equal(d_kp[f, :n].cpu().numpy().view(np.uint8).reshape(-1, 28), kr.view(np.uint8).reshape(-1, 28))
+            assert np.array_equal(d_desc[f, :n].cpu().numpy(), dr)

@@ -62,12 +62,14 @@ def main():
         # round-2 knobs: GaussianBlur arithmetic variant, blur fused into the FAST kernel, lane schedule, host path
         spec = int(rng.choice([0, 0, 1, 2]))
         fused, lanes, piped = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
-        knobs = dict(spec=spec, fused=fused, lanes=lanes, pipelined=piped)
+        fmode = str(rng.choice(["auto", "high", "low"]))
+        knobs = dict(spec=spec, fused=fused, lanes=lanes, pipelined=piped, fast=fmode)
         try:
             o = orc.Oracle(*params, blur_spec=spec)
             e = amd.ORBextractor(*params)
             e.set_blur_spec(spec)
             e.set_fused(fused)
+            e.set_fast_mode(fmode)
             if batch_mode:
                 w, h = min(w, 500), min(h, 400)
                 imgs = np.stack([content(rng, w, h) for _ in range(int(rng.integers(9, 25)))])
