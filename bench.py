@@ -740,6 +740,9 @@ def main():
                     "this process, which a run under a GPU-initialising profiler needs)")
     ap.add_argument("--single-scene", action="store_true", help="mono workloads: render ONE scene for the whole batch, the "
                     "round-1 input (sparser than the default 64-scene batches); for continuity with the round-1 line")
+    ap.add_argument("--dataset", default=os.environ.get("ORBFE_DATASET"), help="real frames for one workload: kitti:<sequence dir> | "
+                    "euroc:<cam0 dir>,<cam1 dir>,<timestamps file> | tum:<sequence dir> (image lists as the reference's example mains "
+                    "read them, orb_slam2_annotate_amd/datasets.py); default: $ORBFE_DATASET, else synthetic")
     ap.add_argument("--input-cache", default=None, help="directory for the rendered synthetic batches (.npy), reused when present")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-in/host-out (PCIe-inclusive) rate of each workload")
     ap.add_argument("--e2e-chunk", type=int, default=0, help="frames per chunk of the pipelined host path (0 = 256)")
@@ -764,7 +767,23 @@ def main():
     batches = {nm: (args.batch if args.batch > 0 else WORKLOADS[nm]["batch"]) for nm in names}
     global SINGLE_SCENE
     SINGLE_SCENE = args.single_scene
-    inputs = render_inputs(names, batches, rank, args.render_procs, None if args.single_scene else args.input_cache)  # may fork workers: before torch / HIP
+    inputs = render_inputs(names, batches, rank, args.render_procs, None if args.single_scene else args.input_cache)
+    data_tag = "synthetic"
+    if args.dataset:  # real frames for the one workload whose layout the spec names (kitti | euroc | tum)
+        from orb_slam2_annotate_amd import datasets
+        kind = args.dataset.partition(":")[0]
+        if kind not in names:
+            raise SystemExit(f"--dataset {kind}:... needs --workload {kind} (or all)")
+        B = batches[kind]
+        wl = WORKLOADS[kind]
+        _, fr = datasets.load_frames(args.dataset, B, device=local_rank)
+        if kind == "euroc":
+            fr = fr[0::2]  # the euroc workload (configs[3]) is the left stream: extract + SearchByBoW(t-1, t)
+        bad = [f.shape for f in fr if f.shape != (wl["h"], wl["w"])]
+        if bad:
+            raise SystemExit(f"--dataset: frames of {bad[0][1]}x{bad[0][0]}, the {kind} workload is {wl['w']}x{wl['h']}")
+        inputs[kind] = fr
+        data_tag = f"synthetic, except {kind}: {args.dataset}"  # may fork workers: before torch / HIP
 
     import torch
     import torch.distributed as dist
@@ -806,7 +825,7 @@ def main():
                 "metric": "ORB extract+match frames/sec (kp/desc/matches bit-exact vs CPU oracle on the checked frames of every run)",
                 "value": head["value"], "unit": head["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "u8", "data": "synthetic",
+                "dtype": "u8", "data": data_tag,
                 "config": {"workload": head["workload"] + (" [single-scene round-1 input]" if args.single_scene else ""), "units_per_gpu_per_step": head["units_per_gpu_per_step"],
                            "images_per_gpu_per_step": head["images_per_gpu_per_step"],
                            "keypoints_per_image": head["keypoints_per_image"],

@@ -89,7 +89,8 @@ struct orbfe_extractor {
   // finished launch measured), 1 = iniThFAST first + per-cell fallback, 2 = one attempt at the lower threshold
   int fastMode = 0;
   bool fastLowFirst = false;                 // current choice in auto mode
-  unsigned int* d_fastStat = nullptr;        // per sub-batch: cells that needed minThFAST
+  static constexpr int kStatSlots = 64;       // counters per sub-batch (k_fast_cells spreads its sampled reports over them)
+  unsigned int* d_fastStat = nullptr;        // per sub-batch: sampled count of cells that needed minThFAST
   unsigned int* h_fastStat = nullptr;        // pinned copy
   hipEvent_t evStat[kMaxStreams] = {};
   bool statPending[kMaxStreams] = {};
@@ -456,7 +457,9 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
       for (int i = 0; i < orbfe_extractor::kMaxStreams; i++)
         if (e->statPending[i] && hipEventQuery(e->evStat[i]) == hipSuccess) {
           e->statPending[i] = false;
-          const double rate = e->statCells[i] > 0 ? (double)e->h_fastStat[i] / e->statCells[i] : 0.0;
+          double hits = 0;
+          for (int k = 0; k < orbfe_extractor::kStatSlots; k++) hits += e->h_fastStat[i * orbfe_extractor::kStatSlots + k];
+          const double rate = e->statCells[i] > 0 ? 8.0 * hits / e->statCells[i] : 0.0;  // every 8th cell reports
           if (rate > 0.50) e->fastLowFirst = true;
           else if (rate < 0.40) e->fastLowFirst = false;
         }
@@ -465,8 +468,8 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
     const bool lowFirst = e->fastMode == 2 || (e->fastMode == 0 && e->fastLowFirst);
     unsigned int* stat = nullptr;
     if (e->fastMode == 0 && sub >= 0 && sub < orbfe_extractor::kMaxStreams && !e->statPending[sub]) {
-      stat = e->d_fastStat + sub;
-      HIPCHK(hipMemsetAsync(stat, 0, sizeof(unsigned int), sV));
+      stat = e->d_fastStat + sub * orbfe_extractor::kStatSlots;
+      HIPCHK(hipMemsetAsync(stat, 0, sizeof(unsigned int) * orbfe_extractor::kStatSlots, sV));
     }
     {
       StageTimer t(e, ORBFE_STAGE_FAST, 1, nFrames, sub, sV);
@@ -474,7 +477,8 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
                         cellCount, g.maxCellW, g.maxCellH, fused ? &blur : nullptr, (int)g.cells.size(), lowFirst, stat);
     }
     if (stat) {
-      HIPCHK(hipMemcpyAsync(e->h_fastStat + sub, stat, sizeof(unsigned int), hipMemcpyDeviceToHost, sV));
+      HIPCHK(hipMemcpyAsync(e->h_fastStat + sub * orbfe_extractor::kStatSlots, stat, sizeof(unsigned int) * orbfe_extractor::kStatSlots,
+                            hipMemcpyDeviceToHost, sV));
       HIPCHK(hipEventRecord(e->evStat[sub], sV));
       e->statPending[sub] = true;
       e->statCells[sub] = (double)nCells * nFrames;
@@ -633,8 +637,9 @@ extern "C" int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlev
     const std::string v(env);
     e->fastMode = v == "high" ? 1 : (v == "low" ? 2 : 0);
   }
-  if (err == hipSuccess) err = hipMalloc((void**)&e->d_fastStat, sizeof(unsigned int) * orbfe_extractor::kMaxStreams);
-  if (err == hipSuccess) err = hipHostMalloc((void**)&e->h_fastStat, sizeof(unsigned int) * orbfe_extractor::kMaxStreams, hipHostMallocDefault);
+  if (err == hipSuccess) err = hipMalloc((void**)&e->d_fastStat, sizeof(unsigned int) * orbfe_extractor::kMaxStreams * orbfe_extractor::kStatSlots);
+  if (err == hipSuccess)
+    err = hipHostMalloc((void**)&e->h_fastStat, sizeof(unsigned int) * orbfe_extractor::kMaxStreams * orbfe_extractor::kStatSlots, hipHostMallocDefault);
   for (int i = 0; i < orbfe_extractor::kMaxStreams && err == hipSuccess; i++) err = hipEventCreateWithFlags(&e->evStat[i], hipEventDisableTiming);
   if (const char* env = getenv("ORBFE_LANES")) e->laneMode = atoi(env) != 0;
   if (const char* env = getenv("ORBFE_FUSED")) e->fused = atoi(env) != 0;
