@@ -1257,6 +1257,35 @@ extern "C" int orbfe_extractor_consumer_end_(orbfe_extractor* e) {
   return ORBFE_OK;
 }
 
+// internal (vocabulary.hip): how the last extract call was split, so that a batched matcher can work per sub-batch on
+// the sub-batch's own stream.  streams / chunkDone: kMaxStreams entries.
+extern "C" int orbfe_extractor_split_(orbfe_extractor* e, int* S, int* per, int* frames, int* lanes, hipStream_t* streams,
+                                      hipEvent_t* chunkDone) {
+  if (!e) return fail(ORBFE_ERR_INVALID, "NULL handle");
+  HIPCHK(hipSetDevice(e->device));
+  *S = e->haveLast ? e->lastS : 0;
+  *per = e->lastPer;
+  *frames = e->lastFrames;
+  *lanes = e->lastLanes ? 1 : 0;
+  for (int i = 0; i < orbfe_extractor::kMaxStreams; i++) {
+    streams[i] = i == 0 ? e->stream : e->extra[i - 1];
+    chunkDone[i] = e->evChunkDone[i];
+  }
+  return ORBFE_OK;
+}
+// internal: stage-timer marks for work another translation unit enqueues on a sub-batch stream
+extern "C" void orbfe_extractor_stage_mark_(orbfe_extractor* e, int stage, int sub, int isEnd, hipStream_t s, int frames) {
+  if (!e || sub < 0 || sub >= orbfe_extractor::kEvSubs || !((e->stageMask >> stage) & 1u)) return;
+  if (!isEnd) {
+    (void)hipEventRecord(e->evA[e->evSlot][sub][stage], s);
+    e->evLaunches[e->evSlot][sub][stage] = 1;
+    e->evFrames[e->evSlot][sub][stage] = frames;
+  } else {
+    (void)hipEventRecord(e->evB[e->evSlot][sub][stage], s);
+    e->evUsed[e->evSlot][sub][stage] = true;
+  }
+}
+
 // Debug: route DistributeOctTree through the host implementation (cross-check of k_octree).
 extern "C" int orbfe_extractor_debug_host_octree(orbfe_extractor* e, int enable) {
   if (!e) return fail(ORBFE_ERR_INVALID, "NULL handle");

@@ -45,6 +45,8 @@ struct orbfe_vocabulary {
   int8_t* w_bin = nullptr;
   size_t wFrames = 0; int wCap = 0;
   hipStream_t lastStream = nullptr;  // stream of the last batched call (its workspace may still be in use there)
+  hipEvent_t evFv[8] = {}, evBoundary[8] = {};  // per sub-batch: FeatureVectors built / boundary pair searched
+  orbfe_extractor* lastMulti = nullptr;  // extractor whose sub-batch streams ran the last per-sub-batch call
 };
 
 namespace {
@@ -187,6 +189,10 @@ static void vocab_free_device(orbfe_vocabulary* v) {
   if (v->w_indices) (void)hipFree(v->w_indices);
   if (v->w_count) (void)hipFree(v->w_count);
   if (v->w_bin) (void)hipFree(v->w_bin);
+  for (int i = 0; i < 8; i++) {
+    if (v->evFv[i]) (void)hipEventDestroy(v->evFv[i]);
+    if (v->evBoundary[i]) (void)hipEventDestroy(v->evBoundary[i]);
+  }
   if (v->stream) (void)hipStreamDestroy(v->stream);
 }
 
@@ -370,6 +376,9 @@ extern "C" int orbfe_vocabulary_featvec_batch_device(orbfe_vocabulary* v, const 
 // F = frame t)  (src/Tracking.cc:836-843, src/ORBmatcher.cc:185-325).
 extern "C" int orbfe_extractor_consumer_begin_(orbfe_extractor* e, hipStream_t* s);
 extern "C" int orbfe_extractor_consumer_end_(orbfe_extractor* e);
+extern "C" int orbfe_extractor_split_(orbfe_extractor* e, int* S, int* per, int* frames, int* lanes, hipStream_t* streams,
+                                      hipEvent_t* chunkDone);
+extern "C" void orbfe_extractor_stage_mark_(orbfe_extractor* e, int stage, int sub, int isEnd, hipStream_t s, int frames);
 
 // e != NULL: enqueue on the extractor's stream, ordered behind every sub-batch of its last extract call, and
 // return without waiting (orbfe_extractor_synchronize() to wait); e == NULL: the vocabulary's own stream, waits.
@@ -384,11 +393,86 @@ static int bow_match_consecutive(orbfe_vocabulary* v, orbfe_extractor* e, int n_
   const int sortN = next_pow2(capacity);
   if ((size_t)sortN * 8 > 64 * 1024) return vfail(ORBFE_ERR_INVALID, "bow_match_consecutive_batch_device: capacity > 8192");
   VHIP(hipSetDevice(v->device));
-  if ((size_t)n_frames > v->wFrames || capacity > v->wCap) {
-    if (v->lastStream) VHIP(hipStreamSynchronize(v->lastStream));  // the workspace may still be in use there
+  int rc;
+  if ((size_t)n_frames > v->wFrames || capacity > v->wCap || (v->lastMulti && v->lastMulti != e)) {
+    // the workspace may still be in use on the streams of the previous call
+    if (v->lastStream) VHIP(hipStreamSynchronize(v->lastStream));
+    if (v->lastMulti && (rc = orbfe_extractor_synchronize(v->lastMulti))) return rc;
+    v->lastMulti = nullptr;
   }
-  int rc = ensure_bow_workspace(v, n_frames, capacity);
+  rc = ensure_bow_workspace(v, n_frames, capacity);
   if (rc) return rc;
+  FeatVecBatch fb = {};
+  fb.desc = d_descriptors; fb.n = d_n; fb.capacity = capacity; fb.sortN = sortN;
+  fb.fvNodes = v->w_nodes; fb.fvOffsets = v->w_offsets; fb.fvIndices = v->w_indices; fb.fvCount = v->w_count;
+  BowBatch bb = {};
+  bb.kp = reinterpret_cast<const float*>(d_keypoints); bb.desc = d_descriptors; bb.capacity = capacity;
+  bb.fvNodes = v->w_nodes; bb.fvOffsets = v->w_offsets; bb.fvIndices = v->w_indices; bb.fvCount = v->w_count;
+  bb.nnratio = nnratio; bb.match = d_match; bb.bin = v->w_bin;
+  const size_t c = (size_t)capacity;
+  auto featvec_range = [&](hipStream_t st, int f0, int n) {
+    FeatVecBatch r = fb;
+    r.desc += (size_t)f0 * c * 32; r.n += f0;
+    r.fvNodes += (size_t)f0 * c; r.fvOffsets += (size_t)f0 * (c + 1); r.fvIndices += (size_t)f0 * c; r.fvCount += f0;
+    launch_vocab_featvec(st, v->d, r, n, v->L - levelsup);
+  };
+  auto search_range = [&](hipStream_t st, int p0, int np) -> int {
+    if (np <= 0) return ORBFE_OK;
+    VHIP(hipMemsetAsync(d_match + (size_t)p0 * c, 0xff, (size_t)np * c * 4, st));
+    VHIP(hipMemsetAsync(v->w_bin + (size_t)p0 * c, 0, (size_t)np * c, st));
+    BowBatch r = bb;
+    r.kp += (size_t)p0 * c * 7; r.desc += (size_t)p0 * c * 32;
+    r.fvNodes += (size_t)p0 * c; r.fvOffsets += (size_t)p0 * (c + 1); r.fvIndices += (size_t)p0 * c; r.fvCount += p0;
+    r.match += (size_t)p0 * c; r.bin += (size_t)p0 * c;
+    launch_search_by_bow_batch(st, r, np, check_orientation, d_nmatches + p0);
+    return ORBFE_OK;
+  };
+  if (e) {
+    int S = 0, per = 0, frames = 0, lanes = 0;
+    hipStream_t streams[8];
+    hipEvent_t chunkDone[8];
+    if ((rc = orbfe_extractor_split_(e, &S, &per, &frames, &lanes, streams, chunkDone))) return rc;
+    if (!lanes && S > 1 && frames == n_frames && per >= 2) {
+      // Per sub-batch, on the sub-batch's own stream right behind its extraction (no join of the streams): the
+      // FeatureVectors of its frames, then its consecutive pairs.  The pair that straddles two sub-batches
+      // (last frame of i-1, first frame of i) runs on stream i behind an event of stream i-1's FeatureVectors, and
+      // stream i-1 is made to wait for it before anything enqueued later (the next extract call) overwrites that frame.
+      if (v->lastStream) { VHIP(hipStreamSynchronize(v->lastStream)); v->lastStream = nullptr; }
+      v->lastMulti = e;
+      for (int i = 0; i < 8; i++)
+        if (!v->evFv[i]) {
+          VHIP(hipEventCreateWithFlags(&v->evFv[i], hipEventDisableTiming));
+          VHIP(hipEventCreateWithFlags(&v->evBoundary[i], hipEventDisableTiming));
+        }
+      int nSub = 0;
+      for (int i = 0; i < S; i++) {
+        const int f0 = i * per, n = f0 + per <= n_frames ? per : n_frames - f0;
+        if (n <= 0) break;
+        nSub = i + 1;
+        orbfe_extractor_stage_mark_(e, ORBFE_STAGE_MATCH, i, 0, streams[i], n);
+        featvec_range(streams[i], f0, n);
+        VHIP(hipEventRecord(v->evFv[i], streams[i]));
+      }
+      for (int i = 0; i < nSub; i++) {
+        const int f0 = i * per, n = f0 + per <= n_frames ? per : n_frames - f0;
+        const int p0 = i == 0 ? 0 : f0 - 1;
+        if (i > 0) VHIP(hipStreamWaitEvent(streams[i], v->evFv[i - 1], 0));
+        if ((rc = search_range(streams[i], p0, f0 + n - 1 - p0))) return rc;
+        orbfe_extractor_stage_mark_(e, ORBFE_STAGE_MATCH, i, 1, streams[i], n);
+        if (i > 0) {
+          VHIP(hipEventRecord(v->evBoundary[i], streams[i]));
+          VHIP(hipStreamWaitEvent(streams[i - 1], v->evBoundary[i], 0));
+          VHIP(hipEventRecord(chunkDone[i], streams[i]));  // "sub-batch i done" now includes its matcher
+        }
+      }
+      VHIP(hipGetLastError());
+      return ORBFE_OK;
+    }
+  }
+  if (v->lastMulti) {  // back to one stream after a per-sub-batch call
+    if ((rc = orbfe_extractor_synchronize(v->lastMulti))) return rc;
+    v->lastMulti = nullptr;
+  }
   hipStream_t s = v->stream;
   if (e) {
     if ((rc = orbfe_extractor_consumer_begin_(e, &s))) return rc;
@@ -397,18 +481,8 @@ static int bow_match_consecutive(orbfe_vocabulary* v, orbfe_extractor* e, int n_
     VHIP(hipStreamSynchronize(v->lastStream));
   }
   v->lastStream = s;
-  FeatVecBatch fb = {};
-  fb.desc = d_descriptors; fb.n = d_n; fb.capacity = capacity; fb.sortN = sortN;
-  fb.fvNodes = v->w_nodes; fb.fvOffsets = v->w_offsets; fb.fvIndices = v->w_indices; fb.fvCount = v->w_count;
-  launch_vocab_featvec(s, v->d, fb, n_frames, v->L - levelsup);
-  const int nPairs = n_frames - 1;
-  VHIP(hipMemsetAsync(d_match, 0xff, (size_t)nPairs * capacity * 4, s));
-  VHIP(hipMemsetAsync(v->w_bin, 0, (size_t)nPairs * capacity, s));
-  BowBatch bb = {};
-  bb.kp = reinterpret_cast<const float*>(d_keypoints); bb.desc = d_descriptors; bb.capacity = capacity;
-  bb.fvNodes = v->w_nodes; bb.fvOffsets = v->w_offsets; bb.fvIndices = v->w_indices; bb.fvCount = v->w_count;
-  bb.nnratio = nnratio; bb.match = d_match; bb.bin = v->w_bin;
-  launch_search_by_bow_batch(s, bb, nPairs, check_orientation, d_nmatches);
+  featvec_range(s, 0, n_frames);
+  if ((rc = search_range(s, 0, n_frames - 1))) return rc;
   VHIP(hipGetLastError());
   if (e) return orbfe_extractor_consumer_end_(e);
   VHIP(hipStreamSynchronize(s));
