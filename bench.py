@@ -731,7 +731,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["all", "kitti_seq"], default="all")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="CPU-baseline budget per variant and workload")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=8,
                     help="sub-batch HIP streams per call in the timed region (1..8): the latency-bound kernels "
                          "of one sub-batch overlap the VALU-bound ones of the others")
     ap.add_argument("--schedule", choices=["streams", "lanes"], default="streams",

@@ -558,7 +558,8 @@ int run_pipeline(orbfe_extractor* e, LevelView level0, int nFrames, orbfe_keypoi
     e->lastSplitFrames = nFrames;
     e->lastSplitStreams = e->laneMode ? -S : S;
   }
-  const int per = (nFrames + S - 1) / S;
+  int per = (nFrames + S - 1) / S;
+  if ((nFrames & 1) == 0 && (per & 1)) per++;  // stereo batches (L0,R0,L1,R1,...): never split a pair across sub-batches
   const bool lanes = e->laneMode && !e->hostOctree && S >= 2;
   e->lastPer = per;
   e->lastS = S;
