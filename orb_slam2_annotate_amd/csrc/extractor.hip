@@ -130,6 +130,7 @@ struct orbfe_extractor {
   int32_t* d_stereoSad = nullptr;  // scratch of the batched stereo matcher
   int32_t* d_stereoRowStart = nullptr;
   int32_t* d_stereoSorted = nullptr;
+  float4* d_stereoRec = nullptr;   // (uR, yR, octave, index) of the right keypoints in row order
   size_t stereoSadCap = 0, stereoRowCap = 0;
   LevelKp* d_levelKp = nullptr;
   int32_t* d_levelCount = nullptr;
@@ -723,6 +724,7 @@ extern "C" void orbfe_extractor_destroy(orbfe_extractor* e) {
   dfree(&e->d_scaleTab);
   dfree(&e->d_stereoRowStart);
   dfree(&e->d_stereoSorted);
+  dfree(&e->d_stereoRec);
   dfree(&e->d_momentTab);
   dfree(&e->d_umax);
   for (int r = 0; r < orbfe_extractor::kEvRing; r++)
@@ -1367,6 +1369,7 @@ extern "C" int orbfe_stereo_match_batch_device(orbfe_extractor* e, int n_pairs, 
     if (rcs) return rcs;
     int rc = dalloc(&e->d_stereoSad, need);
     if (!rc) rc = dalloc(&e->d_stereoSorted, need);
+    if (!rc) rc = dalloc(&e->d_stereoRec, need);
     if (!rc) rc = dalloc(&e->d_stereoRowStart, needRows);
     if (rc) return rc;
     e->stereoSadCap = need;
@@ -1381,6 +1384,7 @@ extern "C" int orbfe_stereo_match_batch_device(orbfe_extractor* e, int n_pairs, 
   if (rows + 1 <= 8192) {  // row index of the right keypoints (k_stereo_bucket)
     a.rowStart = e->d_stereoRowStart;
     a.sortedIdx = e->d_stereoSorted;
+    a.sortedRec = e->d_stereoRec;
     a.rows = rows;
     a.bandR = (int)std::ceil(2.0f * e->tab.scale[e->tab.nlevels - 1]) + 2;
   }
@@ -1400,7 +1404,7 @@ extern "C" int orbfe_stereo_match_batch_device(orbfe_extractor* e, int n_pairs, 
       aa.pyrL.lv[l].base += (size_t)(2 * p0) * aa.pyrL.lv[l].frameStride;
       aa.pyrR.lv[l].base += (size_t)(2 * p0) * aa.pyrR.lv[l].frameStride;
     }
-    if (aa.rowStart) { aa.rowStart += (size_t)p0 * (rows + 1); aa.sortedIdx += (size_t)p0 * capacity; }
+    if (aa.rowStart) { aa.rowStart += (size_t)p0 * (rows + 1); aa.sortedIdx += (size_t)p0 * capacity; aa.sortedRec += (size_t)p0 * capacity; }
     bb.kp += (size_t)(2 * p0) * capacity * 7;
     bb.desc += (size_t)(2 * p0) * capacity * 32;
     bb.n += 2 * p0;

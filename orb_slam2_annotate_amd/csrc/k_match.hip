@@ -301,7 +301,7 @@ struct StereoPair {  // per-pair operands (kept apart from the kernel argument s
   const float* kpR; const uint8_t* descR; int Nr;
   int frameL, frameR;
   float* uRight; float* depth; int32_t* sad;
-  const int32_t* rowStart; const int32_t* sortedIdx;
+  const int32_t* rowStart; const int32_t* sortedIdx; const float4* sortedRec;
 };
 
 __device__ __forceinline__ void stereo_one(const StereoArgs& a, const StereoPair& pp, int iL, int lane) {
@@ -330,29 +330,40 @@ __device__ __forceinline__ void stereo_one(const StereoArgs& a, const StereoPair
     pBeg = pp.rowStart[lo];
     pEnd = pp.rowStart[hi + 1];
   }
+  float bestU = 0.f;  // uR of this lane's best candidate (the winner's is read back after the wave minimum)
   for (int p = pBeg + lane; p < pEnd; p += 64) {
-    const int iR = pp.rowStart ? pp.sortedIdx[p] : p;
-    const float* kr = pp.kpR + (size_t)iR * 7;
-    const int octR = reinterpret_cast<const int32_t*>(kr)[5];
-    const float yR = kr[1];
+    int iR, octR;
+    float yR, uR;
+    if (pp.sortedRec) {  // one 16-byte record per candidate
+      const float4 rc = pp.sortedRec[p];
+      uR = rc.x; yR = rc.y; octR = __float_as_int(rc.z); iR = __float_as_int(rc.w);
+    } else {
+      iR = pp.rowStart ? pp.sortedIdx[p] : p;
+      const float* kr = pp.kpR + (size_t)iR * 7;
+      octR = reinterpret_cast<const int32_t*>(kr)[5];
+      yR = kr[1];
+      uR = kr[0];
+    }
     const float r = __fmul_rn(2.0f, a.scaleTab[octR]);
     const int maxr = (int)ceilf(__fadd_rn(yR, r));
     const int minr = (int)floorf(__fsub_rn(yR, r));
     if (row < minr || row > maxr) continue;
     if (octR < levelL - 1 || octR > levelL + 1) continue;
-    const float uR = kr[0];
     if (!(uR >= minU && uR <= maxU)) continue;
     const uint32_t dist = (uint32_t)hdist(dL, load_desc(pp.descR, iR));
     if (dist >= 100u) continue;  // bestDist starts at TH_HIGH, strict <
     const uint32_t key = (dist << 20) | (uint32_t)iR;
-    best = key < best ? key : best;
+    if (key < best) { best = key; bestU = uR; }
   }
+  const uint32_t mine = best;
   best = wave_min_u32(best);
   if (best == 0xffffffffu) return;
-  const int bestDist = (int)(best >> 20), bestIdxR = (int)(best & 0xfffffu);
+  const int bestDist = (int)(best >> 20);
   if (bestDist >= 75) return;  // thOrbDist = (TH_HIGH+TH_LOW)/2, :517,598
+  // the winning lane (keys are unique: they carry iR) hands over its uR -- no second trip to the keypoint array
+  const unsigned long long win = __ballot(mine == best);
+  const float uR0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bestU), __builtin_ctzll(win)));
   // ---- SAD refinement on the left keypoint's pyramid level (:600-638) ----
-  const float uR0 = pp.kpR[(size_t)bestIdxR * 7];
   const float sf = a.scaleTab[kMaxLevels + levelL];
   const float scaleduL = roundf(__fmul_rn(uL, sf));
   const float scaledvL = roundf(__fmul_rn(vL, sf));
@@ -424,7 +435,7 @@ __device__ __forceinline__ void stereo_one(const StereoArgs& a, const StereoPair
 __global__ __launch_bounds__(256) void k_stereo_bucket(const float* __restrict__ kpBase, const int32_t* __restrict__ nArr,
                                                        int nFixed, int capacity, int rows,
                                                        int32_t* __restrict__ rowStartBase,
-                                                       int32_t* __restrict__ sortedBase) {
+                                                       int32_t* __restrict__ sortedBase, float4* __restrict__ recBase) {
   extern __shared__ int cnt[];  // rows + 1
   __shared__ int waveTot[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = blockIdx.x;
@@ -433,6 +444,7 @@ __global__ __launch_bounds__(256) void k_stereo_bucket(const float* __restrict__
   if (Nr > capacity) Nr = capacity;
   int32_t* rowStart = rowStartBase + (size_t)p * (rows + 1);
   int32_t* sorted = sortedBase + (size_t)p * capacity;
+  float4* rec = recBase ? recBase + (size_t)p * capacity : nullptr;
   for (int i = tid; i <= rows; i += 256) cnt[i] = 0;
   __syncthreads();
   for (int i = tid; i < Nr; i += 256) {
@@ -462,7 +474,10 @@ __global__ __launch_bounds__(256) void k_stereo_bucket(const float* __restrict__
   for (int i = tid; i < Nr; i += 256) {
     int b = (int)floorf(kpR[(size_t)i * 7 + 1]);
     b = b < 0 ? 0 : (b > rows - 1 ? rows - 1 : b);
-    sorted[atomicAdd(&cnt[b], 1)] = i;
+    const int pos = atomicAdd(&cnt[b], 1);
+    sorted[pos] = i;
+    if (rec) rec[pos] = make_float4(kpR[(size_t)i * 7], kpR[(size_t)i * 7 + 1], __int_as_float(reinterpret_cast<const int32_t*>(kpR)[(size_t)i * 7 + 5]),
+                                    __int_as_float(i));
   }
 }
 
@@ -471,7 +486,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a) {
   const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (iL >= a.N) return;
   StereoPair pp = {a.kpL, a.descL, a.N, a.kpR, a.descR, a.Nr, a.frameL, a.frameR, a.uRight, a.depth, a.sad,
-                   a.rowStart, a.sortedIdx};
+                   a.rowStart, a.sortedIdx, a.rowStart ? a.sortedRec : nullptr};
   stereo_one(a, pp, iL, lane);
 }
 
@@ -497,6 +512,7 @@ __global__ __launch_bounds__(256) void k_stereo_match_batch(const StereoArgs a, 
   pp.uRight = b.uRight + oO; pp.depth = b.depth + oO; pp.sad = b.sad + oO;
   pp.rowStart = a.rowStart ? a.rowStart + (size_t)p * (a.rows + 1) : nullptr;
   pp.sortedIdx = a.rowStart ? a.sortedIdx + (size_t)p * b.capacity : nullptr;
+  pp.sortedRec = (a.rowStart && a.sortedRec) ? a.sortedRec + (size_t)p * b.capacity : nullptr;
   stereo_one(a, pp, iL, lane);
 }
 
@@ -565,7 +581,7 @@ void launch_stereo(hipStream_t s, const StereoArgs& a, int32_t* d_nStereo) {
   if (a.rowStart)
     hipLaunchKernelGGL(k_stereo_bucket, dim3(1), dim3(256), (size_t)(a.rows + 1) * sizeof(int), s, a.kpR,
                        (const int32_t*)nullptr, a.Nr, a.Nr, a.rows, const_cast<int32_t*>(a.rowStart),
-                       const_cast<int32_t*>(a.sortedIdx));
+                       const_cast<int32_t*>(a.sortedIdx), const_cast<float4*>(a.sortedRec));
   hipLaunchKernelGGL(k_stereo_match, dim3((a.N + 3) / 4), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_stereo_median_cut, dim3(1), dim3(256), 0, s, a.N, a.sad, a.uRight, a.depth, d_nStereo, 0);
 }
@@ -574,7 +590,8 @@ void launch_stereo_batch(hipStream_t s, const StereoArgs& a, const StereoBatch& 
   if (nPairs <= 0 || b.capacity <= 0) return;
   if (a.rowStart)
     hipLaunchKernelGGL(k_stereo_bucket, dim3(nPairs), dim3(256), (size_t)(a.rows + 1) * sizeof(int), s, b.kp, b.n, 0,
-                       b.capacity, a.rows, const_cast<int32_t*>(a.rowStart), const_cast<int32_t*>(a.sortedIdx));
+                       b.capacity, a.rows, const_cast<int32_t*>(a.rowStart), const_cast<int32_t*>(a.sortedIdx),
+                       const_cast<float4*>(a.sortedRec));
   hipLaunchKernelGGL(k_stereo_match_batch, dim3((b.capacity + 3) / 4, nPairs), dim3(256), 0, s, a, b);
   hipLaunchKernelGGL(k_stereo_median_cut, dim3(nPairs), dim3(256), 0, s, b.capacity, b.sad, b.uRight, b.depth,
                      d_nStereo, b.capacity);

@@ -44,6 +44,10 @@ struct StereoArgs {
   float* uRight; float* depth; int32_t* sad;
   // optional row index of the right keypoints (NULL -> scan all): rows+1 starts and Nr indices per pair
   const int32_t* rowStart; const int32_t* sortedIdx; int rows; int bandR;
+  // sortedRec[p] = (uR, yR, octave, iR) of the right keypoint at sorted position p (written by k_stereo_bucket next
+  // to sortedIdx): the candidate scan reads ONE 16-byte record instead of the index and then three fields of the
+  // 28-byte keypoint, i.e. one dependent memory round trip less per left keypoint
+  const float4* sortedRec;
 };
 
 struct StereoBatch {  // frames 2p / 2p+1 of an extractor batch are the left / right image of pair p
