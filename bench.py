@@ -480,7 +480,7 @@ def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, u
     B = batches[name]
     g = GpuWorkload(name, frames, B, local_rank, torch, voc_path)
     ext, NI = g.ext, g.NI
-    S = max(1, min(8, args.streams))
+    S = max(1, min(32, args.streams))
 
     def barrier():
         g.sync()
@@ -661,7 +661,7 @@ def run_kitti_seq(frames, args, rank, world, local_rank, torch, dist, use_dist, 
     from orb_slam2_annotate_amd import shard
     B = batches["kitti"]
     g = GpuWorkload("kitti", frames, B, local_rank, torch)
-    g.ext.set_streams(max(1, min(8, args.streams)))
+    g.ext.set_streams(max(1, min(32, args.streams)))
     g.ext.set_schedule(args.schedule == "lanes")
     lengths = [max(1, int(round(n * args.seq_scale))) for n in shard.KITTI_00_07]
     out = {}
@@ -732,7 +732,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="CPU-baseline budget per variant and workload")
     ap.add_argument("--streams", type=int, default=8,
-                    help="sub-batch HIP streams per call in the timed region (1..8): the latency-bound kernels "
+                    help="sub-batch HIP streams per call in the timed region (1..32): the latency-bound kernels "
                          "of one sub-batch overlap the VALU-bound ones of the others")
     ap.add_argument("--schedule", choices=["streams", "lanes"], default="streams",
                     help="sub-batches on independent streams, or as the three-lane software pipeline (pyramid | FAST+blur | tail)")

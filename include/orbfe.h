@@ -203,7 +203,7 @@ int orbfe_extractor_set_blur_spec(orbfe_extractor *e, int spec);
 int orbfe_extractor_set_fused(orbfe_extractor *e, int enable);
 
 /* A call's frames are split into n consecutive sub-batches that run concurrently on n HIP
- * streams with private workspace slices (1..8, default 2 or $ORBFE_STREAMS); results do not
+ * streams with private workspace slices (1..32, default 1 or $ORBFE_STREAMS); results do not
  * depend on n.  Stage timing covers the kernels of sub-batch 0 (frames_out reports how many
  * frames those launches processed). */
 int orbfe_extractor_set_streams(orbfe_extractor *e, int n);

@@ -46,8 +46,8 @@ struct orbfe_extractor {
   ExtractorTables tab;
   int device = 0;
   hipStream_t stream = nullptr;              // stream 0: owns the timing events and the copies
-  static constexpr int kMaxStreams = 8;
-  hipStream_t extra[kMaxStreams - 1] = {};   // sub-batch streams 1..7
+  static constexpr int kMaxStreams = 32;
+  hipStream_t extra[kMaxStreams - 1] = {};   // sub-batch streams 1..31
   int nStreams = 1;                          // >1: sub-batches of one call run concurrently
   // cross-stream ordering without host synchronisation: evChunkDone[i] marks the end of sub-batch i of the
   // last extract call (consumers on `stream` wait for it); evConsumerDone marks the end of the last kernel
@@ -71,7 +71,7 @@ struct orbfe_extractor {
   bool lastLanes = false;
   double stageFrames[ORBFE_STAGE_COUNT] = {};
   // stage timing: a ring of event pairs per stage so that asynchronous calls can stay in flight
-  static constexpr int kEvRing = 16;
+  static constexpr int kEvRing = 8;
   static constexpr int kEvSubs = kMaxStreams;  // one event pair per (call slot, sub-batch stream, stage)
   hipEvent_t evA[kEvRing][kEvSubs][ORBFE_STAGE_COUNT] = {}, evB[kEvRing][kEvSubs][ORBFE_STAGE_COUNT] = {};
   bool evUsed[kEvRing][kEvSubs][ORBFE_STAGE_COUNT] = {};
@@ -1340,7 +1340,7 @@ extern "C" int orbfe_extractor_set_schedule(orbfe_extractor* e, int lanes) {
 
 // Number of sub-batch streams one call is split over (1..4; default 1, or $ORBFE_STREAMS).
 extern "C" int orbfe_extractor_set_streams(orbfe_extractor* e, int n) {
-  if (!e || n < 1 || n > orbfe_extractor::kMaxStreams) return fail(ORBFE_ERR_INVALID, "set_streams: 1..8");
+  if (!e || n < 1 || n > orbfe_extractor::kMaxStreams) return fail(ORBFE_ERR_INVALID, "set_streams: 1..32");
   HIPCHK(hipSetDevice(e->device));
   int rc = sync_all(e);
   if (rc) return rc;

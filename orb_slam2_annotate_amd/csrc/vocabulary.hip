@@ -45,7 +45,7 @@ struct orbfe_vocabulary {
   int8_t* w_bin = nullptr;
   size_t wFrames = 0; int wCap = 0;
   hipStream_t lastStream = nullptr;  // stream of the last batched call (its workspace may still be in use there)
-  hipEvent_t evFv[8] = {}, evBoundary[8] = {};  // per sub-batch: FeatureVectors built / boundary pair searched
+  hipEvent_t evFv[32] = {}, evBoundary[32] = {};  // per sub-batch: FeatureVectors built / boundary pair searched
   orbfe_extractor* lastMulti = nullptr;  // extractor whose sub-batch streams ran the last per-sub-batch call
 };
 
@@ -189,7 +189,7 @@ static void vocab_free_device(orbfe_vocabulary* v) {
   if (v->w_indices) (void)hipFree(v->w_indices);
   if (v->w_count) (void)hipFree(v->w_count);
   if (v->w_bin) (void)hipFree(v->w_bin);
-  for (int i = 0; i < 8; i++) {
+  for (int i = 0; i < 32; i++) {
     if (v->evFv[i]) (void)hipEventDestroy(v->evFv[i]);
     if (v->evBoundary[i]) (void)hipEventDestroy(v->evBoundary[i]);
   }
@@ -429,8 +429,8 @@ static int bow_match_consecutive(orbfe_vocabulary* v, orbfe_extractor* e, int n_
   };
   if (e) {
     int S = 0, per = 0, frames = 0, lanes = 0;
-    hipStream_t streams[8];
-    hipEvent_t chunkDone[8];
+    hipStream_t streams[32];  // orbfe_extractor::kMaxStreams
+    hipEvent_t chunkDone[32];
     if ((rc = orbfe_extractor_split_(e, &S, &per, &frames, &lanes, streams, chunkDone))) return rc;
     if (!lanes && S > 1 && frames == n_frames && per >= 2) {
       // Per sub-batch, on the sub-batch's own stream right behind its extraction (no join of the streams): the
@@ -439,7 +439,7 @@ static int bow_match_consecutive(orbfe_vocabulary* v, orbfe_extractor* e, int n_
       // stream i-1 is made to wait for it before anything enqueued later (the next extract call) overwrites that frame.
       if (v->lastStream) { VHIP(hipStreamSynchronize(v->lastStream)); v->lastStream = nullptr; }
       v->lastMulti = e;
-      for (int i = 0; i < 8; i++)
+      for (int i = 0; i < 32; i++)
         if (!v->evFv[i]) {
           VHIP(hipEventCreateWithFlags(&v->evFv[i], hipEventDisableTiming));
           VHIP(hipEventCreateWithFlags(&v->evBoundary[i], hipEventDisableTiming));

@@ -74,7 +74,7 @@ def main():
                 w, h = min(w, 500), min(h, 400)
                 imgs = np.stack([content(rng, w, h) for _ in range(int(rng.integers(9, 25)))])
                 img = imgs[0]
-                e.set_streams(int(rng.integers(1, 9)))
+                e.set_streams(int(rng.choice([1, 2, 3, 4, 5, 8, 12, 16, 32])))
                 e.set_schedule(lanes)
                 res = e.extract_batch_pipelined(imgs, chunk_frames=int(rng.integers(1, 12))) if piped else e.extract_batch(imgs)
                 ok = True
