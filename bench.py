@@ -55,13 +55,13 @@ BCNT_PEAK = 0.585e12 * 64  # popcount-32 lane-ops/s: v_bcnt_u32_b32 measured at 
 
 WORKLOADS = {
     "tum": dict(name="TUM fr1_xyz mono 640x480 nFeatures=1000 extract-only (synthetic frames)",
-                w=640, h=480, nfeatures=1000, ini=20, mn=7, batch=4096),
+                w=640, h=480, nfeatures=1000, ini=20, mn=7, batch=4096, streams=8),
     "kitti": dict(name="KITTI 00 stereo 1241x376 nFeatures=2000: extract L+R + ComputeStereoMatches "
                        "(synthetic stereo pairs; frames/s counts STEREO frames = 2 images each)",
-                  w=1241, h=376, nfeatures=2000, ini=20, mn=7, stereo=True, bf=386.1448, fx=718.856, batch=512),
+                  w=1241, h=376, nfeatures=2000, ini=20, mn=7, stereo=True, bf=386.1448, fx=718.856, batch=512, streams=8),
     "euroc": dict(name="EuRoC MH_01 752x480 nFeatures=1200: extract + ComputeBoW + SearchByBoW(t-1,t) "
                        "(synthetic frames, synthetic k=10 L=2 vocabulary)",
-                  w=752, h=480, nfeatures=1200, ini=20, mn=7, bow=True, batch=2048),
+                  w=752, h=480, nfeatures=1200, ini=20, mn=7, bow=True, batch=2048, streams=4),
 }
 SINGLE_SCENE = False  # --single-scene: the round-1 synthetic input (sparser; for continuity with profiles/history/r01_bench.json)
 GPU_STAGES = ["pyramid", "fast", "octree", "blur", "orient_desc", "match"]
@@ -480,7 +480,7 @@ def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, u
     B = batches[name]
     g = GpuWorkload(name, frames, B, local_rank, torch, voc_path)
     ext, NI = g.ext, g.NI
-    S = max(1, min(32, args.streams))
+    S = max(1, min(32, args.streams if args.streams > 0 else wl.get("streams", 8)))
 
     def barrier():
         g.sync()
@@ -661,7 +661,7 @@ def run_kitti_seq(frames, args, rank, world, local_rank, torch, dist, use_dist, 
     from orb_slam2_annotate_amd import shard
     B = batches["kitti"]
     g = GpuWorkload("kitti", frames, B, local_rank, torch)
-    g.ext.set_streams(max(1, min(32, args.streams)))
+    g.ext.set_streams(max(1, min(32, args.streams if args.streams > 0 else WORKLOADS["kitti"]["streams"])))
     g.ext.set_schedule(args.schedule == "lanes")
     lengths = [max(1, int(round(n * args.seq_scale))) for n in shard.KITTI_00_07]
     out = {}
@@ -731,8 +731,9 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["all", "kitti_seq"], default="all")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="CPU-baseline budget per variant and workload")
-    ap.add_argument("--streams", type=int, default=8,
-                    help="sub-batch HIP streams per call in the timed region (1..32): the latency-bound kernels "
+    ap.add_argument("--streams", type=int, default=0,
+                    help="sub-batch HIP streams per call in the timed region (1..32; 0 = per-workload default from "
+                         "profiles/r02_stream_batch_sweep.txt: kitti 8, tum 8, euroc 4): the latency-bound kernels "
                          "of one sub-batch overlap the VALU-bound ones of the others")
     ap.add_argument("--schedule", choices=["streams", "lanes"], default="streams",
                     help="sub-batches on independent streams, or as the three-lane software pipeline (pyramid | FAST+blur | tail)")
