@@ -49,6 +49,7 @@ struct orbfe_extractor {
   static constexpr int kMaxStreams = 32;
   hipStream_t extra[kMaxStreams - 1] = {};   // sub-batch streams 1..31
   int nStreams = 1;                          // >1: sub-batches of one call run concurrently
+  int subsReady = 0;                         // sub-batches whose stream and events exist (ensure_subs)
   // cross-stream ordering without host synchronisation: evChunkDone[i] marks the end of sub-batch i of the
   // last extract call (consumers on `stream` wait for it); evConsumerDone marks the end of the last kernel
   // on `stream` that READS the workspace / the caller's outputs of all sub-batches (batched stereo matcher),
@@ -176,6 +177,28 @@ template <typename T>
 void dfree(T** p) {
   if (*p) (void)hipFree(*p);
   *p = nullptr;
+}
+
+// Streams and events of sub-batches [e->subsReady, n) are created on first use: a handle for one live camera (1 stream)
+// costs 1 stream + 136 events to create instead of 32 streams + ~4 300 events.
+int ensure_subs(orbfe_extractor* e, int n) {
+  if (n > orbfe_extractor::kMaxStreams) n = orbfe_extractor::kMaxStreams;
+  for (int i = e->subsReady; i < n; i++) {
+    if (i > 0 && !e->extra[i - 1]) HIPCHK(hipStreamCreateWithFlags(&e->extra[i - 1], hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&e->evStat[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->evChunkDone[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->evPyr[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->evFast[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->evBlur[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->evTail[i], hipEventDisableTiming));
+    for (int r = 0; r < orbfe_extractor::kEvRing; r++)
+      for (int st = 0; st < ORBFE_STAGE_COUNT; st++) {
+        HIPCHK(hipEventCreate(&e->evA[r][i][st]));
+        HIPCHK(hipEventCreate(&e->evB[r][i][st]));
+      }
+    e->subsReady = i + 1;
+  }
+  return ORBFE_OK;
 }
 
 void free_geometry(orbfe_extractor* e) {
@@ -632,8 +655,6 @@ extern "C" int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlev
   e->device = device;
   e->tab.init(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST);
   hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
-  for (int i = 0; i < orbfe_extractor::kMaxStreams - 1 && err == hipSuccess; i++)
-    err = hipStreamCreateWithFlags(&e->extra[i], hipStreamNonBlocking);
   if (const char* env = getenv("ORBFE_COPY_UNALIGNED")) e->copyUnaligned = atoi(env) != 0;
   if (const char* env = getenv("ORBFE_FAST_MODE")) {
     const std::string v(env);
@@ -642,7 +663,6 @@ extern "C" int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlev
   if (err == hipSuccess) err = hipMalloc((void**)&e->d_fastStat, sizeof(unsigned int) * orbfe_extractor::kMaxStreams * orbfe_extractor::kStatSlots);
   if (err == hipSuccess)
     err = hipHostMalloc((void**)&e->h_fastStat, sizeof(unsigned int) * orbfe_extractor::kMaxStreams * orbfe_extractor::kStatSlots, hipHostMallocDefault);
-  for (int i = 0; i < orbfe_extractor::kMaxStreams && err == hipSuccess; i++) err = hipEventCreateWithFlags(&e->evStat[i], hipEventDisableTiming);
   if (const char* env = getenv("ORBFE_LANES")) e->laneMode = atoi(env) != 0;
   if (const char* env = getenv("ORBFE_FUSED")) e->fused = atoi(env) != 0;
   if (const char* env = getenv("ORBFE_BLUR_SPEC")) {
@@ -653,20 +673,8 @@ extern "C" int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlev
     int v = atoi(env);
     if (v >= 1 && v <= orbfe_extractor::kMaxStreams) e->nStreams = v;
   }
-  for (int i = 0; i < orbfe_extractor::kMaxStreams && err == hipSuccess; i++) {
-    err = hipEventCreateWithFlags(&e->evChunkDone[i], hipEventDisableTiming);
-    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->evPyr[i], hipEventDisableTiming);
-    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->evFast[i], hipEventDisableTiming);
-    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->evBlur[i], hipEventDisableTiming);
-    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->evTail[i], hipEventDisableTiming);
-  }
   if (err == hipSuccess) err = hipEventCreateWithFlags(&e->evConsumerDone, hipEventDisableTiming);
-  for (int r = 0; r < orbfe_extractor::kEvRing; r++)
-    for (int u = 0; u < orbfe_extractor::kEvSubs; u++)
-      for (int i = 0; i < ORBFE_STAGE_COUNT && err == hipSuccess; i++) {
-        err = hipEventCreate(&e->evA[r][u][i]);
-        if (err == hipSuccess) err = hipEventCreate(&e->evB[r][u][i]);
-      }
+  if (err == hipSuccess && ensure_subs(e, e->nStreams > 3 ? e->nStreams : 3) != ORBFE_OK) err = hipErrorUnknown;  // 3: the lane schedule's P / V / T
   float patF[1024];
   // test i = (x0, y0, x1, y1) in the table; uploaded as (x0, x1, y0, y1) so that k_orient_desc rotates the
   // two points of a test in one packed-fp32 operation per product
@@ -1338,12 +1346,13 @@ extern "C" int orbfe_extractor_set_schedule(orbfe_extractor* e, int lanes) {
   return ORBFE_OK;
 }
 
-// Number of sub-batch streams one call is split over (1..4; default 1, or $ORBFE_STREAMS).
+// Number of sub-batch streams one call is split over (1..32; default 1, or $ORBFE_STREAMS).
 extern "C" int orbfe_extractor_set_streams(orbfe_extractor* e, int n) {
   if (!e || n < 1 || n > orbfe_extractor::kMaxStreams) return fail(ORBFE_ERR_INVALID, "set_streams: 1..32");
   HIPCHK(hipSetDevice(e->device));
   int rc = sync_all(e);
   if (rc) return rc;
+  if ((rc = ensure_subs(e, n))) return rc;
   e->nStreams = n;
   return ORBFE_OK;
 }
