@@ -789,11 +789,14 @@ def main():
     import torch
     import torch.distributed as dist
     use_dist = world > 1 or args.force_dist
-    if use_dist:
-        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)  # before the process group: RCCL binds the communicator to the current device
+    if use_dist:
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     voc_path = None
     if "euroc" in names:

@@ -491,7 +491,8 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
     }
     const bool lowFirst = e->fastMode == 2 || (e->fastMode == 0 && e->fastLowFirst);
     unsigned int* stat = nullptr;
-    if (e->fastMode == 0 && sub >= 0 && sub < orbfe_extractor::kMaxStreams && !e->statPending[sub]) {
+    // (not for the few-frame launches of a live camera: the two tiny copies and the event cost ~10 us of latency there)
+    if (e->fastMode == 0 && nFrames > 8 && sub >= 0 && sub < orbfe_extractor::kMaxStreams && !e->statPending[sub]) {
       stat = e->d_fastStat + sub * orbfe_extractor::kStatSlots;
       HIPCHK(hipMemsetAsync(stat, 0, sizeof(unsigned int) * orbfe_extractor::kStatSlots, sV));
     }
@@ -852,7 +853,7 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* images, in
   if (!images || width <= 0 || height <= 0) return ORBFE_OK;  // empty image: silent return (:1122)
   if (!keypoints || !descriptors || capacity <= 0 || stride < width)
     return fail(ORBFE_ERR_INVALID, "extract_batch: bad output buffers");
-  if (n_frames > 16 && !e->hostOctree && frame_stride >= (size_t)stride * (height - 1) + width)
+  if (n_frames >= 64 && !e->hostOctree && frame_stride >= (size_t)stride * (height - 1) + width)  // below: page-locking costs more than it saves
     // a real batch: chunked H2D / kernels / D2H overlapped on separate streams (the buffers are page-locked for the
     // call when they are not pinned already) instead of upload-all, compute, download-all
     return orbfe_extract_batch_pipelined(e, images, n_frames, width, height, stride, frame_stride, keypoints, descriptors,
