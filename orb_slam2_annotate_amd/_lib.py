@@ -11,7 +11,10 @@ from pathlib import Path
 import numpy as np
 
 PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = PKG_DIR / "liborbfe.so"
+import os as _os
+
+# $ORBFE_LIB: an alternative build of the library (A/B runs of compile-time variants, tools/ab_build.sh); default in-tree
+LIB_PATH = Path(_os.environ["ORBFE_LIB"]) if _os.environ.get("ORBFE_LIB") else PKG_DIR / "liborbfe.so"
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])

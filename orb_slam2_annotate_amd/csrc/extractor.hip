@@ -853,9 +853,16 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* images, in
   if (!images || width <= 0 || height <= 0) return ORBFE_OK;  // empty image: silent return (:1122)
   if (!keypoints || !descriptors || capacity <= 0 || stride < width)
     return fail(ORBFE_ERR_INVALID, "extract_batch: bad output buffers");
-  if (n_frames >= 64 && !e->hostOctree && frame_stride >= (size_t)stride * (height - 1) + width)  // below: page-locking costs more than it saves
-    // a real batch: chunked H2D / kernels / D2H overlapped on separate streams (the buffers are page-locked for the
-    // call when they are not pinned already) instead of upload-all, compute, download-all
+  bool pinnedIn = false;
+  {
+    hipPointerAttribute_t at;
+    pinnedIn = hipPointerGetAttributes(&at, images) == hipSuccess && at.type != hipMemoryTypeUnregistered;
+    (void)hipGetLastError();
+  }
+  if (!e->hostOctree && frame_stride >= (size_t)stride * (height - 1) + width && (pinnedIn ? n_frames >= 32 : n_frames >= 512))
+    // a real batch: chunked H2D / kernels / D2H overlapped on separate streams instead of upload-all, compute,
+    // download-all.  Pageable buffers would have to be page-locked for the call, which costs milliseconds (measured
+    // 5-9 ms for 128 VGA frames) and only pays for very large batches; pinned ones (orbfe_host_alloc) always pay.
     return orbfe_extract_batch_pipelined(e, images, n_frames, width, height, stride, frame_stride, keypoints, descriptors,
                                          capacity, n_out, 0);
   HIPCHK(hipSetDevice(e->device));

@@ -126,7 +126,10 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelViewMut dst,
 // branch, no per-lane control flow); (b*h)>>16 is one v_mul_hi_u32 against b<<16.
 constexpr int kFlatRows = 8;
 template <bool UNALIGNED>
-__global__ __launch_bounds__(256) void k_resize_flat(LevelView src, LevelViewMut dst,
+#ifndef ORBFE_RESIZE_WAVES
+#define ORBFE_RESIZE_WAVES 1
+#endif
+__global__ __launch_bounds__(256, ORBFE_RESIZE_WAVES) void k_resize_flat(LevelView src, LevelViewMut dst,
                                                      const uint4* __restrict__ colrec,
                                                      const uint4* __restrict__ rowrec, int ngx,
                                                      uint32_t magic, int total) {
