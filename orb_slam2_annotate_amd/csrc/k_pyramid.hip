@@ -124,7 +124,10 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelViewMut dst,
 // are requested before the first is used, so one memory round trip serves 16 output pixels; an
 // interpolated source row is reused by the next output row when the whole wave agrees (scalar
 // branch, no per-lane control flow); (b*h)>>16 is one v_mul_hi_u32 against b<<16.
-constexpr int kFlatRows = 8;
+#ifndef ORBFE_FLAT_ROWS
+#define ORBFE_FLAT_ROWS 8
+#endif
+constexpr int kFlatRows = ORBFE_FLAT_ROWS;
 template <bool UNALIGNED>
 #ifndef ORBFE_RESIZE_WAVES
 #define ORBFE_RESIZE_WAVES 1
