@@ -154,39 +154,12 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
       }
     } else {
       const bool rr = kBlur && (cd.flags & kCellRowReflect) != 0;  // frame cell at the top / bottom: reflected row index
-      const uintptr_t addr0 = reinterpret_cast<uintptr_t>(lvb) + (uintptr_t)(x0 - 4);  // row-independent part
-      if ((lv.pitch & 3) == 0) {
-        // a lane moves 16 bytes: (row, part) -> 5 aligned source dwords -> 4 byte-shifted tile dwords
-        const uint32_t a = (uint32_t)(addr0 & 3);     // same misalignment for every row
-        const uint8_t* al = lvb + (x0 - 4) - a;
-        const int parts = (tdw + 3) >> 2;             // 16-byte pieces per tile row (<= 5)
-        const uint32_t invP = kInv16[parts];
-        // bytes of the row still inside the pitch, counted from `al`: never read beyond the level's rows
-        const int rowBytes = lv.pitch - ((x0 - 4) - (int)a);
-        for (int i = lane; i < th * parts; i += 64) {
-          const int ty = (int)(((uint32_t)i * invP) >> 16), part = i - ty * parts;
-          const int sy = rr ? reflect101f(y0 - 3 + ty, lv.h) : y0 - 3 + ty;
-          const uint32_t* row = reinterpret_cast<const uint32_t*>(al + (uint32_t)sy * (uint32_t)lv.pitch) + 4 * part;
-          uint32_t d[5];
-          if (16 * part + 20 <= rowBytes) {
-            const U4 q = *reinterpret_cast<const U4*>(row);
-            d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
-            d[4] = a ? row[4] : 0u;
-          } else {
-#pragma unroll
-            for (int k = 0; k < 5; k++) d[k] = (16 * part + 4 * k + 4 <= rowBytes) ? row[k] : 0u;
-          }
-          uint4 o;
-          o.x = __builtin_amdgcn_alignbyte(d[1], d[0], a);
-          o.y = __builtin_amdgcn_alignbyte(d[2], d[1], a);
-          o.z = __builtin_amdgcn_alignbyte(d[3], d[2], a);
-          o.w = __builtin_amdgcn_alignbyte(d[4], d[3], a);
-          *reinterpret_cast<uint4*>(&tile[ty * kPitchDw + 4 * part]) = o;  // pitch >= 4*parts (launch_fast_cells)
-        }
-      } else {
-        // caller-owned level 0 whose rows are not dword-aligned (e.g. KITTI's tight 1241-byte stride): the same
-        // (row, part) lanes issue ONE byte-aligned 16-byte request each (global_load_dwordx4 takes any address on
-        // gfx950 at full bandwidth, profiles/r02_unaligned.txt) and need no byte shifting at all
+      {
+        // a lane moves 16 bytes: (row, part) -> ONE byte-aligned 16-byte request -> one ds_write_b128.  The tile starts
+        // at x0-4, which is dword-aligned for no cell in particular; global_load_dwordx4 takes any address on gfx950 at
+        // full bandwidth (profiles/r02_unaligned.txt), so there is no byte shifting (round 1 loaded 5 aligned dwords
+        // and shifted them with 4 v_alignbyte: the same stage measured 1 % slower) and caller-owned frames with an odd
+        // stride (KITTI: 1241) take the same path as the handle's own 64-byte pitched levels
         const int parts = (tdw + 3) >> 2;
         const uint32_t invP = kInv16[parts];
         const int rowBytes = lv.pitch - (x0 - 4);  // bytes from the tile's first column to the end of the row
