@@ -132,15 +132,11 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
           const uint8_t* origin = lv.base + (size_t)f * lv.frameStride + (size_t)(ky - 15) * lv.pitch + (kx - 15);
           if (active) {
             const uint8_t* p = origin + (uint32_t)(row * lv.pitch + (half ? 16 : 0));
-            if ((lv.pitch & 3) == 0) {
-              mis[u] = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3);
-              const uint32_t* al = reinterpret_cast<const uint32_t*>(p - mis[u]);
-              const U4 q = *reinterpret_cast<const U4*>(al);  // one 16-byte request instead of four
-              dw[u][0] = q.x; dw[u][1] = q.y; dw[u][2] = q.z; dw[u][3] = q.w;
-              dw[u][4] = mis[u] ? al[4] : 0u;
-            } else {
-              // caller-owned level 0 at an odd stride: one byte-aligned 16-byte request (columns x-15 .. x+16 are
-              // inside the row for every keypoint: 19 <= x <= w-20), mis stays 0
+            {
+              // one byte-aligned 16-byte request per (row, half) whatever the level's pitch and the keypoint's column
+              // (global_load_dwordx4 takes any address on gfx950, profiles/r02_unaligned.txt): no fifth dword, no
+              // v_alignbyte (mis stays 0) -- stage -5 % in a same-box A/B; columns x-15 .. x+16 are inside the row for
+              // every keypoint (19 <= x <= w-20)
               struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };
               const U4u q = *reinterpret_cast<const U4u*>(p);
               dw[u][0] = q.x; dw[u][1] = q.y; dw[u][2] = q.z; dw[u][3] = q.w;

@@ -264,7 +264,13 @@ void launch_resize(hipStream_t s, LevelView src, LevelViewMut dst, const int32_t
     const uint32_t magic = (uint32_t)((1ULL << 32) / (uint32_t)ngx) + 1u;
     const dim3 grid((unsigned)((total + 255) / 256), nFrames);
     static const size_t pad = occupancy_pad_bytes("RESIZE", 0);
+    // byte-aligned dword loads for every level since the end of round 2 (same-box A/B: pipeline +1-3 %, two
+    // v_alignbyte and a load per source row fewer); <false> is kept for A/B builds (-DORBFE_RESIZE_ALIGNED_LOADS)
+#ifdef ORBFE_RESIZE_ALIGNED_LOADS
     if (aligned)
+#else
+    if (false)
+#endif
       hipLaunchKernelGGL(k_resize_flat<false>, grid, dim3(256), pad, s, src, dst, reinterpret_cast<const uint4*>(d_colrec),
                          reinterpret_cast<const uint4*>(d_rowrec), ngx, magic, (int)total);
     else  // caller-owned level 0 at an odd stride: byte-aligned dword loads
