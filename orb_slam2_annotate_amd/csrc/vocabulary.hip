@@ -455,15 +455,17 @@ static int bow_match_consecutive(orbfe_vocabulary* v, orbfe_extractor* e, int n_
       }
       for (int i = 0; i < nSub; i++) {
         const int f0 = i * per, n = f0 + per <= n_frames ? per : n_frames - f0;
-        const int p0 = i == 0 ? 0 : f0 - 1;
-        if (i > 0) VHIP(hipStreamWaitEvent(streams[i], v->evFv[i - 1], 0));
-        if ((rc = search_range(streams[i], p0, f0 + n - 1 - p0))) return rc;
-        orbfe_extractor_stage_mark_(e, ORBFE_STAGE_MATCH, i, 1, streams[i], n);
         if (i > 0) {
+          // the straddling pair first, on its own: the earlier stream is released as soon as this one launch is done
+          // instead of after the whole sub-batch's pairs
+          VHIP(hipStreamWaitEvent(streams[i], v->evFv[i - 1], 0));
+          if ((rc = search_range(streams[i], f0 - 1, 1))) return rc;
           VHIP(hipEventRecord(v->evBoundary[i], streams[i]));
           VHIP(hipStreamWaitEvent(streams[i - 1], v->evBoundary[i], 0));
-          VHIP(hipEventRecord(chunkDone[i], streams[i]));  // "sub-batch i done" now includes its matcher
         }
+        if ((rc = search_range(streams[i], f0, n - 1))) return rc;
+        orbfe_extractor_stage_mark_(e, ORBFE_STAGE_MATCH, i, 1, streams[i], n);
+        if (i > 0) VHIP(hipEventRecord(chunkDone[i], streams[i]));  // "sub-batch i done" now includes its matcher
       }
       VHIP(hipGetLastError());
       return ORBFE_OK;
