@@ -35,11 +35,6 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
   }
   return v;
 }
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
 // rotation-histogram bin, src/ORBmatcher.cc:272-279 (C round(): half away from zero)
 __device__ __forceinline__ int rot_bin(float a1, float a2) {
   const float factor = 1.0f / 30;
@@ -134,9 +129,62 @@ __device__ __forceinline__ void bow_node(const BowArgs& a, const NodePair np, in
   }
 }
 
+// The common case -- both sides of the node hold at most 64 features (k = 10, level 2: ~1 % of a frame each) -- without
+// a memory access inside the sequential query loop: lane p keeps candidate p's descriptor, index, angle and its
+// "claimed" flag in registers, lane q keeps query q's, a query is handed to the wave with v_readlane (q is the loop
+// counter).  bow_node's chain per query was index -> descriptor -> candidate descriptors (three dependent round trips,
+// ~40 us per node); here a node is two round trips plus ~100 ALU cycles per query.  Same scan order, same claims.
+__device__ __forceinline__ void bow_node_small(const BowArgs& a, const NodePair np, int lane) {
+  uint32_t idx1 = 0, idx2 = 0;
+  bool ok1 = false, free2 = false;
+  if (lane < np.cnt1) { idx1 = a.indices1[np.off1 + lane]; ok1 = !(a.hasMp1 && !a.hasMp1[idx1]); }
+  if (lane < np.cnt2) { idx2 = a.indices2[np.off2 + lane]; free2 = !(a.hasMp2 && !a.hasMp2[idx2]); }
+  Desc D1 = {}, D2 = {};
+  float ang1 = 0.f, ang2 = 0.f;
+  if (lane < np.cnt1) { D1 = load_desc(a.desc1, idx1); ang1 = a.angle1[(size_t)idx1 * a.angleStride]; }
+  if (lane < np.cnt2) { D2 = load_desc(a.desc2, idx2); ang2 = a.angle2[(size_t)idx2 * a.angleStride]; }
+  const unsigned long long okMask = __ballot(ok1);
+  for (int q = 0; q < np.cnt1; q++) {
+    if (!((okMask >> q) & 1ull)) continue;  // wave-uniform
+    Desc d1;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d1.w[i] = (uint32_t)__builtin_amdgcn_readlane((int)D1.w[i], q);
+    uint32_t key1 = (256u << 16) | 0xffffu;  // (bestDist1, position) -- first minimum wins
+    uint32_t best2 = 256u;
+    if (free2) key1 = ((uint32_t)hdist(d1, D2) << 16) | (uint32_t)lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t ok1k = (uint32_t)__shfl_xor((int)key1, o, 64);
+      const uint32_t ob2 = (uint32_t)__shfl_xor((int)best2, o, 64);
+      const uint32_t lo = ok1k < key1 ? ok1k : key1, hi = ok1k < key1 ? key1 : ok1k;
+      const uint32_t m2 = ob2 < best2 ? ob2 : best2;
+      key1 = lo;
+      best2 = (hi >> 16) < m2 ? (hi >> 16) : m2;
+    }
+    key1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)key1);
+    best2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)best2);
+    const uint32_t bestDist1 = key1 >> 16, pos = key1 & 0xffffu;
+    const bool pass1 = a.strictLow ? (bestDist1 < 50u) : (bestDist1 <= 50u);  // :263 vs :686
+    if (pass1 && (float)bestDist1 < __fmul_rn(a.nnratio, (float)best2)) {  // wave-uniform; pos < cnt2 here
+      if ((uint32_t)lane == pos) free2 = false;  // :267 / :691
+      const uint32_t i1 = (uint32_t)__builtin_amdgcn_readlane((int)idx1, q);
+      const uint32_t i2 = (uint32_t)__builtin_amdgcn_readlane((int)idx2, (int)pos);
+      const float a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ang1), q));
+      const float a2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ang2), (int)pos));
+      if (lane == 0) {
+        const int bin = rot_bin(a1, a2);
+        if (a.strictLow) { a.match[i1] = (int32_t)i2; a.bin[i1] = (int8_t)bin; }
+        else { a.match[i2] = (int32_t)i1; a.bin[i2] = (int8_t)bin; }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(64) void k_search_by_bow(BowArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t claimed[];  // per position in node 2
-  bow_node(a, a.pairs[blockIdx.x], threadIdx.x, claimed);
+  const NodePair np = a.pairs[blockIdx.x];
+  if (np.cnt1 <= 64 && np.cnt2 <= 64) bow_node_small(a, np, threadIdx.x);
+  else bow_node(a, np, threadIdx.x, claimed);
 }
 
 // Device-resident batch: pair p = SearchByBoW(KF = frame p, F = frame p+1) with the FeatureVectors
@@ -172,7 +220,8 @@ __global__ __launch_bounds__(64) void k_search_by_bow_batch(BowBatch b) {
   a.match = b.match + (size_t)p * c;
   a.bin = b.bin + (size_t)p * c;
   const NodePair np = {off1[i], off1[i + 1] - off1[i], off2[lo], off2[lo + 1] - off2[lo]};
-  bow_node(a, np, lane, claimed);
+  if (np.cnt1 <= 64 && np.cnt2 <= 64) bow_node_small(a, np, lane);
+  else bow_node(a, np, lane, claimed);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -285,10 +334,12 @@ void launch_search_triangulation(hipStream_t s, const TriArgs& a) {
 void launch_rot_prune(hipStream_t s, int32_t* match, const int8_t* bin, int n, int checkOri, int32_t* nMatches) {
   hipLaunchKernelGGL(k_rot_prune, dim3(1), dim3(256), 0, s, match, bin, n, checkOri, nMatches, 0);
 }
-void launch_search_by_bow_batch(hipStream_t s, const BowBatch& b, int nPairs, int checkOri, int32_t* d_nMatches) {
+void launch_search_by_bow_batch(hipStream_t s, const BowBatch& b, int nPairs, int checkOri, int32_t* d_nMatches, int maxNodes) {
   if (nPairs <= 0 || b.capacity <= 0) return;
   const size_t lds = (size_t)((b.capacity + 15) & ~15);
-  hipLaunchKernelGGL(k_search_by_bow_batch, dim3(b.capacity, nPairs), dim3(64), lds, s, b);
+  // a FeatureVector has at most min(capacity, nodes of the vocabulary at that level) entries: no workgroups beyond that
+  const int gx = (maxNodes > 0 && maxNodes < b.capacity) ? maxNodes : b.capacity;
+  hipLaunchKernelGGL(k_search_by_bow_batch, dim3(gx, nPairs), dim3(64), lds, s, b);
   hipLaunchKernelGGL(k_rot_prune, dim3(nPairs), dim3(256), 0, s, b.match, b.bin, b.capacity, checkOri, d_nMatches,
                      b.capacity);
 }
@@ -304,108 +355,158 @@ struct StereoPair {  // per-pair operands (kept apart from the kernel argument s
   const int32_t* rowStart; const int32_t* sortedIdx; const float4* sortedRec;
 };
 
-__device__ __forceinline__ void stereo_one(const StereoArgs& a, const StereoPair& pp, int iL, int lane) {
-  const float* kl = pp.kpL + (size_t)iL * 7;
-  const float uL = kl[0], vL = kl[1];
-  // the left keypoint is wave-uniform: make its level a scalar so the per-level tables of the
-  // kernel argument are read with scalar loads (a vector index would spill the struct to scratch)
-  const int levelL = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int32_t*>(kl)[5]);
-  if (lane == 0) { pp.uRight[iL] = -1.0f; pp.depth[iL] = -1.0f; pp.sad[iL] = -1; }
+// ---- 16 lanes per left keypoint (one DPP row), four keypoints per wavefront ----
+// Round 1 gave a whole wavefront to a left keypoint whose row band holds ~80 right keypoints of which ~9 reach the
+// Hamming distance, and read the 11 x (11 x 11) SAD windows with byte loads: mostly idle lanes and waits (1.35 ms per
+// 512 KITTI pairs; this form 0.85 ms).  A keypoint owns the 16 lanes of a DPP row: the candidate scan strides 16, the SAD gives patch ROW r
+// to lane r (one 16-byte request for the left row, 24 bytes for the 21-pixel right strip all 11 shifts share), the
+// 11 x 11 absolute differences of a shift are v_sad_u16 on packed pairs -- |(l - cL) - (r - cR)| = |(l + cR) - (r + cL)|
+// with both sides in [0, 510] -- and the row sums meet in a rotate-add over the DPP row.  Same results bit for bit
+// (integer sums; the fp32 tail is the same code), a quarter of the wavefronts and ~1/3 of the VALU work per keypoint.
+__device__ __forceinline__ uint32_t row16_min_u32(uint32_t v) {
+  uint32_t t;
+  t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xf, 0xf, false); v = t < v ? t : v;  // row_ror:1
+  t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xf, 0xf, false); v = t < v ? t : v;  // row_ror:2
+  t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xf, 0xf, false); v = t < v ? t : v;  // row_ror:4
+  t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false); v = t < v ? t : v;  // row_ror:8
+  return v;
+}
+__device__ __forceinline__ int row16_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);
+  return v;
+}
+// v_perm_b32 selector: bytes (o, o+1) of the 8 bytes {hi, lo} as a packed u16 pair
+constexpr uint32_t selpair(int o) { return (uint32_t)o | 0x0c00u | ((uint32_t)(o + 1) << 16) | 0x0c000000u; }
+
+// `lv` = per-level views of both pyramids in LDS (a vector level index into the kernel argument would go through scratch)
+struct StereoLds { LevelView L[kMaxLevels], R[kMaxLevels]; };
+
+__device__ __forceinline__ void stereo_row16(const StereoArgs& a, const StereoLds& lv, const StereoPair& pp, int iL, bool alive,
+                                             int lane) {
+  const int sub = lane & 15, rowBase = lane & 48;
+  float uL = 0.f, vL = 0.f;
+  int levelL = 0;
+  if (alive) {
+    const float* kl = pp.kpL + (size_t)iL * 7;
+    uL = kl[0]; vL = kl[1];
+    levelL = reinterpret_cast<const int32_t*>(kl)[5];
+  }
   const int row = (int)vL;
   const float minU = __fsub_rn(uL, a.maxD), maxU = uL;  // minD = 0
-  if (maxU < 0) return;
-  const Desc dL = load_desc(pp.descL, iL);
-  // candidates: right keypoints whose row band [floor(y-r), ceil(y+r)], r = 2*scale[octave],
-  // contains `row` (:522-539), octave within +-1 (:579), uR in [minU, maxU] (:584);
-  // best = strictly smaller distance, i.e. first minimum in ascending iR (:589-593)
-  uint32_t best = 0xffffffffu;  // dist << 20 | iR
-  // right keypoints are bucketed by floor(y) (k_stereo_bucket): only the rows that can hold a
-  // band covering `row` are scanned; ties still resolve to the smallest original index iR
-  int pBeg = 0, pEnd = pp.Nr;
-  if (pp.rowStart) {
+  bool live = alive && !(maxU < 0);
+  int pBeg = 0, pEnd = live ? pp.Nr : 0;
+  if (pp.rowStart && live) {
     int lo = row - a.bandR, hi = row + a.bandR;
     lo = lo < 0 ? 0 : lo;
     hi = hi > a.rows - 1 ? a.rows - 1 : hi;
-    if (lo > hi) return;
-    pBeg = pp.rowStart[lo];
-    pEnd = pp.rowStart[hi + 1];
+    if (lo > hi) { live = false; pEnd = 0; }
+    else { pBeg = pp.rowStart[lo]; pEnd = pp.rowStart[hi + 1]; }
   }
-  float bestU = 0.f;  // uR of this lane's best candidate (the winner's is read back after the wave minimum)
-  for (int p = pBeg + lane; p < pEnd; p += 64) {
-    int iR, octR;
-    float yR, uR;
-    if (pp.sortedRec) {  // one 16-byte record per candidate
-      const float4 rc = pp.sortedRec[p];
-      uR = rc.x; yR = rc.y; octR = __float_as_int(rc.z); iR = __float_as_int(rc.w);
-    } else {
-      iR = pp.rowStart ? pp.sortedIdx[p] : p;
-      const float* kr = pp.kpR + (size_t)iR * 7;
-      octR = reinterpret_cast<const int32_t*>(kr)[5];
-      yR = kr[1];
-      uR = kr[0];
+  Desc dL = {};
+  if (live) dL = load_desc(pp.descL, iL);
+  // ---- candidate scan (:568-594), 16 lanes striding the band's sorted records ----
+  uint32_t best = 0xffffffffu;  // dist << 20 | iR
+  float bestU = 0.f;
+  for (int p = pBeg + sub; __any(p < pEnd); p += 16) {
+    if (p < pEnd) {
+      int iR, octR;
+      float yR, uR;
+      if (pp.sortedRec) {
+        const float4 rc = pp.sortedRec[p];
+        uR = rc.x; yR = rc.y; octR = __float_as_int(rc.z); iR = __float_as_int(rc.w);
+      } else {
+        iR = pp.rowStart ? pp.sortedIdx[p] : p;
+        const float* kr = pp.kpR + (size_t)iR * 7;
+        octR = reinterpret_cast<const int32_t*>(kr)[5];
+        yR = kr[1];
+        uR = kr[0];
+      }
+      const float r = __fmul_rn(2.0f, a.scaleTab[octR]);
+      const int maxr = (int)ceilf(__fadd_rn(yR, r));
+      const int minr = (int)floorf(__fsub_rn(yR, r));
+      const bool cand = row >= minr && row <= maxr && octR >= levelL - 1 && octR <= levelL + 1 && uR >= minU && uR <= maxU;
+      if (cand) {
+        const uint32_t dist = (uint32_t)hdist(dL, load_desc(pp.descR, iR));
+        const uint32_t key = (dist << 20) | (uint32_t)iR;
+        if (dist < 100u && key < best) { best = key; bestU = uR; }  // bestDist starts at TH_HIGH, strict <
+      }
     }
-    const float r = __fmul_rn(2.0f, a.scaleTab[octR]);
-    const int maxr = (int)ceilf(__fadd_rn(yR, r));
-    const int minr = (int)floorf(__fsub_rn(yR, r));
-    if (row < minr || row > maxr) continue;
-    if (octR < levelL - 1 || octR > levelL + 1) continue;
-    if (!(uR >= minU && uR <= maxU)) continue;
-    const uint32_t dist = (uint32_t)hdist(dL, load_desc(pp.descR, iR));
-    if (dist >= 100u) continue;  // bestDist starts at TH_HIGH, strict <
-    const uint32_t key = (dist << 20) | (uint32_t)iR;
-    if (key < best) { best = key; bestU = uR; }
   }
   const uint32_t mine = best;
-  best = wave_min_u32(best);
-  if (best == 0xffffffffu) return;
-  const int bestDist = (int)(best >> 20);
-  if (bestDist >= 75) return;  // thOrbDist = (TH_HIGH+TH_LOW)/2, :517,598
-  // the winning lane (keys are unique: they carry iR) hands over its uR -- no second trip to the keypoint array
+  best = row16_min_u32(best);
+  live = live && best != 0xffffffffu && (int)(best >> 20) < 75;  // thOrbDist = (TH_HIGH+TH_LOW)/2, :517,598
+  // the winning lane of the row (keys are unique: they carry iR) hands over its uR
   const unsigned long long win = __ballot(mine == best);
-  const float uR0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bestU), __builtin_ctzll(win)));
+  const uint32_t winRow = (uint32_t)(win >> rowBase) & 0xffffu;
+  const int src = rowBase + (winRow ? __builtin_ctz(winRow) : 0);
+  const float uR0 = __shfl(bestU, src, 64);
   // ---- SAD refinement on the left keypoint's pyramid level (:600-638) ----
   const float sf = a.scaleTab[kMaxLevels + levelL];
   const float scaleduL = roundf(__fmul_rn(uL, sf));
   const float scaledvL = roundf(__fmul_rn(vL, sf));
   const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
-  const LevelView L = a.pyrL.lv[levelL], R = a.pyrR.lv[levelL];
+  const LevelView L = lv.L[levelL], R = lv.R[levelL];
   const float iniu = scaleduR0 + 5 - 5;
   const float endu = scaleduR0 + 5 + 5 + 1;
-  if (iniu < 0 || endu >= (float)R.w) return;
+  if (iniu < 0 || endu >= (float)R.w) live = false;
   const int cy = (int)scaledvL, cxL = (int)scaleduL, cxR0 = (int)scaleduR0;
-  const uint8_t* IL = L.base + (size_t)pp.frameL * L.frameStride;
-  const uint8_t* IR = R.base + (size_t)pp.frameR * R.frameStride;
-  const int cL = IL[(size_t)cy * L.pitch + cxL];
-  // lanes own patch pixels p = lane, lane+64 of the 11x11 window
-  int pl[2], py[2], px[2];
+  // lane r < 11 of the row holds patch row cy-5+r: left bytes cxL-5 .. cxL+5 in ql[0..2], right bytes cxR0-10 .. cxR0+10 in
+  // qr[0..5].  Keypoints of the extractor lie >= 19 px inside their level, so the 16- and 24-byte requests stay inside the
+  // image row; any other caller's keypoints take byte loads of exactly the pixels the reference reads
+  uint32_t ql[4] = {0u, 0u, 0u, 0u}, qr[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+  if (live && sub < 11) {
+    const uint8_t* pl = L.base + (size_t)pp.frameL * L.frameStride + (ptrdiff_t)(cy + sub - 5) * L.pitch + (cxL - 5);
+    const uint8_t* pr = R.base + (size_t)pp.frameR * R.frameStride + (ptrdiff_t)(cy + sub - 5) * R.pitch + (cxR0 - 10);
+    struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };
+    struct __attribute__((packed, aligned(1))) U2u { uint32_t x, y; };
+    const bool wide = cxL >= 5 && cxL + 10 < L.w && cxR0 >= 10 && cxR0 + 13 < R.w && cy >= 5 && cy + 5 < L.h && cy + 5 < R.h;
+    if (wide) {
+      const U4u a4 = *reinterpret_cast<const U4u*>(pl);
+      const U4u b4 = *reinterpret_cast<const U4u*>(pr);
+      const U2u c2 = *reinterpret_cast<const U2u*>(pr + 16);
+      ql[0] = a4.x; ql[1] = a4.y; ql[2] = a4.z;
+      qr[0] = b4.x; qr[1] = b4.y; qr[2] = b4.z; qr[3] = b4.w; qr[4] = c2.x; qr[5] = c2.y;
+    } else {
 #pragma unroll
-  for (int k = 0; k < 2; k++) {
-    const int p = lane + 64 * k;
-    py[k] = p / 11 - 5;
-    px[k] = p % 11 - 5;
-    pl[k] = p < 121 ? (int)IL[(size_t)(cy + py[k]) * L.pitch + cxL + px[k]] - cL : 0;
+      for (int k = 0; k < 11; k++) ql[k >> 2] |= (uint32_t)pl[k] << (8 * (k & 3));
+#pragma unroll
+      for (int k = 0; k < 21; k++) qr[k >> 2] |= (uint32_t)pr[k] << (8 * (k & 3));
+    }
   }
+  // centres: cL = left (cy, cxL) = row 5, byte 5; cR(inc) = right (cy, cxR0+inc) = row 5, bytes 5 .. 15
+  const uint32_t cL = ((uint32_t)__shfl((int)ql[1], rowBase + 5, 64) >> 8) & 0xffu;
+  const uint32_t c1 = (uint32_t)__shfl((int)qr[1], rowBase + 5, 64), c2 = (uint32_t)__shfl((int)qr[2], rowBase + 5, 64),
+                 c3 = (uint32_t)__shfl((int)qr[3], rowBase + 5, 64);
+  const uint32_t cLL = cL | (cL << 16);
+  uint32_t A[5], B[19], C[11];
+#pragma unroll
+  for (int m = 0; m < 5; m++) A[m] = __builtin_amdgcn_perm(ql[(m >> 1) + 1], ql[m >> 1], selpair((2 * m) & 3));
+  const uint32_t l10 = (ql[2] >> 16) & 0xffu;
+#pragma unroll
+  for (int t = 0; t < 19; t++) B[t] = __builtin_amdgcn_perm(qr[(t >> 2) + 1], qr[t >> 2], selpair(t & 3)) + cLL;
+#pragma unroll
+  for (int t = 10; t < 21; t++) C[t - 10] = ((qr[t >> 2] >> (8 * (t & 3))) & 0xffu) + cL;
   int dists[11];
 #pragma unroll
-  for (int inc = -5; inc <= 5; inc++) {
-    const int cxR = cxR0 + inc;
-    const int cR = IR[(size_t)cy * R.pitch + cxR];
-    int acc = 0;
+  for (int s = 0; s < 11; s++) {  // s = inc + 5
+    const int cb = 5 + s;          // byte of the row-5 strip that is this shift's centre
+    const uint32_t cw = cb < 8 ? c1 : (cb < 12 ? c2 : c3);
+    const uint32_t cR = (cw >> (8 * (cb & 3))) & 0xffu;
+    const uint32_t cRR = cR | (cR << 16);
+    uint32_t acc = 0;
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-      if (lane + 64 * k < 121) {
-        const int v = (int)IR[(size_t)(cy + py[k]) * R.pitch + cxR + px[k]] - cR;
-        const int d = pl[k] - v;
-        acc += d < 0 ? -d : d;
-      }
-    }
-    dists[inc + 5] = wave_sum_i32(acc);
+    for (int m = 0; m < 5; m++) acc = __builtin_amdgcn_sad_u16(A[m] + cRR, B[2 * m + s], acc);
+    acc = __builtin_amdgcn_sad_u16(l10 + cR, C[s], acc);
+    dists[s] = row16_sum_i32(sub < 11 ? (int)acc : 0);
   }
   int bestSad = 0x7fffffff, bestinc = 0;
 #pragma unroll
   for (int i = 0; i < 11; i++)
     if (dists[i] < bestSad) { bestSad = dists[i]; bestinc = i - 5; }
-  if (bestinc == -5 || bestinc == 5) return;
+  if (bestinc == -5 || bestinc == 5) live = false;
   float d1 = 0, d2 = 0, d3 = 0;
 #pragma unroll
   for (int i = 1; i < 10; i++)
@@ -413,20 +514,21 @@ __device__ __forceinline__ void stereo_one(const StereoArgs& a, const StereoPair
   // parabola sub-pixel (:644-651)
   const float deltaR = __fdiv_rn(__fsub_rn(d1, d3),
                                  __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2))));
-  if (deltaR < -1 || deltaR > 1) return;
+  if (deltaR < -1 || deltaR > 1) live = false;
   float bestuR = __fmul_rn(a.scaleTab[levelL], __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));
   float disparity = __fsub_rn(uL, bestuR);
-  if (disparity >= 0 && disparity < a.maxD) {
+  float oU = -1.0f, oD = -1.0f;
+  int oS = -1;
+  if (live && disparity >= 0 && disparity < a.maxD) {
     if (disparity <= 0) {
       disparity = 0.01f;
       bestuR = (float)__dsub_rn((double)uL, 0.01);
     }
-    if (lane == 0) {
-      pp.depth[iL] = __fdiv_rn(a.mbf, disparity);
-      pp.uRight[iL] = bestuR;
-      pp.sad[iL] = bestSad;
-    }
+    oD = __fdiv_rn(a.mbf, disparity);
+    oU = bestuR;
+    oS = bestSad;
   }
+  if (alive && sub == 0) { pp.uRight[iL] = oU; pp.depth[iL] = oD; pp.sad[iL] = oS; }
 }
 
 // Counting sort of the right keypoints by image row floor(y): rowStart[r] .. rowStart[r+1] index
@@ -481,30 +583,40 @@ __global__ __launch_bounds__(256) void k_stereo_bucket(const float* __restrict__
   }
 }
 
+__device__ __forceinline__ void stereo_stage_views(const StereoArgs& a, StereoLds& lv) {
+  const int t = threadIdx.x;
+  if (t < kMaxLevels) lv.L[t] = a.pyrL.lv[t];
+  else if (t < 2 * kMaxLevels) lv.R[t - kMaxLevels] = a.pyrR.lv[t - kMaxLevels];
+  __syncthreads();
+}
+
+// 256 threads = 16 left keypoints (16 lanes each, stereo_row16)
 __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a) {
+  __shared__ StereoLds lv;
+  stereo_stage_views(a, lv);
   const int lane = threadIdx.x & 63;
-  const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (iL >= a.N) return;
+  const int iL = blockIdx.x * 16 + (threadIdx.x >> 4);
   StereoPair pp = {a.kpL, a.descL, a.N, a.kpR, a.descR, a.Nr, a.frameL, a.frameR, a.uRight, a.depth, a.sad,
                    a.rowStart, a.sortedIdx, a.rowStart ? a.sortedRec : nullptr};
-  stereo_one(a, pp, iL, lane);
+  stereo_row16(a, lv, pp, iL, iL < a.N, lane);
 }
 
 // Batched, device-resident form: pair p = frames (2p, 2p+1) of one extractor batch; the
 // keypoint counts are read from device memory (d_n of orbfe_extract_batch_device).
 __global__ __launch_bounds__(256) void k_stereo_match_batch(const StereoArgs a, const StereoBatch b) {
+  __shared__ StereoLds lv;
+  stereo_stage_views(a, lv);
   const int lane = threadIdx.x & 63;
-  const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int iL = blockIdx.x * 16 + (threadIdx.x >> 4);
   const int p = blockIdx.y;
   int N = b.n[2 * p], Nr = b.n[2 * p + 1];
   if (N > b.capacity) N = b.capacity;
   if (Nr > b.capacity) Nr = b.capacity;
-  if (iL >= b.capacity) return;
   const size_t oL = (size_t)(2 * p) * b.capacity, oR = (size_t)(2 * p + 1) * b.capacity, oO = (size_t)p * b.capacity;
-  if (iL >= N) {  // slots past the left frame's keypoints: defined "no stereo" outputs
-    if (lane == 0) { b.uRight[oO + iL] = -1.0f; b.depth[oO + iL] = -1.0f; b.sad[oO + iL] = -1; }
-    return;
+  if (iL < b.capacity && iL >= N && (lane & 15) == 0) {  // slots past the left frame's keypoints: defined "no stereo" outputs
+    b.uRight[oO + iL] = -1.0f; b.depth[oO + iL] = -1.0f; b.sad[oO + iL] = -1;
   }
+  if (blockIdx.x * 16 >= N) return;  // block-uniform: nothing left to match
   StereoPair pp;
   pp.kpL = b.kp + oL * 7; pp.descL = b.desc + oL * 32; pp.N = N;
   pp.kpR = b.kp + oR * 7; pp.descR = b.desc + oR * 32; pp.Nr = Nr;
@@ -513,7 +625,7 @@ __global__ __launch_bounds__(256) void k_stereo_match_batch(const StereoArgs a, 
   pp.rowStart = a.rowStart ? a.rowStart + (size_t)p * (a.rows + 1) : nullptr;
   pp.sortedIdx = a.rowStart ? a.sortedIdx + (size_t)p * b.capacity : nullptr;
   pp.sortedRec = (a.rowStart && a.sortedRec) ? a.sortedRec + (size_t)p * b.capacity : nullptr;
-  stereo_one(a, pp, iL, lane);
+  stereo_row16(a, lv, pp, iL, iL < N, lane);
 }
 
 // Median cut (:672-685): drop matches whose SAD >= 1.5*1.4*median, median = sorted[size/2].
@@ -582,7 +694,7 @@ void launch_stereo(hipStream_t s, const StereoArgs& a, int32_t* d_nStereo) {
     hipLaunchKernelGGL(k_stereo_bucket, dim3(1), dim3(256), (size_t)(a.rows + 1) * sizeof(int), s, a.kpR,
                        (const int32_t*)nullptr, a.Nr, a.Nr, a.rows, const_cast<int32_t*>(a.rowStart),
                        const_cast<int32_t*>(a.sortedIdx), const_cast<float4*>(a.sortedRec));
-  hipLaunchKernelGGL(k_stereo_match, dim3((a.N + 3) / 4), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_stereo_match, dim3((a.N + 15) / 16), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_stereo_median_cut, dim3(1), dim3(256), 0, s, a.N, a.sad, a.uRight, a.depth, d_nStereo, 0);
 }
 
@@ -592,7 +704,7 @@ void launch_stereo_batch(hipStream_t s, const StereoArgs& a, const StereoBatch& 
     hipLaunchKernelGGL(k_stereo_bucket, dim3(nPairs), dim3(256), (size_t)(a.rows + 1) * sizeof(int), s, b.kp, b.n, 0,
                        b.capacity, a.rows, const_cast<int32_t*>(a.rowStart), const_cast<int32_t*>(a.sortedIdx),
                        const_cast<float4*>(a.sortedRec));
-  hipLaunchKernelGGL(k_stereo_match_batch, dim3((b.capacity + 3) / 4, nPairs), dim3(256), 0, s, a, b);
+  hipLaunchKernelGGL(k_stereo_match_batch, dim3((b.capacity + 15) / 16, nPairs), dim3(256), 0, s, a, b);
   hipLaunchKernelGGL(k_stereo_median_cut, dim3(nPairs), dim3(256), 0, s, b.capacity, b.sad, b.uRight, b.depth,
                      d_nStereo, b.capacity);
 }

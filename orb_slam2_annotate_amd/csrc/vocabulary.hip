@@ -410,6 +410,9 @@ static int bow_match_consecutive(orbfe_vocabulary* v, orbfe_extractor* e, int n_
   bb.fvNodes = v->w_nodes; bb.fvOffsets = v->w_offsets; bb.fvIndices = v->w_indices; bb.fvCount = v->w_count;
   bb.nnratio = nnratio; bb.match = d_match; bb.bin = v->w_bin;
   const size_t c = (size_t)capacity;
+  // nodes at level L - levelsup of a k-ary tree: at most k^level (FeatureVector entries per frame)
+  int maxNodes = 1;
+  for (int l = 0; l < v->L - levelsup && maxNodes < capacity; l++) maxNodes = maxNodes > capacity / (v->k > 1 ? v->k : 1) ? capacity : maxNodes * v->k;
   auto featvec_range = [&](hipStream_t st, int f0, int n) {
     FeatVecBatch r = fb;
     r.desc += (size_t)f0 * c * 32; r.n += f0;
@@ -424,7 +427,7 @@ static int bow_match_consecutive(orbfe_vocabulary* v, orbfe_extractor* e, int n_
     r.kp += (size_t)p0 * c * 7; r.desc += (size_t)p0 * c * 32;
     r.fvNodes += (size_t)p0 * c; r.fvOffsets += (size_t)p0 * (c + 1); r.fvIndices += (size_t)p0 * c; r.fvCount += p0;
     r.match += (size_t)p0 * c; r.bin += (size_t)p0 * c;
-    launch_search_by_bow_batch(st, r, np, check_orientation, d_nmatches + p0);
+    launch_search_by_bow_batch(st, r, np, check_orientation, d_nmatches + p0, maxNodes);
     return ORBFE_OK;
   };
   if (e) {
