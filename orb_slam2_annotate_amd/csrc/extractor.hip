@@ -557,7 +557,7 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
       a.kpSize[l] = (float)(int)(kPatchSize * e->tab.scale[l]);  // :905
     }
     launch_orient_desc(sT, a, levelKp, levelCount, e->d_patternF, e->d_momentTab, e->d_umax, nFrames,
-                       d_kp + F * capacity, d_desc + F * (size_t)capacity * 32, d_nOut + F);
+                       d_kp + F * capacity, d_desc + F * (size_t)capacity * 32, d_nOut + F, e->lastS);
   }
   if (lanes) {
     HIPCHK(hipEventRecord(e->evTail[sub], sT));

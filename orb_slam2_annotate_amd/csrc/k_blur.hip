@@ -20,14 +20,14 @@
 //      accumulate), rounding, one 32-bit coalesced store per 4 pixels.
 // Every source byte is read once per tile (+ halo), every output written once; measured: 61 % VALU
 // issue, the rest is waiting for the tile's own staging loads.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace orbfe {
 
 namespace {
-constexpr int kBW = 64, kBH = 64;
-constexpr int kTDW = (kBW + 8) / 4;  // 18 tile dwords per row: columns bx-4 .. bx+67
-constexpr int kTH = kBH + 6;         // rows by-3 .. by+34
+// tile shapes (output columns x rows): 64 x 64 (round 1) and 128 x 32 -- see launch_blur7_levels
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 as_u2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
@@ -54,8 +54,14 @@ struct BlurBatch {
   int nlevels, nFrames;
 };
 
-template <int SPEC>
+template <int SPEC, int kBW, int kBH>
 __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
+  constexpr int kTDW = (kBW + 8) / 4;  // tile dwords per row: columns bx-4 .. bx+kBW+3
+  constexpr int kTH = kBH + 6;         // rows by-3 .. by+kBH+2
+  constexpr int kSR = 256 / kTDW;      // tile rows one staging step of the workgroup covers (14 / 7)
+  constexpr int kSteps = (kTH + kSR - 1) / kSR;
+  constexpr int kGX = kBW / 4;         // 4-pixel output groups per tile row (16 / 32)
+  constexpr int kHR = 256 / kGX;       // output rows one step of the horizontal pass covers (16 / 8)
   constexpr uint32_t K0 = 18, K1 = 34, K2 = SPEC == 0 ? 48 : 49, K3 = SPEC == 0 ? 56 : 55;
   __shared__ uint32_t tin[kTH * kTDW];             // source bytes
   __shared__ uint2 vbuf[kBH * kTDW];               // vertical sums, 4 u16 per entry
@@ -85,21 +91,22 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   // unaligned addresses on gfx950 (profiles/r02_unaligned.txt), so a caller-owned level 0 with an odd stride
   // (KITTI: 1241) runs the same paths as the handle's own 64-byte pitched levels
   struct __attribute__((packed, aligned(1))) U1u { uint32_t x; };
-  // ---- 1. stage: thread (ty0, tj) = (tid / 18, tid % 18) walks down the tile 14 rows at a time ----
-  if (tid < 14 * kTDW) {
-    const int ty0 = (int)(((uint32_t)tid * 3641u) >> 16), tj = tid - ty0 * kTDW;  // tid / 18 for tid < 252
+  // ---- 1. stage: thread (ty0, tj) = (tid / kTDW, tid % kTDW) walks down the tile kSR rows at a time ----
+  if (tid < kSR * kTDW) {
+    const int ty0 = (int)((uint32_t)tid / (uint32_t)kTDW), tj = tid - ty0 * kTDW;
     if (bx >= 4 && bx + kBW + 4 <= src.w && by >= 3 && by + kBH + 3 <= src.h) {
       // interior tile (block-uniform): no reflection, every dword is an aligned in-row load
       const uint8_t* T0 = S + (size_t)(by - 3) * src.pitch + (bx - 4);     // block-uniform (scalar) tile origin
       const uint32_t o0 = (uint32_t)ty0 * (uint32_t)src.pitch + 4u * (uint32_t)tj;  // 32-bit lane offset
 #pragma unroll
-      for (int k = 0; k < 5; k++)
-        tin[(ty0 + 14 * k) * kTDW + tj] = reinterpret_cast<const U1u*>(T0 + (o0 + (uint32_t)(14 * k) * (uint32_t)src.pitch))->x;
+      for (int k = 0; k < kSteps; k++)
+        if ((k + 1) * kSR <= kTH || ty0 + kSR * k < kTH)
+          tin[(ty0 + kSR * k) * kTDW + tj] = reinterpret_cast<const U1u*>(T0 + (o0 + (uint32_t)(kSR * k) * (uint32_t)src.pitch))->x;
     } else if (bx >= 4 && bx + kBW + 4 <= src.w) {
       // top / bottom tile away from the left and right edges: every dword is still an aligned in-row
       // load, only the row index is reflected
       const uint32_t c0 = (uint32_t)(bx - 4) + 4u * (uint32_t)tj;
-      for (int ty = ty0; ty < stageRows; ty += 14) {
+      for (int ty = ty0; ty < stageRows; ty += kSR) {
         const int sy = reflect101c(by - 3 + ty, src.h);
         tin[ty * kTDW + tj] = reinterpret_cast<const U1u*>(S + ((uint32_t)sy * (uint32_t)src.pitch + c0))->x;
       }
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
       int cx[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) cx[k] = reflect101c(c + k, src.w);
-      for (int ty = ty0; ty < stageRows; ty += 14) {
+      for (int ty = ty0; ty < stageRows; ty += kSR) {
         const int sy = reflect101c(by - 3 + ty, src.h);
         const uint8_t* row = S + (size_t)sy * src.pitch;
         uint32_t v;
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   // ---- 2. vertical pass: a thread owns 4 adjacent columns x 4 output rows; the 10 source dwords are
   //         split into u16 pairs once and shared by the 4 rows; 8.8 sums, two pixels per lane-op ----
   for (int i = tid; i < rowBlocks * kTDW; i += 256) {
-    const int rb = (int)(((uint32_t)i * 3641u) >> 16), tj = i - rb * kTDW;  // i / 18 for i < 288
+    const int rb = (int)((uint32_t)i / (uint32_t)kTDW), tj = i - rb * kTDW;
     const uint32_t* tp = &tin[(4 * rb) * kTDW + tj];
     u16x2 te[10], to[10];  // even bytes (0,2) and odd bytes (1,3) of each source dword
 #pragma unroll
@@ -158,14 +165,14 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   }
   __syncthreads();
   // ---- 3. horizontal pass on u16 pairs: out[x] = (sum_i K[i] * v[x+4+i-3] + 2^15) >> 16 ----
-  // thread = (row mod 16, column group): the tile origin D is block-uniform (scalar), the thread keeps a
-  // 32-bit byte offset and an LDS pointer and steps both by 16 rows per iteration
+  // thread = (row mod kHR, column group): the tile origin D is block-uniform (scalar), the thread keeps a
+  // 32-bit byte offset and an LDS pointer and steps both by kHR rows per iteration
   uint8_t* D = dst.base + (size_t)f * dst.frameStride + (size_t)by * dst.pitch + bx;
-  const int gx = tid & 15;
-  uint32_t off = (uint32_t)(tid >> 4) * (uint32_t)dst.pitch + 4u * (uint32_t)gx;
-  const uint2* vp = &vbuf[(tid >> 4) * kTDW + gx];
+  const int gx = tid % kGX;
+  uint32_t off = (uint32_t)(tid / kGX) * (uint32_t)dst.pitch + 4u * (uint32_t)gx;
+  const uint2* vp = &vbuf[(tid / kGX) * kTDW + gx];
   const bool colIn = bx + 4 * gx < dst.w;
-  for (int row = tid >> 4; row < rowsValid; row += 16, off += 16u * (uint32_t)dst.pitch, vp += 16 * kTDW) {
+  for (int row = tid / kGX; row < rowsValid; row += kHR, off += (uint32_t)kHR * (uint32_t)dst.pitch, vp += kHR * kTDW) {
     if (!colIn) continue;
     const uint2 e0 = vp[0], e1 = vp[1], e2 = vp[2];
     // d_k = (v'[2k], v'[2k+1]) with v' indexed from tile column 4*gx
@@ -204,8 +211,9 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   }
 }
 
-void launch_blur7_levels(hipStream_t s, const LevelView* src, const LevelViewMut* dst, int nlevels, int nFrames, int spec) {
-  if (nlevels <= 0 || nFrames <= 0) return;
+namespace {
+template <int kBW, int kBH>
+void launch_blur_tiles(hipStream_t s, const LevelView* src, const LevelViewMut* dst, int nlevels, int nFrames, int spec) {
   BlurBatch bb = {};
   bb.nlevels = nlevels;
   bb.nFrames = nFrames;
@@ -225,9 +233,17 @@ void launch_blur7_levels(hipStream_t s, const LevelView* src, const LevelViewMut
   if (total == 0) return;
   const dim3 grid((total + 7u) / 8u * 8u);
   static const size_t pad = occupancy_pad_bytes("BLUR", 0);
-  if (spec == kBlurSpecCv2Scalar) hipLaunchKernelGGL(k_blur7<1>, grid, dim3(256), pad, s, bb);
-  else if (spec == kBlurSpecCv2Sse2) hipLaunchKernelGGL(k_blur7<2>, grid, dim3(256), pad, s, bb);
-  else hipLaunchKernelGGL(k_blur7<0>, grid, dim3(256), pad, s, bb);
+  if (spec == kBlurSpecCv2Scalar) hipLaunchKernelGGL((k_blur7<1, kBW, kBH>), grid, dim3(256), pad, s, bb);
+  else if (spec == kBlurSpecCv2Sse2) hipLaunchKernelGGL((k_blur7<2, kBW, kBH>), grid, dim3(256), pad, s, bb);
+  else hipLaunchKernelGGL((k_blur7<0, kBW, kBH>), grid, dim3(256), pad, s, bb);
+}
+}  // namespace
+
+void launch_blur7_levels(hipStream_t s, const LevelView* src, const LevelViewMut* dst, int nlevels, int nFrames, int spec) {
+  if (nlevels <= 0 || nFrames <= 0) return;
+  static const int tile = getenv("ORBFE_BLUR_TILE") ? atoi(getenv("ORBFE_BLUR_TILE")) : 0;
+  if (tile == 1) launch_blur_tiles<128, 32>(s, src, dst, nlevels, nFrames, spec);
+  else launch_blur_tiles<64, 64>(s, src, dst, nlevels, nFrames, spec);
 }
 
 void launch_blur7(hipStream_t s, LevelView src, LevelViewMut dst, int nFrames, int spec) {

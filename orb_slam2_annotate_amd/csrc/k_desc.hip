@@ -12,6 +12,8 @@
 //   3. descriptors, one wavefront per keypoint: the 37x48-byte blurred patch is staged in LDS with
 //      16-byte requests, lane l evaluates tests l, l+64, l+128, l+192 on it (rotation in packed
 //      fp32 mul/add, no FMA); a wave ballot IS 8 descriptor bytes.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace orbfe {
@@ -58,13 +60,20 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
   __shared__ __attribute__((aligned(16))) uint32_t s_patch[4 * kUD * kPatchRows * kPatchDw];  // per wave: kUD patches
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // XCD-aware work mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, so block
-  // b takes work item (b % 8) * chunk + b / 8 with work = frame * blocksPerFrame + slot chunk: all
-  // workgroups of a frame run on ONE XCD, back to back, and that L2 fetches every line of the
-  // frame's pyramid once however many keypoint patches overlap it.
-  const unsigned chunkW = gridDim.x >> 3;
-  const unsigned work = (blockIdx.x & 7u) * chunkW + (blockIdx.x >> 3);
-  if (work >= (unsigned)blocksPerFrame * (unsigned)nFrames) return;
+  // XCD-aware work mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, so the workgroups with
+  // blockIdx % 8 == x walk the contiguous chunk x of the work items (work = frame * blocksPerFrame + slot chunk):
+  // all workgroups of a frame run on ONE XCD, back to back, and that L2 fetches every line of the frame's pyramid
+  // once however many keypoint patches overlap it.
+  // PERSISTENT form (gridDim.x < 8 * chunkW): a workgroup takes every (gridDim.x / 8)-th item of its chunk.  The
+  // number of workgroups in flight -- what decides how many frames' patches compete for an L2 -- is then the grid
+  // size, not an LDS reservation, and the LDS and wave slots the kernel does not use stay free for the kernels of the
+  // other streams (round 1 capped the occupancy with 23 KB of dead LDS per workgroup: 4 x 40 KB = the whole CU).
+  const unsigned totalWork = (unsigned)blocksPerFrame * (unsigned)nFrames;
+  const unsigned chunkW = (totalWork + 7u) >> 3;
+  const unsigned perXcd = gridDim.x >> 3;
+  for (unsigned itemInChunk = blockIdx.x >> 3; itemInChunk < chunkW; itemInChunk += perXcd) {
+  const unsigned work = (blockIdx.x & 7u) * chunkW + itemInChunk;
+  if (work >= totalWork) break;  // block-uniform
   const int f = (int)udiv_magic(work, (uint32_t)blocksPerFrame, blocksMagic);  // work / blocksPerFrame
   const int slot0 = (int)(work - (unsigned)f * (unsigned)blocksPerFrame) * kKpPerBlock;
   const int32_t* cnt = levelCount + (size_t)f * a.nlevels;
@@ -285,32 +294,46 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
       }
     }
   }
+  __syncthreads();  // the next item reuses the slot arrays
+  }  // work items of this workgroup
 }
 
 void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d_levelKp,
                         const int32_t* d_levelCount, const float4* d_patternF, const uint4* d_momentTab,
                         const int32_t* d_umax, int nFrames, void* d_kpOut, uint8_t* d_descOut,
-                        int32_t* d_nOut) {
+                        int32_t* d_nOut, int concurrentLaunches) {
   if (nFrames <= 0 || a.kpSlotsPerFrame <= 0) return;
   const bool latencyForm = nFrames <= 8;
   const int kpb = latencyForm ? 16 : 64;
   const int blocksPerFrame = (a.kpSlotsPerFrame + kpb - 1) / kpb;
   const unsigned total = (unsigned)blocksPerFrame * (unsigned)nFrames;
   const uint32_t blocksMagic = udiv_magic_multiplier((uint32_t)blocksPerFrame);
-  // Occupancy cap for the throughput form: 23 KB of unused dynamic LDS leave room for 4 workgroups per CU
-  // instead of 9.  All workgroups of a frame run on one XCD; with fewer frames in flight per XCD their
-  // patches stay in its 4 MB L2 (HBM fetch 1.17 -> 0.63 GB per 256 frames) -- same-box A/B over the
-  // whole pipeline: 291 k -> 303 k frames/s; 3 workgroups per CU measured the same, 2 and 5+ worse.
-  static const size_t kPad = occupancy_pad_bytes("ORIENT", 23);
+  // Occupancy cap for the throughput form.  All workgroups of a frame run on one XCD; with fewer frames in flight per
+  // XCD their patches stay in its 4 MB L2 (HBM fetch 1.17 -> 0.63 GB per 256 frames between 9 and 4 workgroups per CU).
+  // Round 1 set the cap with 23 KB of unused dynamic LDS per workgroup ($ORBFE_PAD_ORIENT, still honoured); round 2 sets
+  // it with the grid: a few workgroups per CU that loop over the work items, so the cap costs no LDS and the other
+  // streams' kernels can share the CUs.  What counts is the number in flight over all the sub-batch streams of the call:
+  // 16 per CU divided by the streams, between 2 and 4 (measured per 4096 VGA frames on 8 streams: 2 per CU 323 k
+  // frames/s, 3: 314 k, 4: 312 k, LDS cap: 298 k; the stage ALONE is fastest at 4); $ORBFE_ORIENT_GRID overrides, 0 = no cap.
+  static const size_t kPad = occupancy_pad_bytes("ORIENT", 0);
+  static const int kGridEnv = getenv("ORBFE_ORIENT_GRID") ? atoi(getenv("ORBFE_ORIENT_GRID")) : -1;
+  int kGridPerCu = kGridEnv;
+  if (kGridPerCu < 0) {
+    kGridPerCu = 16 / (concurrentLaunches < 1 ? 1 : concurrentLaunches);
+    kGridPerCu = kGridPerCu < 2 ? 2 : (kGridPerCu > 4 ? 4 : kGridPerCu);
+  }
   // Round 2 measured the wider form <64, 8, 4> (twice the row / patch loads in flight per wave, 106 VGPRs, same 4
-  // workgroups per CU): stage 3.36 vs 3.38 ms per 4096 VGA frames, pipeline unchanged -- the kernel is not short of
-  // memory-level parallelism (its L2 misses are 3.1 MB per frame = 3.7 TB/s), so <64, 4, 2> stays.
-  if (latencyForm)
-    hipLaunchKernelGGL((k_orient_desc<16, 4, 2>), dim3((total + 7u) / 8u * 8u), dim3(256), 0, s, a, d_levelKp, d_levelCount,
+  // workgroups per CU): stage 3.36 vs 3.38 ms per 4096 VGA frames, pipeline unchanged, so <64, 4, 2> stays.
+  const unsigned full = (total + 7u) / 8u * 8u;
+  if (latencyForm) {
+    hipLaunchKernelGGL((k_orient_desc<16, 4, 2>), dim3(full), dim3(256), 0, s, a, d_levelKp, d_levelCount,
                        d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic);
-  else
-    hipLaunchKernelGGL((k_orient_desc<64, 4, 2>), dim3((total + 7u) / 8u * 8u), dim3(256), kPad, s, a, d_levelKp, d_levelCount,
+  } else {
+    unsigned grid = full;
+    if (kGridPerCu > 0 && (unsigned)kGridPerCu * 256u < full) grid = (unsigned)kGridPerCu * 256u;  // 256 CUs, multiple of 8
+    hipLaunchKernelGGL((k_orient_desc<64, 4, 2>), dim3(grid), dim3(256), kPad, s, a, d_levelKp, d_levelCount,
                        d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic);
+  }
 }
 
 // Weight/mask bytes of a 16-pixel half row of the orientation disc, for every half-width d:

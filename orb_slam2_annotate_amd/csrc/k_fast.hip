@@ -500,7 +500,10 @@ __global__ __launch_bounds__(256) void k_gather_candidates(const CellDesc* __res
                                                            int32_t* __restrict__ cellPrefix,
                                                            int nlevels) {
   __shared__ int waveTot[4];
-  const int l = blockIdx.x, f = blockIdx.y;
+  // grid (nFrames, nlevels): consecutive workgroups -- which go to consecutive XCDs -- are consecutive frames of one
+  // level.  With the level in blockIdx.x, level l of every frame ran on XCD l (8 levels, 8 XCDs) and the XCD with
+  // the level-0 items decided the duration.
+  const int f = blockIdx.x, l = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const LevelGeom g = lvg[l];
   const uint16_t* cnt = cellCount + (size_t)f * cellsPerFrame + g.cellStart;
@@ -543,7 +546,7 @@ void launch_gather_candidates(hipStream_t s, const CellDesc* d_cells, const Leve
                               int slotsPerFrame, const uint16_t* d_cellCount, int cellsPerFrame,
                               Candidate* d_cand, int32_t* d_candCount, int32_t* d_cellPrefix) {
   if (nFrames <= 0) return;
-  hipLaunchKernelGGL(k_gather_candidates, dim3(nlevels, nFrames), dim3(256), 0, s, d_cells, d_lv,
+  hipLaunchKernelGGL(k_gather_candidates, dim3(nFrames, nlevels), dim3(256), 0, s, d_cells, d_lv,
                      d_slots, slotsPerFrame, d_cellCount, cellsPerFrame, d_cand, d_candCount,
                      d_cellPrefix, nlevels);
 }

@@ -14,6 +14,8 @@
 //     (4-way key histogram), a prefix sum over the walk order finds the node at which the
 //     list reaches N (the reference's early break, :774-775).
 // Everything is integer except the root bucketing (float divide, :598) -- identical to the host.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace orbfe {
@@ -22,11 +24,12 @@ namespace {
 
 struct Rect { int16_t x0, x1, y0, y1; };
 
-// exclusive scan of a[0..len) in place (LDS), 256 threads; returns the total to every thread
+// exclusive scan of a[0..len) in place (LDS) by the T threads of the workgroup; returns the total to every thread
+template <int T>
 __device__ int block_scan_excl(int* a, int len, int* waveTot) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int run = 0;
-  for (int base = 0; base < len; base += 256) {
+  for (int base = 0; base < len; base += T) {
     const int i = base + tid;
     const int v = i < len ? a[i] : 0;
     int x = v;
@@ -35,14 +38,22 @@ __device__ int block_scan_excl(int* a, int len, int* waveTot) {
       const int y = __shfl_up(x, o, 64);
       if (lane >= o) x += y;
     }
-    if (lane == 63) waveTot[wave] = x;
-    __syncthreads();
-    int b = run;
-    for (int w = 0; w < wave; w++) b += waveTot[w];
-    run += waveTot[0] + waveTot[1] + waveTot[2] + waveTot[3];
-    if (i < len) a[i] = b + x - v;
-    __syncthreads();
+    if (T == 64) {  // one wavefront: the running total lives in a register
+      const int tot = __builtin_amdgcn_readlane(x, 63);
+      if (i < len) a[i] = run + x - v;
+      run += tot;
+    } else {
+      if (lane == 63) waveTot[wave] = x;
+      __syncthreads();
+      int b = run;
+      for (int w = 0; w < wave; w++) b += waveTot[w];
+#pragma unroll
+      for (int w = 0; w < T / 64; w++) run += waveTot[w];
+      if (i < len) a[i] = b + x - v;
+      __syncthreads();
+    }
   }
+  if (T == 64) __syncthreads();  // orders the LDS stores before the callers' reads (a wave-level fence for 64 threads)
   return run;
 }
 
@@ -71,10 +82,9 @@ __device__ __forceinline__ Rect child_rect(const Rect r, int q) {
 // take the global-memory form of the same loops.
 constexpr int kRegCand = 16;
 
-template <bool REG>
-__device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, int* waveTot, int* sh) {
+template <bool REG, int T>
+__device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, int* waveTot, int* sh, const int l, const int f) {
   const int tid = threadIdx.x;
-  const int l = blockIdx.x, f = blockIdx.y;
   const LevelGeom g = a.lvg[l];
   const int M = a.maxL;
   // LDS carve (M entries each)
@@ -105,14 +115,14 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
 
   // ---- roots (:576-619) ----
   int cur = 0;
-  for (int i = tid; i < nIni; i += 256) scanB[i] = 0;
+  for (int i = tid; i < nIni; i += T) scanB[i] = 0;
   __syncthreads();
   uint32_t kxy[kRegCand];   // REG: candidate coordinates / current node of candidate j*256 + tid
   uint32_t knode[kRegCand];
   if constexpr (REG) {
 #pragma unroll
     for (int j = 0; j < kRegCand; j++) {
-      const int k = j * 256 + tid;
+      const int k = j * T + tid;
       kxy[j] = 0; knode[j] = 0;
       if (k < n) {
         kxy[j] = cand[k].xy;
@@ -127,7 +137,7 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
       }
     }
   } else {
-    for (int k = tid; k < n; k += 256) {
+    for (int k = tid; k < n; k += T) {
       int b = (int)__fdiv_rn((float)(cand[k].xy & 0xffffu), hX);
       if (b >= nIni) b = nIni - 1;
       nodeOf[k] = (uint16_t)b;
@@ -135,10 +145,10 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
     }
   }
   __syncthreads();
-  for (int i = tid; i < nIni; i += 256) { scanA[i] = scanB[i] > 0 ? 1 : 0; }
+  for (int i = tid; i < nIni; i += T) { scanA[i] = scanB[i] > 0 ? 1 : 0; }
   __syncthreads();
-  int L = block_scan_excl(scanA, nIni, waveTot);  // scanA[i] = list position of root i (if non-empty)
-  for (int i = tid; i < nIni; i += 256) {
+  int L = block_scan_excl<T>(scanA, nIni, waveTot);  // scanA[i] = list position of root i (if non-empty)
+  for (int i = tid; i < nIni; i += T) {
     if (scanB[i] > 0) {
       Rect r;
       r.x0 = (int16_t)(int)__fmul_rn(hX, (float)i);
@@ -154,7 +164,7 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
 #pragma unroll
     for (int j = 0; j < kRegCand; j++) knode[j] = (uint32_t)scanA[knode[j]];
   } else {
-    for (int k = tid; k < n; k += 256) nodeOf[k] = (uint16_t)scanA[nodeOf[k]];
+    for (int k = tid; k < n; k += T) nodeOf[k] = (uint16_t)scanA[nodeOf[k]];
   }
   __syncthreads();
 
@@ -165,7 +175,7 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
     Rect* rc = rect[cur];
     int* cn = cnt[cur];
     // A. candidates of this pass
-    for (int p = tid; p < L; p += 256) {
+    for (int p = tid; p < L; p += T) {
       const bool c = phase2 ? (p < C && cn[p] > 1) : (cn[p] > 1);
       inS[p] = c ? 1 : 0;
       child[4 * p] = child[4 * p + 1] = child[4 * p + 2] = child[4 * p + 3] = 0;
@@ -191,13 +201,13 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
           const int j = j0 + u;
           const int p = (int)knode[j];
           int bin = -1;
-          if (j * 256 + tid < n && in4[u]) bin = 4 * p + quadrant(r4[u], (int)(kxy[j] & 0xffffu), (int)(kxy[j] >> 16));
+          if (j * T + tid < n && in4[u]) bin = 4 * p + quadrant(r4[u], (int)(kxy[j] & 0xffffu), (int)(kxy[j] >> 16));
           kbin[j] = bin;
           if (bin >= 0) atomicAdd(&child[bin], 1);
         }
       }
     } else {
-      for (int k = tid; k < n; k += 256) {
+      for (int k = tid; k < n; k += T) {
         const int p = nodeOf[k];
         if (inS[p]) {
           const uint32_t xy = cand[k].xy;
@@ -209,10 +219,10 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
     // C. processing order
     int m;  // nodes actually split in this pass
     if (!phase2) {
-      for (int p = tid; p < L; p += 256) scanA[p] = inS[p];
+      for (int p = tid; p < L; p += T) scanA[p] = inS[p];
       __syncthreads();
-      m = block_scan_excl(scanA, L, waveTot);
-      for (int p = tid; p < L; p += 256)
+      m = block_scan_excl<T>(scanA, L, waveTot);
+      for (int p = tid; p < L; p += T)
         if (inS[p]) { order[scanA[p]] = (uint16_t)p; rankOf[p] = (uint16_t)scanA[p]; }
       __syncthreads();
     } else {
@@ -222,7 +232,7 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
       int nE = 0;
       {
         const int lane = tid & 63, wave = tid >> 6;
-        for (int p = wave; p < C; p += 4) {
+        for (int p = wave; p < C; p += T / 64) {
           if (!inS[p]) continue;  // wave-uniform
           const int c = cn[p];
           int r = 0;
@@ -241,40 +251,40 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
       __syncthreads();
       const int E = sh[0];
       // growth of the list per split: (#non-empty children - 1), in walk order
-      for (int j = tid; j < E; j += 256) {
+      for (int j = tid; j < E; j += T) {
         const int p = order[j];
         scanA[j] = (child[4 * p] > 0) + (child[4 * p + 1] > 0) + (child[4 * p + 2] > 0) + (child[4 * p + 3] > 0) - 1;
       }
       __syncthreads();
-      block_scan_excl(scanA, E, waveTot);  // scanA[j] = growth before split j
+      block_scan_excl<T>(scanA, E, waveTot);  // scanA[j] = growth before split j
       // split j happens iff the list is still < N before it: L + scanA[j] < N (early break :774)
       if (tid == 0) sh[1] = 0;
       __syncthreads();
       int mine = 0;
-      for (int j = tid; j < E; j += 256) mine += (L + scanA[j] < N) ? 1 : 0;
+      for (int j = tid; j < E; j += T) mine += (L + scanA[j] < N) ? 1 : 0;
       if (mine) atomicAdd(&sh[1], mine);
       __syncthreads();
       m = sh[1];
-      for (int j = tid; j < E; j += 256)
+      for (int j = tid; j < E; j += T)
         if (j >= m) inS[order[j]] = 0;
       __syncthreads();
     }
     // D. creation index of the children: exclusive scan of #non-empty children over the walk order
-    for (int j = tid; j < m; j += 256) {
+    for (int j = tid; j < m; j += T) {
       const int p = order[j];
       scanA[j] = (child[4 * p] > 0) + (child[4 * p + 1] > 0) + (child[4 * p + 2] > 0) + (child[4 * p + 3] > 0);
     }
-    for (int p = tid; p < L; p += 256) scanB[p] = inS[p] ? 0 : 1;
+    for (int p = tid; p < L; p += T) scanB[p] = inS[p] ? 0 : 1;
     __syncthreads();
-    const int Cn = block_scan_excl(scanA, m, waveTot);
-    const int nSurv = block_scan_excl(scanB, L, waveTot);
+    const int Cn = block_scan_excl<T>(scanA, m, waveTot);
+    const int nSurv = block_scan_excl<T>(scanB, L, waveTot);
     // E. write the next list: reverse(created) ++ survivors
     Rect* rn = rect[cur ^ 1];
     int* cnn = cnt[cur ^ 1];
     if (tid == 0) sh[2] = 0;
     __syncthreads();
     int expand = 0;
-    for (int j = tid; j < m; j += 256) {
+    for (int j = tid; j < m; j += T) {
       const int p = order[j];
       int ci = scanA[j];
       const Rect r = rc[p];
@@ -291,7 +301,7 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
         }
       }
     }
-    for (int p = tid; p < L; p += 256)
+    for (int p = tid; p < L; p += T)
       if (!inS[p]) {
         const int np = Cn + scanB[p];
         rn[np] = rc[p];
@@ -318,10 +328,10 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
         }
 #pragma unroll
         for (int u = 0; u < 4; u++)
-          if ((j0 + u) * 256 + tid < n) knode[j0 + u] = (uint32_t)v4[u];
+          if ((j0 + u) * T + tid < n) knode[j0 + u] = (uint32_t)v4[u];
       }
     } else {
-      for (int k = tid; k < n; k += 256) {
+      for (int k = tid; k < n; k += T) {
         const int p = nodeOf[k];
         int np;
         if (inS[p]) {
@@ -345,17 +355,17 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
 
   // ---- best response per node, first key wins ties (:787-805) ----
   int* best = scanA;
-  for (int p = tid; p < L; p += 256) best[p] = 0;
+  for (int p = tid; p < L; p += T) best[p] = 0;
   __syncthreads();
   if constexpr (REG) {
 #pragma unroll
     for (int j = 0; j < kRegCand; j++) {
-      const int k = j * 256 + tid;
+      const int k = j * T + tid;
       if (k < n)
         atomicMax(reinterpret_cast<unsigned int*>(&best[knode[j]]), (cand[k].score << 24) | (0xffffffu - (unsigned)k));
     }
   } else {
-    for (int k = tid; k < n; k += 256)
+    for (int k = tid; k < n; k += T)
       atomicMax(reinterpret_cast<unsigned int*>(&best[nodeOf[k]]),
                 (cand[k].score << 24) | (0xffffffu - (unsigned)k));
   }
@@ -365,13 +375,13 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
   // their patches.  `rank` keeps the reference's list position, which decides the output row.
   const int nKp = L < g.kpCap ? L : g.kpCap;
   uint32_t* skey = reinterpret_cast<uint32_t*>(scanB);
-  for (int p = tid; p < nKp; p += 256) {
+  for (int p = tid; p < nKp; p += T) {
     const Candidate c = cand[0xffffffu - ((unsigned)best[p] & 0xffffffu)];
     const uint32_t x = (c.xy & 0xffffu) + kMinBorder, y = (c.xy >> 16) + kMinBorder;  // :909-910
     skey[p] = ((x >> 7) << 26) | ((y & 0x1fffu) << 13) | (x & 0x1fffu);
   }
   __syncthreads();
-  for (int p = tid; p < nKp; p += 256) {
+  for (int p = tid; p < nKp; p += T) {
     const uint32_t key = skey[p];
     int pos = 0;
 #pragma unroll 8
@@ -395,16 +405,31 @@ __global__ __launch_bounds__(256) void k_octree(OctreeArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ int waveTot[4];
   __shared__ int sh[4];
-  octree_body<false>(a, smem, waveTot, sh);
+  // Throughput form: a 1-D grid of gridDim.x workgroups walks the (level, frame) items LEVEL-MAJOR: all frames of level
+  // 0 first, so the long items start first and consecutive workgroups -- which go to consecutive XCDs -- hold equal
+  // work.  Round 1 launched a (level, frame) grid: level l of every frame ran on XCD l (8 levels, 8 XCDs) and the XCD
+  // with the level-0 items decided the duration: stage 1.15 -> 0.70 ms per 1024 KITTI frames, 2.05 -> 1.43 ms per 4096
+  // VGA frames from the ordering alone.  With gridDim.x below the item count ($ORBFE_OCTREE_GRID workgroups per CU) the
+  // grid size, not the LDS, bounds the workgroups in flight, and the rest of each CU stays free for the other streams.
+  const int nItems = a.nlevels * a.nFrames;
+  for (int it = blockIdx.x; it < nItems; it += gridDim.x) {
+    const int l = it / a.nFrames, f = it - l * a.nFrames;
+    octree_body<false, 256>(a, smem, waveTot, sh, l, f);
+    __syncthreads();  // the next item reuses the LDS arrays
+  }
 }
 
+// Measured and dropped (round 2): octree_body<false, 64>, ONE wavefront per (frame, level) with no barrier at all.  The
+// number of resident (frame, level) problems is set by their LDS node lists (6 per CU at 2000 features), not by wave
+// slots, so a problem that is worked on by one wave instead of four just takes longer: stage 1.15 -> 2.97 ms per 1024
+// KITTI frames, 2.05 -> 2.84 ms per 4096 VGA frames, pipeline -17 % / -7 %.  The body stays a template on the size.
 __global__ __launch_bounds__(256) void k_octree_reg(OctreeArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ int waveTot[4];
   __shared__ int sh[4];
   const int n = a.candCount[(size_t)blockIdx.y * a.nlevels + blockIdx.x];  // block-uniform
-  if (n <= 256 * kRegCand) octree_body<true>(a, smem, waveTot, sh);
-  else octree_body<false>(a, smem, waveTot, sh);
+  if (n <= 256 * kRegCand) octree_body<true, 256>(a, smem, waveTot, sh, blockIdx.x, blockIdx.y);
+  else octree_body<false, 256>(a, smem, waveTot, sh, blockIdx.x, blockIdx.y);
 }
 
 // Third build: the node list does not fit in LDS (a level asked for more than ~2 890 keypoints, e.g. 3000 features
@@ -414,8 +439,9 @@ __global__ __launch_bounds__(256) void k_octree_reg(OctreeArgs a) {
 __global__ __launch_bounds__(256) void k_octree_global(OctreeArgs a) {
   __shared__ int waveTot[4];
   __shared__ int sh[4];
-  uint8_t* slab = a.work + ((size_t)blockIdx.y * a.nlevels + blockIdx.x) * a.workStride;
-  octree_body<false>(a, slab, waveTot, sh);
+  const int f = blockIdx.x, l = blockIdx.y;  // frames along x: one level's items spread over the XCDs
+  uint8_t* slab = a.work + ((size_t)f * a.nlevels + l) * a.workStride;
+  octree_body<false, 256>(a, slab, waveTot, sh, l, f);
 }
 
 size_t octree_lds_bytes(int maxL) {
@@ -423,12 +449,14 @@ size_t octree_lds_bytes(int maxL) {
   return (size_t)maxL * (2 * 8 + 2 * 4 + 16 + 4 + 4 + 2 + 2 + 1) + 64;
 }
 
-hipError_t launch_octree(hipStream_t s, const OctreeArgs& a, int nlevels, int nFrames) {
+hipError_t launch_octree(hipStream_t s, const OctreeArgs& args, int nlevels, int nFrames) {
   if (nFrames <= 0) return hipSuccess;
+  OctreeArgs a = args;
+  a.nFrames = nFrames;
   size_t lds = octree_lds_bytes(a.maxL);
   if (lds > kOctreeLdsLimit) {  // node list in global memory
     if (!a.work || a.workStride < lds) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_octree_global, dim3(nlevels, nFrames), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_octree_global, dim3(nFrames, nlevels), dim3(256), 0, s, a);
     return hipSuccess;
   }
   const bool latencyForm = nFrames <= 8;  // too few workgroups to fill the GPU anyway
@@ -442,7 +470,12 @@ hipError_t launch_octree(hipStream_t s, const OctreeArgs& a, int nlevels, int nF
     configured[latencyForm] = lds;
   }
   if (latencyForm) hipLaunchKernelGGL(k_octree_reg, dim3(nlevels, nFrames), dim3(256), lds, s, a);
-  else hipLaunchKernelGGL(k_octree, dim3(nlevels, nFrames), dim3(256), lds, s, a);
+  else {
+    static const int perCu = getenv("ORBFE_OCTREE_GRID") ? atoi(getenv("ORBFE_OCTREE_GRID")) : 4;
+    unsigned grid = (unsigned)nlevels * (unsigned)nFrames;
+    if (perCu > 0 && (unsigned)perCu * 256u < grid) grid = (unsigned)perCu * 256u;
+    hipLaunchKernelGGL(k_octree, dim3(grid), dim3(256), lds, s, a);
+  }
   return hipSuccess;
 }
 

@@ -84,6 +84,7 @@ struct OctreeArgs {
   const int32_t* candCount;   // [frame][level]
   const LevelGeom* lvg;
   int nlevels;
+  int nFrames;                // set by launch_octree
   uint16_t* nodeOf;           // scratch, same indexing as cand
   LevelKp* levelKp;           // out, [frame][kpStart(level) + i]
   int32_t* levelCount;        // out, [frame][level]
@@ -116,7 +117,7 @@ struct OrientDescArgs {
 void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d_levelKp,
                         const int32_t* d_levelCount, const float4* d_patternF, const uint4* d_momentTab,
                         const int32_t* d_umax, int nFrames, void* d_kpOut, uint8_t* d_descOut,
-                        int32_t* d_nOut);
+                        int32_t* d_nOut, int concurrentLaunches = 1 /* sub-batch streams of the call */);
 void build_moment_table(uint8_t* tab /* 1024 bytes */);
 
 // ---- matching ----
