@@ -128,25 +128,13 @@ __global__ __launch_bounds__(256) void k_resize(LevelView src, LevelViewMut dst,
 #define ORBFE_FLAT_ROWS 8
 #endif
 constexpr int kFlatRows = ORBFE_FLAT_ROWS;
-template <bool UNALIGNED>
 #ifndef ORBFE_RESIZE_WAVES
 #define ORBFE_RESIZE_WAVES 1
 #endif
-__global__ __launch_bounds__(256, ORBFE_RESIZE_WAVES) void k_resize_flat(LevelView src, LevelViewMut dst,
-                                                     const uint4* __restrict__ colrec,
-                                                     const uint4* __restrict__ rowrec, int ngx,
-                                                     uint32_t magic, int total) {
-  const int gid = blockIdx.x * 256 + threadIdx.x;
-  const int f = blockIdx.y;
-  if (gid >= total) return;
-  const int rb = (int)__umulhi((uint32_t)gid, magic);  // gid / ngx, exact for gid * ngx < 2^32
-  const int gx = gid - rb * ngx;
-  const int dy0 = rb * kFlatRows;
-  const uint4 s4 = colrec[3 * gx], a4 = colrec[3 * gx + 1];
-  const int sxb = (int)colrec[3 * gx + 2].x;
-  uint4 rr[kFlatRows];
-#pragma unroll
-  for (int r = 0; r < kFlatRows; r++) rr[r] = rowrec[dy0 + r < dst.h ? dy0 + r : dst.h - 1];
+// the rows of one thread: rr[r] = row record of output row dy0 + r (vector or scalar registers, see the kernel)
+template <bool UNALIGNED>
+__device__ __forceinline__ void resize_flat_rows(const LevelView& src, const LevelViewMut& dst, int f, int gx, int dy0,
+                                                 const uint4 s4, const uint4 a4, int sxb, const uint4 (&rr)[kFlatRows]) {
   const uint32_t sel[4] = {s4.x, s4.y, s4.z, s4.w}, al[4] = {a4.x, a4.y, a4.z, a4.w};
   // UNALIGNED: the source rows start at arbitrary byte addresses (a caller-owned level 0 with an odd stride): the
   // 8-byte window is read with two byte-aligned dword loads (fine on gfx950, profiles/r02_unaligned.txt), no third
@@ -213,6 +201,37 @@ __global__ __launch_bounds__(256, ORBFE_RESIZE_WAVES) void k_resize_flat(LevelVi
       packed |= v << (8 * k);
     }
     if (dy0 + r < dst.h) *reinterpret_cast<uint32_t*>(D + (size_t)(dy0 + r) * dst.pitch) = packed;
+  }
+}
+
+template <bool UNALIGNED>
+__global__ __launch_bounds__(256, ORBFE_RESIZE_WAVES) void k_resize_flat(LevelView src, LevelViewMut dst,
+                                                     const uint4* __restrict__ colrec,
+                                                     const uint4* __restrict__ rowrec, int ngx,
+                                                     uint32_t magic, int total) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int f = blockIdx.y;
+  if (gid >= total) return;
+  const int rb = (int)__umulhi((uint32_t)gid, magic);  // gid / ngx, exact for gid * ngx < 2^32
+  const int gx = gid - rb * ngx;
+  const uint4 s4 = colrec[3 * gx], a4 = colrec[3 * gx + 1];
+  const int sxb = (int)colrec[3 * gx + 2].x;
+  // The 8 row records are the same for every lane unless the wave straddles two row blocks (one wave in ~5 on a VGA
+  // level): then they come through the scalar cache into SGPRs -- 8 s_load_dwordx4 instead of 8 vector 16-byte loads
+  // per lane, which were 40 % of the kernel's traffic through the texture addresser (the unit it saturates first:
+  // halving the occupancy did not slow it, profiles/r02_occupancy_pad_sweep.txt).
+  const int rb0 = __builtin_amdgcn_readfirstlane(rb);
+  uint4 rr[kFlatRows];
+  if (__all(rb == rb0)) {
+    const int dyU = rb0 * kFlatRows;
+#pragma unroll
+    for (int r = 0; r < kFlatRows; r++) rr[r] = rowrec[dyU + r < dst.h ? dyU + r : dst.h - 1];
+    resize_flat_rows<UNALIGNED>(src, dst, f, gx, dyU, s4, a4, sxb, rr);
+  } else {
+    const int dy0 = rb * kFlatRows;
+#pragma unroll
+    for (int r = 0; r < kFlatRows; r++) rr[r] = rowrec[dy0 + r < dst.h ? dy0 + r : dst.h - 1];
+    resize_flat_rows<UNALIGNED>(src, dst, f, gx, dy0, s4, a4, sxb, rr);
   }
 }
 
