@@ -59,6 +59,22 @@ def test_search_by_bow_frame(amd, seed, nnratio, ori):
     assert ref_n > 20
 
 
+@pytest.mark.parametrize("n_nodes", [3, 12])
+def test_search_by_bow_large_nodes(amd, n_nodes):
+    """Few vocabulary nodes -> hundreds of features per node: the node no longer fits the register-resident path
+    (64 x 64) and the LDS-claim path runs; 12 nodes mixes both in one call."""
+    k1, d1, k2, d2 = _two_frames(amd, 6)
+    n1, n2 = _nodes(d1, 13, n_nodes), _nodes(d2, 13, n_nodes)
+    assert np.bincount(n1).max() > 64
+    has1 = np.ones(len(k1), np.uint8)
+    ref_n, ref = orc.search_by_bow(d1, has1, k1["angle"], orc.FeatVec(n1), d2, k2["angle"], orc.FeatVec(n2), 0.7, True)
+    m = amd.ORBmatcher(0.7, True)
+    got_n, got = m.SearchByBoW(d1, has1, k1["angle"], amd.FeatureVector.from_node_of_feature(n1), d2, k2["angle"],
+                               amd.FeatureVector.from_node_of_feature(n2))
+    assert ref_n == got_n and np.array_equal(ref, got)
+    assert ref_n > 20
+
+
 @pytest.mark.parametrize("seed", [4, 5])
 def test_search_by_bow_kf(amd, seed):
     k1, d1, k2, d2 = _two_frames(amd, seed)
@@ -143,6 +159,55 @@ def test_compute_stereo_matches(amd, seed, shape, nf, bf, fx):
     assert np.array_equal(u_ref, u)
     assert np.array_equal(d_ref, d)
     assert (u >= 0).sum() > 100
+
+
+def test_compute_stereo_matches_border_keypoints(amd):
+    """Keypoints no extractor would emit (a few pixels from the right / lower edges, every octave): the SAD rows fall
+    back from the 16-byte row requests to byte loads of exactly the pixels the reference reads; still bit-exact."""
+    w, h, nf = 752, 480, 1200
+    left, right = synth.render_stereo(7, w, h)
+    eL = amd.ORBextractor(nf, 1.2, 8, 20, 7)
+    eR = amd.ORBextractor(nf, 1.2, 8, 20, 7)
+    kL0, _ = eL(left)
+    eR(right)
+    o = orc.Oracle(nf, 1.2, 8, 20, 7)
+    _, _, pL = o.extract(left, want_pyramid=True)
+    _, _, pR = o.extract(right, want_pyramid=True)
+    rng = np.random.default_rng(11)
+    sc = np.array(eL.GetScaleFactors(), dtype=np.float32)
+    kl, kr, dl, dr = [], [], [], []
+    for octave in range(8):
+        lw, lh = o.level_sizes(w, h)[octave]
+        for k in range(24):
+            # level coordinates: left x in the last 6..14 columns, right x 0..6 columns further left, rows anywhere legal
+            xl = lw - 6 - int(rng.integers(0, 9))
+            xr = xl - int(rng.integers(0, 7))
+            y = int(rng.integers(6, lh - 6)) if k % 3 else lh - 6 - int(rng.integers(0, 3))
+            d = rng.integers(0, 256, 32, dtype=np.uint8)
+            for lst, x in ((kl, xl), (kr, xr)):
+                kp = np.zeros((), dtype=kL0.dtype)
+                names = kp.dtype.names
+                kp[names[0]] = np.float32(x) * sc[octave]
+                kp[names[1]] = np.float32(y) * sc[octave]
+                kp[names[2]] = 31.0 * sc[octave]
+                kp[names[3]] = 0.0
+                kp[names[4]] = 50.0
+                kp[names[5]] = octave
+                kp[names[6]] = -1
+                lst.append(kp)
+            dl.append(d)
+            d2 = d.copy()
+            d2[int(rng.integers(0, 32))] ^= np.uint8(1 << int(rng.integers(0, 8)))  # distance 1
+            dr.append(d2)
+    kl, kr = np.array(kl, dtype=kL0.dtype), np.array(kr, dtype=kL0.dtype)
+    dl, dr = np.stack(dl), np.stack(dr)
+    mbf = np.float32(47.90639384423901)
+    mb = np.float32(mbf / np.float32(435.2046959714599))
+    u_ref, d_ref = o.stereo(w, h, kl, dl, kr, dr, pL, pR, float(mbf), float(mb))
+    u, d = amd.ComputeStereoMatches(eL, eR, kl, dl, kr, dr, float(mbf), float(mb))
+    assert np.array_equal(u_ref, u)
+    assert np.array_equal(d_ref, d)
+    assert (u >= 0).sum() > 20
 
 
 def test_stereo_batch_device_resident(amd):
