@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Randomised differential test of Frame::ComputeStereoMatches and both SearchByBoW forms against the CPU oracle:
+random stereo frame sizes, feature counts, camera baselines, vocabulary node counts (1 node = hundreds of features
+per node, the LDS-claim path; 150 nodes = the register-resident path), MapPoint masks, ratios.
+    python tools/fuzz_stereo_bow.py [seconds] [seed]
+Exits non-zero on the first mismatch and prints the failing configuration."""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import oracle_lib as orc  # noqa: E402
+import orb_slam2_annotate_amd as amd  # noqa: E402
+from orb_slam2_annotate_amd import synth  # noqa: E402
+
+
+def nodes_of(desc, rng, n_nodes):
+    cent = rng.integers(0, 256, size=(n_nodes, 32), dtype=np.uint8)
+    x = np.unpackbits(desc, axis=1).astype(np.int16)
+    c = np.unpackbits(cent, axis=1).astype(np.int16)
+    d = (x[:, None, :] != c[None, :, :]).sum(axis=2)
+    return d.argmin(axis=1).astype(np.uint32) * 5 + 2
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    last = t0
+    n_cases = n_st = n_bow = 0
+    while time.time() - t0 < seconds:
+        w, h = int(rng.integers(160, 1300)), int(rng.integers(120, 520))
+        if rng.random() < 0.3:
+            w, h = [(1241, 376), (752, 480), (640, 480)][rng.integers(0, 3)]
+        nf = int(rng.choice([300, 1000, 1200, 2000]))
+        nl = int(rng.integers(1, 9))
+        sf = float(rng.choice([1.2, 1.2, 1.1, 1.4]))
+        left, right = synth.render_stereo(int(rng.integers(1 << 30)), w, h)
+        if rng.random() < 0.3:  # noise on top: more ambiguous descriptors, SAD minima at the window edge
+            left = np.clip(left.astype(np.int16) + rng.normal(0, 6, left.shape), 0, 255).astype(np.uint8)
+            right = np.clip(right.astype(np.int16) + rng.normal(0, 6, right.shape), 0, 255).astype(np.uint8)
+        eL = amd.ORBextractor(nf, sf, nl, 20, 7)
+        eR = amd.ORBextractor(nf, sf, nl, 20, 7)
+        kL, dL = eL(left)
+        kR, dR = eR(right)
+        o = orc.Oracle(nf, sf, nl, 20, 7)
+        krL, drL, pL = o.extract(left, want_pyramid=True)
+        krR, drR, pR = o.extract(right, want_pyramid=True)
+        cfg = f"seed={seed} case={n_cases} {w}x{h} nf={nf} sf={sf} nl={nl}"
+        if not (np.array_equal(krL, kL) and np.array_equal(krR, kR) and np.array_equal(drL, dL) and np.array_equal(drR, dR)):
+            print("EXTRACT MISMATCH", cfg)
+            sys.exit(1)
+        n_cases += 1
+        if len(kL) and len(kR):
+            fx = float(rng.uniform(150, 900))
+            mbf = np.float32(fx * float(rng.uniform(0.05, 0.6)))
+            mb = np.float32(mbf / np.float32(fx))
+            u_ref, d_ref = o.stereo(w, h, krL, drL, krR, drR, pL, pR, float(mbf), float(mb))
+            u, d = amd.ComputeStereoMatches(eL, eR, kL, dL, kR, dR, float(mbf), float(mb))
+            if not (np.array_equal(u_ref, u) and np.array_equal(d_ref, d)):
+                bad = np.flatnonzero((u_ref != u) | (d_ref != d))
+                print("STEREO MISMATCH", cfg, f"mbf={mbf} mb={mb} first bad {bad[:5]}", u_ref[bad[:5]], u[bad[:5]])
+                sys.exit(1)
+            n_st += 1
+        if len(kL) > 4 and len(kR) > 4:
+            n_nodes = int(rng.choice([1, 2, 5, 20, 100, 150]))
+            n1, n2 = nodes_of(dL, rng, n_nodes), nodes_of(dR, rng, n_nodes)
+            has1 = (rng.random(len(kL)) < rng.uniform(0.3, 1.0)).astype(np.uint8)
+            has2 = (rng.random(len(kR)) < rng.uniform(0.3, 1.0)).astype(np.uint8)
+            nnr = float(rng.choice([0.6, 0.7, 0.75, 0.9]))
+            ori = bool(rng.random() < 0.7)
+            m = amd.ORBmatcher(nnr, ori)
+            fv1, fv2 = amd.FeatureVector.from_node_of_feature(n1), amd.FeatureVector.from_node_of_feature(n2)
+            rn, r = orc.search_by_bow(dL, has1, kL["angle"], orc.FeatVec(n1), dR, kR["angle"], orc.FeatVec(n2), nnr, ori)
+            gn, g = m.SearchByBoW(dL, has1, kL["angle"], fv1, dR, kR["angle"], fv2)
+            if rn != gn or not np.array_equal(r, g):
+                print("BOW (KF, F) MISMATCH", cfg, f"nodes={n_nodes} nnratio={nnr} ori={ori}")
+                sys.exit(1)
+            rn, r = orc.search_by_bow_kf(dL, has1, kL["angle"], orc.FeatVec(n1), dR, has2, kR["angle"], orc.FeatVec(n2), nnr, ori)
+            gn, g = m.SearchByBoW(dL, has1, kL["angle"], fv1, dR, kR["angle"], fv2, has_mp2=has2)
+            if rn != gn or not np.array_equal(r, g):
+                print("BOW (KF, KF) MISMATCH", cfg, f"nodes={n_nodes} nnratio={nnr} ori={ori}")
+                sys.exit(1)
+            n_bow += 2
+        if time.time() - last > 50:
+            print(f"... {n_cases} frames pairs, {n_st} stereo, {n_bow} bow searches, {time.time() - t0:.0f} s", flush=True)
+            last = time.time()
+    print(f"fuzz_stereo_bow: {n_cases} random stereo pairs: {n_st} ComputeStereoMatches and {n_bow} SearchByBoW calls "
+          f"identical to the oracle in {seconds:.0f} s (seed {seed})")
+
+
+if __name__ == "__main__":
+    main()
