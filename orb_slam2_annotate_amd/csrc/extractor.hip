@@ -221,8 +221,8 @@ void free_outputs(orbfe_extractor* e) {
 
 int ensure_geometry(orbfe_extractor* e, int W, int H) {
   if (e->geom.W == W && e->geom.H == H && e->d_lvgeom) return ORBFE_OK;
-  if (W > 8191 || H > 8191)  // 13-bit coordinate fields (spatial slot keys of k_octree), 16-bit elsewhere
-    return fail(ORBFE_ERR_INVALID, "images larger than 8191 x 8191 are not supported");
+  if (W > 32767 || H > 32767)  // signed 16-bit node rectangles in k_octree (unsigned 16-bit coordinates elsewhere)
+    return fail(ORBFE_ERR_INVALID, "images larger than 32767 x 32767 are not supported");
   free_geometry(e);
   free_workspace(e);
   e->haveLast = false;

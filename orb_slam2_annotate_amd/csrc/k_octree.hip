@@ -378,7 +378,7 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
   for (int p = tid; p < nKp; p += T) {
     const Candidate c = cand[0xffffffu - ((unsigned)best[p] & 0xffffffu)];
     const uint32_t x = (c.xy & 0xffffu) + kMinBorder, y = (c.xy >> 16) + kMinBorder;  // :909-910
-    skey[p] = ((x >> 7) << 26) | ((y & 0x1fffu) << 13) | (x & 0x1fffu);
+    skey[p] = ((x >> 7) << 23) | (y << 7) | (x & 127u);  // strip (9 bits), row (16), column inside the strip (7): unique for x, y < 65536
   }
   __syncthreads();
   for (int p = tid; p < nKp; p += T) {

@@ -125,8 +125,10 @@ def test_empty_and_errors(amd):
     with pytest.raises(amd.OrbfeError) as ei:
         e(synth.render_frame(1), capacity=10)
     assert ei.value.code == -2
-    with pytest.raises(amd.OrbfeError):  # coordinate fields are 13 bits wide
-        e(np.zeros((40, 8200), dtype=np.uint8))
+    with pytest.raises(amd.OrbfeError):  # node rectangles are signed 16-bit
+        e(np.zeros((40, 32800), dtype=np.uint8))
+    k, d = e(np.zeros((40, 8200), dtype=np.uint8))  # (round 1 refused anything beyond 8191 px)
+    assert len(k) == 0
 
 
 @pytest.mark.parametrize("params,shape,kind", [((3000, 1.3, 1, 20, 7), (640, 480), "noise"),
@@ -237,6 +239,15 @@ def test_large_and_tiny_images(amd):
     _check_frame(amd, synth.render_frame(71, 96, 80, n_shapes=30), (200, 1.2, 8, 20, 7))
     _check_frame(amd, synth.render_frame(72, 66, 64, n_shapes=20), (100, 1.2, 8, 20, 7))
     _check_frame(amd, synth.adversarial("noise", 100, 72, seed=9), (500, 1.2, 8, 20, 7))
+
+
+def test_images_beyond_8191_pixels(amd):
+    # round 1 refused images wider / higher than 8191 px (13-bit fields in the octree's spatial slot key)
+    wide = np.tile(synth.render_frame(73, 1500, 96, n_shapes=300), (1, 6))[:, :8700].copy()
+    assert _check_frame(amd, wide, (1500, 1.2, 4, 20, 7)) > 500
+    # (much taller than wide gives round(width / height) = 0 octree roots and no keypoints, src/ORBextractor.cc:570)
+    tall = np.tile(synth.render_frame(74, 850, 1700, n_shapes=300), (5, 5))[:8400, :4250].copy()
+    assert _check_frame(amd, tall, (800, 1.2, 2, 20, 7)) > 100
 
 
 def test_noise_fullsize_stresses_cell_capacity(amd):
