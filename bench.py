@@ -220,14 +220,14 @@ def _latest_profile(suffix, workload):
     return best
 
 
-def pmc_traffic(stage, workload, images_per_launch):
+def pmc_traffic(stage, workload, images_per_launch, stage_kernels=None):
     """HBM bytes per launch group of the stage's kernels from the committed rocprofv3 --pmc summary
     (profiles/*_traffic.json, tools/collect_traffic.py), scaled to the images one timed launch processes."""
     t = _latest_profile("traffic", workload)
     if t is None:
         return None
     tot, found = 0.0, False
-    for k, n in STAGE_KERNELS[stage]:
+    for k, n in (stage_kernels or STAGE_KERNELS)[stage]:
         if k in t["kernels"]:
             tot += t["kernels"][k]["traffic_bytes_per_launch"] * n
             found = True
@@ -532,6 +532,16 @@ def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, u
         check, dist_per_unit, _ = g.check(voc_path)
         sizes = [ext.level_size(g.W, g.H, l) for l in range(ext.GetLevels())]
         alg = algorithmic_bytes(sizes, n_kp, wl, n_st)
+        stage_kernels = dict(STAGE_KERNELS)
+        fused_pyramid_blur = excl["blur"] <= 0 < excl["pyramid"]
+        if fused_pyramid_blur:
+            # k_blur7<.., RESIZE>: one kernel per level blurs level l and writes level l+1 from the same staged tiles
+            # (csrc/k_blur.hip); the "pyramid" stage then carries both stages' algorithmic bytes (the
+            # fraction is computed from the algorithmic figure whatever a fused kernel really moves)
+            alg["pyramid"] += alg["blur"]
+            alg["blur"] = 0
+            stage_kernels["pyramid"] = [("k_copy2d", 1), ("k_blur7", len(sizes))]
+            stage_kernels["blur"] = []
         ipu = NI / B  # images per unit (2 for stereo)
         per_launch_units = {s_: (B if s_ == "match" else NI) for s_ in GPU_STAGES}  # exclusive launches: whole batch
 
@@ -539,7 +549,7 @@ def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, u
             return alg[s_] * (images / ipu if s_ == "match" else images)
 
         value = total_units / dt_max
-        n_groups = max(prof[dom][1] / (1 if dom == "match" else sum(n for k, n in STAGE_KERNELS[dom] if k != "k_copy2d")), 1)
+        n_groups = max(prof[dom][1] / (1 if dom == "match" else sum(n for k, n in stage_kernels[dom] if k != "k_copy2d")), 1)
         dom_ms = prof[dom][0] / n_groups
         dom_imgs = prof[dom][2] / n_groups
         ach = stage_bytes(dom, prof[dom][2]) / (prof[dom][0] * 1e-3) / 1e9 if prof[dom][0] > 0 else 0.0
@@ -554,13 +564,13 @@ def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, u
                           "hbm_frac_live": (b / (live[s_] * 1e-3) / 1e9 / HBM_PEAK_GBS) if live[s_] > 0 else None}
         pipe_bytes = alg["extract_total"] * ipu + alg["match"]
         roof = {
-            "bound": "hbm", "kernel": "+".join(k for k, _ in STAGE_KERNELS[dom] if k != "k_copy2d" or name == "kitti"),
+            "bound": "hbm", "kernel": "+".join(k for k, _ in stage_kernels[dom] if k != "k_copy2d" or name == "kitti"),
             "stage": dom, "dominant_by": "largest live (multi-stream) HIP-event time of a step",
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(dom, name, dom_imgs),
+            "traffic": pmc_traffic(dom, name, dom_imgs, stage_kernels),
             "algorithmic_bytes_per_launch_group": stage_bytes(dom, dom_imgs), "ms_per_launch_group": dom_ms,
             "images_per_launch": dom_imgs, "launch_groups_timed": n_groups, "streams": S, "schedule": args.schedule,
-            "stages": stages,
+            "stages": stages, "fused_pyramid_blur": fused_pyramid_blur,
             "pipeline": {"algorithmic_bytes_per_unit": pipe_bytes, "achieved": pipe_bytes * value / world / 1e9,
                          "frac": pipe_bytes * value / world / 1e9 / HBM_PEAK_GBS,
                          "sum_exclusive_ms": sum(excl.values()), "ms_per_step": 1e3 * dt_max / args.steps},
@@ -581,7 +591,7 @@ def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, u
             tot = v.get("total_" + key)
             per = {}
             for s_ in GPU_STAGES:
-                ks = [k for k, _ in STAGE_KERNELS[s_] if k in v["kernels"]]
+                ks = [k for k, _ in stage_kernels[s_] if k in v["kernels"]]
                 if not ks or excl[s_] <= 0:
                     continue
                 wi = sum(v["kernels"][k][key] for k in ks) * NI

@@ -202,6 +202,13 @@ int orbfe_extractor_set_blur_spec(orbfe_extractor *e, int spec);
  * are identical; the fused form measured no faster and is kept as a parity-tested alternative. */
 int orbfe_extractor_set_fused(orbfe_extractor *e, int enable);
 
+/* ComputePyramid (src/ORBextractor.cc:1203-1234) and the per-level GaussianBlur (:1169-1175) as ONE kernel per level
+ * -- the tile staged for the blur of level l also yields the part of level l+1 whose taps start in it -- (1, the
+ * default; $ORBFE_PYRBLUR) or as separate resize and blur launches (0).  Identical results; the fused form reads every
+ * level once instead of twice (KITTI +4 % stereo frames/s).  Ignored with the lane schedule and with
+ * orbfe_extractor_set_fused(1). */
+int orbfe_extractor_set_pyramid_blur(orbfe_extractor *e, int enable);
+
 /* A call's frames are split into n consecutive sub-batches that run concurrently on n HIP
  * streams with private workspace slices (1..32, default 1 or $ORBFE_STREAMS); results do not
  * depend on n.  Stage timing covers the kernels of sub-batch 0 (frames_out reports how many

@@ -116,6 +116,10 @@ struct orbfe_extractor {
   int16_t* d_beta[kMaxLevels] = {};
   uint32_t* d_colrec[kMaxLevels] = {};
   uint32_t* d_rowrec[kMaxLevels] = {};
+  int32_t* d_tileGx[kMaxLevels] = {};   // ownership tables of the fused blur + resize kernel (ResizeTables::tileGx / tileDy)
+  int32_t* d_tileDy[kMaxLevels] = {};
+  bool pyrBlur = true;                  // blur level l and write level l+1 from the same staged tiles ($ORBFE_PYRBLUR,
+                                        // orbfe_extractor_set_pyramid_blur)
   // per-batch workspace
   uint8_t* d_pyr = nullptr;
   uint8_t* d_blur = nullptr;
@@ -204,7 +208,7 @@ int ensure_subs(orbfe_extractor* e, int n) {
 void free_geometry(orbfe_extractor* e) {
   dfree(&e->d_cells);
   dfree(&e->d_lvgeom);
-  for (int l = 0; l < kMaxLevels; l++) { dfree(&e->d_xofs[l]); dfree(&e->d_alpha[l]); dfree(&e->d_yofs[l]); dfree(&e->d_beta[l]); dfree(&e->d_colrec[l]); dfree(&e->d_rowrec[l]); }
+  for (int l = 0; l < kMaxLevels; l++) { dfree(&e->d_xofs[l]); dfree(&e->d_alpha[l]); dfree(&e->d_yofs[l]); dfree(&e->d_beta[l]); dfree(&e->d_colrec[l]); dfree(&e->d_rowrec[l]); dfree(&e->d_tileGx[l]); dfree(&e->d_tileDy[l]); }
 }
 void free_workspace(orbfe_extractor* e) {
   dfree(&e->d_pyr); dfree(&e->d_blur); dfree(&e->d_slots); dfree(&e->d_cand);
@@ -262,6 +266,12 @@ int ensure_geometry(orbfe_extractor* e, int W, int H) {
       if ((rc = dalloc(&e->d_rowrec[l], t.rowrec.size()))) return rc;
       HIPCHK(hipMemcpy(e->d_colrec[l], t.colrec.data(), t.colrec.size() * 4, hipMemcpyHostToDevice));
       HIPCHK(hipMemcpy(e->d_rowrec[l], t.rowrec.data(), t.rowrec.size() * 4, hipMemcpyHostToDevice));
+      if (!t.tileGx.empty()) {
+        if ((rc = dalloc(&e->d_tileGx[l], t.tileGx.size()))) return rc;
+        if ((rc = dalloc(&e->d_tileDy[l], t.tileDy.size()))) return rc;
+        HIPCHK(hipMemcpy(e->d_tileGx[l], t.tileGx.data(), t.tileGx.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d_tileDy[l], t.tileDy.data(), t.tileDy.size() * 4, hipMemcpyHostToDevice));
+      }
     }
   }
   return ORBFE_OK;
@@ -450,9 +460,23 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
   int32_t* candCount = e->d_candCount + F * g.nlevels;
   LevelKp* levelKp = e->d_levelKp + F * g.totalKpCap;
   int32_t* levelCount = e->d_levelCount + F * g.nlevels;
+  // pyrBlur: level l is blurred and level l+1 written by ONE kernel per level (the staged tile serves both), so the
+  // separate blur launch below is skipped; needs the packed resize tables and the unfused FAST kernel
+  const bool pyrBlur = e->pyrBlur && !fused && !lanes;
   {  // ComputePyramid, :1203-1234
-    StageTimer t(e, ORBFE_STAGE_PYRAMID, g.nlevels - 1, nFrames, sub, s);
-    for (int l = 1; l < g.nlevels; l++) {
+    StageTimer t(e, ORBFE_STAGE_PYRAMID, pyrBlur ? g.nlevels : g.nlevels - 1, nFrames, sub, s);
+    for (int l = 1; l <= g.nlevels; l++) {
+      if (pyrBlur) {
+        LevelViewMut bdst{const_cast<uint8_t*>(blur.lv[l - 1].base), g.pyrBytes, g.lv[l - 1].pitch, g.lv[l - 1].w, g.lv[l - 1].h};
+        if (l < g.nlevels && e->d_tileGx[l]) {
+          LevelViewMut next{const_cast<uint8_t*>(pyr.lv[l].base), g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
+          launch_blur7_resize(s, pyr.lv[l - 1], bdst, next, e->d_colrec[l], e->d_rowrec[l], e->d_tileGx[l], e->d_tileDy[l],
+                              nFrames, e->blurSpec);
+          continue;
+        }
+        launch_blur7(s, pyr.lv[l - 1], bdst, nFrames, e->blurSpec);
+      }
+      if (l == g.nlevels) break;
       LevelViewMut dst{const_cast<uint8_t*>(pyr.lv[l].base), g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
       launch_resize(s, pyr.lv[l - 1], dst, e->d_xofs[l], e->d_alpha[l], e->d_yofs[l], e->d_beta[l], e->d_colrec[l],
                     e->d_rowrec[l], nFrames);
@@ -472,7 +496,7 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
       dsts[l] = LevelViewMut{const_cast<uint8_t*>(blur.lv[l].base), g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
     launch_blur7_levels(sV, pyr.lv, dsts, g.nlevels, nFrames, e->blurSpec);
   };
-  const bool blurFirst = !lanes && !fused && (sub & 1) != 0;  // measured +1.7 % frames/s (A/B on one box, 4 runs each)
+  const bool blurFirst = !lanes && !fused && !pyrBlur && (sub & 1) != 0;  // measured +1.7 % frames/s (A/B on one box, 4 runs each)
   if (blurFirst) do_blur();
   {  // FAST grid stage, :846-896; fused: the same wavefronts also write the blurred level (:1169-1175)
     // threshold order: results are identical either way; auto follows the fallback rate of the launches that have
@@ -512,7 +536,7 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
   if (lanes) {  // the tail lane starts on the candidates while the VALU lane goes on with the blur
     HIPCHK(hipEventRecord(e->evFast[sub], sV));
     HIPCHK(hipStreamWaitEvent(sT, e->evFast[sub], 0));
-    if (!fused) do_blur();
+    if (!fused && !pyrBlur) do_blur();
     HIPCHK(hipEventRecord(e->evBlur[sub], sV));
   }
   if (!e->hostOctree) {  // candidate ordering + DistributeOctTree, :566-808, one workgroup per (frame, level)
@@ -539,7 +563,7 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
     int rc = run_host_octree(e, nFrames);  // single-stream debug path: f0 == 0
     if (rc) return rc;
   }
-  if (!lanes && !blurFirst && !fused) do_blur();
+  if (!lanes && !blurFirst && !fused && !pyrBlur) do_blur();
   if (lanes) HIPCHK(hipStreamWaitEvent(sT, e->evBlur[sub], 0));
 
   {  // computeOrientation + computeDescriptors + output records
@@ -666,6 +690,7 @@ extern "C" int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlev
     err = hipHostMalloc((void**)&e->h_fastStat, sizeof(unsigned int) * orbfe_extractor::kMaxStreams * orbfe_extractor::kStatSlots, hipHostMallocDefault);
   if (const char* env = getenv("ORBFE_LANES")) e->laneMode = atoi(env) != 0;
   if (const char* env = getenv("ORBFE_FUSED")) e->fused = atoi(env) != 0;
+  if (const char* env = getenv("ORBFE_PYRBLUR")) e->pyrBlur = atoi(env) != 0;
   if (const char* env = getenv("ORBFE_BLUR_SPEC")) {
     const int v = atoi(env);
     if (v >= 0 && v <= 2) e->blurSpec = v;
@@ -1340,6 +1365,17 @@ extern "C" int orbfe_extractor_set_fused(orbfe_extractor* e, int enable) {
   int rc = sync_all(e);
   if (rc) return rc;
   e->fused = enable != 0;
+  return ORBFE_OK;
+}
+
+// ComputePyramid and the per-level GaussianBlur as ONE kernel per level (1, the default; $ORBFE_PYRBLUR) or as the
+// separate resize and blur launches (0).  Identical results.
+extern "C" int orbfe_extractor_set_pyramid_blur(orbfe_extractor* e, int enable) {
+  if (!e) return fail(ORBFE_ERR_INVALID, "NULL handle");
+  HIPCHK(hipSetDevice(e->device));
+  int rc = sync_all(e);
+  if (rc) return rc;
+  e->pyrBlur = enable != 0;
   return ORBFE_OK;
 }
 

@@ -52,11 +52,17 @@ struct BlurBatch {
   unsigned tileStart[kMaxLevels + 1];  // in units of (tile, frame) work items
   uint32_t perFrameMagic[kMaxLevels], tilesXMagic[kMaxLevels];  // udiv_magic multipliers
   int nlevels, nFrames;
+  // RESIZE form (one level per launch): the tile that is staged for the blur also produces the part of the NEXT
+  // pyramid level whose bilinear taps start inside it (ResizeTables::tileGx / tileDy give the ownership)
+  LevelViewMut next;
+  const uint4* colrec; const uint4* rowrec; const int32_t* tileGx; const int32_t* tileDy;
 };
 
-template <int SPEC, int kBW, int kBH>
+template <int SPEC, int kBW, int kBH, bool RESIZE>
 __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
-  constexpr int kTDW = (kBW + 8) / 4;  // tile dwords per row: columns bx-4 .. bx+kBW+3
+  constexpr int kVDW = (kBW + 8) / 4;  // dword columns the blur needs: bx-4 .. bx+kBW+3
+  // RESIZE: one more staged dword per row -- an 8-byte tap window that starts in the tile's last column ends at bx+kBW+6
+  constexpr int kTDW = kVDW + (RESIZE ? 1 : 0);
   constexpr int kTH = kBH + 6;         // rows by-3 .. by+kBH+2
   constexpr int kSR = 256 / kTDW;      // tile rows one staging step of the workgroup covers (14 / 7)
   constexpr int kSteps = (kTH + kSR - 1) / kSR;
@@ -64,7 +70,9 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   constexpr int kHR = 256 / kGX;       // output rows one step of the horizontal pass covers (16 / 8)
   constexpr uint32_t K0 = 18, K1 = 34, K2 = SPEC == 0 ? 48 : 49, K3 = SPEC == 0 ? 56 : 55;
   __shared__ uint32_t tin[kTH * kTDW];             // source bytes
-  __shared__ uint2 vbuf[kBH * kTDW];               // vertical sums, 4 u16 per entry
+  __shared__ uint2 vbuf[kBH * kVDW];               // vertical sums, 4 u16 per entry
+  __shared__ uint4 s_col[RESIZE ? 48 : 1];         // RESIZE: column records of the groups this tile owns
+  __shared__ int s_g0, s_nG, s_d0, s_d1;
   const int tid = threadIdx.x;
   // XCD-aware work mapping (speed only): block b -> work item (b % 8) * chunk + b / 8, so the
   // tiles one XCD's L2 sees are a contiguous raster run and share their halo rows there
@@ -91,10 +99,16 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   // unaligned addresses on gfx950 (profiles/r02_unaligned.txt), so a caller-owned level 0 with an odd stride
   // (KITTI: 1241) runs the same paths as the handle's own 64-byte pitched levels
   struct __attribute__((packed, aligned(1))) U1u { uint32_t x; };
+  if (RESIZE) {  // ownership of the next level (scalar loads) and the owned groups' column records, for phase 1b
+    const int txI = (int)(rem - (unsigned)tyI * (unsigned)tilesX);
+    const int g0 = bb.tileGx[txI], nG = bb.tileGx[txI + 1] - g0;
+    if (tid == 0) { s_g0 = g0; s_nG = nG; s_d0 = bb.tileDy[tyI]; s_d1 = bb.tileDy[tyI + 1]; }
+    if (tid >= 256 - 48 && tid - (256 - 48) < 3 * nG) s_col[tid - (256 - 48)] = bb.colrec[3 * g0 + (tid - (256 - 48))];
+  }
   // ---- 1. stage: thread (ty0, tj) = (tid / kTDW, tid % kTDW) walks down the tile kSR rows at a time ----
   if (tid < kSR * kTDW) {
     const int ty0 = (int)((uint32_t)tid / (uint32_t)kTDW), tj = tid - ty0 * kTDW;
-    if (bx >= 4 && bx + kBW + 4 <= src.w && by >= 3 && by + kBH + 3 <= src.h) {
+    if (bx >= 4 && bx - 4 + 4 * kTDW <= src.w && by >= 3 && by + kBH + 3 <= src.h) {
       // interior tile (block-uniform): no reflection, every dword is an aligned in-row load
       const uint8_t* T0 = S + (size_t)(by - 3) * src.pitch + (bx - 4);     // block-uniform (scalar) tile origin
       const uint32_t o0 = (uint32_t)ty0 * (uint32_t)src.pitch + 4u * (uint32_t)tj;  // 32-bit lane offset
@@ -102,7 +116,7 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
       for (int k = 0; k < kSteps; k++)
         if ((k + 1) * kSR <= kTH || ty0 + kSR * k < kTH)
           tin[(ty0 + kSR * k) * kTDW + tj] = reinterpret_cast<const U1u*>(T0 + (o0 + (uint32_t)(kSR * k) * (uint32_t)src.pitch))->x;
-    } else if (bx >= 4 && bx + kBW + 4 <= src.w) {
+    } else if (bx >= 4 && bx - 4 + 4 * kTDW <= src.w) {
       // top / bottom tile away from the left and right edges: every dword is still an aligned in-row
       // load, only the row index is reflected
       const uint32_t c0 = (uint32_t)(bx - 4) + 4u * (uint32_t)tj;
@@ -132,10 +146,45 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
     }
   }
   __syncthreads();
+  if (RESIZE) {
+    // ---- 1b. the next pyramid level from the staged tile (cv::resize INTER_LINEAR, the arithmetic of k_resize_flat:
+    //      host-built column / row records, v_perm + v_dot2 horizontally, two v_mul_hi vertically).  The tile owns the
+    //      column groups [g0, g0+nG) x output rows [d0, d1) whose taps start inside it (at most 16 groups per 64 source
+    //      columns, scale >= 1; ~14 x 54 at 1.2); the items are numbered flat, row-major, so the 256 threads stay busy
+    //      (a (group, row slot) thread grid ran 73 % full).  The taps are read from LDS: the level is fetched from
+    //      memory once for blur and resize together ----
+    const int nItems = s_nG * (s_d1 - s_d0);
+    const uint32_t invG = 65536u / (uint32_t)(s_nG > 0 ? s_nG : 1) + 1u;  // exact i / nG for i < 4096 (nG <= 16)
+    for (int i = tid; i < nItems; i += 256) {
+      const int r = (int)(((uint32_t)i * invG) >> 16), g = i - r * s_nG;
+      const int dy = s_d0 + r;
+      const uint4 s4 = s_col[3 * g], a4 = s_col[3 * g + 1];
+      const int wofs = (int)s_col[3 * g + 2].x - (bx - 4);  // window start, tile-local byte column (>= 4)
+      const uint32_t mis = (uint32_t)wofs & 3u;
+      const uint32_t* tw = &tin[wofs >> 2];
+      const uint32_t sel[4] = {s4.x, s4.y, s4.z, s4.w}, al[4] = {a4.x, a4.y, a4.z, a4.w};
+      const uint4 rr = bb.rowrec[dy];  // source rows r0, r1 (clamped), b0 << 16, b1 << 16
+      const uint32_t* pa = tw + ((int)rr.x - (by - 3)) * kTDW;
+      const uint32_t* pb = tw + ((int)rr.y - (by - 3)) * kTDW;
+      const uint32_t a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
+      const uint32_t loA = __builtin_amdgcn_alignbyte(a1, a0, mis), hiA = __builtin_amdgcn_alignbyte(a2, a1, mis);
+      const uint32_t loB = __builtin_amdgcn_alignbyte(b1, b0, mis), hiB = __builtin_amdgcn_alignbyte(b2, b1, mis);
+      uint32_t packed = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t hA = __builtin_amdgcn_udot2(as_u2(__builtin_amdgcn_perm(hiA, loA, sel[k])), as_u2(al[k]), 0u, false) >> 4;
+        const uint32_t hB = __builtin_amdgcn_udot2(as_u2(__builtin_amdgcn_perm(hiB, loB, sel[k])), as_u2(al[k]), 0u, false) >> 4;
+        const uint32_t v = (__umulhi(hA, rr.z) + __umulhi(hB, rr.w) + 2u) >> 2;
+        packed |= v << (8 * k);
+      }
+      uint8_t* N = bb.next.base + (size_t)f * bb.next.frameStride + (size_t)dy * bb.next.pitch + 4 * (s_g0 + g);
+      *reinterpret_cast<uint32_t*>(N) = packed;  // owned levels: pitch % 64 == 0, in-row
+    }
+  }
   // ---- 2. vertical pass: a thread owns 4 adjacent columns x 4 output rows; the 10 source dwords are
   //         split into u16 pairs once and shared by the 4 rows; 8.8 sums, two pixels per lane-op ----
-  for (int i = tid; i < rowBlocks * kTDW; i += 256) {
-    const int rb = (int)((uint32_t)i / (uint32_t)kTDW), tj = i - rb * kTDW;
+  for (int i = tid; i < rowBlocks * kVDW; i += 256) {
+    const int rb = (int)((uint32_t)i / (uint32_t)kVDW), tj = i - rb * kVDW;
     const uint32_t* tp = &tin[(4 * rb) * kTDW + tj];
     u16x2 te[10], to[10];  // even bytes (0,2) and odd bytes (1,3) of each source dword
 #pragma unroll
@@ -146,7 +195,7 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
     }
     const u16x2 k18 = {(unsigned short)K0, (unsigned short)K0}, k34 = {(unsigned short)K1, (unsigned short)K1},
                 k48 = {(unsigned short)K2, (unsigned short)K2}, k56 = {(unsigned short)K3, (unsigned short)K3};
-    uint2* vo = &vbuf[(4 * rb) * kTDW + tj];
+    uint2* vo = &vbuf[(4 * rb) * kVDW + tj];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       u16x2 a = (te[r] + te[r + 6]) * k18;
@@ -160,7 +209,7 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
       uint2 o;
       o.x = __builtin_amdgcn_perm(B, A, 0x05040100u);  // (v0, v1)
       o.y = __builtin_amdgcn_perm(B, A, 0x07060302u);  // (v2, v3)
-      vo[r * kTDW] = o;
+      vo[r * kVDW] = o;
     }
   }
   __syncthreads();
@@ -170,9 +219,9 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   uint8_t* D = dst.base + (size_t)f * dst.frameStride + (size_t)by * dst.pitch + bx;
   const int gx = tid % kGX;
   uint32_t off = (uint32_t)(tid / kGX) * (uint32_t)dst.pitch + 4u * (uint32_t)gx;
-  const uint2* vp = &vbuf[(tid / kGX) * kTDW + gx];
+  const uint2* vp = &vbuf[(tid / kGX) * kVDW + gx];
   const bool colIn = bx + 4 * gx < dst.w;
-  for (int row = tid / kGX; row < rowsValid; row += kHR, off += (uint32_t)kHR * (uint32_t)dst.pitch, vp += kHR * kTDW) {
+  for (int row = tid / kGX; row < rowsValid; row += kHR, off += (uint32_t)kHR * (uint32_t)dst.pitch, vp += kHR * kVDW) {
     if (!colIn) continue;
     const uint2 e0 = vp[0], e1 = vp[1], e2 = vp[2];
     // d_k = (v'[2k], v'[2k+1]) with v' indexed from tile column 4*gx
@@ -233,9 +282,9 @@ void launch_blur_tiles(hipStream_t s, const LevelView* src, const LevelViewMut* 
   if (total == 0) return;
   const dim3 grid((total + 7u) / 8u * 8u);
   static const size_t pad = occupancy_pad_bytes("BLUR", 0);
-  if (spec == kBlurSpecCv2Scalar) hipLaunchKernelGGL((k_blur7<1, kBW, kBH>), grid, dim3(256), pad, s, bb);
-  else if (spec == kBlurSpecCv2Sse2) hipLaunchKernelGGL((k_blur7<2, kBW, kBH>), grid, dim3(256), pad, s, bb);
-  else hipLaunchKernelGGL((k_blur7<0, kBW, kBH>), grid, dim3(256), pad, s, bb);
+  if (spec == kBlurSpecCv2Scalar) hipLaunchKernelGGL((k_blur7<1, kBW, kBH, false>), grid, dim3(256), pad, s, bb);
+  else if (spec == kBlurSpecCv2Sse2) hipLaunchKernelGGL((k_blur7<2, kBW, kBH, false>), grid, dim3(256), pad, s, bb);
+  else hipLaunchKernelGGL((k_blur7<0, kBW, kBH, false>), grid, dim3(256), pad, s, bb);
 }
 }  // namespace
 
@@ -244,6 +293,34 @@ void launch_blur7_levels(hipStream_t s, const LevelView* src, const LevelViewMut
   static const int tile = getenv("ORBFE_BLUR_TILE") ? atoi(getenv("ORBFE_BLUR_TILE")) : 0;
   if (tile == 1) launch_blur_tiles<128, 32>(s, src, dst, nlevels, nFrames, spec);
   else launch_blur_tiles<64, 64>(s, src, dst, nlevels, nFrames, spec);
+}
+
+// One level: blur it and write the next pyramid level from the same staged tiles (see k_blur7<.., RESIZE = true>).
+void launch_blur7_resize(hipStream_t s, LevelView src, LevelViewMut dst, LevelViewMut next, const uint32_t* d_colrec,
+                         const uint32_t* d_rowrec, const int32_t* d_tileGx, const int32_t* d_tileDy, int nFrames, int spec) {
+  if (dst.w <= 0 || dst.h <= 0 || nFrames <= 0) return;
+  BlurBatch bb = {};
+  bb.nlevels = 1;
+  bb.nFrames = nFrames;
+  bb.src[0] = src;
+  bb.dst[0] = dst;
+  bb.tilesX[0] = (dst.w + 63) / 64;
+  bb.tilesY[0] = (dst.h + 63) / 64;
+  bb.tileStart[0] = 0;
+  const unsigned perFrame = (unsigned)bb.tilesX[0] * (unsigned)bb.tilesY[0];
+  bb.perFrameMagic[0] = udiv_magic_multiplier(perFrame);
+  bb.tilesXMagic[0] = udiv_magic_multiplier((uint32_t)bb.tilesX[0]);
+  const unsigned total = perFrame * (unsigned)nFrames;
+  bb.tileStart[1] = total;
+  bb.next = next;
+  bb.colrec = reinterpret_cast<const uint4*>(d_colrec);
+  bb.rowrec = reinterpret_cast<const uint4*>(d_rowrec);
+  bb.tileGx = d_tileGx;
+  bb.tileDy = d_tileDy;
+  const dim3 grid((total + 7u) / 8u * 8u);
+  if (spec == kBlurSpecCv2Scalar) hipLaunchKernelGGL((k_blur7<1, 64, 64, true>), grid, dim3(256), 0, s, bb);
+  else if (spec == kBlurSpecCv2Sse2) hipLaunchKernelGGL((k_blur7<2, 64, 64, true>), grid, dim3(256), 0, s, bb);
+  else hipLaunchKernelGGL((k_blur7<0, 64, 64, true>), grid, dim3(256), 0, s, bb);
 }
 
 void launch_blur7(hipStream_t s, LevelView src, LevelViewMut dst, int nFrames, int spec) {

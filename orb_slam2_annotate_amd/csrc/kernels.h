@@ -99,6 +99,8 @@ hipError_t launch_octree(hipStream_t s, const OctreeArgs& a, int nlevels, int nF
 
 // ---- blur (GaussianBlur 7x7 sigma 2 reflect-101, :1169-1175) ----
 void launch_blur7(hipStream_t s, LevelView src, LevelViewMut dst, int nFrames, int spec = kBlurSpecCv4);
+void launch_blur7_resize(hipStream_t s, LevelView src, LevelViewMut dst, LevelViewMut next, const uint32_t* d_colrec,
+                         const uint32_t* d_rowrec, const int32_t* d_tileGx, const int32_t* d_tileDy, int nFrames, int spec);
 void launch_blur7_levels(hipStream_t s, const LevelView* src, const LevelViewMut* dst, int nlevels, int nFrames,
                          int spec = kBlurSpecCv4);
 

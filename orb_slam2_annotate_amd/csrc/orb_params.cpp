@@ -115,6 +115,23 @@ void build_resize_tables(int sw, int sh, int dw, int dh, ResizeTables* t) {
       rec[2] = (uint32_t)(uint16_t)t->beta[2 * dy] << 16;
       rec[3] = (uint32_t)(uint16_t)t->beta[2 * dy + 1] << 16;
     }
+    // ownership of the output by 64 x 64 source tiles (window starts and upper source rows are non-decreasing)
+    const int tilesX = (sw + 63) / 64, tilesY = (sh + 63) / 64;
+    t->tileGx.assign((size_t)tilesX + 1, ngx);
+    t->tileDy.assign((size_t)tilesY + 1, dh);
+    for (int tx = tilesX - 1, g = ngx - 1; tx >= 0; tx--) {
+      while (g >= 0 && (int)t->colrec[12 * (size_t)g + 8] >= 64 * tx) g--;
+      t->tileGx[tx] = g + 1;
+    }
+    for (int ty = tilesY - 1, dy = dh - 1; ty >= 0; ty--) {
+      while (dy >= 0 && (int)t->rowrec[4 * (size_t)dy] >= 64 * ty) dy--;
+      t->tileDy[ty] = dy + 1;
+    }
+    for (int tx = 0; tx < tilesX; tx++)  // the kernel keeps the column records of a tile in 16 LDS slots
+      if (t->tileGx[tx + 1] - t->tileGx[tx] > 16) { t->tileGx.clear(); t->tileDy.clear(); break; }
+  } else {
+    t->tileGx.clear();
+    t->tileDy.clear();
   }
 }
 

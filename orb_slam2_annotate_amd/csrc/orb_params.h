@@ -54,6 +54,10 @@ struct ResizeTables {  // cv::resize INTER_LINEAR fixed-point coefficients (leve
   // colrec: 12 dwords per group of 4 output columns = v_perm selectors x4 | (a0,a1) u16 pairs x4 | window start, 0,0,0
   // rowrec: 4 dwords per output row = clamped source rows r0, r1 | b0 << 16 | b1 << 16
   std::vector<uint32_t> colrec, rowrec;
+  // for the fused blur + resize kernel (64 x 64 tiles of the SOURCE level): tileGx[tx] = first column group whose window
+  // starts at or right of column 64*tx, tileDy[ty] = first output row whose upper source row is >= 64*ty; both end with
+  // the totals, so tile (tx, ty) owns groups [tileGx[tx], tileGx[tx+1]) x rows [tileDy[ty], tileDy[ty+1])
+  std::vector<int32_t> tileGx, tileDy;
 };
 
 struct FrameGeom {

@@ -244,6 +244,10 @@ class ORBextractor:
         2: the same with the SSE2 column pass (include/orbfe.h ORBFE_BLUR_*)."""
         check(self._L.orbfe_extractor_set_blur_spec(self._h, int(spec)))
 
+    def set_pyramid_blur(self, enable: bool):
+        """ComputePyramid + GaussianBlur as one kernel per level (default) or as separate launches; identical results."""
+        check(self._L.orbfe_extractor_set_pyramid_blur(self._h, int(bool(enable))))
+
     def set_fused(self, enable: bool):
         """GaussianBlur inside the FAST kernel (default) or as its own launch; identical results."""
         check(self._L.orbfe_extractor_set_fused(self._h, int(bool(enable))))

@@ -313,13 +313,15 @@ def test_fused_and_separate_blur_agree_with_the_oracle(amd, shape, params):
         o = orc.Oracle(nf, sf, nl, ini, mn)
         kr, dr, pyr = o.extract(img, want_pyramid=True)
         levels = o.split_pyramid(pyr, w, h)
-        for fused in (True, False):
+        for fused, pyrblur in ((True, True), (False, True), (False, False)):
             e = amd.ORBextractor(nf, sf, nl, ini, mn)
             e.set_fused(fused)
+            e.set_pyramid_blur(pyrblur)  # (ignored with the fused FAST + blur kernel)
             kps, desc = e(img)
             for l, ref in enumerate(levels):
                 got = e.debug_blurred_level(l)
-                assert np.array_equal(orc.gaussian_blur7(ref), got), f"blur level {l} fused={fused} seed={seed}"
+                assert np.array_equal(orc.gaussian_blur7(ref), got), f"blur level {l} fused={fused} pyrblur={pyrblur} seed={seed}"
+                assert np.array_equal(ref, e.pyramid_level(l)), f"pyramid level {l} fused={fused} pyrblur={pyrblur}"
             _kp_equal(kr, kps)
             assert np.array_equal(dr, desc)
     # batch of frames on several streams, strided caller-owned input (odd pitch = byte staging of level 0)

@@ -63,12 +63,14 @@ def main():
         spec = int(rng.choice([0, 0, 1, 2]))
         fused, lanes, piped = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
         fmode = str(rng.choice(["auto", "high", "low"]))
-        knobs = dict(spec=spec, fused=fused, lanes=lanes, pipelined=piped, fast=fmode)
+        pyrblur = bool(rng.integers(0, 2))
+        knobs = dict(spec=spec, fused=fused, lanes=lanes, pipelined=piped, fast=fmode, pyrblur=pyrblur)
         try:
             o = orc.Oracle(*params, blur_spec=spec)
             e = amd.ORBextractor(*params)
             e.set_blur_spec(spec)
             e.set_fused(fused)
+            e.set_pyramid_blur(pyrblur)
             e.set_fast_mode(fmode)
             if batch_mode:
                 w, h = min(w, 500), min(h, 400)
@@ -102,7 +104,7 @@ def main():
         if time.time() - last_report > 60:  # progress line (long runs must not look hung)
             last_report = time.time()
             print(f"  ... {n} cases so far", flush=True)
-    print(f"fuzz_parity: {n} random cases bit-exact in {time.time() - t0:.0f} s (seed {seed}; blur specs 0/1/2, fused / separate blur, stream / lane schedule, direct / pipelined host path drawn at random)")
+    print(f"fuzz_parity: {n} random cases bit-exact in {time.time() - t0:.0f} s (seed {seed}; blur specs 0/1/2, fused / separate blur, pyramid+blur fused / separate, stream / lane schedule, direct / pipelined host path drawn at random)")
 
 
 if __name__ == "__main__":

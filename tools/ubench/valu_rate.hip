@@ -21,9 +21,12 @@
 #define N_ACC 16
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-enum Op { ADD_U32, FMA_F32, MIN3_I32, PERM_B32, PK_FMA_F32, BCNT, XOR_B32, PK_MIN_I16, N_OPS };
+enum Op { ADD_U32, FMA_F32, MIN3_I32, PERM_B32, PK_FMA_F32, BCNT, XOR_B32, PK_MIN_I16,
+          MUL_HI_U32, MUL_LO_U32, MUL_U32_U24, MAD_U32_U24, DOT2_U32_U16, DOT4_U32_U8, ALIGNBYTE, SAD_U16, PK_MAD_U16, LSHRREV, N_OPS };
 static const char* kOpName[N_OPS] = {"v_add_u32", "v_fma_f32", "v_min3_i32", "v_perm_b32", "v_pk_fma_f32",
-                                     "v_bcnt_u32_b32", "v_xor_b32", "v_pk_min_i16"};
+                                      "v_bcnt_u32_b32", "v_xor_b32", "v_pk_min_i16", "v_mul_hi_u32", "v_mul_lo_u32",
+                                      "v_mul_u32_u24", "v_mad_u32_u24", "v_dot2_u32_u16", "v_dot4_u32_u8", "v_alignbyte_b32",
+                                      "v_sad_u16", "v_pk_mad_u16", "v_lshrrev_b32"};
 
 template <int OP>
 __device__ __forceinline__ void body(uint32_t (&a)[N_ACC], uint32_t b, uint32_t c) {
@@ -36,6 +39,16 @@ __device__ __forceinline__ void body(uint32_t (&a)[N_ACC], uint32_t b, uint32_t 
     if (OP == BCNT) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
     if (OP == XOR_B32) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
     if (OP == PK_MIN_I16) asm volatile("v_pk_min_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+    if (OP == MUL_HI_U32) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+    if (OP == MUL_LO_U32) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+    if (OP == MUL_U32_U24) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+    if (OP == MAD_U32_U24) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+    if (OP == DOT2_U32_U16) asm volatile("v_dot2_u32_u16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+    if (OP == DOT4_U32_U8) asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+    if (OP == ALIGNBYTE) asm volatile("v_alignbyte_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+    if (OP == SAD_U16) asm volatile("v_sad_u16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+    if (OP == PK_MAD_U16) asm volatile("v_pk_mad_u16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+    if (OP == LSHRREV) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(a[i]));
   }
 }
 template <>
@@ -130,5 +143,17 @@ int main() {
   sweep<BCNT>(nCU);
   sweep<XOR_B32>(nCU);
   sweep<PK_MIN_I16>(nCU);
+  // round 2, second half: the integer multiply / dot / shift family the resize and blur arithmetic is built from
+  // (full EXEC, 4 waves per SIMD only)
+  run<MUL_HI_U32, 0>(4, nCU);
+  run<MUL_LO_U32, 0>(4, nCU);
+  run<MUL_U32_U24, 0>(4, nCU);
+  run<MAD_U32_U24, 0>(4, nCU);
+  run<DOT2_U32_U16, 0>(4, nCU);
+  run<DOT4_U32_U8, 0>(4, nCU);
+  run<ALIGNBYTE, 0>(4, nCU);
+  run<SAD_U16, 0>(4, nCU);
+  run<PK_MAD_U16, 0>(4, nCU);
+  run<LSHRREV, 0>(4, nCU);
   return 0;
 }
