@@ -18,7 +18,7 @@ from pathlib import Path
 
 def kname(full):
     """orbfe::k_x(args) / void orbfe::k_y<64>(args) -> k_x / k_y"""
-    n = full.split("(")[0].replace("void ", "").replace("orbfe::", "")
+    n = full.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("orbfe::", "")
     return n.split("<")[0]
 
 

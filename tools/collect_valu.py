@@ -17,7 +17,8 @@ import sys
 from collections import defaultdict
 from pathlib import Path
 
-LAUNCHES_PER_STEP = {"k_resize_flat": 7, "k_resize": 7}
+# launches per step of a kernel = its sampled dispatches / those of k_fast_cells (one launch per step): 7 for k_resize_flat,
+# 8 for k_blur7 when the pyramid is fused into the per-level blur (7 fused launches + the top level), 1 otherwise
 N_SIMD = 256 * 4
 N_XCD = 8  # rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs (checked against HIP-event times: k_blur7 at 256
            # frames counts 3.90 M = 8 x 488 k cycles = 8 x 0.203 ms at 2.4 GHz, its event time); the SQ counters are chip sums
@@ -25,7 +26,7 @@ N_XCD = 8  # rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs (checked a
 
 def kname(full):
     """orbfe::k_x(args) / void orbfe::k_y<64>(args) -> k_x / k_y"""
-    n = full.split("(")[0].replace("void ", "").replace("orbfe::", "")
+    n = full.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("orbfe::", "")
     return n.split("<")[0]
 
 
@@ -41,10 +42,11 @@ def main():
     res = {"batch": int(images), "workload": workload,
            "unit": "VALU wave64 instructions (SQ_INSTS_VALU) per image; valu_busy = 4*SQ_ACTIVE_INST_VALU/(1024 SIMDs*GRBM_GUI_ACTIVE/8)",
            "kernels": {}}
+    base = len(acc["k_fast_cells"]["SQ_INSTS_VALU"]) if "k_fast_cells" in acc else 0
     for k, c in sorted(acc.items()):
         if not c["SQ_INSTS_VALU"]:
             continue
-        n = LAUNCHES_PER_STEP.get(k, 1)
+        n = max(1, round(len(c["SQ_INSTS_VALU"]) / base)) if base else 1
         valu = sum(c["SQ_INSTS_VALU"]) / len(c["SQ_INSTS_VALU"]) * n
         waves = sum(c["SQ_WAVES"]) / len(c["SQ_WAVES"]) * n
         e = {"dispatches_sampled": len(c["SQ_INSTS_VALU"]), "dispatches_per_step": n,
