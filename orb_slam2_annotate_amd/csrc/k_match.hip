@@ -399,7 +399,17 @@ __device__ __forceinline__ void stereo_row16(const StereoArgs& a, const StereoLd
   bool live = alive && !(maxU < 0);
   int pBeg = 0, pEnd = live ? pp.Nr : 0;
   if (pp.rowStart && live) {
-    int lo = row - a.bandR, hi = row + a.bandR;
+    // rows that can hold a candidate: a right keypoint of octave o covers image rows floor(y - r) .. ceil(y + r) with
+    // r = 2 * scale[o], and only octaves <= levelL + 1 are accepted (:579) -- so the bucket rows within
+    // ceil(2 * scale[levelL + 1]) + 2 of `row` are enough (a.bandR is that bound for the top octave; most keypoints sit
+    // on the low octaves, whose band is 4 rows instead of 10: half the records to scan)
+    int band = a.bandR;
+    {
+      const int oMax = levelL + 1 < a.pyrL.nlevels ? levelL + 1 : a.pyrL.nlevels - 1;
+      const int bl = (int)ceilf(__fmul_rn(2.0f, a.scaleTab[oMax < 0 ? 0 : oMax])) + 2;
+      band = bl < band ? bl : band;
+    }
+    int lo = row - band, hi = row + band;
     lo = lo < 0 ? 0 : lo;
     hi = hi > a.rows - 1 ? a.rows - 1 : hi;
     if (lo > hi) { live = false; pEnd = 0; }
