@@ -137,11 +137,19 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
       }
     }
   } else {
-    for (int k = tid; k < n; k += T) {
-      int b = (int)__fdiv_rn((float)(cand[k].xy & 0xffffu), hX);
-      if (b >= nIni) b = nIni - 1;
-      nodeOf[k] = (uint16_t)b;
-      atomicAdd(&scanB[b], 1);
+    for (int k0 = tid; k0 < n; k0 += 4 * T) {
+      uint32_t xy4[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) xy4[u] = k0 + u * T < n ? cand[k0 + u * T].xy : 0u;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int k = k0 + u * T;
+        if (k >= n) continue;
+        int b = (int)__fdiv_rn((float)(xy4[u] & 0xffffu), hX);
+        if (b >= nIni) b = nIni - 1;
+        nodeOf[k] = (uint16_t)b;
+        atomicAdd(&scanB[b], 1);
+      }
     }
   }
   __syncthreads();
@@ -207,12 +215,22 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
         }
       }
     } else {
-      for (int k = tid; k < n; k += T) {
-        const int p = nodeOf[k];
-        if (inS[p]) {
-          const uint32_t xy = cand[k].xy;
-          atomicAdd(&child[4 * p + quadrant(rc[p], (int)(xy & 0xffffu), (int)(xy >> 16))], 1);
+      // four keys per thread and trip: their node ids and coordinates are requested together and unconditionally, so a
+      // trip is ONE memory round trip instead of two dependent ones per key (node id -> is it split? -> coordinates);
+      // the sweeps over the keys are most of a pass (level 0 of a 1241 x 376 frame: ~5000 keys, 20 per thread)
+      for (int k0 = tid; k0 < n; k0 += 4 * T) {
+        int p4[4];
+        uint32_t xy4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int k = k0 + u * T;
+          p4[u] = k < n ? (int)nodeOf[k] : 0;
+          xy4[u] = k < n ? cand[k].xy : 0u;
         }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (k0 + u * T < n && inS[p4[u]])
+            atomicAdd(&child[4 * p4[u] + quadrant(rc[p4[u]], (int)(xy4[u] & 0xffffu), (int)(xy4[u] >> 16))], 1);
       }
     }
     __syncthreads();
@@ -331,16 +349,23 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
           if ((j0 + u) * T + tid < n) knode[j0 + u] = (uint32_t)v4[u];
       }
     } else {
-      for (int k = tid; k < n; k += T) {
-        const int p = nodeOf[k];
-        int np;
-        if (inS[p]) {
-          const uint32_t xy = cand[k].xy;
-          np = child[4 * p + quadrant(rc[p], (int)(xy & 0xffffu), (int)(xy >> 16))];
-        } else {
-          np = scanB[p];
+      for (int k0 = tid; k0 < n; k0 += 4 * T) {  // batched like pass B
+        int p4[4];
+        uint32_t xy4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int k = k0 + u * T;
+          p4[u] = k < n ? (int)nodeOf[k] : 0;
+          xy4[u] = k < n ? cand[k].xy : 0u;
         }
-        nodeOf[k] = (uint16_t)np;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int k = k0 + u * T;
+          if (k >= n) continue;
+          const int p = p4[u];
+          const int np = inS[p] ? child[4 * p + quadrant(rc[p], (int)(xy4[u] & 0xffffu), (int)(xy4[u] >> 16))] : scanB[p];
+          nodeOf[k] = (uint16_t)np;
+        }
       }
     }
     const int nToExpand = sh[2];
@@ -365,9 +390,20 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
         atomicMax(reinterpret_cast<unsigned int*>(&best[knode[j]]), (cand[k].score << 24) | (0xffffffu - (unsigned)k));
     }
   } else {
-    for (int k = tid; k < n; k += T)
-      atomicMax(reinterpret_cast<unsigned int*>(&best[nodeOf[k]]),
-                (cand[k].score << 24) | (0xffffffu - (unsigned)k));
+    for (int k0 = tid; k0 < n; k0 += 4 * T) {
+      int p4[4];
+      uint32_t sc4[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int k = k0 + u * T;
+        p4[u] = k < n ? (int)nodeOf[k] : 0;
+        sc4[u] = k < n ? cand[k].score : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (k0 + u * T < n)
+          atomicMax(reinterpret_cast<unsigned int*>(&best[p4[u]]), (sc4[u] << 24) | (0xffffffu - (unsigned)(k0 + u * T)));
+    }
   }
   __syncthreads();
   // The keypoints leave in SPATIAL order (128-byte column strip, then row): consecutive slots are
