@@ -57,6 +57,32 @@ __device__ int block_scan_excl(int* a, int len, int* waveTot) {
   return run;
 }
 
+// single-wavefront steps inside a larger workgroup (HYB form of octree_body): LDS accesses of one wave are performed
+// in program order, so a compiler-level fence is all "the other lanes' stores are visible" needs -- no s_barrier
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// exclusive scan of a[0..len) in place by ONE wavefront (lane = 0..63); returns the total to every lane
+__device__ __forceinline__ int wave_scan_excl(int* a, int len, int lane) {
+  int run = 0;
+  for (int base = 0; base < len; base += 64) {
+    const int i = base + lane;
+    const int v = i < len ? a[i] : 0;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (i < len) a[i] = run + x - v;
+    run += __builtin_amdgcn_readlane(x, 63);
+  }
+  wave_sync();
+  return run;
+}
+
 __device__ __forceinline__ int quadrant(const Rect r, int x, int y) {
   const int mx = r.x0 + ((r.x1 - r.x0 + 1) >> 1);  // UL.x + ceil((UR.x-UL.x)/2), :500
   const int my = r.y0 + ((r.y1 - r.y0 + 1) >> 1);
@@ -82,7 +108,7 @@ __device__ __forceinline__ Rect child_rect(const Rect r, int q) {
 // take the global-memory form of the same loops.
 constexpr int kRegCand = 16;
 
-template <bool REG, int T>
+template <bool REG, int T, bool HYB = false>
 __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, int* waveTot, int* sh, const int l, const int f) {
   const int tid = threadIdx.x;
   const LevelGeom g = a.lvg[l];
@@ -234,22 +260,16 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
       }
     }
     __syncthreads();
-    // C. processing order
-    int m;  // nodes actually split in this pass
-    if (!phase2) {
-      for (int p = tid; p < L; p += T) scanA[p] = inS[p];
-      __syncthreads();
-      m = block_scan_excl<T>(scanA, L, waveTot);
-      for (int p = tid; p < L; p += T)
-        if (inS[p]) { order[scanA[p]] = (uint16_t)p; rankOf[p] = (uint16_t)scanA[p]; }
-      __syncthreads();
-    } else {
-      // rank by (count desc, list position asc) among the candidates (all have p < C)
-      // one wavefront per candidate p (p = wave, wave+4, ...), its lanes sweep p2: a ballot counts
-      // the candidates that walk before p
-      int nE = 0;
-      {
-        const int lane = tid & 63, wave = tid >> 6;
+    int Cn, nSurv;
+    Rect* rn = rect[cur ^ 1];
+    int* cnn = cnt[cur ^ 1];
+    if constexpr (HYB) {
+      // C-E on the node list belong to wave 0 alone: ~20 short dependent LDS steps that cost a workgroup barrier each
+      // when 256 threads share them (a barrier is ~1 us with 8 workgroups of 4 waves on the CU) and only a compiler
+      // fence when one wave walks the list 64 nodes at a time.  The other waves wait at the barrier before pass F; the
+      // phase-2 ranking, quadratic in the candidates, stays on all waves.
+      const int lane = tid & 63, wave = tid >> 6;
+      if (phase2) {
         for (int p = wave; p < C; p += T / 64) {
           if (!inS[p]) continue;  // wave-uniform
           const int c = cn[p];
@@ -260,74 +280,171 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
             if (p2 < C && inS[p2]) { const int c2 = cn[p2]; before = (c2 > c) || (c2 == c && p2 < p); }
             r += __popcll(__ballot(before));
           }
-          if (lane == 0) { order[r] = (uint16_t)p; rankOf[p] = (uint16_t)r; nE++; }
+          if (lane == 0) { order[r] = (uint16_t)p; rankOf[p] = (uint16_t)r; }
         }
+        __syncthreads();
       }
-      if (tid == 0) sh[0] = 0;
-      __syncthreads();
-      if (nE) atomicAdd(&sh[0], nE);
-      __syncthreads();
-      const int E = sh[0];
-      // growth of the list per split: (#non-empty children - 1), in walk order
-      for (int j = tid; j < E; j += T) {
-        const int p = order[j];
-        scanA[j] = (child[4 * p] > 0) + (child[4 * p + 1] > 0) + (child[4 * p + 2] > 0) + (child[4 * p + 3] > 0) - 1;
-      }
-      __syncthreads();
-      block_scan_excl<T>(scanA, E, waveTot);  // scanA[j] = growth before split j
-      // split j happens iff the list is still < N before it: L + scanA[j] < N (early break :774)
-      if (tid == 0) sh[1] = 0;
-      __syncthreads();
-      int mine = 0;
-      for (int j = tid; j < E; j += T) mine += (L + scanA[j] < N) ? 1 : 0;
-      if (mine) atomicAdd(&sh[1], mine);
-      __syncthreads();
-      m = sh[1];
-      for (int j = tid; j < E; j += T)
-        if (j >= m) inS[order[j]] = 0;
-      __syncthreads();
-    }
-    // D. creation index of the children: exclusive scan of #non-empty children over the walk order
-    for (int j = tid; j < m; j += T) {
-      const int p = order[j];
-      scanA[j] = (child[4 * p] > 0) + (child[4 * p + 1] > 0) + (child[4 * p + 2] > 0) + (child[4 * p + 3] > 0);
-    }
-    for (int p = tid; p < L; p += T) scanB[p] = inS[p] ? 0 : 1;
-    __syncthreads();
-    const int Cn = block_scan_excl<T>(scanA, m, waveTot);
-    const int nSurv = block_scan_excl<T>(scanB, L, waveTot);
-    // E. write the next list: reverse(created) ++ survivors
-    Rect* rn = rect[cur ^ 1];
-    int* cnn = cnt[cur ^ 1];
-    if (tid == 0) sh[2] = 0;
-    __syncthreads();
-    int expand = 0;
-    for (int j = tid; j < m; j += T) {
-      const int p = order[j];
-      int ci = scanA[j];
-      const Rect r = rc[p];
+      if (wave == 0) {
+        int m;
+        if (!phase2) {
+          for (int p = lane; p < L; p += 64) scanA[p] = inS[p];
+          wave_sync();
+          m = wave_scan_excl(scanA, L, lane);
+          for (int p = lane; p < L; p += 64)
+            if (inS[p]) { order[scanA[p]] = (uint16_t)p; rankOf[p] = (uint16_t)scanA[p]; }
+          wave_sync();
+        } else {
+          int E = 0;  // candidates of this pass (all have p < C)
+          for (int p0 = 0; p0 < C; p0 += 64) E += __popcll(__ballot(p0 + lane < C && inS[p0 + lane]));
+          // growth of the list per split: (#non-empty children - 1), in walk order
+          for (int j = lane; j < E; j += 64) {
+            const int p = order[j];
+            scanA[j] = (child[4 * p] > 0) + (child[4 * p + 1] > 0) + (child[4 * p + 2] > 0) + (child[4 * p + 3] > 0) - 1;
+          }
+          wave_sync();
+          wave_scan_excl(scanA, E, lane);  // scanA[j] = growth before split j
+          // split j happens iff the list is still < N before it: L + scanA[j] < N (early break :774)
+          m = 0;
+          for (int j0 = 0; j0 < E; j0 += 64) m += __popcll(__ballot(j0 + lane < E && L + scanA[j0 + lane] < N));
+          for (int j = m + lane; j < E; j += 64) inS[order[j]] = 0;
+          wave_sync();
+        }
+        // D. creation index of the children: exclusive scan of #non-empty children over the walk order
+        for (int j = lane; j < m; j += 64) {
+          const int p = order[j];
+          scanA[j] = (child[4 * p] > 0) + (child[4 * p + 1] > 0) + (child[4 * p + 2] > 0) + (child[4 * p + 3] > 0);
+        }
+        for (int p = lane; p < L; p += 64) scanB[p] = inS[p] ? 0 : 1;
+        wave_sync();
+        const int cn0 = wave_scan_excl(scanA, m, lane);
+        const int ns0 = wave_scan_excl(scanB, L, lane);
+        // E. write the next list: reverse(created) ++ survivors
+        int expand = 0;
+        for (int j = lane; j < m; j += 64) {
+          const int p = order[j];
+          int ci = scanA[j];
+          const Rect r = rc[p];
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int c = child[4 * p + q];
-        if (c > 0) {
-          const int np = Cn - 1 - ci;
-          rn[np] = child_rect(r, q);
-          cnn[np] = c;
-          child[4 * p + q] = np;
-          expand += (c > 1);
-          ci++;
+          for (int q = 0; q < 4; q++) {
+            const int c = child[4 * p + q];
+            if (c > 0) {
+              const int np = cn0 - 1 - ci;
+              rn[np] = child_rect(r, q);
+              cnn[np] = c;
+              child[4 * p + q] = np;
+              expand += (c > 1);
+              ci++;
+            }
+          }
+        }
+        for (int p = lane; p < L; p += 64)
+          if (!inS[p]) {
+            const int np = cn0 + scanB[p];
+            rn[np] = rc[p];
+            cnn[np] = cn[p];
+            scanB[p] = np;
+          }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) expand += __shfl_xor(expand, o, 64);
+        if (lane == 0) { sh[0] = cn0; sh[1] = ns0; sh[2] = expand; }
+      }
+      __syncthreads();
+      Cn = sh[0];
+      nSurv = sh[1];
+    } else {
+      // C. processing order
+      int m;  // nodes actually split in this pass
+      if (!phase2) {
+        for (int p = tid; p < L; p += T) scanA[p] = inS[p];
+        __syncthreads();
+        m = block_scan_excl<T>(scanA, L, waveTot);
+        for (int p = tid; p < L; p += T)
+          if (inS[p]) { order[scanA[p]] = (uint16_t)p; rankOf[p] = (uint16_t)scanA[p]; }
+        __syncthreads();
+      } else {
+        // rank by (count desc, list position asc) among the candidates (all have p < C)
+        // one wavefront per candidate p (p = wave, wave+4, ...), its lanes sweep p2: a ballot counts
+        // the candidates that walk before p
+        int nE = 0;
+        {
+          const int lane = tid & 63, wave = tid >> 6;
+          for (int p = wave; p < C; p += T / 64) {
+            if (!inS[p]) continue;  // wave-uniform
+            const int c = cn[p];
+            int r = 0;
+            for (int p0 = 0; p0 < C; p0 += 64) {
+              const int p2 = p0 + lane;
+              bool before = false;
+              if (p2 < C && inS[p2]) { const int c2 = cn[p2]; before = (c2 > c) || (c2 == c && p2 < p); }
+              r += __popcll(__ballot(before));
+            }
+            if (lane == 0) { order[r] = (uint16_t)p; rankOf[p] = (uint16_t)r; nE++; }
+          }
+        }
+        if (tid == 0) sh[0] = 0;
+        __syncthreads();
+        if (nE) atomicAdd(&sh[0], nE);
+        __syncthreads();
+        const int E = sh[0];
+        // growth of the list per split: (#non-empty children - 1), in walk order
+        for (int j = tid; j < E; j += T) {
+          const int p = order[j];
+          scanA[j] = (child[4 * p] > 0) + (child[4 * p + 1] > 0) + (child[4 * p + 2] > 0) + (child[4 * p + 3] > 0) - 1;
+        }
+        __syncthreads();
+        block_scan_excl<T>(scanA, E, waveTot);  // scanA[j] = growth before split j
+        // split j happens iff the list is still < N before it: L + scanA[j] < N (early break :774)
+        if (tid == 0) sh[1] = 0;
+        __syncthreads();
+        int mine = 0;
+        for (int j = tid; j < E; j += T) mine += (L + scanA[j] < N) ? 1 : 0;
+        if (mine) atomicAdd(&sh[1], mine);
+        __syncthreads();
+        m = sh[1];
+        for (int j = tid; j < E; j += T)
+          if (j >= m) inS[order[j]] = 0;
+        __syncthreads();
+      }
+      // D. creation index of the children: exclusive scan of #non-empty children over the walk order
+      for (int j = tid; j < m; j += T) {
+        const int p = order[j];
+        scanA[j] = (child[4 * p] > 0) + (child[4 * p + 1] > 0) + (child[4 * p + 2] > 0) + (child[4 * p + 3] > 0);
+      }
+      for (int p = tid; p < L; p += T) scanB[p] = inS[p] ? 0 : 1;
+      __syncthreads();
+      Cn = block_scan_excl<T>(scanA, m, waveTot);
+      nSurv = block_scan_excl<T>(scanB, L, waveTot);
+      // E. write the next list: reverse(created) ++ survivors
+      if (tid == 0) sh[2] = 0;
+      __syncthreads();
+      int expand = 0;
+      for (int j = tid; j < m; j += T) {
+        const int p = order[j];
+        int ci = scanA[j];
+        const Rect r = rc[p];
+  #pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int c = child[4 * p + q];
+          if (c > 0) {
+            const int np = Cn - 1 - ci;
+            rn[np] = child_rect(r, q);
+            cnn[np] = c;
+            child[4 * p + q] = np;
+            expand += (c > 1);
+            ci++;
+          }
         }
       }
+      for (int p = tid; p < L; p += T)
+        if (!inS[p]) {
+          const int np = Cn + scanB[p];
+          rn[np] = rc[p];
+          cnn[np] = cn[p];
+          scanB[p] = np;
+        }
+      if (expand) atomicAdd(&sh[2], expand);
+      __syncthreads();
     }
-    for (int p = tid; p < L; p += T)
-      if (!inS[p]) {
-        const int np = Cn + scanB[p];
-        rn[np] = rc[p];
-        cnn[np] = cn[p];
-        scanB[p] = np;
-      }
-    if (expand) atomicAdd(&sh[2], expand);
-    __syncthreads();
     // F. re-home the keys
     if constexpr (REG) {
       // a split that the early break cancelled (inS cleared in C) keeps its node; the vote of pass B
@@ -450,7 +567,7 @@ __global__ __launch_bounds__(256) void k_octree(OctreeArgs a) {
   const int nItems = a.nlevels * a.nFrames;
   for (int it = blockIdx.x; it < nItems; it += gridDim.x) {
     const int l = it / a.nFrames, f = it - l * a.nFrames;
-    octree_body<false, 256>(a, smem, waveTot, sh, l, f);
+    octree_body<false, 256, true>(a, smem, waveTot, sh, l, f);
     __syncthreads();  // the next item reuses the LDS arrays
   }
 }
