@@ -62,14 +62,14 @@ template <int SPEC, int kBW, int kBH, bool RESIZE>
 __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   constexpr int kVDW = (kBW + 8) / 4;  // dword columns the blur needs: bx-4 .. bx+kBW+3
   // RESIZE: one more staged dword per row -- an 8-byte tap window that starts in the tile's last column ends at bx+kBW+6
-  constexpr int kTDW = kVDW + (RESIZE ? 1 : 0);
+  constexpr int kTDW = kVDW + (RESIZE ? 2 : 0);  // (19 dwords are needed; 20 keep the rows 16-byte aligned for b128 staging)
   constexpr int kTH = kBH + 6;         // rows by-3 .. by+kBH+2
   constexpr int kSR = 256 / kTDW;      // tile rows one staging step of the workgroup covers (14 / 7)
   constexpr int kSteps = (kTH + kSR - 1) / kSR;
   constexpr int kGX = kBW / 4;         // 4-pixel output groups per tile row (16 / 32)
   constexpr int kHR = 256 / kGX;       // output rows one step of the horizontal pass covers (16 / 8)
   constexpr uint32_t K0 = 18, K1 = 34, K2 = SPEC == 0 ? 48 : 49, K3 = SPEC == 0 ? 56 : 55;
-  __shared__ uint32_t tin[kTH * kTDW];             // source bytes
+  __shared__ __attribute__((aligned(16))) uint32_t tin[kTH * kTDW];  // source bytes
   __shared__ uint2 vbuf[kBH * kVDW];               // vertical sums, 4 u16 per entry
   __shared__ uint4 s_col[RESIZE ? 48 : 1];         // RESIZE: column records of the groups this tile owns
   __shared__ int s_g0, s_nG, s_d0, s_d1;
@@ -106,9 +106,27 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
     if (tid >= 256 - 48 && tid - (256 - 48) < 3 * nG) s_col[tid - (256 - 48)] = bb.colrec[3 * g0 + (tid - (256 - 48))];
   }
   // ---- 1. stage: thread (ty0, tj) = (tid / kTDW, tid % kTDW) walks down the tile kSR rows at a time ----
-  if (tid < kSR * kTDW) {
+  const bool interior = bx >= 4 && bx - 4 + 4 * kTDW <= src.w && by >= 3 && by + kBH + 3 <= src.h;  // block-uniform
+  if (RESIZE && bx >= 4 && bx - 4 + 4 * kTDW <= src.w) {
+    // fused form, tile away from the left / right edges (block-uniform): 16-byte requests (any byte address,
+    // profiles/r02_unaligned.txt) and ds_write_b128, 2 staging instructions per thread instead of 6 -- the memory
+    // instructions of a wave, not the bytes, are what the texture addresser meters; top / bottom tiles reflect the row
+    struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };
+    constexpr int kParts = kTDW / 4;  // 5 x 16 bytes per tile row
+    const uint8_t* T0 = S + (bx - 4);  // block-uniform (scalar)
+#pragma unroll
+    for (int k = 0; k < (kTH * kParts + 255) / 256; k++) {
+      const int i = tid + 256 * k;
+      const int row = (int)((uint32_t)i / (uint32_t)kParts), part = i - row * kParts;
+      if (row < stageRows) {
+        const int sy = interior ? by - 3 + row : reflect101c(by - 3 + row, src.h);
+        const U4u q = *reinterpret_cast<const U4u*>(T0 + ((uint32_t)sy * (uint32_t)src.pitch + 16u * (uint32_t)part));
+        *reinterpret_cast<uint4*>(&tin[row * kTDW + 4 * part]) = make_uint4(q.x, q.y, q.z, q.w);
+      }
+    }
+  } else if (tid < kSR * kTDW) {
     const int ty0 = (int)((uint32_t)tid / (uint32_t)kTDW), tj = tid - ty0 * kTDW;
-    if (bx >= 4 && bx - 4 + 4 * kTDW <= src.w && by >= 3 && by + kBH + 3 <= src.h) {
+    if (interior) {
       // interior tile (block-uniform): no reflection, every dword is an aligned in-row load
       const uint8_t* T0 = S + (size_t)(by - 3) * src.pitch + (bx - 4);     // block-uniform (scalar) tile origin
       const uint32_t o0 = (uint32_t)ty0 * (uint32_t)src.pitch + 4u * (uint32_t)tj;  // 32-bit lane offset
@@ -217,17 +235,10 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   // thread = (row mod kHR, column group): the tile origin D is block-uniform (scalar), the thread keeps a
   // 32-bit byte offset and an LDS pointer and steps both by kHR rows per iteration
   uint8_t* D = dst.base + (size_t)f * dst.frameStride + (size_t)by * dst.pitch + bx;
-  const int gx = tid % kGX;
-  uint32_t off = (uint32_t)(tid / kGX) * (uint32_t)dst.pitch + 4u * (uint32_t)gx;
-  const uint2* vp = &vbuf[(tid / kGX) * kVDW + gx];
-  const bool colIn = bx + 4 * gx < dst.w;
-  for (int row = tid / kGX; row < rowsValid; row += kHR, off += (uint32_t)kHR * (uint32_t)dst.pitch, vp += kHR * kVDW) {
-    if (!colIn) continue;
-    const uint2 e0 = vp[0], e1 = vp[1], e2 = vp[2];
-    // d_k = (v'[2k], v'[2k+1]) with v' indexed from tile column 4*gx
+  // one 4-pixel group from three consecutive vbuf entries (d_k = (v'[2k], v'[2k+1]) with v' indexed from the group's column)
+  auto hgroup = [&](const uint2 e0, const uint2 e1, const uint2 e2, const bool simdCols) -> uint32_t {
     const uint32_t d0 = e0.x, d1 = e0.y, d2 = e1.x, d3 = e1.y, d4 = e2.x, d5 = e2.y;
     // SPEC 2, SIMD columns: no bias here, round-half-even below
-    const bool simdCols = SPEC == 2 && bx + 4 * gx < (dst.w & ~3);
     const uint32_t R = (SPEC == 2 && simdCols) ? 0u : (1u << 15);
     uint32_t o0 = dot2(d0, pk(0, K0), R);   // taps v'1..v'7
     o0 = dot2(d1, pk(K1, K2), o0);
@@ -256,7 +267,19 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
     // the rounded sums are < 2^24: byte 2 of each is the result; two v_perm gather them
     const uint32_t lo = __builtin_amdgcn_perm(o1, o0, 0x0c0c0602u);   // (o0.b2, o1.b2, 0, 0)
     const uint32_t hi = __builtin_amdgcn_perm(o3, o2, 0x06020c0cu);   // (0, 0, o2.b2, o3.b2)
-    *reinterpret_cast<uint32_t*>(D + off) = lo | hi;
+    return lo | hi;
+  };
+  {
+    // (measured and dropped: 16 pixels per thread from three ds_read_b128 with one 16-byte store -- KITTI +0.8 %, TUM -1.9 %,
+    // EuRoC -0.5 % in a same-box A/B: noise)
+    const int gx = tid % kGX;
+    uint32_t off = (uint32_t)(tid / kGX) * (uint32_t)dst.pitch + 4u * (uint32_t)gx;
+    const uint2* vp = &vbuf[(tid / kGX) * kVDW + gx];
+    const bool colIn = bx + 4 * gx < dst.w;
+    for (int row = tid / kGX; row < rowsValid; row += kHR, off += (uint32_t)kHR * (uint32_t)dst.pitch, vp += kHR * kVDW) {
+      if (!colIn) continue;
+      *reinterpret_cast<uint32_t*>(D + off) = hgroup(vp[0], vp[1], vp[2], SPEC == 2 && bx + 4 * gx < (dst.w & ~3));
+    }
   }
 }
 
