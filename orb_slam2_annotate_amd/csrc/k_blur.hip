@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   __shared__ __attribute__((aligned(16))) uint32_t tin[kTH * kTDW];  // source bytes
   __shared__ uint2 vbuf[kBH * kVDW];               // vertical sums, 4 u16 per entry
   __shared__ uint4 s_col[RESIZE ? 48 : 1];         // RESIZE: column records of the groups this tile owns
+  __shared__ uint4 s_row[RESIZE ? 80 : 1];         //         and row records of the output rows it owns (<= 65 at scale >= 1)
   __shared__ int s_g0, s_nG, s_d0, s_d1;
   const int tid = threadIdx.x;
   // XCD-aware work mapping (speed only): block b -> work item (b % 8) * chunk + b / 8, so the
@@ -102,8 +103,10 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   if (RESIZE) {  // ownership of the next level (scalar loads) and the owned groups' column records, for phase 1b
     const int txI = (int)(rem - (unsigned)tyI * (unsigned)tilesX);
     const int g0 = bb.tileGx[txI], nG = bb.tileGx[txI + 1] - g0;
-    if (tid == 0) { s_g0 = g0; s_nG = nG; s_d0 = bb.tileDy[tyI]; s_d1 = bb.tileDy[tyI + 1]; }
+    const int d0 = bb.tileDy[tyI], d1 = bb.tileDy[tyI + 1];
+    if (tid == 0) { s_g0 = g0; s_nG = nG; s_d0 = d0; s_d1 = d1; }  // d1 - d0 <= 80 (build_resize_tables)
     if (tid >= 256 - 48 && tid - (256 - 48) < 3 * nG) s_col[tid - (256 - 48)] = bb.colrec[3 * g0 + (tid - (256 - 48))];
+    if (tid < d1 - d0 && tid < 80) s_row[tid] = bb.rowrec[d0 + tid];
   }
   // ---- 1. stage: thread (ty0, tj) = (tid / kTDW, tid % kTDW) walks down the tile kSR rows at a time ----
   const bool interior = bx >= 4 && bx - 4 + 4 * kTDW <= src.w && by >= 3 && by + kBH + 3 <= src.h;  // block-uniform
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
       const uint32_t mis = (uint32_t)wofs & 3u;
       const uint32_t* tw = &tin[wofs >> 2];
       const uint32_t sel[4] = {s4.x, s4.y, s4.z, s4.w}, al[4] = {a4.x, a4.y, a4.z, a4.w};
-      const uint4 rr = bb.rowrec[dy];  // source rows r0, r1 (clamped), b0 << 16, b1 << 16
+      const uint4 rr = s_row[r];  // source rows r0, r1 (clamped), b0 << 16, b1 << 16
       const uint32_t* pa = tw + ((int)rr.x - (by - 3)) * kTDW;
       const uint32_t* pb = tw + ((int)rr.y - (by - 3)) * kTDW;
       const uint32_t a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];

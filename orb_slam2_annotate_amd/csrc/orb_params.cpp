@@ -127,8 +127,10 @@ void build_resize_tables(int sw, int sh, int dw, int dh, ResizeTables* t) {
       while (dy >= 0 && (int)t->rowrec[4 * (size_t)dy] >= 64 * ty) dy--;
       t->tileDy[ty] = dy + 1;
     }
-    for (int tx = 0; tx < tilesX; tx++)  // the kernel keeps the column records of a tile in 16 LDS slots
-      if (t->tileGx[tx + 1] - t->tileGx[tx] > 16) { t->tileGx.clear(); t->tileDy.clear(); break; }
+    bool fits = true;  // the kernel keeps a tile's column records in 16 LDS slots and its row records in 80
+    for (int tx = 0; tx < tilesX; tx++) fits = fits && t->tileGx[tx + 1] - t->tileGx[tx] <= 16;
+    for (int ty = 0; ty < tilesY; ty++) fits = fits && t->tileDy[ty + 1] - t->tileDy[ty] <= 80;
+    if (!fits) { t->tileGx.clear(); t->tileDy.clear(); }
   } else {
     t->tileGx.clear();
     t->tileDy.clear();
