@@ -382,7 +382,7 @@ __device__ __forceinline__ int row16_sum_i32(int v) {
 constexpr uint32_t selpair(int o) { return (uint32_t)o | 0x0c00u | ((uint32_t)(o + 1) << 16) | 0x0c000000u; }
 
 // `lv` = per-level views of both pyramids in LDS (a vector level index into the kernel argument would go through scratch)
-struct StereoLds { LevelView L[kMaxLevels], R[kMaxLevels]; };
+struct StereoLds { LevelView L[kMaxLevels], R[kMaxLevels]; float scale[2 * kMaxLevels]; };  // scale: mvScaleFactor | mvInvScaleFactor
 
 __device__ __forceinline__ void stereo_row16(const StereoArgs& a, const StereoLds& lv, const StereoPair& pp, int iL, bool alive,
                                              int lane) {
@@ -406,7 +406,7 @@ __device__ __forceinline__ void stereo_row16(const StereoArgs& a, const StereoLd
     int band = a.bandR;
     {
       const int oMax = levelL + 1 < a.pyrL.nlevels ? levelL + 1 : a.pyrL.nlevels - 1;
-      const int bl = (int)ceilf(__fmul_rn(2.0f, a.scaleTab[oMax < 0 ? 0 : oMax])) + 2;
+      const int bl = (int)ceilf(__fmul_rn(2.0f, lv.scale[oMax < 0 ? 0 : oMax])) + 2;
       band = bl < band ? bl : band;
     }
     int lo = row - band, hi = row + band;
@@ -434,7 +434,7 @@ __device__ __forceinline__ void stereo_row16(const StereoArgs& a, const StereoLd
         yR = kr[1];
         uR = kr[0];
       }
-      const float r = __fmul_rn(2.0f, a.scaleTab[octR]);
+      const float r = __fmul_rn(2.0f, lv.scale[octR]);
       const int maxr = (int)ceilf(__fadd_rn(yR, r));
       const int minr = (int)floorf(__fsub_rn(yR, r));
       const bool cand = row >= minr && row <= maxr && octR >= levelL - 1 && octR <= levelL + 1 && uR >= minU && uR <= maxU;
@@ -454,7 +454,7 @@ __device__ __forceinline__ void stereo_row16(const StereoArgs& a, const StereoLd
   const int src = rowBase + (winRow ? __builtin_ctz(winRow) : 0);
   const float uR0 = __shfl(bestU, src, 64);
   // ---- SAD refinement on the left keypoint's pyramid level (:600-638) ----
-  const float sf = a.scaleTab[kMaxLevels + levelL];
+  const float sf = lv.scale[kMaxLevels + levelL];
   const float scaleduL = roundf(__fmul_rn(uL, sf));
   const float scaledvL = roundf(__fmul_rn(vL, sf));
   const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
@@ -525,7 +525,7 @@ __device__ __forceinline__ void stereo_row16(const StereoArgs& a, const StereoLd
   const float deltaR = __fdiv_rn(__fsub_rn(d1, d3),
                                  __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2))));
   if (deltaR < -1 || deltaR > 1) live = false;
-  float bestuR = __fmul_rn(a.scaleTab[levelL], __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));
+  float bestuR = __fmul_rn(lv.scale[levelL], __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));
   float disparity = __fsub_rn(uL, bestuR);
   float oU = -1.0f, oD = -1.0f;
   int oS = -1;
@@ -597,6 +597,7 @@ __device__ __forceinline__ void stereo_stage_views(const StereoArgs& a, StereoLd
   const int t = threadIdx.x;
   if (t < kMaxLevels) lv.L[t] = a.pyrL.lv[t];
   else if (t < 2 * kMaxLevels) lv.R[t - kMaxLevels] = a.pyrR.lv[t - kMaxLevels];
+  else if (t < 4 * kMaxLevels) lv.scale[t - 2 * kMaxLevels] = a.scaleTab[t - 2 * kMaxLevels];  // (the table holds 2 x 16 floats)
   __syncthreads();
 }
 
