@@ -462,7 +462,9 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
   int32_t* levelCount = e->d_levelCount + F * g.nlevels;
   // pyrBlur: level l is blurred and level l+1 written by ONE kernel per level (the staged tile serves both), so the
   // separate blur launch below is skipped; needs the packed resize tables and the unfused FAST kernel
-  const bool pyrBlur = e->pyrBlur && !fused && !lanes;
+  // (not for the few-frame launches of a live camera: there the 8 dependent blur + resize launches are a longer critical
+  // path than 7 small resize launches followed by one blur launch -- 0.195 vs 0.167 ms per single frame)
+  const bool pyrBlur = e->pyrBlur && !fused && !lanes && nFrames > 8;
   {  // ComputePyramid, :1203-1234
     StageTimer t(e, ORBFE_STAGE_PYRAMID, pyrBlur ? g.nlevels : g.nlevels - 1, nFrames, sub, s);
     for (int l = 1; l <= g.nlevels; l++) {

@@ -581,8 +581,8 @@ __global__ __launch_bounds__(256) void k_octree_reg(OctreeArgs a) {
   __shared__ int waveTot[4];
   __shared__ int sh[4];
   const int n = a.candCount[(size_t)blockIdx.y * a.nlevels + blockIdx.x];  // block-uniform
-  if (n <= 256 * kRegCand) octree_body<true, 256>(a, smem, waveTot, sh, blockIdx.x, blockIdx.y);
-  else octree_body<false, 256>(a, smem, waveTot, sh, blockIdx.x, blockIdx.y);
+  if (n <= 256 * kRegCand) octree_body<true, 256, true>(a, smem, waveTot, sh, blockIdx.x, blockIdx.y);
+  else octree_body<false, 256, true>(a, smem, waveTot, sh, blockIdx.x, blockIdx.y);
 }
 
 // Third build: the node list does not fit in LDS (a level asked for more than ~2 890 keypoints, e.g. 3000 features
