@@ -564,7 +564,7 @@ def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, u
                           "hbm_frac_live": (b / (live[s_] * 1e-3) / 1e9 / HBM_PEAK_GBS) if live[s_] > 0 else None}
         pipe_bytes = alg["extract_total"] * ipu + alg["match"]
         roof = {
-            "bound": "hbm", "kernel": "+".join(k for k, _ in stage_kernels[dom] if k != "k_copy2d" or name == "kitti"),
+            "bound": "hbm", "kernel": "+".join(k for k, _ in stage_kernels[dom] if k != "k_copy2d"),  # (k_copy2d only runs under $ORBFE_COPY_UNALIGNED)
             "stage": dom, "dominant_by": "largest live (multi-stream) HIP-event time of a step",
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": pmc_traffic(dom, name, dom_imgs, stage_kernels),
