@@ -61,7 +61,7 @@ WORKLOADS = {
                   w=1241, h=376, nfeatures=2000, ini=20, mn=7, stereo=True, bf=386.1448, fx=718.856, batch=512, streams=8),
     "euroc": dict(name="EuRoC MH_01 752x480 nFeatures=1200: extract + ComputeBoW + SearchByBoW(t-1,t) "
                        "(synthetic frames, synthetic k=10 L=2 vocabulary)",
-                  w=752, h=480, nfeatures=1200, ini=20, mn=7, bow=True, batch=2048, streams=4),
+                  w=752, h=480, nfeatures=1200, ini=20, mn=7, bow=True, batch=2048, streams=8),
 }
 SINGLE_SCENE = False  # --single-scene: the round-1 synthetic input (sparser; for continuity with profiles/history/r01_bench.json)
 GPU_STAGES = ["pyramid", "fast", "octree", "blur", "orient_desc", "match"]
