@@ -163,26 +163,47 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
         const int parts = (tdw + 3) >> 2;
         const uint32_t invP = kInv16[parts];
         const int rowBytes = lv.pitch - (x0 - 4);  // bytes from the tile's first column to the end of the row
-        for (int i = lane; i < th * parts; i += 64) {
-          const int ty = (int)(((uint32_t)i * invP) >> 16), part = i - ty * parts;
-          const int sy = rr ? reflect101f(y0 - 3 + ty, lv.h) : y0 - 3 + ty;
-          const uint8_t* p = lvb + (size_t)sy * lv.pitch + (x0 - 4) + 16 * part;
-          uint4 o;
-          if (16 * part + 16 <= rowBytes) {
-            const U4u q = *reinterpret_cast<const U4u*>(p);
-            o = make_uint4(q.x, q.y, q.z, q.w);
-          } else {  // the last piece of a right-edge cell: stay inside the row (and the caller's buffer)
-            uint32_t d[4];
+        // two pieces per lane and trip, both requested before either is stored: a ~31 x 32 cell is 114 pieces, i.e. ONE
+        // memory round trip at the head of the wave instead of two dependent ones
+        for (int i0 = lane; i0 < th * parts; i0 += 128) {
+          const uint8_t* pp[2];
+          int dsti[2], partv[2];
+          bool ok[2], wide[2];
+          uint4 o[2];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-              d[k] = 0;
-#pragma unroll
-              for (int b = 0; b < 4; b++)
-                if (16 * part + 4 * k + b < rowBytes) d[k] |= (uint32_t)p[4 * k + b] << (8 * b);
-            }
-            o = make_uint4(d[0], d[1], d[2], d[3]);
+          for (int u = 0; u < 2; u++) {
+            const int i = i0 + 64 * u;
+            ok[u] = i < th * parts;
+            const int ty = (int)(((uint32_t)i * invP) >> 16), part = i - ty * parts;
+            const int sy = rr ? reflect101f(y0 - 3 + ty, lv.h) : y0 - 3 + ty;
+            pp[u] = lvb + (size_t)sy * lv.pitch + (x0 - 4) + 16 * part;
+            dsti[u] = ty * kPitchDw + 4 * part;
+            partv[u] = part;
+            wide[u] = ok[u] && 16 * part + 16 <= rowBytes;
+            o[u] = make_uint4(0u, 0u, 0u, 0u);
           }
-          *reinterpret_cast<uint4*>(&tile[ty * kPitchDw + 4 * part]) = o;
+#pragma unroll
+          for (int u = 0; u < 2; u++)
+            if (wide[u]) {
+              const U4u q = *reinterpret_cast<const U4u*>(pp[u]);
+              o[u] = make_uint4(q.x, q.y, q.z, q.w);
+            }
+#pragma unroll
+          for (int u = 0; u < 2; u++)
+            if (ok[u] && !wide[u]) {  // the last piece of a right-edge cell: stay inside the row (and the caller's buffer)
+              uint32_t d[4];
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                d[k] = 0;
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++)
+                  if (16 * partv[u] + 4 * k + bb < rowBytes) d[k] |= (uint32_t)pp[u][4 * k + bb] << (8 * bb);
+              }
+              o[u] = make_uint4(d[0], d[1], d[2], d[3]);
+            }
+#pragma unroll
+          for (int u = 0; u < 2; u++)
+            if (ok[u]) *reinterpret_cast<uint4*>(&tile[dsti[u]]) = o[u];
         }
       }
     }
