@@ -75,30 +75,63 @@ T* carve(Arena* a, size_t n) {
 }
 inline size_t pad(size_t bytes) { return ((bytes + 255) & ~(size_t)255) + 256; }
 
-template <typename T>
-hipError_t up(Arena* a, T** d, const T* h, size_t n) {
-  *d = carve<T>(a, n ? n : 1);
-  if (n == 0) return hipSuccess;
-  const size_t off = (size_t)(reinterpret_cast<uint8_t*>(*d) - a->base), bytes = n * sizeof(T);
-  if (off + bytes > a->hcap) {  // grow the mirror, keeping what earlier up() calls of this call put there
-    const size_t want = (off + bytes) + (off + bytes) / 2 + (1u << 16);
-    uint8_t* nh = nullptr;
-    hipError_t e = hipHostMalloc((void**)&nh, want, hipHostMallocDefault);
-    if (e != hipSuccess) return e;
-    if (a->hmirror) {
-      if (a->dirtyHi > a->dirtyLo) std::memcpy(nh + a->dirtyLo, a->hmirror + a->dirtyLo, a->dirtyHi - a->dirtyLo);
-      (void)hipHostFree(a->hmirror);
-    }
-    a->hmirror = nh;
-    a->hcap = want;
+// the pinned mirror covers arena offsets [0, upto); what earlier up() calls of this call staged is kept
+hipError_t grow_mirror(Arena* a, size_t upto) {
+  if (upto <= a->hcap) return hipSuccess;
+  const size_t want = upto + upto / 2 + (1u << 16);
+  uint8_t* nh = nullptr;
+  hipError_t e = hipHostMalloc((void**)&nh, want, hipHostMallocDefault);
+  if (e != hipSuccess) return e;
+  if (a->hmirror) {
+    if (a->dirtyHi > a->dirtyLo) std::memcpy(nh + a->dirtyLo, a->hmirror + a->dirtyLo, a->dirtyHi - a->dirtyLo);
+    (void)hipHostFree(a->hmirror);
   }
-  std::memcpy(a->hmirror + off, h, bytes);
+  a->hmirror = nh;
+  a->hcap = want;
+  return hipSuccess;
+}
+inline void mark_dirty(Arena* a, size_t off, size_t bytes) {
   if (a->dirtyHi == a->dirtyLo) { a->dirtyLo = off; a->dirtyHi = off + bytes; }
   else {
     if (off < a->dirtyLo) a->dirtyLo = off;
     if (off + bytes > a->dirtyHi) a->dirtyHi = off + bytes;
   }
+}
+template <typename T>
+hipError_t up(Arena* a, T** d, const T* h, size_t n) {
+  *d = carve<T>(a, n ? n : 1);
+  if (n == 0) return hipSuccess;
+  const size_t off = (size_t)(reinterpret_cast<uint8_t*>(*d) - a->base), bytes = n * sizeof(T);
+  hipError_t e = grow_mirror(a, off + bytes);
+  if (e != hipSuccess) return e;
+  std::memcpy(a->hmirror + off, h, bytes);
+  mark_dirty(a, off, bytes);
   return hipSuccess;
+}
+// a device array of n elements whose bytes all start as `byteValue`: filled in the mirror, so it travels with the one
+// host-to-device copy of the call instead of costing a fill kernel of its own
+template <typename T>
+hipError_t up_fill(Arena* a, T** d, size_t n, int byteValue) {
+  *d = carve<T>(a, n ? n : 1);
+  const size_t off = (size_t)(reinterpret_cast<uint8_t*>(*d) - a->base), bytes = (n ? n : 1) * sizeof(T);
+  hipError_t e = grow_mirror(a, off + bytes);
+  if (e != hipSuccess) return e;
+  std::memset(a->hmirror + off, byteValue, bytes);
+  mark_dirty(a, off, bytes);
+  return hipSuccess;
+}
+// results: ONE device-to-host copy of the arena range [first, last) into the pinned mirror (same offsets), to be read
+// through mirror_of() after the stream is synchronised -- instead of one pageable copy per output array
+hipError_t down_range(Arena* a, const void* first, const void* last) {
+  const size_t lo = (size_t)(reinterpret_cast<const uint8_t*>(first) - a->base);
+  const size_t hi = (size_t)(reinterpret_cast<const uint8_t*>(last) - a->base);
+  hipError_t e = grow_mirror(a, hi);
+  if (e != hipSuccess) return e;
+  return hipMemcpyAsync(a->hmirror + lo, a->base + lo, hi - lo, hipMemcpyDeviceToHost, a->stream);
+}
+template <typename T>
+const T* mirror_of(Arena* a, const T* d) {
+  return reinterpret_cast<const T*>(a->hmirror + (reinterpret_cast<const uint8_t*>(d) - a->base));
 }
 // one H2D copy for everything up() staged since arena_begin(); call before the first kernel launch
 hipError_t flush(Arena* a) {
@@ -222,11 +255,11 @@ static int bow_common(int device, const uint8_t* desc1, const uint8_t* has_mp1, 
   MHIP(up(ar, &da2, angle2, (size_t)n2));
   MHIP(up(ar, &di1, fv1->indices, t1));
   MHIP(up(ar, &di2, fv2->indices, t2));
-  int32_t* dmatch = carve<int32_t>(ar, nOut);
-  int8_t* dbin = carve<int8_t>(ar, nOut);
+  int32_t* dmatch;
+  int8_t* dbin;
+  MHIP(up_fill(ar, &dmatch, (size_t)nOut, 0xff));
   int32_t* dcount = carve<int32_t>(ar, 1);
-  MHIP(hipMemsetAsync(dmatch, 0xff, (size_t)nOut * 4, ar->stream));
-  MHIP(hipMemsetAsync(dbin, 0, (size_t)nOut, ar->stream));
+  MHIP(up_fill(ar, &dbin, (size_t)nOut, 0));
   a.pairs = dp; a.desc1 = dd1; a.hasMp1 = dm1; a.angle1 = da1; a.indices1 = di1;
   a.desc2 = dd2; a.hasMp2 = dm2; a.angle2 = da2; a.indices2 = di2;
   a.angleStride = 1;
@@ -235,11 +268,10 @@ static int bow_common(int device, const uint8_t* desc1, const uint8_t* has_mp1, 
   launch_search_by_bow(ar->stream, a, (int)pairs.size(), maxCnt2);
   launch_rot_prune(ar->stream, dmatch, dbin, nOut, check_ori, dcount);
   MHIP(hipGetLastError());
-  int32_t cnt = 0;
-  MHIP(hipMemcpyAsync(match, dmatch, (size_t)nOut * 4, hipMemcpyDeviceToHost, ar->stream));
-  MHIP(hipMemcpyAsync(&cnt, dcount, 4, hipMemcpyDeviceToHost, ar->stream));
+  MHIP(down_range(ar, dmatch, dcount + 1));  // match[nOut] and the count, contiguous in the arena
   MHIP(hipStreamSynchronize(ar->stream));
-  return cnt;
+  std::memcpy(match, mirror_of(ar, dmatch), (size_t)nOut * 4);
+  return *mirror_of(ar, dcount);
 }
 
 extern "C" int orbfe_search_by_bow(int device, const uint8_t* desc1, const uint8_t* has_mp1, const float* angle1,
@@ -316,11 +348,11 @@ extern "C" int orbfe_search_for_triangulation(int device, const uint8_t* desc1, 
   MHIP(up(ar, &dF, F12, (size_t)9));
   MHIP(up(ar, &dsf, scale_factors2, (size_t)n_levels2));
   MHIP(up(ar, &dsg, level_sigma2_2, (size_t)n_levels2));
-  int32_t* dmatch = carve<int32_t>(ar, n1);
-  int8_t* dbin = carve<int8_t>(ar, n1);
+  int32_t* dmatch;
+  int8_t* dbin;
+  MHIP(up_fill(ar, &dmatch, (size_t)n1, 0xff));
   int32_t* dcount = carve<int32_t>(ar, 1);
-  MHIP(hipMemsetAsync(dmatch, 0xff, (size_t)n1 * 4, ar->stream));
-  MHIP(hipMemsetAsync(dbin, 0, (size_t)n1, ar->stream));
+  MHIP(up_fill(ar, &dbin, (size_t)n1, 0));
   a.queries = dq; a.nQueries = (int)queries.size();
   a.desc1 = dd1; a.x1 = dx1; a.y1 = dy1; a.angle1 = da1; a.stereo1 = ds1;
   a.desc2 = dd2; a.hasMp2 = dm2; a.x2 = dx2; a.y2 = dy2; a.angle2 = da2; a.octave2 = doc2; a.stereo2 = ds2;
@@ -330,11 +362,10 @@ extern "C" int orbfe_search_for_triangulation(int device, const uint8_t* desc1, 
   launch_search_triangulation(ar->stream, a);
   launch_rot_prune(ar->stream, dmatch, dbin, n1, check_orientation, dcount);
   MHIP(hipGetLastError());
-  int32_t cnt = 0;
-  MHIP(hipMemcpyAsync(match12, dmatch, (size_t)n1 * 4, hipMemcpyDeviceToHost, ar->stream));
-  MHIP(hipMemcpyAsync(&cnt, dcount, 4, hipMemcpyDeviceToHost, ar->stream));
+  MHIP(down_range(ar, dmatch, dcount + 1));  // match12[n1] and the count, contiguous in the arena
   MHIP(hipStreamSynchronize(ar->stream));
-  return cnt;
+  std::memcpy(match12, mirror_of(ar, dmatch), (size_t)n1 * 4);
+  return *mirror_of(ar, dcount);
 }
 
 // implemented in extractor.hip (needs the handle internals)
@@ -382,6 +413,7 @@ extern "C" int orbfe_compute_stereo_matches(orbfe_extractor* left, int frameL, o
   a.maxD = mbf / mb;  // minZ = mb, maxD = mbf/minZ (:542-544)
   a.uRight = carve<float>(ar, N);
   a.depth = carve<float>(ar, N);
+  int32_t* dcount = carve<int32_t>(ar, 1);  // (right behind the two outputs: one copy brings all three back)
   a.sad = carve<int32_t>(ar, N);
   if (rows + 1 <= 8192) {  // row index of the right keypoints (k_stereo_bucket)
     a.rowStart = carve<int32_t>(ar, (size_t)rows + 1);
@@ -389,16 +421,14 @@ extern "C" int orbfe_compute_stereo_matches(orbfe_extractor* left, int frameL, o
     a.rows = rows;
     a.bandR = (int)std::ceil(2.0f * scL[nlL - 1]) + 2;
   }
-  int32_t* dcount = carve<int32_t>(ar, 1);
   MHIP(flush(ar));
   launch_stereo(ar->stream, a, dcount);
   MHIP(hipGetLastError());
-  int32_t cnt = 0;
-  MHIP(hipMemcpyAsync(uRight, a.uRight, (size_t)N * 4, hipMemcpyDeviceToHost, ar->stream));
-  MHIP(hipMemcpyAsync(depth, a.depth, (size_t)N * 4, hipMemcpyDeviceToHost, ar->stream));
-  MHIP(hipMemcpyAsync(&cnt, dcount, 4, hipMemcpyDeviceToHost, ar->stream));
+  MHIP(down_range(ar, a.uRight, dcount + 1));
   MHIP(hipStreamSynchronize(ar->stream));
-  return cnt;
+  std::memcpy(uRight, mirror_of(ar, a.uRight), (size_t)N * 4);
+  std::memcpy(depth, mirror_of(ar, a.depth), (size_t)N * 4);
+  return *mirror_of(ar, dcount);
 }
 
 // ---------------------------------------------------------------------------------------------
