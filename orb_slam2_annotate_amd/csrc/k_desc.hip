@@ -326,6 +326,10 @@ void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d
   if (kGridPerCu < 0) {
     kGridPerCu = 16 / (concurrentLaunches < 1 ? 1 : concurrentLaunches);
     kGridPerCu = kGridPerCu < 2 ? 2 : (kGridPerCu > 4 ? 4 : kGridPerCu);
+    // frames with many keypoints on a large pyramid (1241 x 376 / 2000 features: 32 workgroups and 2.9 MB of pyramid +
+    // blurred levels per frame) want ONE frame's workgroups per XCD in flight: 1 per CU measured 100.1 k vs 94.7 k
+    // stereo frames/s on 8 streams, while 640 x 480 / 1000 features lose 5 % that way (same-box A/B)
+    if (blocksPerFrame >= 24 && concurrentLaunches >= 8) kGridPerCu = 1;
   }
   // Round 2 measured the wider form <64, 8, 4> (twice the row / patch loads in flight per wave, 106 VGPRs, same 4
   // workgroups per CU): stage 3.36 vs 3.38 ms per 4096 VGA frames, pipeline unchanged, so <64, 4, 2> stays.
