@@ -167,6 +167,12 @@ int orbfe_debug_geometry(int nfeatures, float scaleFactor, int nlevels, int iniT
                          int16_t *cells5, int cell_cap);
 int orbfe_debug_resize_tables(int sw, int sh, int dw, int dh, int32_t *xofs, int16_t *alpha, int32_t *yofs,
                               int16_t *beta);
+/* Tile ownership of the fused blur + resize kernel for one level pair: tile_gx[(sw+63)/64 + 1] / tile_dy[(sh+63)/64 + 1]
+ * (first 4-column group / output row owned by each 64 x 64 source tile, then the totals), group_start[(dw+3)/4] (first
+ * source column of each group's 8-byte tap window), row_upper[dh] (upper source row of each output row, clamped).
+ * *n_tiles_x / *n_tiles_y are 0 when the fused kernel is not used for these sizes. */
+int orbfe_debug_resize_tiles(int sw, int sh, int dw, int dh, int32_t *tile_gx, int *n_tiles_x, int32_t *tile_dy,
+                             int *n_tiles_y, int32_t *group_start, int32_t *row_upper);
 
 /* Debug cross-check: when enabled, DistributeOctTree runs in the library's host implementation
  * (D2H/H2D round trip) instead of the device kernel.  Off by default; results are identical. */

@@ -1547,6 +1547,27 @@ extern "C" int orbfe_debug_geometry(int nfeatures, float scaleFactor, int nlevel
   return g.nFastCells;
 }
 
+// Ownership tables of the fused blur + resize kernel (ResizeTables::tileGx / tileDy) with the window start of every
+// 4-column group and the upper source row of every output row, for the host-logic test.  n_tiles_x / n_tiles_y come
+// back 0 when the fused kernel is not used for this pair of sizes.
+extern "C" int orbfe_debug_resize_tiles(int sw, int sh, int dw, int dh, int32_t* tile_gx, int* n_tiles_x, int32_t* tile_dy,
+                                        int* n_tiles_y, int32_t* group_start, int32_t* row_upper) {
+  if (sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || !tile_gx || !n_tiles_x || !tile_dy || !n_tiles_y || !group_start || !row_upper)
+    return fail(ORBFE_ERR_INVALID, "debug_resize_tiles: bad argument");
+  ResizeTables t;
+  build_resize_tables(sw, sh, dw, dh, &t);
+  *n_tiles_x = *n_tiles_y = 0;
+  if (t.tileGx.empty()) return ORBFE_OK;
+  *n_tiles_x = (int)t.tileGx.size() - 1;
+  *n_tiles_y = (int)t.tileDy.size() - 1;
+  std::memcpy(tile_gx, t.tileGx.data(), t.tileGx.size() * 4);   // caller: (sw + 63) / 64 + 1 entries
+  std::memcpy(tile_dy, t.tileDy.data(), t.tileDy.size() * 4);   // caller: (sh + 63) / 64 + 1 entries
+  const int ngx = (dw + 3) / 4;
+  for (int g = 0; g < ngx; g++) group_start[g] = (int32_t)t.colrec[12 * (size_t)g + 8];
+  for (int dy = 0; dy < dh; dy++) row_upper[dy] = (int32_t)t.rowrec[4 * (size_t)dy];
+  return ORBFE_OK;
+}
+
 // cv::resize coefficient tables (xofs, alpha pairs, yofs, beta pairs) the resize kernel uses.
 extern "C" int orbfe_debug_resize_tables(int sw, int sh, int dw, int dh, int32_t* xofs, int16_t* alpha, int32_t* yofs,
                                          int16_t* beta) {

@@ -70,6 +70,35 @@ def test_resize_tables_reproduce_oracle_resize(sizes):
     assert np.array_equal(out, orc.resize_linear(img.astype(np.uint8), dw, dh))
 
 
+@pytest.mark.parametrize("sizes", [(640, 480, 533, 400), (1241, 376, 1034, 313), (214, 161, 179, 134), (752, 480, 627, 400),
+                                   (900, 700, 600, 467), (300, 200, 273, 182), (70, 66, 58, 55)])
+def test_fused_blur_resize_tile_ownership(sizes):
+    """Every 4-column group / output row of the next pyramid level belongs to exactly one 64 x 64 source tile, its tap
+    window (8 bytes from group_start; rows row_upper and row_upper + 1) lies inside what that tile stages (columns
+    bx-4 .. bx+75, rows by-3 .. by+66), and a tile owns at most 16 groups and 80 rows (the kernel's LDS slots)."""
+    import ctypes as C
+    sw, sh, dw, dh = sizes
+    L = _lib.load()
+    tx, ty = (sw + 63) // 64, (sh + 63) // 64
+    gx = np.zeros(tx + 1, np.int32); dy = np.zeros(ty + 1, np.int32)
+    ngx = (dw + 3) // 4
+    gs = np.zeros(ngx, np.int32); ru = np.zeros(dh, np.int32)
+    nx, ny = C.c_int(0), C.c_int(0)
+    assert L.orbfe_debug_resize_tiles(sw, sh, dw, dh, _lib.ptr(gx), C.byref(nx), _lib.ptr(dy), C.byref(ny), _lib.ptr(gs), _lib.ptr(ru)) == 0
+    assert (nx.value, ny.value) == (tx, ty)
+    assert gx[0] == 0 and gx[-1] == ngx and dy[0] == 0 and dy[-1] == dh
+    assert (np.diff(gx) >= 0).all() and (np.diff(dy) >= 0).all()
+    assert np.diff(gx).max() <= 16 and np.diff(dy).max() <= 80
+    for t in range(tx):
+        g = np.arange(gx[t], gx[t + 1])
+        assert ((gs[g] >= 64 * t) & (gs[g] < 64 * (t + 1))).all()          # window start inside the tile's core
+        assert (gs[g] + 7 <= 64 * t + 75).all() and (gs[g] + 7 < sw).all()  # whole window staged, and inside the image
+    for t in range(ty):
+        r = np.arange(dy[t], dy[t + 1])
+        assert ((ru[r] >= 64 * t) & (ru[r] < 64 * (t + 1))).all()
+        assert (np.minimum(ru[r] + 1, sh - 1) <= 64 * t + 66).all()
+
+
 def _octree_product(xs, ys, rs, minX, maxX, minY, maxY, N):
     L = _lib.load()
     n = len(xs)
