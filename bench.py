@@ -63,6 +63,8 @@ WORKLOADS = {
                        "(synthetic frames, synthetic k=10 L=2 vocabulary)",
                   w=752, h=480, nfeatures=1200, ini=20, mn=7, bow=True, batch=2048, streams=8),
 }
+STEREO_SCENE = "textured"  # --stereo-scene: "textured" (one scene in both eyes, piecewise-planar sub-pixel disparity: >= 50 % of the
+#   left keypoints obtain a stereo match, as on a rectified KITTI pair) | "shapes" (rounds 1-2: per-object integer shifts, 14 % match)
 SINGLE_SCENE = False  # --single-scene: the round-1 synthetic input (sparser; for continuity with profiles/history/r01_bench.json)
 GPU_STAGES = ["pyramid", "fast", "octree", "blur", "orient_desc", "match"]
 STAGE_KERNELS = {  # kernels (and launches per step) behind each timed stage
@@ -120,8 +122,8 @@ def launch_ranks(n: int) -> int:
 def _render_task(t):
     from orb_slam2_annotate_amd import synth
     kind, seed, n, w, h = t
-    if kind == "stereo":
-        l, r = synth.render_stereo(seed, w, h)
+    if kind.startswith("stereo"):
+        l, r = synth.STEREO_SCENES[kind.partition(":")[2] or "shapes"](seed, w, h)
         return [l, r]
     return synth.render_sequence(seed, n, w, h, step=1.5)
 
@@ -131,8 +133,13 @@ def render_inputs(names, batches, rank, procs=0, cache=None):
     seed); stereo: one scene per pair, ordered L0,R0,L1,R1,...  `cache`: directory holding the rendered batches
     as .npy (written on first use) -- the profiler passes of tools/profile_round.sh reuse what the plain run rendered."""
     out, todo = {}, []
+
+    def cache_file(nm):
+        tag = f"_{STEREO_SCENE}" if WORKLOADS[nm].get("stereo") else ""
+        return Path(cache) / f"{nm}{tag}_{batches[nm]}_{rank}.npy"
+
     for nm in names:
-        f = Path(cache) / f"{nm}_{batches[nm]}_{rank}.npy" if cache else None
+        f = cache_file(nm) if cache else None
         if f is not None and f.exists():
             out[nm] = list(np.load(f))
         else:
@@ -143,7 +150,7 @@ def render_inputs(names, batches, rank, procs=0, cache=None):
             out[nm] = rendered[nm]
             if cache:
                 Path(cache).mkdir(parents=True, exist_ok=True)
-                np.save(Path(cache) / f"{nm}_{batches[nm]}_{rank}.npy", np.stack(rendered[nm]))
+                np.save(cache_file(nm), np.stack(rendered[nm]))
     return out
 
 
@@ -156,7 +163,7 @@ def _render(names, batches, rank, procs=0):
             owner.append(nm)
         elif wl.get("stereo"):
             for i in range(B):
-                tasks.append(("stereo", 5000 + 100000 * rank + i, 1, wl["w"], wl["h"]))
+                tasks.append(("stereo:" + STEREO_SCENE, 5000 + 100000 * rank + i, 1, wl["w"], wl["h"]))
                 owner.append(nm)
         else:
             for c in range(0, B, 64):
@@ -436,7 +443,7 @@ class GpuWorkload:
         o = orc.Oracle(wl["nfeatures"], 1.2, 8, wl["ini"], wl["mn"])
         n = self.d_n.cpu().numpy()
         units = sorted({0, B // 2, B - 1})
-        dist_calls, matched = [], []
+        dist_calls, matched, scanned, sads, cpu_ms = [], [], [], [], []
         vo = orc.Vocabulary(voc_path) if self.bow else None
         for ui in units:
             imgs = [2 * ui, 2 * ui + 1] if self.stereo else ([ui - 1, ui] if (self.bow and ui > 0) else [ui])
@@ -453,8 +460,13 @@ class GpuWorkload:
             if self.stereo:
                 (kL, dL, pL), (kR, dR, pR) = ref
                 orc.distance_calls_reset()
+                t1 = time.perf_counter()
                 u_ref, dep_ref = o.stereo(self.W, self.H, kL, dL, kR, dR, pL, pR, float(self.mbf), float(self.mb))
+                cpu_ms.append(1e3 * (time.perf_counter() - t1))
                 dist_calls.append(orc.distance_calls())
+                sc, sd = orc.stereo_counters()
+                scanned.append(sc)
+                sads.append(sd)
                 matched.append(int((u_ref >= 0).sum()))
                 if not (np.array_equal(self.d_u[ui, :len(kL)].cpu().numpy(), u_ref) and
                         np.array_equal(self.d_dep[ui, :len(kL)].cpu().numpy(), dep_ref)):
@@ -472,7 +484,15 @@ class GpuWorkload:
                "compared": "keypoints (28-byte records) and descriptors bit-identical"
                            + (", mvuRight / mvDepth identical" if self.stereo else "")
                            + (", SearchByBoW match arrays identical" if self.bow else "")}
-        return rep, (float(np.mean(dist_calls)) if dist_calls else 0.0), (float(np.mean(matched)) if matched else 0.0)
+        mean = lambda v: float(np.mean(v)) if v else 0.0  # noqa: E731
+        work = {"distance_pairs_per_unit": mean(dist_calls), "matches_per_unit_oracle": mean(matched)}
+        if self.stereo:
+            work.update({"bucket_entries_scanned_per_unit": mean(scanned), "sad_refinements_per_unit": mean(sads),
+                         "cpu_oracle_stereo_ms": mean(cpu_ms),
+                         "note": "oracle counts on the checked units: row-bucket entries a left keypoint walks (src/Frame.cc:573-595), of "
+                                 "which the octave (:579) and disparity-range (:584) gates let distance_pairs through to DescriptorDistance; "
+                                 "SAD refinements = 11 windows of 11x11 each (:598-652)"})
+        return rep, work
 
 
 def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, use_dist, voc_path, batches):
@@ -529,7 +549,8 @@ def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, u
     dt_max, total_units = reduce_report(dt, float(B * args.steps), torch, dist, use_dist, g.dev)
     res = None
     if rank == 0:
-        check, dist_per_unit, _ = g.check(voc_path)
+        check, work = g.check(voc_path)
+        dist_per_unit = work["distance_pairs_per_unit"]
         sizes = [ext.level_size(g.W, g.H, l) for l in range(ext.GetLevels())]
         alg = algorithmic_bytes(sizes, n_kp, wl, n_st)
         stage_kernels = dict(STAGE_KERNELS)
@@ -580,7 +601,7 @@ def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, u
             roof["matching"] = {
                 "what": "256-bit Hamming distances of the matcher stage (the reference's DescriptorDistance calls, counted "
                         "by the oracle on the checked units), alone on the GPU",
-                "distance_pairs_per_unit": dist_per_unit, "distance_pairs_per_s": pairs / (excl["match"] * 1e-3),
+                **work, "distance_pairs_per_s": pairs / (excl["match"] * 1e-3),
                 "popcount32_per_s": 8 * pairs / (excl["match"] * 1e-3), "peak": BCNT_PEAK, "unit": "popcount-32 lane-ops/s",
                 "frac": 8 * pairs / (excl["match"] * 1e-3) / BCNT_PEAK,
                 "note": "v_bcnt_u32_b32 peak measured by tools/ubench/valu_rate.hip (0.585 T wave-instr/s x 64 lanes); the "
@@ -751,6 +772,10 @@ def main():
                     "this process, which a run under a GPU-initialising profiler needs)")
     ap.add_argument("--single-scene", action="store_true", help="mono workloads: render ONE scene for the whole batch, the "
                     "round-1 input (sparser than the default 64-scene batches); for continuity with the round-1 line")
+    ap.add_argument("--stereo-scene", choices=["textured", "shapes"], default="textured",
+                    help="synthetic stereo pairs: 'textured' = one scene in both eyes with a piecewise-planar sub-pixel disparity field "
+                         "(>= 50 %% of the left keypoints obtain a stereo match; default and headline), 'shapes' = the round-1/2 "
+                         "generator (per-object integer shifts, ~14 %% match)")
     ap.add_argument("--dataset", default=os.environ.get("ORBFE_DATASET"), help="real frames for one workload: kitti:<sequence dir> | "
                     "euroc:<cam0 dir>,<cam1 dir>,<timestamps file> | tum:<sequence dir> (image lists as the reference's example mains "
                     "read them, orb_slam2_annotate_amd/datasets.py); default: $ORBFE_DATASET, else synthetic")
@@ -776,8 +801,9 @@ def main():
 
     names = ["kitti", "tum", "euroc"] if args.workload == "all" else (["kitti"] if args.workload == "kitti_seq" else [args.workload])
     batches = {nm: (args.batch if args.batch > 0 else WORKLOADS[nm]["batch"]) for nm in names}
-    global SINGLE_SCENE
+    global SINGLE_SCENE, STEREO_SCENE
     SINGLE_SCENE = args.single_scene
+    STEREO_SCENE = args.stereo_scene
     inputs = render_inputs(names, batches, rank, args.render_procs, None if args.single_scene else args.input_cache)
     data_tag = "synthetic"
     if args.dataset:  # real frames for the one workload whose layout the spec names (kitti | euroc | tum)

@@ -852,6 +852,10 @@ int orc_extract(orc_extractor *e, const uint8_t *img, int W, int H, int stride, 
 static __thread int64_t g_distance_calls = 0;
 void orc_distance_calls_reset(void) { g_distance_calls = 0; }
 int64_t orc_distance_calls(void) { return g_distance_calls; }
+/* work counters of the last orc_compute_stereo_matches call of this thread (bench.py reports them next to the
+   distance count): row-bucket entries scanned (src/Frame.cc:573-595), SAD refinements entered (:598-652) */
+static __thread int64_t g_stereo_scanned = 0, g_stereo_sad = 0;
+void orc_stereo_counters(int64_t *out) { out[0] = g_stereo_scanned; out[1] = g_stereo_sad; }
 
 int orc_descriptor_distance(const uint8_t *a, const uint8_t *b) { /* :1828-1844 */
   int dist = 0;
@@ -1096,6 +1100,8 @@ int orc_compute_stereo_matches(const orc_extractor *e, int W, int H, const orc_k
   const float minZ = mb, minD = 0, maxD = mbf / minZ;
   distidx *vDistIdx = (distidx *)malloc(sizeof(distidx) * (N > 0 ? N : 1));
   int nDist = 0;
+  g_stereo_scanned = 0;
+  g_stereo_sad = 0;
   for (int iL = 0; iL < N; iL++) {
     const orc_keypoint *kl = &kpL[iL];
     const int levelL = kl->octave;
@@ -1108,6 +1114,7 @@ int orc_compute_stereo_matches(const orc_extractor *e, int W, int H, const orc_k
     int bestDist = TH_HIGH;
     int bestIdxR = 0;
     const uint8_t *dL = descL + (size_t)iL * 32;
+    g_stereo_scanned += rowCnt[row];
     for (int iC = 0; iC < rowCnt[row]; iC++) {
       const int iR = rowIdx[row][iC];
       const orc_keypoint *kr = &kpR[iR];
@@ -1134,6 +1141,7 @@ int orc_compute_stereo_matches(const orc_extractor *e, int W, int H, const orc_k
       const float iniu = scaleduR0 + L - w;
       const float endu = scaleduR0 + L + w + 1;
       if (iniu < 0 || endu >= (float)lw[lv]) continue;
+      g_stereo_sad++;
       const int cL = IL[(size_t)cy * st + cxL];
       for (int incR = -L; incR <= +L; incR++) {
         const int cxR = (int)(scaleduR0 + (float)incR);

@@ -101,6 +101,7 @@ int orc_descriptor_distance(const uint8_t *a, const uint8_t *b); /* :1828-1844 *
 /* number of orc_descriptor_distance calls of the calling thread since the last reset (measurement aid) */
 void orc_distance_calls_reset(void);
 int64_t orc_distance_calls(void);
+void orc_stereo_counters(int64_t *out); /* [bucket entries scanned, SAD refinements] of this thread's last stereo call */
 void orc_three_maxima(const int *histo_sizes, int L, int *ind1, int *ind2, int *ind3); /* :1777-1821 */
 
 /* A DBoW2::FeatureVector flattened: node_ids ascending, CSR offsets into indices. */

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["render_frame", "render_stereo", "render_sequence", "adversarial"]
+__all__ = ["render_frame", "render_stereo", "render_stereo_textured", "STEREO_SCENES", "render_sequence", "adversarial"]
 
 
 def _background(rng: np.random.Generator, w: int, h: int) -> np.ndarray:
@@ -121,6 +121,65 @@ def render_stereo(seed: int, w: int = 1241, h: int = 376, n_shapes: int | None =
     _paint(left, shapes, 0.0)
     _paint(right, shapes, 1.0)
     return _finish(left, rng, sigma), _finish(right, rng, sigma)
+
+
+def _disparity_planes(rng: np.random.Generator, w: int, h: int, max_disp: float) -> np.ndarray:
+    """Piecewise-planar, sub-pixel disparity field of a driving scene in RIGHT-view coordinates: a far backdrop above the
+    horizon, a ground plane (disparity grows linearly with the image row, as bf*(y - cy)/(fy*h_cam) does), two slanted
+    side walls and a few fronto-parallel / slanted boxes in front of them.  Nearer surfaces overwrite farther ones."""
+    ys = np.arange(h, dtype=np.float64)[:, None]
+    xs = np.arange(w, dtype=np.float64)[None, :]
+    horizon = h * rng.uniform(0.40, 0.52)
+    far = rng.uniform(0.6, 3.0)
+    ground_gain = rng.uniform(0.55, 0.95) * max_disp / max(h - horizon, 1.0)
+    d = np.full((h, w), far) + 0.0 * xs
+    d = np.maximum(d, far + ground_gain * (ys - horizon))
+    # side walls: disparity falls off linearly from the image border towards a vanishing column
+    for side in (0, 1):
+        reach = w * rng.uniform(0.18, 0.36)
+        near = rng.uniform(0.35, 0.8) * max_disp
+        top = horizon - h * rng.uniform(0.25, 0.45)
+        t = (reach - xs) / reach if side == 0 else (xs - (w - reach)) / reach
+        wall = far + (near - far) * np.clip(t, 0.0, 1.0)
+        m = (t > 0) & (ys > top + (horizon - top) * (1 - np.clip(t, 0, 1))) & (wall > d)
+        d = np.where(m, wall, d)
+    for _ in range(int(rng.integers(3, 8))):  # boxes ("cars", "signs"): planes with a small horizontal / vertical slant
+        bw, bh = w * rng.uniform(0.05, 0.2), h * rng.uniform(0.12, 0.4)
+        cx, cy = rng.uniform(0, w), horizon + rng.uniform(-0.15, 0.35) * h
+        d0 = rng.uniform(0.1, 0.9) * max_disp
+        gx, gy = rng.uniform(-0.03, 0.03), rng.uniform(-0.02, 0.02)
+        plane = d0 + gx * (xs - cx) + gy * (ys - cy)
+        m = (np.abs(xs - cx) < bw / 2) & (np.abs(ys - cy) < bh / 2) & (plane > d)
+        d = np.where(m, plane, d)
+    return np.clip(d, 0.25, max_disp)
+
+
+def render_stereo_textured(seed: int, w: int = 1241, h: int = 376, n_shapes: int | None = None,
+                           max_disp: float = 72.0, sigma: float = 3.0):
+    """Left/right pair of ONE textured scene: the same scene content in both eyes, related by a piecewise-planar
+    SUB-PIXEL disparity field, plus independent sensor noise per eye.  The left view is a window of a wide canvas
+    (value-noise background + shapes at all scales, as render_frame); the right view samples that canvas bilinearly at
+    x + D_R(x, y) (x_R = x_L - d), so almost every left corner has its counterpart on the same row -- what a rectified
+    KITTI pair looks like to Frame::ComputeStereoMatches (src/Frame.cc:512-686), unlike render_stereo's per-object
+    integer shifts whose corners are mostly occlusion junctions."""
+    rng = np.random.default_rng([0x7E87ED, int(seed)])
+    if n_shapes is None:
+        n_shapes = int(rng.integers(400, 1500) * (w * h) / (640 * 480))
+    pad = int(np.ceil(max_disp)) + 2
+    W = w + pad
+    canvas = _background(rng, W, h)
+    _paint(canvas, _make_shapes(rng, W, h, int(n_shapes * W / w), 0), 0.0)
+    d = _disparity_planes(rng, w, h, float(max_disp))
+    sx = np.arange(w, dtype=np.float64)[None, :] + d
+    x0 = np.floor(sx).astype(np.int64)
+    fx = sx - x0
+    x0 = np.clip(x0, 0, W - 2)
+    rows = np.arange(h)[:, None]
+    right = canvas[rows, x0] * (1.0 - fx) + canvas[rows, x0 + 1] * fx
+    return _finish(canvas[:, :w].copy(), rng, sigma), _finish(right, rng, sigma)
+
+
+STEREO_SCENES = {"shapes": render_stereo, "textured": render_stereo_textured}
 
 
 def render_sequence(seed: int, n_frames: int, w: int = 640, h: int = 480,

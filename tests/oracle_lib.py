@@ -66,6 +66,13 @@ def distance_calls() -> int:
     return int(lib().orc_distance_calls())
 
 
+def stereo_counters():
+    """(row-bucket entries scanned, SAD refinements entered) of this thread's last Oracle.stereo call."""
+    out = (C.c_int64 * 2)()
+    lib().orc_stereo_counters(out)
+    return int(out[0]), int(out[1])
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 

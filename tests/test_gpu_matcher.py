@@ -139,11 +139,12 @@ def test_bow_edge_cases(amd):
     assert gn == 0 and (g == -1).all()
 
 
+@pytest.mark.parametrize("scene", ["shapes", "textured"])
 @pytest.mark.parametrize("seed,shape,nf,bf,fx", [(1, (1241, 376), 2000, 386.1448, 718.856),
                                                    (2, (752, 480), 1200, 47.90639384423901, 435.2046959714599)])
-def test_compute_stereo_matches(amd, seed, shape, nf, bf, fx):
+def test_compute_stereo_matches(amd, seed, shape, nf, bf, fx, scene):
     w, h = shape
-    left, right = synth.render_stereo(seed, w, h)
+    left, right = synth.STEREO_SCENES[scene](seed, w, h)
     eL = amd.ORBextractor(nf, 1.2, 8, 20, 7)
     eR = amd.ORBextractor(nf, 1.2, 8, 20, 7)
     kL, dL = eL(left)
@@ -158,7 +159,7 @@ def test_compute_stereo_matches(amd, seed, shape, nf, bf, fx):
     u, d = amd.ComputeStereoMatches(eL, eR, kL, dL, kR, dR, float(mbf), float(mb))
     assert np.array_equal(u_ref, u)
     assert np.array_equal(d_ref, d)
-    assert (u >= 0).sum() > 100
+    assert (u >= 0).sum() > (0.5 * len(kL) if scene == "textured" else 100)
 
 
 def test_compute_stereo_matches_border_keypoints(amd):

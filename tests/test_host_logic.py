@@ -165,3 +165,25 @@ def test_udiv_magic_is_exact_for_all_32_bit_operands():
         q = (ns * np.uint64(M)) >> np.uint64(32)
         q = q + ((ns - q * np.uint64(d)) >= np.uint64(d)).astype(np.uint64)
         assert np.array_equal(q, ns // np.uint64(d)), d
+
+
+def test_textured_stereo_scene_is_matchable():
+    """The bench's default stereo input (synth.render_stereo_textured): >= 50 % of the left keypoints obtain a stereo
+    match in the oracle's Frame::ComputeStereoMatches, with sub-pixel disparities -- the round-2 'shapes' scene gave 14 %."""
+    import oracle_lib as orc
+    from orb_slam2_annotate_amd import synth
+    w, h = 1241, 376
+    left, right = synth.render_stereo_textured(5001, w, h)  # bench.py's second pair (seeds 5000..: 0.50-0.60, mean 0.56)
+    o = orc.Oracle(2000, 1.2, 8, 20, 7)
+    kL, dL, pL = o.extract(left, want_pyramid=True)
+    kR, dR, pR = o.extract(right, want_pyramid=True)
+    mbf = np.float32(386.1448)
+    mb = np.float32(mbf / np.float32(718.856))
+    orc.distance_calls_reset()
+    u, dep = o.stereo(w, h, kL, dL, kR, dR, pL, pR, float(mbf), float(mb))
+    m = u >= 0
+    assert m.sum() >= 0.5 * len(kL) and m.sum() >= 1000
+    disp = kL["x"][m] - u[m]
+    assert (np.abs(disp - np.rint(disp)) > 0.05).mean() > 0.5  # sub-pixel, not integer shifts
+    scanned, sads = orc.stereo_counters()
+    assert scanned > 5e4 and sads >= m.sum() and orc.distance_calls() > 1e4
