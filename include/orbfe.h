@@ -337,6 +337,13 @@ typedef struct orbfe_vocabulary orbfe_vocabulary;
  * Deviation: empty lines are ignored (the reference turns the file's trailing empty line into a
  * child of the root with an UNINITIALISED descriptor). */
 int orbfe_vocabulary_load_text(const char *path, int device, orbfe_vocabulary **out);
+/* The same tree from arrays -- what the node lines of the text file hold (:1374-1417): entry i is node i+1 (the
+ * root is node 0), parent[i] the NodeId of its parent, is_leaf[i] != 0 makes it the next word (word ids count leaves
+ * in array order, :1402-1408), descriptors[32*i ..] and weight[i] as in the line.  k, L, scoring, weighting = the
+ * header line.  For callers that hold or convert a vocabulary in memory (ORBvoc.txt is 145 MB of text). */
+int orbfe_vocabulary_create(int k, int L, int scoring, int weighting, int n_nodes, const int32_t *parent,
+                            const uint8_t *is_leaf, const uint8_t *descriptors, const double *weight,
+                            int device, orbfe_vocabulary **out);
 void orbfe_vocabulary_destroy(orbfe_vocabulary *v);
 int orbfe_vocabulary_info(const orbfe_vocabulary *v, int *k, int *L, int *n_nodes, int *n_words);
 

@@ -1198,6 +1198,19 @@ int orc_compute_stereo_matches(const orc_extractor *e, int W, int H, const orc_k
 /* DBoW2 vocabulary: text loader and transform                         */
 /* Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1424, 1127-1259   */
 /* ------------------------------------------------------------------ */
+/* children lists in file order (m_nodes[pid].children.push_back(nid), :1386) */
+static void vocab_link_children(orc_vocab *v) {
+  const int n = v->n_nodes;
+  v->child_off = (int32_t *)calloc((size_t)n + 1, sizeof(int32_t));
+  v->child_idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 1 ? n - 1 : 1));
+  for (int i = 1; i < n; i++) v->child_off[v->parent[i] + 1]++;
+  for (int i = 0; i < n; i++) v->child_off[i + 1] += v->child_off[i];
+  int32_t *cur = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+  memcpy(cur, v->child_off, sizeof(int32_t) * (size_t)n);
+  for (int i = 1; i < n; i++) v->child_idx[cur[v->parent[i]]++] = i;
+  free(cur);
+}
+
 orc_vocab *orc_vocab_load_text(const char *path) {
   FILE *f = fopen(path, "rb");
   if (!f) return NULL;
@@ -1251,16 +1264,31 @@ orc_vocab *orc_vocab_load_text(const char *path) {
     line = end ? end + 1 : txt + sz;
   }
   v->n_nodes = n;
-  /* children lists in file order */
-  v->child_off = (int32_t *)calloc((size_t)n + 1, sizeof(int32_t));
-  v->child_idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 1 ? n - 1 : 1));
-  for (int i = 1; i < n; i++) v->child_off[v->parent[i] + 1]++;
-  for (int i = 0; i < n; i++) v->child_off[i + 1] += v->child_off[i];
-  int32_t *cur = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
-  memcpy(cur, v->child_off, sizeof(int32_t) * (size_t)n);
-  for (int i = 1; i < n; i++) v->child_idx[cur[v->parent[i]]++] = i;
-  free(cur);
   free(txt);
+  vocab_link_children(v);
+  return v;
+}
+
+/* the same tree from arrays: entry i = node i+1 = one node line of the text file (:1374-1417) */
+orc_vocab *orc_vocab_from_arrays(int k, int L, int n_nodes, const int32_t *parent, const uint8_t *is_leaf,
+                                 const uint8_t *desc, const double *weight) {
+  orc_vocab *v = (orc_vocab *)calloc(1, sizeof(orc_vocab));
+  const int n = n_nodes + 1;
+  v->k = k; v->L = L;
+  v->parent = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+  v->desc = (uint8_t *)calloc((size_t)n * 32, 1);
+  v->weight = (double *)calloc((size_t)n, sizeof(double));
+  v->word_id = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+  v->parent[0] = 0;
+  v->word_id[0] = -1;
+  for (int i = 0; i < n_nodes; i++) {
+    v->parent[i + 1] = parent[i];
+    v->weight[i + 1] = weight[i];
+    v->word_id[i + 1] = is_leaf[i] ? v->n_words++ : -1;
+  }
+  memcpy(v->desc + 32, desc, (size_t)n_nodes * 32);
+  v->n_nodes = n;
+  vocab_link_children(v);
   return v;
 }
 

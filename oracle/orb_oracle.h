@@ -265,6 +265,8 @@ typedef struct orc_vocab {
 /* loadFromTextFile (:1338-1424).  Deviation: an empty (trailing) line is ignored; the reference
  * turns it into a child of the root with an UNINITIALISED descriptor (UB). */
 orc_vocab *orc_vocab_load_text(const char *path);
+orc_vocab *orc_vocab_from_arrays(int k, int L, int n_nodes, const int32_t *parent, const uint8_t *is_leaf,
+                                 const uint8_t *desc, const double *weight);
 void orc_vocab_free(orc_vocab *v);
 /* transform(feature, word_id, weight, nid, levelsup) (:1218-1259) for n features.
  * Returns the number of features with weight > 0 (the ones transform(features,...) :1127-1194

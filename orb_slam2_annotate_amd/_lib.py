@@ -54,7 +54,7 @@ EXPORTS = [
     "orbfe_debug_resize_tables", "orbfe_debug_resize_tiles", "orbfe_extractor_set_streams", "orbfe_extractor_set_fused", "orbfe_extractor_set_pyramid_blur", "orbfe_extractor_set_fast_mode", "orbfe_extractor_set_schedule", "orbfe_extractor_set_blur_spec", "orbfe_gaussian_blur7_spec", "orbfe_extractor_profile", "orbfe_extractor_profile_get",
     "orbfe_stage_name", "orbfe_resize_linear", "orbfe_gaussian_blur7", "orbfe_descriptor_distance",
     "orbfe_hamming_matrix", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",
-    "orbfe_search_for_triangulation", "orbfe_compute_stereo_matches", "orbfe_stereo_match_batch_device", "orbfe_vocabulary_load_text", "orbfe_vocabulary_destroy",
+    "orbfe_search_for_triangulation", "orbfe_compute_stereo_matches", "orbfe_stereo_match_batch_device", "orbfe_vocabulary_load_text", "orbfe_vocabulary_create", "orbfe_vocabulary_destroy",
     "orbfe_vocabulary_info", "orbfe_vocabulary_transform", "orbfe_vocabulary_featvec_batch_device",
     "orbfe_bow_match_consecutive_batch_device", "orbfe_bow_match_consecutive_batch_device_async", "orbfe_cvt_gray", "orbfe_cvt_gray_batch_device",
     "orbfe_distinctive_descriptors", "orbfe_features_in_area", "orbfe_search_by_projection",
@@ -147,6 +147,7 @@ def load():
     L.orbfe_compute_stereo_matches.argtypes = [vp, ci, vp, ci, vp, vp, ci, vp, vp, ci, cf, cf, vp, vp]
     L.orbfe_stereo_match_batch_device.argtypes = [vp, ci, vp, vp, vp, ci, cf, cf, vp, vp, vp]
     L.orbfe_vocabulary_load_text.argtypes = [C.c_char_p, ci, C.POINTER(C.c_void_p)]
+    L.orbfe_vocabulary_create.argtypes = [ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, C.POINTER(C.c_void_p)]
     L.orbfe_vocabulary_destroy.argtypes = [vp]
     L.orbfe_vocabulary_destroy.restype = None
     L.orbfe_vocabulary_info.argtypes = [vp, vp, vp, vp, vp]

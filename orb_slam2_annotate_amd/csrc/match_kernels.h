@@ -55,13 +55,21 @@ struct StereoBatch {  // frames 2p / 2p+1 of an extractor batch are the left / r
   float* uRight; float* depth; int32_t* sad;   // [nPairs * capacity]
 };
 
-// DBoW2 vocabulary tree on the device (vocabulary.hip)
+// DBoW2 vocabulary tree on the device (vocabulary.hip).  Nodes are renumbered breadth-first so that the children of a
+// node are ADJACENT records, in file order (the order TemplatedVocabulary::transform scans them in, :1236-1250): one
+// level of the descent is one contiguous read of nChild x 48 bytes, and the record a lane loads to take its child's
+// distance already carries what the next level needs if that child wins.
+struct VocabNode {       // 48 bytes
+  uint32_t d[8];         // FORB descriptor
+  uint32_t firstChild;   // BFS position of the first child
+  uint32_t nChild;       // bits 0-7: number of children (0 = leaf); bit 8: weight > 0
+  uint32_t id;           // NodeId of the reference = line order of the text file (root = 0)
+  int32_t word;          // WordId (leaves, in file order) or -1
+};
 struct VocabDevice {
-  const uint8_t* desc;      // [nNodes][32]
-  const int32_t* childOff;  // [nNodes+1]
-  const int32_t* childIdx;  // children in file order
-  const int32_t* wordId;    // -1 when the node is not a word
-  const double* weight;
+  const VocabNode* nodes;  // [nNodes], BFS order, root at 0
+  const double* weight;    // [nNodes], by BFS position
+  uint32_t rootChildren;   // children of the root (positions 1 .. rootChildren)
 };
 
 // Batched FeatureVector construction: frame f uses desc[f*capacity ..], n[f] descriptors
@@ -69,6 +77,7 @@ struct FeatVecBatch {
   const uint8_t* desc; const int32_t* n; int capacity;
   int sortN;                 // power of two >= capacity
   uint32_t* word; double* weight;          // optional per-feature outputs [nFrames*capacity]
+  unsigned long long* keys;  // [nFrames*capacity] scratch: (node << 32 | feature) of the used features, ~0 otherwise
   uint32_t* fvNodes;         // [nFrames*capacity] node ids ascending
   int32_t* fvOffsets;        // [nFrames*(capacity+1)]
   uint32_t* fvIndices;       // [nFrames*capacity]

@@ -33,6 +33,24 @@ class ORBVocabulary:
         self._h = h
         return True
 
+    def createFromArrays(self, arrays) -> bool:
+        """arrays = (k, L, parent[n], is_leaf[n], descriptors[n,32], weight[n]): the node lines of a text vocabulary
+        (node i+1 = entry i) without the text file -- see synthetic_vocabulary_arrays."""
+        k, L, parent, leaf, desc, weight = arrays
+        parent = np.ascontiguousarray(parent, np.int32)
+        leaf = np.ascontiguousarray(leaf, np.uint8)
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        weight = np.ascontiguousarray(weight, np.float64)
+        h = C.c_void_p()
+        rc = self._L.orbfe_vocabulary_create(int(k), int(L), 0, 0, len(parent), ptr(parent), ptr(leaf), ptr(desc), ptr(weight),
+                                             self.device, C.byref(h))
+        if rc != 0:
+            return False
+        if self._h:
+            self._L.orbfe_vocabulary_destroy(self._h)
+        self._h = h
+        return True
+
     def info(self):
         k, L, n, w = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         check(self._L.orbfe_vocabulary_info(self._h, C.byref(k), C.byref(L), C.byref(n), C.byref(w)))
@@ -87,6 +105,46 @@ class ORBVocabulary:
                                                                C.c_void_p(d_n), capacity, levelsup, float(nnratio),
                                                                int(bool(check_orientation)), C.c_void_p(d_match),
                                                                C.c_void_p(d_nmatches)))
+
+
+def synthetic_vocabulary_arrays(k: int = 10, L: int = 6, seed: int = 0):
+    """A seeded full k-ary, L-level ORB vocabulary as arrays, breadth-first like DBoW2 saves its nodes -- k = 10,
+    L = 6 is the shape of ORBvoc.txt (1 111 110 nodes below the root, 10^6 words; src/Frame.cc:438 descends it with
+    levelsup = 4).  Level-1 centroids are random; a deeper child is its parent's centroid with about a quarter of the
+    bits flipped (byte masks r1 & r2); leaves carry a positive IDF-like weight.  Returns (k, L, parent, is_leaf,
+    descriptors, weight) for ORBVocabulary.createFromArrays / the oracle's Vocabulary.from_arrays."""
+    rng = np.random.default_rng([0xB0B6, seed])
+    parents, leafs, descs, weights = [], [], [], []
+    prev_ids = np.zeros(1, np.int64)
+    prev_desc = None
+    next_id = 1
+    for depth in range(1, L + 1):
+        n = len(prev_ids) * k
+        par = np.repeat(prev_ids, k)
+        if depth == 1:
+            d = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        else:
+            mask = rng.integers(0, 256, size=(n, 32), dtype=np.uint8) & rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+            d = np.repeat(prev_desc, k, axis=0) ^ mask
+        leaf = depth == L
+        parents.append(par.astype(np.int32))
+        leafs.append(np.full(n, 1 if leaf else 0, np.uint8))
+        descs.append(d)
+        weights.append(np.round(rng.uniform(0.5, 6.0, size=n), 6) if leaf else np.zeros(n))
+        prev_ids = np.arange(next_id, next_id + n, dtype=np.int64)
+        prev_desc = d
+        next_id += n
+    return k, L, np.concatenate(parents), np.concatenate(leafs), np.concatenate(descs), np.concatenate(weights)
+
+
+def write_vocabulary_text(path, arrays):
+    """DBoW2 text format (TemplatedVocabulary::saveToTextFile layout) of such arrays."""
+    k, L, parent, leaf, desc, weight = arrays
+    with open(path, "w") as f:
+        f.write(f"{k} {L} 0 0\n")  # scoring L1_NORM, weighting TF_IDF
+        for i in range(len(parent)):
+            f.write(f"{int(parent[i])} {int(leaf[i])} " + " ".join(map(str, desc[i].tolist())) + f" {weight[i]:.6f}\n")
+    return len(parent) + 1
 
 
 def write_synthetic_vocabulary(path, k: int = 10, L: int = 2, seed: int = 0, flip_bits: int = 60):

@@ -227,11 +227,16 @@ def three_maxima(sizes):
 class FeatVec:
     """Flattened DBoW2::FeatureVector (node ids ascending, CSR)."""
 
-    def __init__(self, node_of_feature: np.ndarray):
+    def __init__(self, node_of_feature: np.ndarray, used=None):
+        """used: mask of the features transform() adds (weight > 0, TemplatedVocabulary.h:1161); default all"""
         node_of_feature = np.asarray(node_of_feature)
+        feat = np.arange(len(node_of_feature))
+        if used is not None:
+            feat = feat[np.asarray(used, bool)]
+            node_of_feature = node_of_feature[feat]
         ids = np.unique(node_of_feature)
         self.node_ids = ids.astype(np.uint32)
-        order = np.argsort(node_of_feature, kind="stable")
+        order = feat[np.argsort(node_of_feature, kind="stable")]
         self.indices = order.astype(np.uint32)
         counts = np.array([(node_of_feature == i).sum() for i in ids], dtype=np.int64)
         self.offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
@@ -286,14 +291,26 @@ class OrcVocab(C.Structure):
 class Vocabulary:
     """oracle restatement of DBoW2 loadFromTextFile + transform"""
 
-    def __init__(self, path):
+    def __init__(self, path=None, arrays=None):
         L = lib()
         L.orc_vocab_load_text.restype = C.POINTER(OrcVocab)
         L.orc_vocab_load_text.argtypes = [C.c_char_p]
+        L.orc_vocab_from_arrays.restype = C.POINTER(OrcVocab)
+        L.orc_vocab_from_arrays.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_vocab_free.argtypes = [C.POINTER(OrcVocab)]
-        self.v = L.orc_vocab_load_text(str(path).encode())
+        if arrays is not None:  # (k, L, parent, is_leaf, descriptors, weight): the node lines of a text file
+            k, Lv, parent, leaf, desc, weight = arrays
+            parent = np.ascontiguousarray(parent, np.int32); leaf = np.ascontiguousarray(leaf, np.uint8)
+            desc = np.ascontiguousarray(desc, np.uint8); weight = np.ascontiguousarray(weight, np.float64)
+            self.v = L.orc_vocab_from_arrays(int(k), int(Lv), len(parent), _p(parent), _p(leaf), _p(desc), _p(weight))
+        else:
+            self.v = L.orc_vocab_load_text(str(path).encode())
         if not self.v:
             raise RuntimeError("orc_vocab_load_text failed")
+
+    @classmethod
+    def from_arrays(cls, arrays):
+        return cls(arrays=arrays)
 
     def __del__(self):
         if getattr(self, "v", None):
