@@ -16,7 +16,8 @@ Workloads (BASELINE.json configs), `--workload all` (default) runs the three of 
          (src/ORBextractor.cc:1119-1197) + Frame::ComputeStereoMatches (src/Frame.cc:512-686)
   tum    (secondary)        configs[1]: 640x480 mono stream, nFeatures=1000, extract only
   euroc  (secondary)        configs[3]: 752x480, nFeatures=1200, extract + ComputeBoW + SearchByBoW(t-1, t)
-         (src/ORBmatcher.cc:185-325) with a synthetic k=10 L=2 vocabulary (ORBvoc.txt is not in the reference)
+         (src/ORBmatcher.cc:185-325) with a synthetic vocabulary of ORBvoc's shape (k=10, L=6: 1 111 111 nodes) descended
+         with levelsup=4 as src/Frame.cc:438 does (ORBvoc.txt itself is not in the reference); --voc-shape 10,2,0 = rounds 1-2
   kitti_seq                 configs[4]: the KITTI 00-07 sequence lengths sharded over the ranks by shard.py's
          `sequence` (one sequence per GPU) and `round_robin` (balanced) plans -- strong scaling, both reported
 Inputs are synthetic (no datasets offline), rendered before the GPU is touched and resident in HBM
@@ -31,7 +32,6 @@ import os
 import socket
 import subprocess
 import sys
-import tempfile
 import time
 from pathlib import Path
 
@@ -60,12 +60,13 @@ WORKLOADS = {
                        "(synthetic stereo pairs; frames/s counts STEREO frames = 2 images each)",
                   w=1241, h=376, nfeatures=2000, ini=20, mn=7, stereo=True, bf=386.1448, fx=718.856, batch=512, streams=8),
     "euroc": dict(name="EuRoC MH_01 752x480 nFeatures=1200: extract + ComputeBoW + SearchByBoW(t-1,t) "
-                       "(synthetic frames, synthetic k=10 L=2 vocabulary)",
+                       "(synthetic frames, synthetic vocabulary of ORBvoc's shape k=10 L=6, levelsup=4)",
                   w=752, h=480, nfeatures=1200, ini=20, mn=7, bow=True, batch=2048, streams=8),
 }
 STEREO_SCENE = "textured"  # --stereo-scene: "textured" (one scene in both eyes, piecewise-planar sub-pixel disparity: >= 50 % of the
 #   left keypoints obtain a stereo match, as on a rectified KITTI pair) | "shapes" (rounds 1-2: per-object integer shifts, 14 % match)
 SINGLE_SCENE = False  # --single-scene: the round-1 synthetic input (sparser; for continuity with profiles/history/r01_bench.json)
+VOC_SHAPE = (10, 6, 4)  # (k, L, levelsup) of the euroc workload's vocabulary: ORBvoc.txt's shape and src/Frame.cc:438's levelsup
 GPU_STAGES = ["pyramid", "fast", "octree", "blur", "orient_desc", "match"]
 STAGE_KERNELS = {  # kernels (and launches per step) behind each timed stage
     "pyramid": [("k_copy2d", 1), ("k_resize_flat", 7)], "fast": [("k_fast_cells", 1)],
@@ -251,11 +252,11 @@ def pmc_valu(workload):
 class _CpuUnit:
     """One unit of the workload's CPU path = one frame (tum, euroc) or one stereo frame (kitti)."""
 
-    def __init__(self, wlname, frames, voc_path=None):
+    def __init__(self, wlname, frames, voc_arrays=None):
         sys.path.insert(0, str(ROOT / "tests"))
         import oracle_lib as orc
         self.orc, self.wl, self.name, self.frames = orc, WORKLOADS[wlname], wlname, frames
-        self.voc = orc.Vocabulary(voc_path) if voc_path else None
+        self.voc = orc.Vocabulary.from_arrays(voc_arrays) if voc_arrays is not None else None
         self.units = len(frames) // 2 if self.wl.get("stereo") else len(frames)
         wl = self.wl
         self.mbf = float(np.float32(wl.get("bf", 0)))
@@ -281,7 +282,7 @@ class _CpuUnit:
             o0.stereo(wl["w"], wl["h"], kL, dL, kR, dR, pL, pR, self.mbf, self.mb)
         elif wl.get("bow"):
             k, d = o.extract(fr[i])
-            fv = orc.FeatVec(self.voc.transform(d, 0)[3])
+            fv = orc.FeatVec(self.voc.transform(d, VOC_SHAPE[2])[3])
             prev = state.get("prev")
             if prev is not None and prev[0] == i - 1:
                 _, k0, d0, fv0 = prev
@@ -319,13 +320,13 @@ def _timed_loop(fn, seconds, min_units=3):
     return dict(value=len(per) / dt, units=len(per), mean_ms=1e3 * float(np.mean(per)), median_ms=1e3 * float(np.median(per)))
 
 
-def cpu_baseline(wlname, frames, voc_path, seconds):
+def cpu_baseline(wlname, frames, voc_arrays, seconds):
     """The CPU oracle (oracle/orb_oracle.c, scalar C, gcc -O3) timed like the reference examples time Track
     (steady wall clock around each unit, mean and median as Examples/Stereo/stereo_kitti.cc:113-122), in the three
     threadings BASELINE.md 2 names.  `value` is the reference's own threading for the workload."""
     import threading
     from concurrent.futures import ThreadPoolExecutor
-    u = _CpuUnit(wlname, frames, voc_path)
+    u = _CpuUnit(wlname, frames, voc_arrays)
     wl = u.wl
     unit = "stereo frames/s" if wl.get("stereo") else "frames/s"
     variants = {}
@@ -384,7 +385,7 @@ def cpu_baseline(wlname, frames, voc_path, seconds):
 # one GPU workload
 # ------------------------------------------------------------------------------------------------
 class GpuWorkload:
-    def __init__(self, name, frames, B, local_rank, torch, voc_path=None):
+    def __init__(self, name, frames, B, local_rank, torch, voc_arrays=None):
         import orb_slam2_annotate_amd as amd
         self.amd, self.torch, self.name = amd, torch, name
         wl = self.wl = WORKLOADS[name]
@@ -408,7 +409,7 @@ class GpuWorkload:
             self.d_ns = torch.zeros((B,), dtype=torch.int32, device=dev)
         if self.bow:
             self.voc = amd.ORBVocabulary(device=local_rank)
-            assert self.voc.loadFromTextFile(voc_path)
+            assert self.voc.createFromArrays(voc_arrays)
             self.d_match = torch.zeros((NI - 1, cap), dtype=torch.int32, device=dev)
             self.d_nm = torch.zeros((NI - 1,), dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
@@ -428,13 +429,13 @@ class GpuWorkload:
             self.voc.bow_match_consecutive_batch_device(ni, self.d_kp.data_ptr(), self.d_desc.data_ptr(),
                                                         self.d_n.data_ptr(), cap, self.d_match.data_ptr(),
                                                         self.d_nm.data_ptr(), nnratio=0.7, check_orientation=True,
-                                                        levelsup=0, extractor=ext)
+                                                        levelsup=VOC_SHAPE[2], extractor=ext)
 
     def sync(self):
         self.ext.synchronize()
         self.torch.cuda.synchronize()
 
-    def check(self, voc_path):
+    def check(self, voc_arrays):
         """>= 3 frames of the resident batch against the CPU oracle (first, middle = another sub-batch, last);
         returns the report and the oracle's DescriptorDistance call count per frame of the matching stage."""
         sys.path.insert(0, str(ROOT / "tests"))
@@ -444,7 +445,7 @@ class GpuWorkload:
         n = self.d_n.cpu().numpy()
         units = sorted({0, B // 2, B - 1})
         dist_calls, matched, scanned, sads, cpu_ms = [], [], [], [], []
-        vo = orc.Vocabulary(voc_path) if self.bow else None
+        vo = orc.Vocabulary.from_arrays(voc_arrays) if self.bow else None
         for ui in units:
             imgs = [2 * ui, 2 * ui + 1] if self.stereo else ([ui - 1, ui] if (self.bow and ui > 0) else [ui])
             ref = []
@@ -473,7 +474,7 @@ class GpuWorkload:
                     raise SystemExit(f"PARITY FAILURE ({self.name}): mvuRight/mvDepth of pair {ui} differ from the oracle")
             if self.bow and ui > 0:
                 (k0, de0, _), (k1, de1, _) = ref
-                fv0, fv1 = orc.FeatVec(vo.transform(de0, 0)[3]), orc.FeatVec(vo.transform(de1, 0)[3])
+                fv0, fv1 = orc.FeatVec(vo.transform(de0, VOC_SHAPE[2])[3]), orc.FeatVec(vo.transform(de1, VOC_SHAPE[2])[3])
                 orc.distance_calls_reset()
                 rn, rm = orc.search_by_bow(de0, np.ones(len(k0), np.uint8), k0["angle"], fv0, de1, k1["angle"], fv1, 0.7, True)
                 dist_calls.append(orc.distance_calls())
@@ -495,10 +496,10 @@ class GpuWorkload:
         return rep, work
 
 
-def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, use_dist, voc_path, batches):
+def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, use_dist, voc_arrays, batches):
     wl = WORKLOADS[name]
     B = batches[name]
-    g = GpuWorkload(name, frames, B, local_rank, torch, voc_path)
+    g = GpuWorkload(name, frames, B, local_rank, torch, voc_arrays)
     ext, NI = g.ext, g.NI
     S = max(1, min(32, args.streams if args.streams > 0 else wl.get("streams", 8)))
 
@@ -549,7 +550,7 @@ def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, u
     dt_max, total_units = reduce_report(dt, float(B * args.steps), torch, dist, use_dist, g.dev)
     res = None
     if rank == 0:
-        check, work = g.check(voc_path)
+        check, work = g.check(voc_arrays)
         dist_per_unit = work["distance_pairs_per_unit"]
         sizes = [ext.level_size(g.W, g.H, l) for l in range(ext.GetLevels())]
         alg = algorithmic_bytes(sizes, n_kp, wl, n_st)
@@ -636,7 +637,7 @@ def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, u
                "units_per_gpu_per_step": B, "images_per_gpu_per_step": NI, "keypoints_per_image": n_kp,
                "stereo_matches_per_frame": n_st if g.stereo else None, "roofline": roof, "parity_check": check}
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(name, frames[: min(len(frames), 256)], voc_path, args.cpu_seconds)
+            res["cpu_baseline"] = cpu_baseline(name, frames[: min(len(frames), 256)], voc_arrays, args.cpu_seconds)
             res["vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
         if not args.no_e2e:
             res["e2e"] = e2e_rate(g, args)
@@ -776,6 +777,8 @@ def main():
                     help="synthetic stereo pairs: 'textured' = one scene in both eyes with a piecewise-planar sub-pixel disparity field "
                          "(>= 50 %% of the left keypoints obtain a stereo match; default and headline), 'shapes' = the round-1/2 "
                          "generator (per-object integer shifts, ~14 %% match)")
+    ap.add_argument("--voc-shape", default="10,6,4", help="k,L,levelsup of the euroc workload's synthetic vocabulary (default: ORBvoc.txt's "
+                    "shape with the levelsup of src/Frame.cc:438; 10,2,0 = the cache-resident tree of rounds 1-2)")
     ap.add_argument("--dataset", default=os.environ.get("ORBFE_DATASET"), help="real frames for one workload: kitti:<sequence dir> | "
                     "euroc:<cam0 dir>,<cam1 dir>,<timestamps file> | tum:<sequence dir> (image lists as the reference's example mains "
                     "read them, orb_slam2_annotate_amd/datasets.py); default: $ORBFE_DATASET, else synthetic")
@@ -801,7 +804,10 @@ def main():
 
     names = ["kitti", "tum", "euroc"] if args.workload == "all" else (["kitti"] if args.workload == "kitti_seq" else [args.workload])
     batches = {nm: (args.batch if args.batch > 0 else WORKLOADS[nm]["batch"]) for nm in names}
-    global SINGLE_SCENE, STEREO_SCENE
+    global SINGLE_SCENE, STEREO_SCENE, VOC_SHAPE
+    VOC_SHAPE = tuple(int(x) for x in args.voc_shape.split(","))
+    if len(VOC_SHAPE) != 3 or VOC_SHAPE != (10, 6, 4):
+        WORKLOADS["euroc"]["name"] = WORKLOADS["euroc"]["name"].replace("ORBvoc's shape k=10 L=6, levelsup=4", "k=%d L=%d, levelsup=%d" % VOC_SHAPE)
     SINGLE_SCENE = args.single_scene
     STEREO_SCENE = args.stereo_scene
     inputs = render_inputs(names, batches, rank, args.render_procs, None if args.single_scene else args.input_cache)
@@ -834,11 +840,10 @@ def main():
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
-    voc_path = None
+    voc_arrays = None
     if "euroc" in names:
-        from orb_slam2_annotate_amd.vocabulary import write_synthetic_vocabulary
-        voc_path = os.path.join(tempfile.gettempdir(), f"orbfe_voc_{os.getpid()}.txt")
-        write_synthetic_vocabulary(voc_path, k=10, L=2, seed=1)
+        from orb_slam2_annotate_amd.vocabulary import synthetic_vocabulary_arrays
+        voc_arrays = synthetic_vocabulary_arrays(VOC_SHAPE[0], VOC_SHAPE[1], seed=1)
 
     if args.workload == "kitti_seq":
         plans, lengths, check = run_kitti_seq(inputs["kitti"], args, rank, world, local_rank, torch, dist, use_dist, batches)
@@ -857,7 +862,7 @@ def main():
     else:
         results = []
         for nm in names:
-            r = run_gpu_workload(nm, inputs.pop(nm), args, rank, world, local_rank, torch, dist, use_dist, voc_path, batches)
+            r = run_gpu_workload(nm, inputs.pop(nm), args, rank, world, local_rank, torch, dist, use_dist, voc_arrays, batches)
             results.append(r)
         if rank == 0:
             head = results[0]
@@ -878,11 +883,6 @@ def main():
             if len(results) > 1:
                 out["secondary"] = results[1:]
             print(json.dumps(out), flush=True)
-    if voc_path:
-        try:
-            os.unlink(voc_path)
-        except OSError:
-            pass
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
