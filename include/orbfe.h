@@ -384,6 +384,17 @@ int orbfe_bow_match_consecutive_batch_device_async(orbfe_vocabulary *v, orbfe_ex
                                                    int check_orientation, int32_t *d_match,
                                                    int32_t *d_nmatches);
 
+/* The same over the LEFT frames of an (L0, R0, L1, R1, ...) stereo batch of extractor e -- a stereo Frame's
+ * ComputeBoW / SearchByBoW use its left keypoints (mvKeys, mDescriptors; src/Frame.cc:61-117): pair t-1 against
+ * pair t for t = 1..n_pairs-1; d_match[(t-1)*capacity + j], d_nmatches[t-1] as above.  d_keypoints / d_descriptors /
+ * d_n are the extractor batch's arrays (2*n_pairs frames). */
+int orbfe_bow_match_consecutive_stereo_batch_device_async(orbfe_vocabulary *v, orbfe_extractor *e, int n_pairs,
+                                                          const orbfe_keypoint *d_keypoints,
+                                                          const uint8_t *d_descriptors, const int32_t *d_n,
+                                                          int capacity, int levelsup, float nnratio,
+                                                          int check_orientation, int32_t *d_match,
+                                                          int32_t *d_nmatches);
+
 /* ------------------------------------------------------------------------- */
 /* Next to the path                                */
 /* ------------------------------------------------------------------------- */
@@ -528,6 +539,19 @@ int orbfe_remap(orbfe_rectifier *r, const uint8_t *src, int src_width, int src_h
 int orbfe_remap_batch_device(orbfe_rectifier *r, const uint8_t *d_src, int n_frames, int src_width,
                              int src_height, int src_stride, size_t src_frame_stride, uint8_t *d_dst,
                              int dst_stride, size_t dst_frame_stride);
+
+/* The stereo front end of Examples/Stereo/stereo_euroc.cc for a device-resident batch of RAW pairs: cv::remap of the
+ * left and of the right image (:136-137) and the two ExtractORB calls of the stereo Frame constructor
+ * (src/Frame.cc:78-81), enqueued sub-batch by sub-batch on extractor e's streams (returns at once, like
+ * orbfe_extract_batch_device_async; no host wait between rectification and extraction).  Raw frame p of either eye at
+ * d_raw_*[p*src_frame_stride ..]; rectified frames are written tightly packed and interleaved to d_rectified
+ * (2*n_pairs frames of width x height of the rectifiers: L0, R0, L1, R1, ...), which is also where the extractor's
+ * level 0 -- and orbfe_stereo_match_batch_device's SAD windows -- are read from, so it must stay valid until the
+ * matchers of this batch are done.  Outputs as orbfe_extract_batch_device for 2*n_pairs frames. */
+int orbfe_extract_stereo_rectified_batch_device_async(
+    orbfe_extractor *e, orbfe_rectifier *rect_left, orbfe_rectifier *rect_right, const uint8_t *d_raw_left,
+    const uint8_t *d_raw_right, int n_pairs, int src_width, int src_height, int src_stride, size_t src_frame_stride,
+    uint8_t *d_rectified, orbfe_keypoint *d_keypoints, uint8_t *d_descriptors, int capacity, int32_t *d_n_out);
 
 /* cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK) as Frame::UndistortKeyPoints and
  * Frame::ComputeImageBounds call it (src/Frame.cc:443-475, 481-510).  K4 = fx, fy, cx, cy (the

@@ -56,11 +56,11 @@ EXPORTS = [
     "orbfe_hamming_matrix", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",
     "orbfe_search_for_triangulation", "orbfe_compute_stereo_matches", "orbfe_stereo_match_batch_device", "orbfe_vocabulary_load_text", "orbfe_vocabulary_create", "orbfe_vocabulary_destroy",
     "orbfe_vocabulary_info", "orbfe_vocabulary_transform", "orbfe_vocabulary_featvec_batch_device",
-    "orbfe_bow_match_consecutive_batch_device", "orbfe_bow_match_consecutive_batch_device_async", "orbfe_cvt_gray", "orbfe_cvt_gray_batch_device",
+    "orbfe_bow_match_consecutive_batch_device", "orbfe_bow_match_consecutive_batch_device_async", "orbfe_bow_match_consecutive_stereo_batch_device_async", "orbfe_cvt_gray", "orbfe_cvt_gray_batch_device",
     "orbfe_distinctive_descriptors", "orbfe_features_in_area", "orbfe_search_by_projection",
     "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_keyframe",
     "orbfe_search_by_projection_sim3", "orbfe_search_for_initialization", "orbfe_fuse_search", "orbfe_search_by_sim3",
-    "orbfe_rectifier_create", "orbfe_rectifier_destroy", "orbfe_remap", "orbfe_remap_batch_device",
+    "orbfe_rectifier_create", "orbfe_rectifier_destroy", "orbfe_remap", "orbfe_remap_batch_device", "orbfe_extract_stereo_rectified_batch_device_async",
     "orbfe_undistort_points", "orbfe_undistort_keypoints_batch_device", "orbfe_compute_image_bounds",
     "orbfe_stereo_from_rgbd",
 ]
@@ -173,6 +173,8 @@ def load():
     L.orbfe_rectifier_destroy.restype = None
     L.orbfe_remap.argtypes = [vp, vp, ci, ci, ci, vp, ci]
     L.orbfe_remap_batch_device.argtypes = [vp, vp, ci, ci, ci, ci, cs, vp, ci, cs]
+    L.orbfe_extract_stereo_rectified_batch_device_async.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, cs, vp, vp, vp, ci, vp]
+    L.orbfe_bow_match_consecutive_stereo_batch_device_async.argtypes = [vp, vp, ci, vp, vp, vp, ci, ci, cf, ci, vp, vp]
     L.orbfe_undistort_points.argtypes = [ci, vp, ci, vp, vp, ci, vp]
     L.orbfe_undistort_keypoints_batch_device.argtypes = [ci, vp, vp, ci, ci, vp, vp, ci, vp]
     L.orbfe_compute_image_bounds.argtypes = [ci, ci, ci, vp, vp, ci, vp]

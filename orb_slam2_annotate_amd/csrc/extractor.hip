@@ -596,8 +596,17 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
 // One call = up to nStreams sub-batches of consecutive frames, each on its own HIP stream with
 // its own slice of the workspace: the VALU-bound kernels (FAST, blur) of one sub-batch overlap the
 // gather/latency-bound ones (orientation+descriptor, octree, resize) of the other.
+// `pre`: work enqueued on a sub-batch's stream in FRONT of its kernels (frames [f0, f0 + n) of the batch), e.g. the
+// rectification that produces those frames -- stream order is the only synchronisation it needs, and what the previous
+// call left on that stream (its kernels and matchers, which read the same frame slots) is behind it by construction.
+struct PreChunk {
+  int (*fn)(void* ctx, hipStream_t s, int f0, int n) = nullptr;
+  void* ctx = nullptr;
+};
+
 int run_pipeline(orbfe_extractor* e, LevelView level0, int nFrames, orbfe_keypoint* d_kp,
-                 uint8_t* d_desc, int capacity, int32_t* d_nOut, const hipEvent_t* waitFor = nullptr, int nWait = 0) {
+                 uint8_t* d_desc, int capacity, int32_t* d_nOut, const hipEvent_t* waitFor = nullptr, int nWait = 0,
+                 const PreChunk* pre = nullptr) {
   int S = e->hostOctree ? 1 : e->nStreams;
   if (S > nFrames) S = nFrames;
   if (S < 1) S = 1;
@@ -628,6 +637,10 @@ int run_pipeline(orbfe_extractor* e, LevelView level0, int nFrames, orbfe_keypoi
       if (n <= 0) break;
       // slice i of the workspace is free once the previous call's tail lane has finished with it
       if (e->tailPending[i]) HIPCHK(hipStreamWaitEvent(sP, e->evTail[i], 0));
+      if (pre && pre->fn) {  // (slice i's readers of the previous call: behind evTail[i] / evConsumerDone, waited for above)
+        int rcp = pre->fn(pre->ctx, sP, f0, n);
+        if (rcp) return rcp;
+      }
       int rc = run_chunk(e, sP, i, level0, f0, n, d_kp, d_desc, capacity, d_nOut, i == 0 ? &e->lastPyr : nullptr,
                          i == 0 ? &e->lastBlur : nullptr, sV, sT);
       if (rc) return rc;
@@ -646,6 +659,10 @@ int run_pipeline(orbfe_extractor* e, LevelView level0, int nFrames, orbfe_keypoi
     hipStream_t s = i == 0 ? e->stream : e->extra[i - 1];
     if (i > 0 && e->consumerPending) HIPCHK(hipStreamWaitEvent(s, e->evConsumerDone, 0));
     for (int k = 0; k < nWait; k++) HIPCHK(hipStreamWaitEvent(s, waitFor[k], 0));  // e.g. the H2D copy of this chunk
+    if (pre && pre->fn) {
+      int rcp = pre->fn(pre->ctx, s, f0, n);
+      if (rcp) return rcp;
+    }
     int rc = run_chunk(e, s, i, level0, f0, n, d_kp, d_desc, capacity, d_nOut, i == 0 ? &e->lastPyr : nullptr,
                        i == 0 ? &e->lastBlur : nullptr);
     if (rc) return rc;
@@ -845,6 +862,68 @@ extern "C" int orbfe_extract_batch_device_async(orbfe_extractor* e, const uint8_
   next_event_slot(e);
   LevelView l0{d_images, frame_stride, stride, width, height};
   return run_pipeline(e, l0, n_frames, d_keypoints, d_descriptors, capacity, d_n_out);
+}
+
+// Examples/Stereo/stereo_euroc.cc:136-137 (cv::remap of the left and of the right image) in front of the two ExtractORB
+// calls of the stereo Frame constructor (src/Frame.cc:78-81), for a device-resident batch of raw pairs: sub-batch by
+// sub-batch, on the sub-batch's own stream -- rectified frames are written interleaved (L0, R0, L1, R1, ...), the layout
+// orbfe_stereo_match_batch_device reads.
+extern "C" int orbfe_remap_launch_(orbfe_rectifier* r, const uint8_t* d_src, int n_frames, int sw, int sh, int sstride,
+                                   size_t sFrame, uint8_t* d_dst, int dstride, size_t dFrame, hipStream_t stream, int* w, int* h,
+                                   int* device);
+namespace {
+struct RectifyCtx {
+  orbfe_rectifier *rl, *rr;
+  const uint8_t *rawL, *rawR;
+  int sw, sh, sstride;
+  size_t sFrame;
+  uint8_t* rect;
+  int w, h;
+};
+int rectify_chunk(void* c, hipStream_t s, int f0, int n) {
+  const RectifyCtx* x = static_cast<const RectifyCtx*>(c);
+  if ((f0 & 1) || (n & 1)) return fail(ORBFE_ERR_INVALID, "extract_stereo_rectified: a sub-batch splits a stereo pair");
+  const size_t fr = (size_t)x->w * x->h;
+  const int p0 = f0 / 2, np = n / 2;
+  int rc = orbfe_remap_launch_(x->rl, x->rawL + (size_t)p0 * x->sFrame, np, x->sw, x->sh, x->sstride, x->sFrame,
+                               x->rect + (size_t)f0 * fr, x->w, 2 * fr, s, nullptr, nullptr, nullptr);
+  if (rc) return rc;
+  return orbfe_remap_launch_(x->rr, x->rawR + (size_t)p0 * x->sFrame, np, x->sw, x->sh, x->sstride, x->sFrame,
+                             x->rect + (size_t)(f0 + 1) * fr, x->w, 2 * fr, s, nullptr, nullptr, nullptr);
+}
+}  // namespace
+
+extern "C" int orbfe_extract_stereo_rectified_batch_device_async(
+    orbfe_extractor* e, orbfe_rectifier* rect_left, orbfe_rectifier* rect_right, const uint8_t* d_raw_left,
+    const uint8_t* d_raw_right, int n_pairs, int src_width, int src_height, int src_stride, size_t src_frame_stride,
+    uint8_t* d_rectified, orbfe_keypoint* d_keypoints, uint8_t* d_descriptors, int capacity, int32_t* d_n_out) {
+  if (!e || !rect_left || !rect_right || !d_keypoints || !d_descriptors || !d_n_out || capacity <= 0 || n_pairs < 0)
+    return fail(ORBFE_ERR_INVALID, "extract_stereo_rectified: bad argument");
+  if (n_pairs == 0) return ORBFE_OK;
+  if (!d_raw_left || !d_raw_right || !d_rectified || src_width <= 0 || src_height <= 0 || src_stride < src_width ||
+      src_frame_stride < (size_t)src_stride * (src_height - 1) + src_width)
+    return fail(ORBFE_ERR_INVALID, "extract_stereo_rectified: bad image");
+  int wl, hl, dl, wr, hr, dr, rc;
+  if ((rc = orbfe_remap_launch_(rect_left, nullptr, 0, 0, 0, 0, 0, nullptr, 0, 0, nullptr, &wl, &hl, &dl))) return rc;
+  if ((rc = orbfe_remap_launch_(rect_right, nullptr, 0, 0, 0, 0, 0, nullptr, 0, 0, nullptr, &wr, &hr, &dr))) return rc;
+  if (wl != wr || hl != hr || dl != e->device || dr != e->device)
+    return fail(ORBFE_ERR_INVALID, "extract_stereo_rectified: the two rectifiers differ in size or device from each other / the extractor");
+  HIPCHK(hipSetDevice(e->device));
+  const int n_frames = 2 * n_pairs;
+  if (e->geom.W != wl || e->geom.H != hl || n_frames > e->capFrames) {
+    int rcs = sync_all(e);  // the workspace is about to be re-allocated
+    if (rcs) return rcs;
+  }
+  if ((rc = ensure_geometry(e, wl, hl))) return rc;
+  if ((rc = ensure_workspace(e, n_frames))) return rc;
+  next_event_slot(e);
+  RectifyCtx ctx{rect_left, rect_right, d_raw_left, d_raw_right, src_width, src_height, src_stride, src_frame_stride,
+                 d_rectified, wl, hl};
+  PreChunk pre;
+  pre.fn = rectify_chunk;
+  pre.ctx = &ctx;
+  LevelView l0{d_rectified, (size_t)wl * hl, wl, wl, hl};
+  return run_pipeline(e, l0, n_frames, d_keypoints, d_descriptors, capacity, d_n_out, nullptr, 0, &pre);
 }
 
 extern "C" int orbfe_extractor_synchronize(orbfe_extractor* e) {

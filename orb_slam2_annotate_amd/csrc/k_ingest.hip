@@ -247,6 +247,18 @@ int remap_launch(orbfe_rectifier* r, const uint8_t* d_src, int n_frames, int sw,
 
 }  // namespace
 
+// internal (extractor.hip): the rectification of a sub-batch enqueued on that sub-batch's own stream
+extern "C" int orbfe_remap_launch_(orbfe_rectifier* r, const uint8_t* d_src, int n_frames, int sw, int sh, int sstride,
+                                   size_t sFrame, uint8_t* d_dst, int dstride, size_t dFrame, hipStream_t stream, int* w, int* h,
+                                   int* device) {
+  if (!r) return ifail(ORBFE_ERR_INVALID, "NULL rectifier");
+  if (w) *w = r->width;
+  if (h) *h = r->height;
+  if (device) *device = r->device;
+  if (!d_src || n_frames <= 0) return ORBFE_OK;  // query only
+  return remap_launch(r, d_src, n_frames, sw, sh, sstride, sFrame, d_dst, dstride, dFrame, stream);
+}
+
 extern "C" int orbfe_rectifier_create(int device, const float* map_x, const float* map_y, int width, int height,
                                   int map_stride, orbfe_rectifier** out) {
   if (!map_x || !map_y || !out || width <= 0 || height <= 0 || map_stride < width || width > 32767 || height > 32767)

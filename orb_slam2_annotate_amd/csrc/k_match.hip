@@ -208,12 +208,13 @@ __global__ __launch_bounds__(64) void k_search_by_bow_batch(BowBatch b) {
   }
   if (lo >= n2 || nodes2[lo] != id) return;
   BowArgs a = {};
-  a.desc1 = b.desc + (size_t)p * c * 32;
-  a.desc2 = b.desc + (size_t)(p + 1) * c * 32;
+  const size_t st = b.frameStep > 1 ? (size_t)b.frameStep : 1;
+  a.desc1 = b.desc + (size_t)p * st * c * 32;
+  a.desc2 = b.desc + (size_t)(p + 1) * st * c * 32;
   a.indices1 = b.fvIndices + (size_t)p * c;
   a.indices2 = b.fvIndices + (size_t)(p + 1) * c;
-  a.angle1 = b.kp + (size_t)p * c * 7 + 3;        // cv::KeyPoint::angle
-  a.angle2 = b.kp + (size_t)(p + 1) * c * 7 + 3;
+  a.angle1 = b.kp + (size_t)p * st * c * 7 + 3;        // cv::KeyPoint::angle
+  a.angle2 = b.kp + (size_t)(p + 1) * st * c * 7 + 3;
   a.angleStride = 7;
   a.nnratio = b.nnratio;
   a.strictLow = 0;

@@ -75,6 +75,7 @@ struct VocabDevice {
 // Batched FeatureVector construction: frame f uses desc[f*capacity ..], n[f] descriptors
 struct FeatVecBatch {
   const uint8_t* desc; const int32_t* n; int capacity;
+  int frameStep;             // frame f reads slot f*frameStep of desc / n (2: the left frames of an L,R-interleaved batch); 0 = 1
   int sortN;                 // power of two >= capacity
   uint32_t* word; double* weight;          // optional per-feature outputs [nFrames*capacity]
   unsigned long long* keys;  // [nFrames*capacity] scratch: (node << 32 | feature) of the used features, ~0 otherwise
@@ -87,6 +88,7 @@ void launch_vocab_featvec(hipStream_t s, const VocabDevice& v, const FeatVecBatc
 
 struct BowBatch {  // consecutive-frame SearchByBoW over a device-resident batch
   const float* kp; const uint8_t* desc; int capacity;
+  int frameStep;             // frame p reads slot p*frameStep of kp / desc (as FeatVecBatch); 0 = 1
   const uint32_t* fvNodes; const int32_t* fvOffsets; const uint32_t* fvIndices; const int32_t* fvCount;
   float nnratio;
   int32_t* match; int8_t* bin;  // [nPairs*capacity], match pre-set to -1

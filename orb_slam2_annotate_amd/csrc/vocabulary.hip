@@ -92,15 +92,16 @@ __device__ __forceinline__ uint32_t hdist(const uint4 fa, const uint4 fb, const 
 template <int U>
 __global__ __launch_bounds__(256) void k_vocab_transform16(VocabDevice v, const uint8_t* __restrict__ desc,
                                                            const int32_t* __restrict__ nPerFrame, int nFixed, int capacity,
-                                                           int nidLevel, uint32_t* __restrict__ word,
+                                                           int frameStep, int nidLevel, uint32_t* __restrict__ word,
                                                            double* __restrict__ weight, uint32_t* __restrict__ node,
                                                            unsigned long long* __restrict__ keys) {
   const int tid = threadIdx.x, c = tid & 15, row = tid >> 4, f = blockIdx.y;
-  int n = nPerFrame ? nPerFrame[f] : nFixed;
+  const int fi = f * frameStep;  // input slot (descriptors, count); outputs are dense per frame
+  int n = nPerFrame ? nPerFrame[fi] : nFixed;
   if (n > capacity) n = capacity;
   const int base = (blockIdx.x * 16 + row) * U;
   if (blockIdx.x * 16 * U >= n && !keys) return;  // whole workgroup past the frame's count
-  const size_t fo = (size_t)f * capacity;
+  const size_t fo = (size_t)f * capacity, fin = (size_t)fi * capacity;
   const int laneBase = (tid & 63) & ~15;
   uint4 fa[U], fb[U];
   uint32_t first[U], cnt[U], nid[U], leafWord[U], leafPos[U], leafPositive[U];
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void k_vocab_transform16(VocabDevice v, const 
   for (int u = 0; u < U; u++) {
     const int i = base + u;
     live[u] = i < n && v.rootChildren > 0;  // an empty vocabulary leaves (0, 0, 0), :1134
-    const uint4* q = reinterpret_cast<const uint4*>(desc + (fo + (size_t)(live[u] ? i : 0)) * 32);
+    const uint4* q = reinterpret_cast<const uint4*>(desc + (fin + (size_t)(live[u] ? i : 0)) * 32);
     fa[u] = live[u] ? q[0] : make_uint4(0, 0, 0, 0);
     fb[u] = live[u] ? q[1] : make_uint4(0, 0, 0, 0);
     first[u] = 1; cnt[u] = live[u] ? v.rootChildren : 0;
@@ -239,17 +240,17 @@ __global__ __launch_bounds__(256) void k_vocab_featvec(FeatVecBatch b) {
 namespace orbfe {
 constexpr int kVocabU = 2;  // descriptors per 16-lane row
 void launch_vocab_transform(hipStream_t s, const VocabDevice& v, const uint8_t* desc, const int32_t* nPerFrame, int nFixed,
-                            int capacity, int nFrames, int nidLevel, uint32_t* word, double* weight, uint32_t* node,
+                            int capacity, int frameStep, int nFrames, int nidLevel, uint32_t* word, double* weight, uint32_t* node,
                             unsigned long long* keys) {
   if (nFrames <= 0 || capacity <= 0) return;
   const int per = 16 * kVocabU, span = (nPerFrame || keys) ? capacity : nFixed;
   if (span <= 0) return;
   hipLaunchKernelGGL(k_vocab_transform16<kVocabU>, dim3((span + per - 1) / per, nFrames), dim3(256), 0, s, v, desc, nPerFrame,
-                     nFixed, capacity, nidLevel, word, weight, node, keys);
+                     nFixed, capacity, frameStep > 1 ? frameStep : 1, nidLevel, word, weight, node, keys);
 }
 void launch_vocab_featvec(hipStream_t s, const VocabDevice& v, const FeatVecBatch& b, int nFrames, int nidLevel) {
   if (nFrames <= 0) return;
-  launch_vocab_transform(s, v, b.desc, b.n, 0, b.capacity, nFrames, nidLevel, b.word, b.weight, nullptr, b.keys);
+  launch_vocab_transform(s, v, b.desc, b.n, 0, b.capacity, b.frameStep, nFrames, nidLevel, b.word, b.weight, nullptr, b.keys);
   hipLaunchKernelGGL(k_vocab_featvec, dim3(nFrames), dim3(256), (size_t)b.sortN * 8, s, b);
 }
 }  // namespace orbfe
@@ -460,7 +461,7 @@ extern "C" int orbfe_vocabulary_transform(orbfe_vocabulary* v, const uint8_t* de
     v->scratchCap = cap;
   }
   VHIP(hipMemcpyAsync(v->d_desc, descriptors, (size_t)n * 32, hipMemcpyHostToDevice, v->stream));
-  launch_vocab_transform(v->stream, v->d, v->d_desc, nullptr, n, n, 1, v->L - levelsup, v->d_word, v->d_weight, v->d_node,
+  launch_vocab_transform(v->stream, v->d, v->d_desc, nullptr, n, n, 1, 1, v->L - levelsup, v->d_word, v->d_weight, v->d_node,
                          nullptr);
   VHIP(hipGetLastError());
   VHIP(hipMemcpyAsync(word_id, v->d_word, (size_t)n * 4, hipMemcpyDeviceToHost, v->stream));
@@ -542,10 +543,11 @@ extern "C" void orbfe_extractor_stage_mark_(orbfe_extractor* e, int stage, int s
 
 // e != NULL: enqueue on the extractor's stream, ordered behind every sub-batch of its last extract call, and
 // return without waiting (orbfe_extractor_synchronize() to wait); e == NULL: the vocabulary's own stream, waits.
+// step: frame t of the call is frame slot t*step of the arrays (2 = the left frames of an L,R-interleaved stereo batch)
 static int bow_match_consecutive(orbfe_vocabulary* v, orbfe_extractor* e, int n_frames,
                                  const orbfe_keypoint* d_keypoints, const uint8_t* d_descriptors,
                                  const int32_t* d_n, int capacity, int levelsup, float nnratio,
-                                 int check_orientation, int32_t* d_match, int32_t* d_nmatches) {
+                                 int check_orientation, int32_t* d_match, int32_t* d_nmatches, int step = 1) {
   if (!v || n_frames < 0 || capacity <= 0 || capacity > 65535 || !d_keypoints || !d_descriptors || !d_n || !d_match ||
       !d_nmatches)
     return vfail(ORBFE_ERR_INVALID, "bow_match_consecutive_batch_device: bad argument");
@@ -563,11 +565,11 @@ static int bow_match_consecutive(orbfe_vocabulary* v, orbfe_extractor* e, int n_
   rc = ensure_bow_workspace(v, n_frames, capacity);
   if (rc) return rc;
   FeatVecBatch fb = {};
-  fb.desc = d_descriptors; fb.n = d_n; fb.capacity = capacity; fb.sortN = sortN;
+  fb.desc = d_descriptors; fb.n = d_n; fb.capacity = capacity; fb.sortN = sortN; fb.frameStep = step;
   fb.fvNodes = v->w_nodes; fb.fvOffsets = v->w_offsets; fb.fvIndices = v->w_indices; fb.fvCount = v->w_count;
   fb.keys = v->w_keys;
   BowBatch bb = {};
-  bb.kp = reinterpret_cast<const float*>(d_keypoints); bb.desc = d_descriptors; bb.capacity = capacity;
+  bb.kp = reinterpret_cast<const float*>(d_keypoints); bb.desc = d_descriptors; bb.capacity = capacity; bb.frameStep = step;
   bb.fvNodes = v->w_nodes; bb.fvOffsets = v->w_offsets; bb.fvIndices = v->w_indices; bb.fvCount = v->w_count;
   bb.nnratio = nnratio; bb.match = d_match; bb.bin = v->w_bin;
   const size_t c = (size_t)capacity;
@@ -576,7 +578,7 @@ static int bow_match_consecutive(orbfe_vocabulary* v, orbfe_extractor* e, int n_
   for (int l = 0; l < v->L - levelsup && maxNodes < capacity; l++) maxNodes = maxNodes > capacity / (v->k > 1 ? v->k : 1) ? capacity : maxNodes * v->k;
   auto featvec_range = [&](hipStream_t st, int f0, int n) {
     FeatVecBatch r = fb;
-    r.desc += (size_t)f0 * c * 32; r.n += f0;
+    r.desc += (size_t)f0 * step * c * 32; r.n += (size_t)f0 * step;
     r.fvNodes += (size_t)f0 * c; r.fvOffsets += (size_t)f0 * (c + 1); r.fvIndices += (size_t)f0 * c; r.fvCount += f0;
     r.keys += (size_t)f0 * c;
     launch_vocab_featvec(st, v->d, r, n, v->L - levelsup);
@@ -586,7 +588,7 @@ static int bow_match_consecutive(orbfe_vocabulary* v, orbfe_extractor* e, int n_
     VHIP(hipMemsetAsync(d_match + (size_t)p0 * c, 0xff, (size_t)np * c * 4, st));
     VHIP(hipMemsetAsync(v->w_bin + (size_t)p0 * c, 0, (size_t)np * c, st));
     BowBatch r = bb;
-    r.kp += (size_t)p0 * c * 7; r.desc += (size_t)p0 * c * 32;
+    r.kp += (size_t)p0 * step * c * 7; r.desc += (size_t)p0 * step * c * 32;
     r.fvNodes += (size_t)p0 * c; r.fvOffsets += (size_t)p0 * (c + 1); r.fvIndices += (size_t)p0 * c; r.fvCount += p0;
     r.match += (size_t)p0 * c; r.bin += (size_t)p0 * c;
     launch_search_by_bow_batch(st, r, np, check_orientation, d_nmatches + p0, maxNodes);
@@ -597,7 +599,8 @@ static int bow_match_consecutive(orbfe_vocabulary* v, orbfe_extractor* e, int n_
     hipStream_t streams[32];  // orbfe_extractor::kMaxStreams
     hipEvent_t chunkDone[32];
     if ((rc = orbfe_extractor_split_(e, &S, &per, &frames, &lanes, streams, chunkDone))) return rc;
-    if (!lanes && S > 1 && frames == n_frames && per >= 2) {
+    if (!lanes && S > 1 && frames == n_frames * step && per % step == 0 && per / step >= 2) {
+      per /= step;  // frames of THIS call per sub-batch
       // Per sub-batch, on the sub-batch's own stream right behind its extraction (no join of the streams): the
       // FeatureVectors of its frames, then its consecutive pairs.  The pair that straddles two sub-batches
       // (last frame of i-1, first frame of i) runs on stream i behind an event of stream i-1's FeatureVectors, and
@@ -675,6 +678,19 @@ extern "C" int orbfe_bow_match_consecutive_batch_device_async(orbfe_vocabulary* 
   if (!e) return vfail(ORBFE_ERR_INVALID, "bow_match_consecutive_batch_device_async: NULL extractor");
   return bow_match_consecutive(v, e, n_frames, d_keypoints, d_descriptors, d_n, capacity, levelsup, nnratio,
                                check_orientation, d_match, d_nmatches);
+}
+
+// The same over the LEFT frames of an (L0, R0, L1, R1, ...) stereo batch: Frame::ComputeBoW and SearchByBoW work on a
+// stereo Frame's left keypoints (mvKeys / mDescriptors, src/Frame.cc:61-117); pair t-1 against pair t for t = 1..n_pairs-1.
+extern "C" int orbfe_bow_match_consecutive_stereo_batch_device_async(orbfe_vocabulary* v, orbfe_extractor* e, int n_pairs,
+                                                                     const orbfe_keypoint* d_keypoints,
+                                                                     const uint8_t* d_descriptors, const int32_t* d_n,
+                                                                     int capacity, int levelsup, float nnratio,
+                                                                     int check_orientation, int32_t* d_match,
+                                                                     int32_t* d_nmatches) {
+  if (!e) return vfail(ORBFE_ERR_INVALID, "bow_match_consecutive_stereo_batch_device_async: NULL extractor");
+  return bow_match_consecutive(v, e, n_pairs, d_keypoints, d_descriptors, d_n, capacity, levelsup, nnratio,
+                               check_orientation, d_match, d_nmatches, 2);
 }
 
 // internal: device view for the batched BoW path (extractor.hip)

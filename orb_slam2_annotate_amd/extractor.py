@@ -166,6 +166,19 @@ class ORBextractor:
                  C.c_void_p(d_keypoints), C.c_void_p(d_descriptors), capacity, C.c_void_p(d_n_out)))
         self._last_shape = (n_frames, height, width)
 
+    def extract_stereo_rectified_batch_device(self, rect_left, rect_right, d_raw_left: int, d_raw_right: int, n_pairs: int,
+                                              src_width: int, src_height: int, src_stride: int, src_frame_stride: int,
+                                              d_rectified: int, d_keypoints: int, d_descriptors: int, capacity: int,
+                                              d_n_out: int):
+        """cv::remap of both eyes (Examples/Stereo/stereo_euroc.cc:136-137) + the two ExtractORB calls of the stereo
+        Frame (src/Frame.cc:78-81) for a device-resident batch of raw pairs; rectified frames land interleaved
+        (L0, R0, L1, R1, ...) in d_rectified.  Enqueues only: synchronize() before reading results."""
+        check(self._L.orbfe_extract_stereo_rectified_batch_device_async(
+            self._h, rect_left._h, rect_right._h, C.c_void_p(d_raw_left), C.c_void_p(d_raw_right), n_pairs, src_width,
+            src_height, src_stride, src_frame_stride, C.c_void_p(d_rectified), C.c_void_p(d_keypoints),
+            C.c_void_p(d_descriptors), capacity, C.c_void_p(d_n_out)))
+        self._last_shape = (2 * n_pairs, rect_left.height, rect_left.width)
+
     def stereo_match_batch_device(self, n_pairs: int, d_keypoints: int, d_descriptors: int, d_n: int, capacity: int,
                                   mbf: float, mb: float, d_uRight: int, d_depth: int, d_n_stereo: int):
         """Frame::ComputeStereoMatches for pairs (2p, 2p+1) of the last device batch; device addresses."""

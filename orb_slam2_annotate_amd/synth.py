@@ -11,7 +11,8 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["render_frame", "render_stereo", "render_stereo_textured", "STEREO_SCENES", "render_sequence", "adversarial"]
+__all__ = ["render_frame", "render_stereo", "render_stereo_textured", "STEREO_SCENES", "render_stereo_raw", "rectify_maps", "EUROC_CAM0", "EUROC_CAM1",
+           "render_sequence", "adversarial"]
 
 
 def _background(rng: np.random.Generator, w: int, h: int) -> np.ndarray:
@@ -180,6 +181,66 @@ def render_stereo_textured(seed: int, w: int = 1241, h: int = 376, n_shapes: int
 
 
 STEREO_SCENES = {"shapes": render_stereo, "textured": render_stereo_textured}
+
+# shape of the EuRoC cam0 / cam1 calibrations (Examples/Stereo/EuRoC.yaml: LEFT.K / LEFT.D, RIGHT.K / RIGHT.D)
+EUROC_CAM0 = dict(fx=458.654, fy=457.296, cx=367.215, cy=248.375, k1=-0.28340811, k2=0.07395907, p1=0.00019359,
+                  p2=1.76187114e-05, rot_deg=0.4)
+EUROC_CAM1 = dict(fx=457.587, fy=456.134, cx=379.999, cy=255.238, k1=-0.28368365, k2=0.07451284, p1=-0.00010473,
+                  p2=-3.55590700e-05, rot_deg=-0.3)
+
+
+def _rectify_forward(x, y, fx, fy, cx, cy, k1, k2, p1, p2, k3=0.0, rot_deg=0.4, new_f_scale=1.0):
+    """rectified pixel (x, y) -> raw pixel (u, v): a radial-tangential camera behind a small rectifying rotation."""
+    a = np.deg2rad(rot_deg)
+    R = np.array([[np.cos(a), -np.sin(a), 0.002], [np.sin(a), np.cos(a), -0.003], [-0.002, 0.003, 1.0]])
+    nfx, nfy = fx * new_f_scale, fy * new_f_scale
+    pts = np.stack([(x - cx) / nfx, (y - cy) / nfy, np.ones_like(x)], axis=-1) @ np.linalg.inv(R).T
+    xn, yn = pts[..., 0] / pts[..., 2], pts[..., 1] / pts[..., 2]
+    r2 = xn * xn + yn * yn
+    kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+    u = fx * (xn * kr + 2 * p1 * xn * yn + p2 * (r2 + 2 * xn * xn)) + cx
+    v = fy * (yn * kr + p1 * (r2 + 2 * yn * yn) + 2 * p2 * xn * yn) + cy
+    return u, v
+
+
+def rectify_maps(w, h, fx, fy, cx, cy, k1, k2, p1, p2, k3=0.0, rot_deg=0.4, new_f_scale=1.0):
+    """Test / bench data generator (NOT a restatement of cv::initUndistortRectifyMap, which is outside the path): the
+    two CV_32F maps of a radial-tangential camera with a small rectifying rotation -- same model and output type as
+    the EuRoC setup of Examples/Stereo/stereo_euroc.cc:97-98."""
+    x, y = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    u, v = _rectify_forward(x, y, fx, fy, cx, cy, k1, k2, p1, p2, k3, rot_deg, new_f_scale)
+    return u.astype(np.float32), v.astype(np.float32)
+
+
+def _unrectify(img: np.ndarray, cam: dict) -> np.ndarray:
+    """The raw (distorted) image whose rectification with rectify_maps(**cam) gives `img` back (up to the two bilinear
+    resamplings): raw(u, v) = img(M^-1(u, v)), M^-1 by fixed-point iteration on the forward model; float result."""
+    h, w = img.shape
+    u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    x, y = u.copy(), v.copy()
+    for _ in range(12):
+        fu, fv = _rectify_forward(x, y, **cam)
+        x += u - fu
+        y += v - fv
+    x0 = np.floor(x).astype(np.int64)
+    y0 = np.floor(y).astype(np.int64)
+    ax, ay = x - x0, y - y0
+    inside = (x0 >= 0) & (x0 < w - 1) & (y0 >= 0) & (y0 < h - 1)
+    x0 = np.clip(x0, 0, w - 2)
+    y0 = np.clip(y0, 0, h - 2)
+    f = img.astype(np.float64)
+    out = (f[y0, x0] * (1 - ax) + f[y0, x0 + 1] * ax) * (1 - ay) + (f[y0 + 1, x0] * (1 - ax) + f[y0 + 1, x0 + 1] * ax) * ay
+    return np.where(inside, out, 0.0)
+
+
+def render_stereo_raw(seed: int, w: int = 752, h: int = 480, max_disp: float = 40.0, sigma: float = 3.0,
+                      cam_left: dict = EUROC_CAM0, cam_right: dict = EUROC_CAM1):
+    """A RAW (unrectified) EuRoC-like stereo pair: the textured scene of render_stereo_textured seen through two
+    radial-tangential cameras, sensor noise added on the raw images.  cv::remap with rectify_maps(w, h, **cam_left) /
+    (**cam_right) -- Examples/Stereo/stereo_euroc.cc:136-137 -- brings the pair back to a row-aligned, matchable one."""
+    left, right = render_stereo_textured(seed, w, h, max_disp=max_disp, sigma=0.0)
+    rng = np.random.default_rng([0xE0C0, int(seed)])
+    return (_finish(_unrectify(left, cam_left), rng, sigma), _finish(_unrectify(right, cam_right), rng, sigma))
 
 
 def render_sequence(seed: int, n_frames: int, w: int = 640, h: int = 480,

@@ -94,8 +94,14 @@ class ORBVocabulary:
 
     def bow_match_consecutive_batch_device(self, n_frames, d_kp, d_desc, d_n, capacity, d_match, d_nmatches,
                                            nnratio: float = 0.7, check_orientation: bool = True, levelsup: int = 4,
-                                           extractor=None):
-        """extractor given: enqueued on that extractor's stream behind its last extract call, returns at once."""
+                                           extractor=None, stereo: bool = False):
+        """extractor given: enqueued on that extractor's stream behind its last extract call, returns at once.
+        stereo: n_frames counts PAIRS of an (L0, R0, L1, R1, ...) batch and the left frames are matched (needs extractor)."""
+        if stereo:
+            check(self._L.orbfe_bow_match_consecutive_stereo_batch_device_async(
+                self._h, extractor._h, n_frames, C.c_void_p(d_kp), C.c_void_p(d_desc), C.c_void_p(d_n), capacity,
+                levelsup, float(nnratio), int(bool(check_orientation)), C.c_void_p(d_match), C.c_void_p(d_nmatches)))
+            return
         if extractor is not None:
             check(self._L.orbfe_bow_match_consecutive_batch_device_async(
                 self._h, extractor._h, n_frames, C.c_void_p(d_kp), C.c_void_p(d_desc), C.c_void_p(d_n), capacity,

@@ -476,20 +476,12 @@ def remap_linear(src, map_x, map_y):
     return out
 
 
-def rectify_maps(w, h, fx, fy, cx, cy, k1, k2, p1, p2, k3=0.0, rot_deg=0.4, new_f_scale=1.0):
-    """Test-data generator (NOT a restatement of cv::initUndistortRectifyMap): maps of a radial-tangential
-    camera with a small rectifying rotation, same model and float32 output type as the EuRoC setup."""
-    a = np.deg2rad(rot_deg)
-    R = np.array([[np.cos(a), -np.sin(a), 0.002], [np.sin(a), np.cos(a), -0.003], [-0.002, 0.003, 1.0]])
-    nfx, nfy = fx * new_f_scale, fy * new_f_scale
-    u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
-    pts = np.stack([(u - cx) / nfx, (v - cy) / nfy, np.ones_like(u)], axis=-1) @ np.linalg.inv(R).T
-    x, y = pts[..., 0] / pts[..., 2], pts[..., 1] / pts[..., 2]
-    r2 = x * x + y * y
-    kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
-    mx = fx * (x * kr + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)) + cx
-    my = fy * (y * kr + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y) + cy
-    return mx.astype(np.float32), my.astype(np.float32)
+def rectify_maps(*args, **kw):
+    """synthetic rectification maps (a data generator, not a restatement of anything): orb_slam2_annotate_amd.synth"""
+    import sys
+    sys.path.insert(0, str(ROOT))
+    from orb_slam2_annotate_amd import synth
+    return synth.rectify_maps(*args, **kw)
 
 
 def undistort_points(xy, K4, dist):

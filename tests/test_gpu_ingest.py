@@ -213,3 +213,79 @@ def test_undistort_keypoints_batch_device_and_rgbd():
     with pytest.raises(amd.OrbfeError):
         bad = k0.copy(); bad["x"][0] = 640.0
         amd.ComputeStereoFromRGBD(bad, u0, depth, 40.0)
+
+
+@pytest.mark.parametrize("streams", [1, 2])
+def test_euroc_stereo_chain_matches_oracle(streams):
+    """The whole EuRoC stereo frame of the reference, device-resident and without a host wait inside: cv::remap of both
+    eyes (Examples/Stereo/stereo_euroc.cc:136-137) -> ExtractORB L + R (src/Frame.cc:78-81) -> ComputeStereoMatches
+    (:90) -> ComputeBoW on ORBvoc's shape with levelsup 4 (:433-440) -> SearchByBoW(pair t-1, pair t) on the left
+    keypoints (src/ORBmatcher.cc:185-325); two batches back to back on the same buffers, each step against the oracle."""
+    torch = pytest.importorskip("torch")
+    import orb_slam2_annotate_amd as amd
+    from orb_slam2_annotate_amd import synth
+    from orb_slam2_annotate_amd.vocabulary import synthetic_vocabulary_arrays
+    w, h, P, NF = 752, 480, 4, 1200
+    mapsL, mapsR = synth.rectify_maps(w, h, **synth.EUROC_CAM0), synth.rectify_maps(w, h, **synth.EUROC_CAM1)
+    rl, rr = amd.Rectifier(*mapsL), amd.Rectifier(*mapsR)
+    arrays = synthetic_vocabulary_arrays(10, 6, 5)
+    vo = orc.Vocabulary.from_arrays(arrays)
+    voc = amd.ORBVocabulary()
+    assert voc.createFromArrays(arrays)
+    e = amd.ORBextractor(NF, 1.2, 8, 20, 7)
+    e.set_streams(streams)
+    cap = e.max_keypoints(w, h)
+    dev = torch.device("cuda", 0)
+    batches = [[synth.render_stereo_raw(700 + 10 * b + p, w, h) for p in range(P)] for b in range(2)]
+    d_rawL = [torch.from_numpy(np.stack([x[0] for x in bt])).to(dev) for bt in batches]
+    d_rawR = [torch.from_numpy(np.stack([x[1] for x in bt])).to(dev) for bt in batches]
+    d_rect = torch.zeros((2 * P, h, w), dtype=torch.uint8, device=dev)
+    d_kp = torch.zeros((2 * P, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((2 * P, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros((2 * P,), dtype=torch.int32, device=dev)
+    d_u = torch.zeros((2, P, cap), dtype=torch.float32, device=dev)
+    d_dep = torch.zeros((2, P, cap), dtype=torch.float32, device=dev)
+    d_ns = torch.zeros((2, P), dtype=torch.int32, device=dev)
+    d_match = torch.zeros((2, P - 1, cap), dtype=torch.int32, device=dev)
+    d_nm = torch.zeros((2, P - 1), dtype=torch.int32, device=dev)
+    mbf = np.float32(47.90639384423901)
+    mb = np.float32(mbf / np.float32(435.2046959714599))
+    torch.cuda.synchronize()
+    outs = []
+    for b in range(2):
+        e.extract_stereo_rectified_batch_device(rl, rr, d_rawL[b].data_ptr(), d_rawR[b].data_ptr(), P, w, h, w, w * h,
+                                                d_rect.data_ptr(), d_kp.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr())
+        e.stereo_match_batch_device(P, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, float(mbf), float(mb),
+                                    d_u[b].data_ptr(), d_dep[b].data_ptr(), d_ns[b].data_ptr())
+        voc.bow_match_consecutive_batch_device(P, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap,
+                                               d_match[b].data_ptr(), d_nm[b].data_ptr(), nnratio=0.7,
+                                               check_orientation=True, levelsup=4, extractor=e, stereo=True)
+        if b == 1:
+            e.synchronize()
+            outs.append((d_rect.cpu().numpy(), d_kp.cpu().numpy(), d_desc.cpu().numpy(), d_n.cpu().numpy()))
+    o = orc.Oracle(NF, 1.2, 8, 20, 7)
+    for b in range(2):
+        prev, tot_st, tot_bow = None, 0, 0
+        for p in range(P):
+            rectL, rectR = orc.remap_linear(batches[b][p][0], *mapsL), orc.remap_linear(batches[b][p][1], *mapsR)
+            kL, dL, pL = o.extract(rectL, want_pyramid=True)
+            kR, dR, pR = o.extract(rectR, want_pyramid=True)
+            if b == 1:  # the buffers hold the last batch
+                rect, kp, desc, n = outs[0]
+                assert np.array_equal(rect[2 * p], rectL) and np.array_equal(rect[2 * p + 1], rectR)
+                assert n[2 * p] == len(kL) and n[2 * p + 1] == len(kR)
+                assert np.array_equal(desc[2 * p, :len(kL)], dL) and np.array_equal(desc[2 * p + 1, :len(kR)], dR)
+                assert np.array_equal(kp[2 * p, :len(kL)].view(np.uint8).reshape(-1, 28), kL.view(np.uint8).reshape(-1, 28))
+            u_ref, dep_ref = o.stereo(w, h, kL, dL, kR, dR, pL, pR, float(mbf), float(mb))
+            assert np.array_equal(d_u[b, p, :len(kL)].cpu().numpy(), u_ref), (b, p)
+            assert np.array_equal(d_dep[b, p, :len(kL)].cpu().numpy(), dep_ref), (b, p)
+            tot_st += int((u_ref >= 0).sum())
+            fv = orc.FeatVec(vo.transform(dL, 4)[3])
+            if prev is not None:
+                k0, d0, fv0 = prev
+                rn, rm = orc.search_by_bow(d0, np.ones(len(k0), np.uint8), k0["angle"], fv0, dL, kL["angle"], fv, 0.7, True)
+                assert int(d_nm[b, p - 1].item()) == rn, (b, p)
+                assert np.array_equal(d_match[b, p - 1, :len(kL)].cpu().numpy(), rm), (b, p)
+                tot_bow += rn
+            prev = (kL, dL, fv)
+        assert tot_st > 0.4 * P * NF
