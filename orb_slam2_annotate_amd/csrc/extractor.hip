@@ -638,6 +638,7 @@ int run_pipeline(orbfe_extractor* e, LevelView level0, int nFrames, orbfe_keypoi
       // slice i of the workspace is free once the previous call's tail lane has finished with it
       if (e->tailPending[i]) HIPCHK(hipStreamWaitEvent(sP, e->evTail[i], 0));
       if (pre && pre->fn) {  // (slice i's readers of the previous call: behind evTail[i] / evConsumerDone, waited for above)
+        StageTimer t(e, ORBFE_STAGE_H2D, 2, n, i, sP);  // "h2d" = the ingest stage of a call: here the rectification
         int rcp = pre->fn(pre->ctx, sP, f0, n);
         if (rcp) return rcp;
       }
@@ -660,6 +661,7 @@ int run_pipeline(orbfe_extractor* e, LevelView level0, int nFrames, orbfe_keypoi
     if (i > 0 && e->consumerPending) HIPCHK(hipStreamWaitEvent(s, e->evConsumerDone, 0));
     for (int k = 0; k < nWait; k++) HIPCHK(hipStreamWaitEvent(s, waitFor[k], 0));  // e.g. the H2D copy of this chunk
     if (pre && pre->fn) {
+      StageTimer t(e, ORBFE_STAGE_H2D, 2, n, i, s);  // "h2d" = the ingest stage of a call: here the rectification
       int rcp = pre->fn(pre->ctx, s, f0, n);
       if (rcp) return rcp;
     }
@@ -1366,9 +1368,13 @@ extern "C" int orbfe_extractor_consumer_begin_(orbfe_extractor* e, hipStream_t* 
   for (int i = 1; i < e->chunksPending; i++) HIPCHK(hipStreamWaitEvent(e->stream, e->evChunkDone[i], 0));
   *s = e->stream;
   if ((e->stageMask >> ORBFE_STAGE_MATCH) & 1u) {  // same ring slot as the extract call it follows, sub-batch 0
-    HIPCHK(hipEventRecord(e->evA[e->evSlot][0][ORBFE_STAGE_MATCH], e->stream));
-    e->evLaunches[e->evSlot][0][ORBFE_STAGE_MATCH] = 1;
-    e->evFrames[e->evSlot][0][ORBFE_STAGE_MATCH] = e->lastFrames;
+    if (e->evUsed[e->evSlot][0][ORBFE_STAGE_MATCH]) {  // a second matcher behind the same call: one interval for both
+      e->evLaunches[e->evSlot][0][ORBFE_STAGE_MATCH]++;
+    } else {
+      HIPCHK(hipEventRecord(e->evA[e->evSlot][0][ORBFE_STAGE_MATCH], e->stream));
+      e->evLaunches[e->evSlot][0][ORBFE_STAGE_MATCH] = 1;
+      e->evFrames[e->evSlot][0][ORBFE_STAGE_MATCH] = e->lastFrames;
+    }
   }
   return ORBFE_OK;
 }
@@ -1402,6 +1408,9 @@ extern "C" int orbfe_extractor_split_(orbfe_extractor* e, int* S, int* per, int*
 extern "C" void orbfe_extractor_stage_mark_(orbfe_extractor* e, int stage, int sub, int isEnd, hipStream_t s, int frames) {
   if (!e || sub < 0 || sub >= orbfe_extractor::kEvSubs || !((e->stageMask >> stage) & 1u)) return;
   if (!isEnd) {
+    // a second matcher behind the same sub-batch on the same stream (stereo, then BoW): one interval from the first
+    // one's start to the last one's end
+    if (e->evUsed[e->evSlot][sub][stage]) { e->evLaunches[e->evSlot][sub][stage]++; return; }
     (void)hipEventRecord(e->evA[e->evSlot][sub][stage], s);
     e->evLaunches[e->evSlot][sub][stage] = 1;
     e->evFrames[e->evSlot][sub][stage] = frames;
