@@ -483,6 +483,8 @@ class GpuWorkload:
         of the unit (and of the previous one where the unit's SearchByBoW needs it) re-extracted by the oracle -- after the
         oracle's own cv::remap for raw pairs --, then the match outputs.  Returns the report and the oracle's work
         counters per unit of the matching stage."""
+        if os.environ.get("ORBFE_BENCH_NO_CHECK"):  # kernel ablation runs (tools/ablate_desc_tiles.sh): results are NOT valid
+            return {"ok": None, "skipped": "ORBFE_BENCH_NO_CHECK set: timing experiment, outputs unchecked"}, {"distance_pairs_per_unit": 0.0}
         sys.path.insert(0, str(ROOT / "tests"))
         import oracle_lib as orc
         wl, fr, B = self.wl, self.frames, self.B

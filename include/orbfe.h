@@ -185,6 +185,10 @@ int orbfe_extractor_debug_host_octree(orbfe_extractor *e, int enable);
  * launch measured.  The results are identical in every mode. */
 int orbfe_extractor_set_fast_mode(orbfe_extractor *e, int mode);
 
+/* Orientation + descriptor stage: 0 (default) = per-keypoint gathers (k_orient_desc), 1 = tile form (k_orient_desc_tiles:
+ * a workgroup stages a 128 x 128 tile of the level and of the blurred level in LDS once for all keypoints inside it),
+ * -1 = $ORBFE_DESC_TILES or the default.  Identical results; see DESIGN.md 4 for when which one is faster. */
+int orbfe_extractor_set_desc_tiles(orbfe_extractor *e, int enable);
 /* How the sub-batches of a device-batch call (orbfe_extractor_set_streams) are scheduled: 0 = one independent HIP
  * stream per sub-batch; 1 ($ORBFE_LANES) = three lanes shared by all sub-batches -- pyramid | FAST + blur |
  * gather + octree + orientation/descriptors -- ordered by events into a software pipeline, so that exactly one

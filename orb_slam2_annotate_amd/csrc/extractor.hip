@@ -107,6 +107,9 @@ struct orbfe_extractor {
   // constant device tables
   float4* d_patternF = nullptr;
   uint4* d_momentTab = nullptr;
+  DescTile* d_descTiles = nullptr;  // tile form of the orientation + descriptor stage (k_desc_tiles.hip)
+  int nDescTiles = 0;
+  int descTilesMode = -1;           // -1: $ORBFE_DESC_TILES or the default (on for batches of more than 8 frames); 0 / 1 forced
   int32_t* d_umax = nullptr;
   CellDesc* d_cells = nullptr;
   LevelGeom* d_lvgeom = nullptr;
@@ -208,6 +211,8 @@ int ensure_subs(orbfe_extractor* e, int n) {
 void free_geometry(orbfe_extractor* e) {
   dfree(&e->d_cells);
   dfree(&e->d_lvgeom);
+  dfree(&e->d_descTiles);
+  e->nDescTiles = 0;
   for (int l = 0; l < kMaxLevels; l++) { dfree(&e->d_xofs[l]); dfree(&e->d_alpha[l]); dfree(&e->d_yofs[l]); dfree(&e->d_beta[l]); dfree(&e->d_colrec[l]); dfree(&e->d_rowrec[l]); dfree(&e->d_tileGx[l]); dfree(&e->d_tileDy[l]); }
 }
 void free_workspace(orbfe_extractor* e) {
@@ -251,6 +256,14 @@ int ensure_geometry(orbfe_extractor* e, int W, int H) {
   if (!g.cells.empty()) HIPCHK(hipMemcpy(e->d_cells, g.cells.data(), g.cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
   if ((rc = dalloc(&e->d_lvgeom, (size_t)kMaxLevels))) return rc;
   HIPCHK(hipMemcpy(e->d_lvgeom, g.lv, sizeof(LevelGeom) * kMaxLevels, hipMemcpyHostToDevice));
+  {
+    const std::vector<DescTile> tiles = build_desc_tiles(g.lv, g.nlevels);
+    e->nDescTiles = (int)tiles.size();
+    if (!tiles.empty()) {
+      if ((rc = dalloc(&e->d_descTiles, tiles.size()))) return rc;
+      HIPCHK(hipMemcpy(e->d_descTiles, tiles.data(), tiles.size() * sizeof(DescTile), hipMemcpyHostToDevice));
+    }
+  }
   for (int l = 1; l < g.nlevels; l++) {
     const ResizeTables& t = g.rz[l];
     if ((rc = dalloc(&e->d_xofs[l], t.xofs.size()))) return rc;
@@ -582,8 +595,18 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
       a.scale[l] = e->tab.scale[l];
       a.kpSize[l] = (float)(int)(kPatchSize * e->tab.scale[l]);  // :905
     }
-    launch_orient_desc(sT, a, levelKp, levelCount, e->d_patternF, e->d_momentTab, e->d_umax, nFrames,
-                       d_kp + F * capacity, d_desc + F * (size_t)capacity * 32, d_nOut + F, e->lastS);
+    // Tile form (k_desc_tiles.hip, round 3): a third of the HBM / L2 traffic of the per-keypoint gathers, but 1.6x their
+    // VALU instructions (every tile pays its staging and list scan for ~19 keypoints) -- on this instruction-bound
+    // pipeline it measures 2 % slower, so it is an option (orbfe_extractor_set_desc_tiles / $ORBFE_DESC_TILES=1), not
+    // the default; DESIGN.md 4 has the counters.
+    static const int kTilesEnv = getenv("ORBFE_DESC_TILES") ? atoi(getenv("ORBFE_DESC_TILES")) : 0;
+    const int tilesMode = e->descTilesMode >= 0 ? e->descTilesMode : kTilesEnv;
+    if (tilesMode && e->nDescTiles > 0)
+      launch_orient_desc_tiles(sT, a, e->d_descTiles, e->nDescTiles, levelKp, levelCount, e->d_patternF, e->d_momentTab,
+                               e->d_umax, nFrames, d_kp + F * capacity, d_desc + F * (size_t)capacity * 32, d_nOut + F, e->lastS);
+    else
+      launch_orient_desc(sT, a, levelKp, levelCount, e->d_patternF, e->d_momentTab, e->d_umax, nFrames,
+                         d_kp + F * capacity, d_desc + F * (size_t)capacity * 32, d_nOut + F, e->lastS);
   }
   if (lanes) {
     HIPCHK(hipEventRecord(e->evTail[sub], sT));
@@ -1471,6 +1494,12 @@ extern "C" int orbfe_extractor_set_pyramid_blur(orbfe_extractor* e, int enable) 
 
 // Schedule of the sub-batches of a call: 0 = one independent stream per sub-batch, 1 = three lanes shared by all
 // sub-batches (pyramid | FAST + blur | gather + octree + orientation/descriptors) as a software pipeline.
+extern "C" int orbfe_extractor_set_desc_tiles(orbfe_extractor* e, int enable) {
+  if (!e) return fail(ORBFE_ERR_INVALID, "NULL handle");
+  e->descTilesMode = enable < 0 ? -1 : (enable ? 1 : 0);
+  return ORBFE_OK;
+}
+
 extern "C" int orbfe_extractor_set_schedule(orbfe_extractor* e, int lanes) {
   if (!e) return fail(ORBFE_ERR_INVALID, "NULL handle");
   HIPCHK(hipSetDevice(e->device));

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "orb_params.h"
 
 namespace orbfe {
@@ -121,6 +123,15 @@ void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d
                         const int32_t* d_umax, int nFrames, void* d_kpOut, uint8_t* d_descOut,
                         int32_t* d_nOut, int concurrentLaunches = 1 /* sub-batch streams of the call */);
 void build_moment_table(uint8_t* tab /* 1024 bytes */);
+// tile form (k_desc_tiles.hip): one workgroup per 128 x 128 tile of a level, level and blurred level staged in LDS once
+struct DescTile {  // core origin (x0, y0), staged window origin (cx0, ry0) and rows, in level coordinates; 32-bit fields:
+  int32_t level, x0, y0, cx0, ry0, nrows, first /* the frame's first tile */, pad;  // read with scalar loads
+};
+std::vector<DescTile> build_desc_tiles(const LevelGeom* lv, int nlevels);
+void launch_orient_desc_tiles(hipStream_t s, const OrientDescArgs& a, const DescTile* d_tiles, int tilesPerFrame,
+                              const LevelKp* d_levelKp, const int32_t* d_levelCount, const float4* d_patternF,
+                              const uint4* d_momentTab, const int32_t* d_umax, int nFrames, void* d_kpOut,
+                              uint8_t* d_descOut, int32_t* d_nOut, int concurrentLaunches = 1);
 
 // ---- matching ----
 void launch_hamming_pairs(hipStream_t s, const uint8_t* a, const uint8_t* b, int n, int32_t* out);

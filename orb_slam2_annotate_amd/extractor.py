@@ -247,6 +247,10 @@ class ORBextractor:
         """Sub-batches on independent streams (False) or as a three-lane software pipeline (True); same results."""
         check(self._L.orbfe_extractor_set_schedule(self._h, int(bool(lanes))))
 
+    def set_desc_tiles(self, enable):
+        """Orientation + descriptor stage in tile form (True), per-keypoint form (False, default) or $ORBFE_DESC_TILES (None)."""
+        check(self._L.orbfe_extractor_set_desc_tiles(self._h, -1 if enable is None else int(bool(enable))))
+
     def set_fast_mode(self, mode):
         """FAST threshold order: 'auto' (default), 'high' (iniThFAST first, per-cell fallback) or 'low' (one attempt
         at the lower threshold); identical results, different speed depending on the image content."""

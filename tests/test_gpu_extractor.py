@@ -537,3 +537,46 @@ def test_fast_threshold_order_modes_are_equivalent(amd, mode):
             assert n == len(kr)
             assert np.array_equal(d_kp[f, :n].cpu().numpy().view(np.uint8).reshape(-1, 28), kr.view(np.uint8).reshape(-1, 28))
             assert np.array_equal(d_desc[f, :n].cpu().numpy(), dr)
+
+
+@pytest.mark.parametrize("shape,params", [((640, 480), (1000, 1.2, 8, 20, 7)), ((1241, 376), (2000, 1.2, 8, 20, 7)),
+                                          ((752, 480), (1200, 1.2, 8, 20, 7)), ((333, 217), (500, 1.2, 8, 20, 7)),
+                                          ((97, 81), (300, 1.2, 8, 20, 7)), ((200, 64), (200, 1.5, 4, 20, 7)),
+                                          ((400, 300), (3000, 1.2, 1, 20, 7))])
+def test_orient_desc_tile_form_matches_the_oracle(amd, shape, params):
+    """k_orient_desc_tiles (one workgroup per 128 x 128 tile of a level, level and blurred level staged in LDS once) gives
+    the oracle's keypoints and descriptors: single frames, batches on several streams with a strided level 0, noise
+    (every tile crowded; the 1-level / 3000-feature case puts > 64 keypoints in a tile = several list windows), a
+    constant image (all tiles empty)."""
+    w, h = shape
+    nf, sf, nl, ini, mn = params
+    o = orc.Oracle(nf, sf, nl, ini, mn)
+    for img in (synth.render_frame(41, w, h), synth.adversarial("noise", w, h, seed=5), synth.adversarial("constant", w, h)):
+        e = amd.ORBextractor(nf, sf, nl, ini, mn)
+        e.set_desc_tiles(True)
+        kps, desc = e(img)
+        kr, dr = o.extract(img)
+        _kp_equal(kr, kps)
+        assert np.array_equal(dr, desc)
+    torch = pytest.importorskip("torch")
+    B = 11
+    frames = np.stack([synth.render_frame(70 + i, w, h) for i in range(B)])
+    dev = torch.device("cuda", 0)
+    stride = w + 5
+    buf = torch.zeros((B, h, stride), dtype=torch.uint8, device=dev)
+    buf[:, :, :w] = torch.from_numpy(frames).to(dev)
+    e = amd.ORBextractor(nf, sf, nl, ini, mn)
+    e.set_desc_tiles(True)
+    e.set_streams(3)
+    cap = e.max_keypoints(w, h)
+    d_kp = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros((B,), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    e.extract_batch_device(buf.data_ptr(), B, w, h, stride, stride * h, d_kp.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr())
+    n = d_n.cpu().numpy()
+    for f in range(B):
+        kr, dr = o.extract(frames[f])
+        assert n[f] == len(kr), f
+        assert np.array_equal(d_kp[f, :n[f]].cpu().numpy().view(np.uint8).reshape(-1, 28), kr.view(np.uint8).reshape(-1, 28)), f
+        assert np.array_equal(d_desc[f, :n[f]].cpu().numpy(), dr), f

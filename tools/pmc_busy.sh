@@ -1,16 +1,18 @@
 #!/bin/bash
 # Per-kernel utilisation of the shared execution resources (exclusive, 1 stream): VALU issue, LDS array, memory wait.
 # GRBM_GUI_ACTIVE comes summed over the 8 XCDs (see tools/collect_valu.py), hence the /8 in the busy fractions.
-#   tools/pmc_busy.sh tum 256      -> gpurun_out/pmc_busy_<workload>.txt
+#   tools/pmc_busy.sh tum 256      -> gpurun_out/pmc_busy_<workload>[_$TAG].txt   (every pass under `timeout -k 10 240`,
+#   a progress line after each: a pass that dies must not leave the call silent)
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 W=${1:-tum}; B=${2:-256}
-OUT=gpurun_out/pmc_busy_$W
+OUT=gpurun_out/pmc_busy_$W${TAG:+_$TAG}
+mkdir -p gpurun_out
 rm -rf ${OUT}_a ${OUT}_b ${OUT}_c
 ARGS="--workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --render-procs 1 --streams 1 --batch $B"
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d ${OUT}_a -- python3 bench.py $ARGS > /dev/null 2>${OUT}_a.err
-rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d ${OUT}_b -- python3 bench.py $ARGS > /dev/null 2>${OUT}_b.err
-rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d ${OUT}_c -- python3 bench.py $ARGS > /dev/null 2>${OUT}_c.err
+timeout -k 10 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d ${OUT}_a -- python3 bench.py $ARGS > /dev/null 2>${OUT}_a.err; echo "pass a done rc=$? $(date +%T)" >> ${OUT}.progress
+timeout -k 10 240 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d ${OUT}_b -- python3 bench.py $ARGS > /dev/null 2>${OUT}_b.err; echo "pass b done rc=$? $(date +%T)" >> ${OUT}.progress
+timeout -k 10 240 rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d ${OUT}_c -- python3 bench.py $ARGS > /dev/null 2>${OUT}_c.err; echo "pass c done rc=$? $(date +%T)" >> ${OUT}.progress
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
