@@ -435,7 +435,23 @@ typedef struct orbfe_frame_view {
   const float *u_right;     /* mvuRight, NULL for monocular frames */
   const uint8_t *desc;      /* mDescriptors, n x 32 */
   float min_x, max_x, min_y, max_y;
+  const struct orbfe_frame *resident; /* NULL, or the handle orbfe_frame_upload made of this frame: the search then
+                                         uploads nothing of the frame (use orbfe_frame_get_view) */
 } orbfe_frame_view;
+
+/* Device-resident Frame / KeyFrame operands.  LocalMapping matches one key frame against 10-20 neighbours
+ * (src/LocalMapping.cc:256-315, 517-573), relocalisation one frame against several candidates
+ * (src/Tracking.cc:1478-1498): orbfe_frame_upload moves what a frame contributes to any search -- keypoint arrays,
+ * descriptors, the 64 x 48 grid of Frame::AssignFeaturesToGrid (built once), the FeatureVector's index list (fv may be
+ * NULL for frames that only take part in projection searches) -- to the device once.  The view needs x, y, octave,
+ * desc and the bounds; angle / u_right as the searches it will take part in need them.  The handle copies what it
+ * needs (the caller's arrays may go away), is immutable, and may be used from any thread concurrently. */
+typedef struct orbfe_frame orbfe_frame;
+int orbfe_frame_upload(int device, const orbfe_frame_view *view, const orbfe_featvec *fv, orbfe_frame **out);
+void orbfe_frame_release(orbfe_frame *f);
+/* The handle's own view (host copies inside the handle, `resident` set): pass it wherever an orbfe_frame_view is
+ * taken.  Valid until orbfe_frame_release. */
+const orbfe_frame_view *orbfe_frame_get_view(const orbfe_frame *f);
 
 /* Frame::AssignFeaturesToGrid + Frame::GetFeaturesInArea (src/Frame.cc:246-267, 358-427) for
  * n_queries windows at once: count[q] features lie in the window of query q; the first
@@ -459,6 +475,33 @@ int orbfe_search_by_projection(int device, const orbfe_frame_view *F, const floa
                                const float *proj_y, const float *proj_xr, const uint8_t *mp_desc,
                                const uint8_t *mp_obs_positive, float th, float nnratio,
                                int32_t *match, int32_t *n_matches);
+
+/* The FeatureVector searches on resident frames (uploaded WITH their FeatureVector and angles): per call only the
+ * shared-node list, the MapPoint masks and the result travel.  Semantics and outputs of orbfe_search_by_bow /
+ * orbfe_search_by_bow_kf. */
+int orbfe_search_by_bow_resident(const orbfe_frame *kf, const uint8_t *has_mp_kf, const orbfe_frame *f, float nnratio,
+                                 int check_orientation, int32_t *match_f);
+int orbfe_search_by_bow_kf_resident(const orbfe_frame *kf1, const uint8_t *has_mp1, const orbfe_frame *kf2,
+                                    const uint8_t *has_mp2, float nnratio, int check_orientation, int32_t *match12);
+/* ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:754-928) of ONE key frame against n_neighbours key frames in
+ * one call -- the loop of LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:283-315): F12[9*k ..], ex[k], ey[k]
+ * the fundamental matrix and epipole of neighbour k, has_mp2[k] its MapPoint mask; the stereo flags come from the
+ * frames' u_right.  match12[k*n1 + i] = feature of neighbour k matched to feature i of kf1, or -1; n_matches[k].
+ * One upload, 2 launches per neighbour on one stream, one download. */
+int orbfe_search_for_triangulation_multi(const orbfe_frame *kf1, const uint8_t *has_mp1, int n_neighbours,
+                                         const orbfe_frame *const *kf2, const uint8_t *const *has_mp2,
+                                         const float *F12, const float *ex, const float *ey,
+                                         const float *scale_factors2, const float *level_sigma2_2, int n_levels2,
+                                         int only_stereo, int check_orientation, int32_t *match12,
+                                         int32_t *n_matches);
+/* The per-point search of ORBmatcher::Fuse (orbfe_fuse_search) for the SAME n map points against n_keyframes key
+ * frames in one call -- LocalMapping::SearchInNeighbors (src/LocalMapping.cc:542-549).  valid / u / v / ur / level /
+ * best_idx are [k*n + i]; mp_desc [n*32] is shared; resident views upload nothing of the key frames. */
+int orbfe_fuse_search_multi(int device, int n_keyframes, const orbfe_frame_view *const *KF,
+                            const float *scale_factors, const float *inv_level_sigma2, int n_levels, int n,
+                            const uint8_t *valid, const float *u, const float *v, const float *ur,
+                            const int32_t *level, const uint8_t *mp_desc, float th, int chi2_gate,
+                            int32_t *best_idx);
 
 /* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th,
  * const bool bMono) (src/ORBmatcher.cc:1484-1633) after the caller's pose arithmetic: last-frame

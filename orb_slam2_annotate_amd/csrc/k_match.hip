@@ -335,6 +335,10 @@ void launch_search_triangulation(hipStream_t s, const TriArgs& a) {
 void launch_rot_prune(hipStream_t s, int32_t* match, const int8_t* bin, int n, int checkOri, int32_t* nMatches) {
   hipLaunchKernelGGL(k_rot_prune, dim3(1), dim3(256), 0, s, match, bin, n, checkOri, nMatches, 0);
 }
+void launch_rot_prune_batch(hipStream_t s, int32_t* match, const int8_t* bin, int n, int nArrays, int checkOri, int32_t* nMatches) {
+  if (nArrays <= 0) return;  // array k at match + k*n, count at nMatches[k]
+  hipLaunchKernelGGL(k_rot_prune, dim3(nArrays), dim3(256), 0, s, match, bin, n, checkOri, nMatches, n);
+}
 void launch_search_by_bow_batch(hipStream_t s, const BowBatch& b, int nPairs, int checkOri, int32_t* d_nMatches, int maxNodes) {
   if (nPairs <= 0 || b.capacity <= 0) return;
   const size_t lds = (size_t)((b.capacity + 15) & ~15);

@@ -158,6 +158,10 @@ void shared_nodes(const orbfe_featvec* f1, const orbfe_featvec* f2, std::vector<
   }
 }
 
+// pinned staging of the calling thread (defined with the window searches below)
+hipError_t staging_reserve_(size_t bytes);
+uint8_t* staging_ptr_();
+
 bool featvec_ok(const orbfe_featvec* f, int n) {
   if (!f || f->n_nodes < 0) return false;
   if (f->n_nodes == 0) return true;
@@ -368,6 +372,265 @@ extern "C" int orbfe_search_for_triangulation(int device, const uint8_t* desc1, 
   return *mirror_of(ar, dcount);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Device-resident Frame / KeyFrame operands (round 3).  The live system matches one key frame against 10-20
+// neighbours (LocalMapping::CreateNewMapPoints / SearchInNeighbors, src/LocalMapping.cc:256-315, 517-573) and one
+// frame against several candidates (Tracking::Relocalization, src/Tracking.cc:1478-1498): with host-pointer operands
+// every call uploaded both frames' descriptors again.  orbfe_frame_upload moves what a frame contributes to ANY search
+// -- keypoint arrays, descriptors, the 64 x 48 grid (built once), the FeatureVector's index list -- to the device once;
+// the handle is immutable afterwards, so any thread may use it concurrently.
+// ---------------------------------------------------------------------------------------------
+struct orbfe_frame {
+  int device = 0, n = 0;
+  std::vector<float> hx, hy, hangle, hur;   // host copies: the claim loops and chi-square gates read them
+  std::vector<int32_t> hoct;
+  std::vector<uint8_t> hstereo;             // mvuRight[i] >= 0
+  std::vector<uint32_t> nodeIds;            // FeatureVector (host side of the merge-walk)
+  std::vector<int32_t> offsets;
+  std::vector<uint32_t> hindices;
+  orbfe_featvec fv = {};
+  bool haveFv = false;
+  uint8_t* slab = nullptr;                  // one device allocation
+  float *dx = nullptr, *dy = nullptr, *dangle = nullptr, *dur = nullptr;
+  int32_t* doct = nullptr;
+  uint8_t *ddesc = nullptr, *dstereo = nullptr;
+  uint32_t *dkey = nullptr, *dindices = nullptr;
+  int32_t* dcell = nullptr;
+  std::vector<uint8_t> hdesc;               // (the host-pointer fallbacks of a view need it)
+  orbfe_frame_view view = {};               // canonical view: host copies + resident = this
+};
+
+namespace {
+inline const orbfe_frame_view* canon(const orbfe_frame_view* f) { return (f && f->resident) ? &f->resident->view : f; }
+}
+
+extern "C" void orbfe_frame_release(orbfe_frame* f) {
+  if (!f) return;
+  (void)hipSetDevice(f->device);
+  if (f->slab) (void)hipFree(f->slab);
+  delete f;
+}
+
+extern "C" const orbfe_frame_view* orbfe_frame_get_view(const orbfe_frame* f) { return f ? &f->view : nullptr; }
+
+extern "C" int orbfe_frame_upload(int device, const orbfe_frame_view* v, const orbfe_featvec* fv, orbfe_frame** out) {
+  if (!out) return mfail(ORBFE_ERR_INVALID, "frame_upload: NULL argument");
+  *out = nullptr;
+  if (!v || v->n < 0 || v->n > GRID_MAX_FEATURES || !(v->max_x > v->min_x) || !(v->max_y > v->min_y) ||
+      (v->n > 0 && (!v->x || !v->y || !v->octave || !v->desc)))
+    return mfail(ORBFE_ERR_INVALID, "frame_upload: bad frame view (x, y, octave, desc and the image bounds are required)");
+  const int n = v->n;
+  if (fv && !featvec_ok(fv, n)) return mfail(ORBFE_ERR_INVALID, "frame_upload: malformed FeatureVector");
+  orbfe_frame* f = new (std::nothrow) orbfe_frame();
+  if (!f) return mfail(ORBFE_ERR_NOMEM, "out of memory");
+  f->device = device; f->n = n;
+  f->hx.assign(v->x, v->x + n); f->hy.assign(v->y, v->y + n); f->hoct.assign(v->octave, v->octave + n);
+  f->hdesc.assign(v->desc, v->desc + (size_t)n * 32);
+  if (v->angle) f->hangle.assign(v->angle, v->angle + n);
+  if (v->u_right) f->hur.assign(v->u_right, v->u_right + n);
+  f->hstereo.assign((size_t)n, 0);
+  if (v->u_right) for (int i = 0; i < n; i++) f->hstereo[i] = v->u_right[i] >= 0 ? 1 : 0;
+  size_t nIdx = 0;
+  if (fv) {
+    f->haveFv = true;
+    f->nodeIds.assign(fv->node_ids, fv->node_ids + fv->n_nodes);
+    f->offsets.assign(fv->offsets, fv->offsets + fv->n_nodes + 1);
+    nIdx = fv->n_nodes ? (size_t)fv->offsets[fv->n_nodes] : 0;
+    f->hindices.assign(fv->indices, fv->indices + nIdx);
+    if (f->offsets.empty()) f->offsets.push_back(0);
+    f->fv.n_nodes = fv->n_nodes; f->fv.node_ids = f->nodeIds.data(); f->fv.offsets = f->offsets.data(); f->fv.indices = f->hindices.data();
+  }
+  orbfe_frame_view& c = f->view;
+  c.n = n; c.x = f->hx.data(); c.y = f->hy.data(); c.octave = f->hoct.data();
+  c.angle = v->angle ? f->hangle.data() : nullptr;
+  c.u_right = v->u_right ? f->hur.data() : nullptr;
+  c.desc = f->hdesc.data();
+  c.min_x = v->min_x; c.max_x = v->max_x; c.min_y = v->min_y; c.max_y = v->max_y;
+  c.resident = f;
+  // one slab: x y angle u_right | octave | key | cell | indices | desc | stereo
+  const size_t N = (size_t)(n ? n : 1);
+  size_t off = 0;
+  auto place = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t oX = place(N * 4), oY = place(N * 4), oA = place(N * 4), oU = place(N * 4), oO = place(N * 4), oK = place(N * 4),
+               oC = place(3073 * 4), oI = place((nIdx ? nIdx : 1) * 4), oD = place(N * 32), oS = place(N);
+  hipError_t err = hipSetDevice(device);
+  if (err == hipSuccess) err = hipMalloc((void**)&f->slab, off);
+  if (err != hipSuccess) { delete f; return mfail(err == hipErrorOutOfMemory ? ORBFE_ERR_NOMEM : ORBFE_ERR_HIP, std::string("frame_upload: ") + hipGetErrorString(err)); }
+  uint8_t* b = f->slab;
+  f->dx = (float*)(b + oX); f->dy = (float*)(b + oY); f->dangle = (float*)(b + oA); f->dur = (float*)(b + oU);
+  f->doct = (int32_t*)(b + oO); f->dkey = (uint32_t*)(b + oK); f->dcell = (int32_t*)(b + oC); f->dindices = (uint32_t*)(b + oI);
+  f->ddesc = b + oD; f->dstereo = b + oS;
+  Arena* ar;
+  // staged through the thread's pinned mirror: one copy up, then the grid build (Frame::AssignFeaturesToGrid, once)
+  err = arena_begin(device, 1024, &ar);
+  if (err == hipSuccess) err = staging_reserve_(off);
+  if (err == hipSuccess) {
+    uint8_t* h = staging_ptr_();
+    std::memset(h, 0, off);
+    if (n) {
+      std::memcpy(h + oX, f->hx.data(), (size_t)n * 4); std::memcpy(h + oY, f->hy.data(), (size_t)n * 4);
+      if (v->angle) std::memcpy(h + oA, f->hangle.data(), (size_t)n * 4);
+      if (v->u_right) std::memcpy(h + oU, f->hur.data(), (size_t)n * 4);
+      std::memcpy(h + oO, f->hoct.data(), (size_t)n * 4);
+      std::memcpy(h + oD, f->hdesc.data(), (size_t)n * 32);
+      std::memcpy(h + oS, f->hstereo.data(), (size_t)n);
+    }
+    if (nIdx) std::memcpy(h + oI, f->hindices.data(), nIdx * 4);
+    err = hipMemcpyAsync(b, h, off, hipMemcpyHostToDevice, ar->stream);
+  }
+  if (err == hipSuccess) {
+    GridFrame g{};
+    g.x = f->dx; g.y = f->dy; g.octave = f->doct; g.uRight = v->u_right ? f->dur : nullptr; g.desc = f->ddesc; g.n = n;
+    g.minX = v->min_x; g.minY = v->min_y;
+    g.wInv = 64.0f / (v->max_x - v->min_x);
+    g.hInv = 48.0f / (v->max_y - v->min_y);
+    launch_grid_build(ar->stream, g, f->dkey, f->dcell);
+    err = hipGetLastError();
+  }
+  if (err == hipSuccess) err = hipStreamSynchronize(ar->stream);
+  if (err != hipSuccess) { orbfe_frame_release(f); return mfail(ORBFE_ERR_HIP, std::string("frame_upload: ") + hipGetErrorString(err)); }
+  *out = f;
+  return ORBFE_OK;
+}
+
+// ---- the FeatureVector searches on resident frames: per call only the shared-node list, the map-point masks and
+//      the result arrays travel ----
+static int bow_resident(const orbfe_frame* k1, const uint8_t* has_mp1, const orbfe_frame* k2, const uint8_t* has_mp2,
+                        float nnratio, int check_ori, int kfkf, int32_t* match) {
+  if (!k1 || !k2 || !match) return mfail(ORBFE_ERR_INVALID, "search_by_bow_resident: NULL argument");
+  if (k1->device != k2->device) return mfail(ORBFE_ERR_INVALID, "search_by_bow_resident: frames on different devices");
+  const int n1 = k1->n, n2 = k2->n, nOut = kfkf ? n1 : n2;
+  for (int i = 0; i < nOut; i++) match[i] = -1;
+  if (n1 == 0 || n2 == 0) return 0;
+  if (!k1->haveFv || !k2->haveFv || k1->hangle.empty() || k2->hangle.empty() || !has_mp1 || (kfkf && !has_mp2))
+    return mfail(ORBFE_ERR_INVALID, "search_by_bow_resident: the frames were uploaded without FeatureVector / angles, or a mask is NULL");
+  std::vector<NodePair> pairs;
+  shared_nodes(&k1->fv, &k2->fv, &pairs);
+  if (pairs.empty()) return 0;
+  int maxCnt2 = 0;
+  for (const NodePair& p : pairs) maxCnt2 = p.cnt2 > maxCnt2 ? p.cnt2 : maxCnt2;
+  if (maxCnt2 > 65535) return mfail(ORBFE_ERR_INVALID, "search_by_bow: more than 65535 features in one node");
+  Arena* ar;
+  MHIP(arena_begin(k1->device, pad(pairs.size() * sizeof(NodePair)) + pad(n1) + pad(n2) + 2 * pad((size_t)nOut * 4) + 4096, &ar));
+  NodePair* dp;
+  uint8_t *dm1, *dm2 = nullptr;
+  MHIP(up(ar, &dp, pairs.data(), pairs.size()));
+  MHIP(up(ar, &dm1, has_mp1, (size_t)n1));
+  if (kfkf) MHIP(up(ar, &dm2, has_mp2, (size_t)n2));
+  int32_t* dmatch;
+  int8_t* dbin;
+  MHIP(up_fill(ar, &dmatch, (size_t)nOut, 0xff));
+  int32_t* dcount = carve<int32_t>(ar, 1);
+  MHIP(up_fill(ar, &dbin, (size_t)nOut, 0));
+  BowArgs a = {};
+  a.pairs = dp; a.desc1 = k1->ddesc; a.hasMp1 = dm1; a.angle1 = k1->dangle; a.indices1 = k1->dindices;
+  a.desc2 = k2->ddesc; a.hasMp2 = dm2; a.angle2 = k2->dangle; a.indices2 = k2->dindices;
+  a.angleStride = 1;
+  a.nnratio = nnratio; a.strictLow = kfkf; a.match = dmatch; a.bin = dbin;
+  MHIP(flush(ar));
+  launch_search_by_bow(ar->stream, a, (int)pairs.size(), maxCnt2);
+  launch_rot_prune(ar->stream, dmatch, dbin, nOut, check_ori, dcount);
+  MHIP(hipGetLastError());
+  MHIP(down_range(ar, dmatch, dcount + 1));
+  MHIP(hipStreamSynchronize(ar->stream));
+  std::memcpy(match, mirror_of(ar, dmatch), (size_t)nOut * 4);
+  return *mirror_of(ar, dcount);
+}
+
+extern "C" int orbfe_search_by_bow_resident(const orbfe_frame* kf, const uint8_t* has_mp_kf, const orbfe_frame* f,
+                                            float nnratio, int check_orientation, int32_t* match_f) {
+  return bow_resident(kf, has_mp_kf, f, nullptr, nnratio, check_orientation, 0, match_f);
+}
+extern "C" int orbfe_search_by_bow_kf_resident(const orbfe_frame* kf1, const uint8_t* has_mp1, const orbfe_frame* kf2,
+                                               const uint8_t* has_mp2, float nnratio, int check_orientation,
+                                               int32_t* match12) {
+  return bow_resident(kf1, has_mp1, kf2, has_mp2, nnratio, check_orientation, 1, match12);
+}
+
+// ORBmatcher::SearchForTriangulation of ONE key frame against K neighbours (LocalMapping::CreateNewMapPoints,
+// src/LocalMapping.cc:256-315: the same mpCurrentKeyFrame, a new F12 per neighbour): one upload of the K query lists,
+// masks and matrices, 2 K launches on one stream, one download of the K match arrays.
+extern "C" int orbfe_search_for_triangulation_multi(const orbfe_frame* kf1, const uint8_t* has_mp1, int n_neighbours,
+                                                    const orbfe_frame* const* kf2, const uint8_t* const* has_mp2,
+                                                    const float* F12, const float* ex, const float* ey,
+                                                    const float* scale_factors2, const float* level_sigma2_2,
+                                                    int n_levels2, int only_stereo, int check_orientation,
+                                                    int32_t* match12, int32_t* n_matches) {
+  if (!kf1 || n_neighbours < 0 || (n_neighbours > 0 && (!kf2 || !has_mp2 || !F12 || !ex || !ey || !match12 || !n_matches)) ||
+      !scale_factors2 || !level_sigma2_2 || n_levels2 <= 0 || n_levels2 > ORBFE_MAX_LEVELS)
+    return mfail(ORBFE_ERR_INVALID, "search_for_triangulation_multi: bad argument");
+  const int n1 = kf1->n, K = n_neighbours;
+  for (size_t i = 0; i < (size_t)K * n1; i++) match12[i] = -1;
+  for (int k = 0; k < K; k++) n_matches[k] = 0;
+  if (K == 0 || n1 == 0) return ORBFE_OK;
+  if (!has_mp1 || !kf1->haveFv || kf1->hangle.empty())
+    return mfail(ORBFE_ERR_INVALID, "search_for_triangulation_multi: key frame uploaded without FeatureVector / angles, or NULL mask");
+  // host: the shared nodes and the query list of every neighbour (:787-811)
+  std::vector<std::vector<TriQuery>> queries((size_t)K);
+  size_t bytes = pad((size_t)K * 9 * 4) + 2 * pad((size_t)n_levels2 * 4) + 2 * pad((size_t)K * n1 * 4) + pad((size_t)K * 4) + 8192;
+  std::vector<NodePair> pairs;
+  for (int k = 0; k < K; k++) {
+    const orbfe_frame* k2 = kf2[k];
+    if (!k2 || (!has_mp2[k] && k2->n > 0)) return mfail(ORBFE_ERR_INVALID, "search_for_triangulation_multi: NULL neighbour");
+    if (k2->device != kf1->device) return mfail(ORBFE_ERR_INVALID, "search_for_triangulation_multi: frames on different devices");
+    if (k2->n > 0 && (!k2->haveFv || k2->hangle.empty()))
+      return mfail(ORBFE_ERR_INVALID, "search_for_triangulation_multi: neighbour uploaded without FeatureVector / angles");
+    for (int i = 0; i < k2->n; i++)
+      if (k2->hoct[i] < 0 || k2->hoct[i] >= n_levels2) return mfail(ORBFE_ERR_INVALID, "search_for_triangulation: octave out of range");
+    pairs.clear();
+    if (k2->n > 0) shared_nodes(&kf1->fv, &k2->fv, &pairs);
+    for (const NodePair& p : pairs) {
+      if (p.cnt2 > 65535) return mfail(ORBFE_ERR_INVALID, "search_for_triangulation: more than 65535 features in one node");
+      for (int i = 0; i < p.cnt1; i++) {
+        const uint32_t idx1 = kf1->hindices[p.off1 + i];
+        if (has_mp1[idx1]) continue;                         // :800-803
+        if (only_stereo && !kf1->hstereo[idx1]) continue;    // :807-809
+        queries[k].push_back(TriQuery{idx1, p.off2, p.cnt2});
+      }
+    }
+    bytes += pad(queries[k].size() * sizeof(TriQuery)) + pad((size_t)k2->n);
+  }
+  Arena* ar;
+  MHIP(arena_begin(kf1->device, bytes, &ar));
+  float *dF, *dsf, *dsg;
+  MHIP(up(ar, &dF, F12, (size_t)K * 9));
+  MHIP(up(ar, &dsf, scale_factors2, (size_t)n_levels2));
+  MHIP(up(ar, &dsg, level_sigma2_2, (size_t)n_levels2));
+  std::vector<TriQuery*> dq((size_t)K, nullptr);
+  std::vector<uint8_t*> dm2((size_t)K, nullptr);
+  for (int k = 0; k < K; k++) {
+    if (queries[k].empty()) continue;
+    MHIP(up(ar, &dq[k], queries[k].data(), queries[k].size()));
+    MHIP(up(ar, &dm2[k], has_mp2[k], (size_t)kf2[k]->n));
+  }
+  int32_t* dmatch;
+  int8_t* dbin;
+  MHIP(up_fill(ar, &dmatch, (size_t)K * n1, 0xff));   // match arrays and counts adjacent: one copy back
+  int32_t* dcount;
+  MHIP(up_fill(ar, &dcount, (size_t)K, 0));
+  MHIP(up_fill(ar, &dbin, (size_t)K * n1, 0));
+  MHIP(flush(ar));
+  for (int k = 0; k < K; k++) {
+    if (queries[k].empty()) continue;
+    const orbfe_frame* k2 = kf2[k];
+    TriArgs a = {};
+    a.queries = dq[k]; a.nQueries = (int)queries[k].size();
+    a.desc1 = kf1->ddesc; a.x1 = kf1->dx; a.y1 = kf1->dy; a.angle1 = kf1->dangle; a.stereo1 = kf1->dstereo;
+    a.desc2 = k2->ddesc; a.hasMp2 = dm2[k]; a.x2 = k2->dx; a.y2 = k2->dy; a.angle2 = k2->dangle; a.octave2 = k2->doct;
+    a.stereo2 = k2->dstereo; a.indices2 = k2->dindices;
+    a.F12 = dF + (size_t)k * 9; a.ex = ex[k]; a.ey = ey[k]; a.scaleFactors2 = dsf; a.levelSigma2_2 = dsg;
+    a.onlyStereo = only_stereo; a.match = dmatch + (size_t)k * n1; a.bin = dbin + (size_t)k * n1;
+    launch_search_triangulation(ar->stream, a);
+  }
+  launch_rot_prune_batch(ar->stream, dmatch, dbin, n1, K, check_orientation, dcount);  // all K histograms in one launch
+  MHIP(hipGetLastError());
+  MHIP(down_range(ar, dmatch, dcount + K));
+  MHIP(hipStreamSynchronize(ar->stream));
+  std::memcpy(match12, mirror_of(ar, dmatch), (size_t)K * n1 * 4);
+  std::memcpy(n_matches, mirror_of(ar, dcount), (size_t)K * 4);
+  return ORBFE_OK;
+}
+
 // implemented in extractor.hip (needs the handle internals)
 extern "C" int orbfe_stereo_views_(orbfe_extractor* e, int frame, PyramidViews* pv, float* scale, float* invScale,
                                    int* nlevels, int* device, const float** d_scaleTab);
@@ -462,6 +725,11 @@ struct Staging {
 };
 thread_local Staging t_staging;
 
+hipError_t staging_reserve(size_t bytes);
+}  // namespace
+namespace {
+hipError_t staging_reserve_(size_t bytes) { return staging_reserve(bytes); }
+uint8_t* staging_ptr_() { return t_staging.h; }
 hipError_t staging_reserve(size_t bytes) {
   if (bytes <= t_staging.cap) return hipSuccess;
   if (t_staging.h) (void)hipHostFree(t_staging.h);
@@ -473,83 +741,156 @@ hipError_t staging_reserve(size_t bytes) {
   return e;
 }
 
-// Upload the frame + queries, build the grid, search every window; grows K until every list fits.
-int window_search(int device, const orbfe_frame_view* f, int nq, const float* qx, const float* qy, const float* qr,
-                  const int32_t* qmin, const int32_t* qmax, const uint8_t* qactive, const float* qur,
-                  const uint8_t* qdesc, int K0, WindowResult* res) {
+// One window search = one frame + one set of query windows.  Several jobs of a call (Fuse against K neighbour key frames,
+// the two directions of SearchBySim3) share ONE upload, one group of launches, one download and one synchronisation.
+struct WindowJob {
+  const orbfe_frame_view* f;
+  int nq;
+  const float *qx, *qy, *qr;
+  const int32_t *qmin, *qmax;
+  const uint8_t* qactive;
+  const float* qur;
+  const uint8_t* qdesc;  // jobs that pass the SAME pointer share one device copy
+  WindowResult* res;
+};
+
+// Upload frames (unless resident: keypoint arrays, descriptors and grid are on the device already) + queries, build the
+// grids, search every window; grows K until every list fits.
+int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
   int K = K0 < 8 ? 8 : K0;
-  const size_t n = (size_t)f->n, q = (size_t)nq;
-  const bool withDesc = f->desc && qdesc;
-  const bool withUr = qur && f->u_right;
-  // packed input block: offsets (256-byte aligned) of every array inside it
+  struct Lay { size_t oX, oY, oOct, oUr, oDesc, oQx, oQy, oQr, oQmin, oQmax, oQact, oQur, oQdesc, oOut; bool withDesc, withUr, res; };
+  std::vector<Lay> lay((size_t)nJobs);
   size_t off = 0;
   auto place = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-  const size_t oX = place(n * 4), oY = place(n * 4), oOct = place(n * 4);
-  const size_t oUr = f->u_right ? place(n * 4) : 0, oDesc = withDesc ? place(n * 32) : 0;
-  const size_t oQx = place(q * 4), oQy = place(q * 4), oQr = place(q * 4), oQmin = place(q * 4), oQmax = place(q * 4);
-  const size_t oQact = qactive ? place(q) : 0, oQur = withUr ? place(q * 4) : 0, oQdesc = withDesc ? place(q * 32) : 0;
+  for (int j = 0; j < nJobs; j++) {
+    const WindowJob& J = jobs[j];
+    Lay& L = lay[j];
+    const size_t n = (size_t)J.f->n, q = (size_t)J.nq;
+    L.res = J.f->resident != nullptr;
+    if (L.res && J.f->resident->device != device) return mfail(ORBFE_ERR_INVALID, "resident frame lives on another device");
+    L.withDesc = J.f->desc && J.qdesc;
+    L.withUr = J.qur && J.f->u_right;
+    L.oX = L.oY = L.oOct = L.oUr = L.oDesc = 0;
+    if (!L.res) {
+      L.oX = place(n * 4); L.oY = place(n * 4); L.oOct = place(n * 4);
+      L.oUr = J.f->u_right ? place(n * 4) : 0;
+      L.oDesc = L.withDesc ? place(n * 32) : 0;
+    }
+    L.oQx = place(q * 4); L.oQy = place(q * 4); L.oQr = place(q * 4); L.oQmin = place(q * 4); L.oQmax = place(q * 4);
+    L.oQact = J.qactive ? place(q) : 0;
+    L.oQur = L.withUr ? place(q * 4) : 0;
+    L.oQdesc = 0;
+    if (L.withDesc) {
+      int shared = -1;
+      for (int k = 0; k < j; k++)
+        if (lay[k].withDesc && jobs[k].qdesc == J.qdesc && jobs[k].nq == J.nq) { shared = k; break; }
+      L.oQdesc = shared >= 0 ? lay[shared].oQdesc : place(q * 32);
+    }
+  }
   const size_t inBytes = off ? off : 256;
   for (;;) {
     Arena* ar;
-    const size_t outBytes = pad(q * 4) + pad(q * (size_t)K * 4);
-    MHIP(arena_begin(device, pad(inBytes) + pad(n * 4) + pad(3073 * 4) + outBytes + 1024, &ar));
+    size_t outBytes = 0, gridBytes = 0;
+    for (int j = 0; j < nJobs; j++) {
+      lay[j].oOut = outBytes;
+      outBytes += pad((size_t)jobs[j].nq * 4) + pad((size_t)jobs[j].nq * (size_t)K * 4);
+      if (!lay[j].res) gridBytes += pad((size_t)jobs[j].f->n * 4) + pad(3073 * 4);
+    }
+    MHIP(arena_begin(device, pad(inBytes) + gridBytes + outBytes + 1024, &ar));
     MHIP(staging_reserve(inBytes > outBytes ? inBytes : outBytes));
     uint8_t* h = t_staging.h;
-    if (n) {
-      std::memcpy(h + oX, f->x, n * 4); std::memcpy(h + oY, f->y, n * 4); std::memcpy(h + oOct, f->octave, n * 4);
-      if (f->u_right) std::memcpy(h + oUr, f->u_right, n * 4);
-      if (withDesc) std::memcpy(h + oDesc, f->desc, n * 32);
-    }
-    if (q) {
-      std::memcpy(h + oQx, qx, q * 4); std::memcpy(h + oQy, qy, q * 4); std::memcpy(h + oQr, qr, q * 4);
-      std::memcpy(h + oQmin, qmin, q * 4); std::memcpy(h + oQmax, qmax, q * 4);
-      if (qactive) std::memcpy(h + oQact, qactive, q);
-      if (withUr) std::memcpy(h + oQur, qur, q * 4);
-      if (withDesc) std::memcpy(h + oQdesc, qdesc, q * 32);
+    for (int j = 0; j < nJobs; j++) {
+      const WindowJob& J = jobs[j];
+      const Lay& L = lay[j];
+      const size_t n = (size_t)J.f->n, q = (size_t)J.nq;
+      if (!L.res && n) {
+        std::memcpy(h + L.oX, J.f->x, n * 4); std::memcpy(h + L.oY, J.f->y, n * 4); std::memcpy(h + L.oOct, J.f->octave, n * 4);
+        if (J.f->u_right) std::memcpy(h + L.oUr, J.f->u_right, n * 4);
+        if (L.withDesc) std::memcpy(h + L.oDesc, J.f->desc, n * 32);
+      }
+      if (q) {
+        std::memcpy(h + L.oQx, J.qx, q * 4); std::memcpy(h + L.oQy, J.qy, q * 4); std::memcpy(h + L.oQr, J.qr, q * 4);
+        std::memcpy(h + L.oQmin, J.qmin, q * 4); std::memcpy(h + L.oQmax, J.qmax, q * 4);
+        if (J.qactive) std::memcpy(h + L.oQact, J.qactive, q);
+        if (L.withUr) std::memcpy(h + L.oQur, J.qur, q * 4);
+        if (L.withDesc) std::memcpy(h + L.oQdesc, J.qdesc, q * 32);
+      }
     }
     uint8_t* din = carve<uint8_t>(ar, inBytes);
     MHIP(hipMemcpyAsync(din, h, inBytes, hipMemcpyHostToDevice, ar->stream));
-    GridFrame g{};
-    g.x = reinterpret_cast<const float*>(din + oX); g.y = reinterpret_cast<const float*>(din + oY);
-    g.octave = reinterpret_cast<const int32_t*>(din + oOct);
-    g.uRight = f->u_right ? reinterpret_cast<const float*>(din + oUr) : nullptr;
-    g.desc = withDesc ? din + oDesc : nullptr;
-    g.n = f->n;
-    g.minX = f->min_x; g.minY = f->min_y;
-    g.wInv = 64.0f / (f->max_x - f->min_x);  // src/Frame.cc:109-110 (FRAME_GRID_COLS / ROWS)
-    g.hInv = 48.0f / (f->max_y - f->min_y);
-    uint32_t* dkey = carve<uint32_t>(ar, n ? n : 1);
-    int32_t* dcell = carve<int32_t>(ar, 3073);
-    launch_grid_build(ar->stream, g, dkey, dcell);
-    MHIP(hipGetLastError());
-    WindowQueries wq{};
-    wq.x = reinterpret_cast<const float*>(din + oQx); wq.y = reinterpret_cast<const float*>(din + oQy);
-    wq.r = reinterpret_cast<const float*>(din + oQr);
-    wq.minLevel = reinterpret_cast<const int32_t*>(din + oQmin); wq.maxLevel = reinterpret_cast<const int32_t*>(din + oQmax);
-    wq.active = qactive ? din + oQact : nullptr;
-    wq.ur = withUr ? reinterpret_cast<const float*>(din + oQur) : nullptr;
-    wq.desc = withDesc ? din + oQdesc : nullptr;
-    wq.n = nq; wq.K = K;
-    // counts and candidate lists are adjacent: one copy back
-    uint8_t* dout = carve<uint8_t>(ar, outBytes);
-    int32_t* dcount = reinterpret_cast<int32_t*>(dout);
-    uint32_t* dcand = reinterpret_cast<uint32_t*>(dout + pad(q * 4));
-    launch_window_search(ar->stream, g, dkey, dcell, wq, dcount, dcand);
-    MHIP(hipGetLastError());
-    res->count.assign(q, 0);
-    res->cand.resize(q * (size_t)K);
-    res->K = K;
-    if (nq > 0) MHIP(hipMemcpyAsync(h, dout, pad(q * 4) + q * (size_t)K * 4, hipMemcpyDeviceToHost, ar->stream));
-    MHIP(hipStreamSynchronize(ar->stream));
-    if (nq > 0) {
-      std::memcpy(res->count.data(), h, q * 4);
-      std::memcpy(res->cand.data(), h + pad(q * 4), q * (size_t)K * 4);
+    uint8_t* dgrid = carve<uint8_t>(ar, gridBytes ? gridBytes : 1);
+    uint8_t* dout = carve<uint8_t>(ar, outBytes ? outBytes : 1);
+    size_t goff = 0;
+    for (int j = 0; j < nJobs; j++) {
+      const WindowJob& J = jobs[j];
+      const Lay& L = lay[j];
+      const size_t n = (size_t)J.f->n, q = (size_t)J.nq;
+      GridFrame g{};
+      const uint32_t* dkey;
+      const int32_t* dcell;
+      if (L.res) {
+        const orbfe_frame* R = J.f->resident;
+        g.x = R->dx; g.y = R->dy; g.octave = R->doct; g.uRight = J.f->u_right ? R->dur : nullptr;
+        g.desc = L.withDesc ? R->ddesc : nullptr;
+        dkey = R->dkey; dcell = R->dcell;
+      } else {
+        g.x = reinterpret_cast<const float*>(din + L.oX); g.y = reinterpret_cast<const float*>(din + L.oY);
+        g.octave = reinterpret_cast<const int32_t*>(din + L.oOct);
+        g.uRight = J.f->u_right ? reinterpret_cast<const float*>(din + L.oUr) : nullptr;
+        g.desc = L.withDesc ? din + L.oDesc : nullptr;
+      }
+      g.n = J.f->n;
+      g.minX = J.f->min_x; g.minY = J.f->min_y;
+      g.wInv = 64.0f / (J.f->max_x - J.f->min_x);  // src/Frame.cc:109-110 (FRAME_GRID_COLS / ROWS)
+      g.hInv = 48.0f / (J.f->max_y - J.f->min_y);
+      if (!L.res) {
+        uint32_t* k = reinterpret_cast<uint32_t*>(dgrid + goff);
+        goff += pad(n * 4);
+        int32_t* c = reinterpret_cast<int32_t*>(dgrid + goff);
+        goff += pad(3073 * 4);
+        launch_grid_build(ar->stream, g, k, c);
+        MHIP(hipGetLastError());
+        dkey = k; dcell = c;
+      }
+      WindowQueries wq{};
+      wq.x = reinterpret_cast<const float*>(din + L.oQx); wq.y = reinterpret_cast<const float*>(din + L.oQy);
+      wq.r = reinterpret_cast<const float*>(din + L.oQr);
+      wq.minLevel = reinterpret_cast<const int32_t*>(din + L.oQmin); wq.maxLevel = reinterpret_cast<const int32_t*>(din + L.oQmax);
+      wq.active = J.qactive ? din + L.oQact : nullptr;
+      wq.ur = L.withUr ? reinterpret_cast<const float*>(din + L.oQur) : nullptr;
+      wq.desc = L.withDesc ? din + L.oQdesc : nullptr;
+      wq.n = J.nq; wq.K = K;
+      // counts and candidate lists of a job are adjacent, the jobs' blocks too: one copy back
+      int32_t* dcount = reinterpret_cast<int32_t*>(dout + L.oOut);
+      uint32_t* dcand = reinterpret_cast<uint32_t*>(dout + L.oOut + pad(q * 4));
+      launch_window_search(ar->stream, g, dkey, dcell, wq, dcount, dcand);
+      MHIP(hipGetLastError());
     }
+    if (outBytes) MHIP(hipMemcpyAsync(h, dout, outBytes, hipMemcpyDeviceToHost, ar->stream));
+    MHIP(hipStreamSynchronize(ar->stream));
     int mx = 0;
-    for (int i = 0; i < nq; i++) mx = res->count[i] > mx ? res->count[i] : mx;
+    for (int j = 0; j < nJobs; j++) {
+      const size_t q = (size_t)jobs[j].nq;
+      WindowResult* res = jobs[j].res;
+      res->count.assign(q, 0);
+      res->cand.resize(q * (size_t)K);
+      res->K = K;
+      if (q) {
+        std::memcpy(res->count.data(), h + lay[j].oOut, q * 4);
+        std::memcpy(res->cand.data(), h + lay[j].oOut + pad(q * 4), q * (size_t)K * 4);
+      }
+      for (size_t i = 0; i < q; i++) mx = res->count[i] > mx ? res->count[i] : mx;
+    }
     if (mx <= K) return ORBFE_OK;
     K = mx;  // a window held more features than the list: search again with room for the largest
   }
+}
+
+int window_search(int device, const orbfe_frame_view* f, int nq, const float* qx, const float* qy, const float* qr,
+                  const int32_t* qmin, const int32_t* qmax, const uint8_t* qactive, const float* qur,
+                  const uint8_t* qdesc, int K0, WindowResult* res) {
+  WindowJob j{f, nq, qx, qy, qr, qmin, qmax, qactive, qur, qdesc, res};
+  return window_search_multi(device, &j, 1, K0);
 }
 
 // ComputeThreeMaxima, src/ORBmatcher.cc:1635-1690, over bin sizes
@@ -570,6 +911,7 @@ void three_maxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, in
 extern "C" int orbfe_features_in_area(int device, const orbfe_frame_view* frame, int n_queries, const float* x,
                                       const float* y, const float* r, const int32_t* min_level,
                                       const int32_t* max_level, int capacity, int32_t* count, int32_t* indices) {
+  frame = canon(frame);
   if (!frame_ok(frame) || n_queries < 0 || capacity < 0 ||
       (n_queries > 0 && (!x || !y || !r || !min_level || !max_level || !count || (capacity > 0 && !indices))))
     return mfail(ORBFE_ERR_INVALID, "features_in_area: bad argument");
@@ -595,6 +937,7 @@ extern "C" int orbfe_search_by_projection(int device, const orbfe_frame_view* F,
                                           const float* proj_y, const float* proj_xr, const uint8_t* mp_desc,
                                           const uint8_t* mp_obs_positive, float th, float nnratio, int32_t* match,
                                           int32_t* n_matches) {
+  F = canon(F);
   if (!frame_ok(F) || !scale_factors || n_levels <= 0 || n_mp < 0 || !n_matches || (F->n > 0 && (!match || !F->desc)) ||
       (n_mp > 0 && (!in_view || !level || !view_cos || !proj_x || !proj_y || !mp_desc)) || (F->u_right && n_mp > 0 && !proj_xr))
     return mfail(ORBFE_ERR_INVALID, "search_by_projection: bad argument");
@@ -654,6 +997,7 @@ extern "C" int orbfe_search_by_projection_last_frame(int device, const orbfe_fra
                                                      const uint8_t* mp_desc, const uint8_t* obs_positive, int mode,
                                                      float th, int check_orientation, int32_t* match_cur,
                                                      int32_t* n_matches) {
+  Cur = canon(Cur);
   if (!frame_ok(Cur) || !scale_factors || n_levels <= 0 || n_last < 0 || !n_matches || mode < 0 || mode > 2 ||
       (Cur->n > 0 && (!match_cur || !Cur->desc)) || (check_orientation && Cur->n > 0 && !Cur->angle) ||
       (n_last > 0 && (!valid || !u || !v || !last_octave || !mp_desc || (check_orientation && !last_angle))) ||
@@ -761,6 +1105,7 @@ extern "C" int orbfe_search_by_projection_keyframe(int device, const orbfe_frame
                                                    const float* kf_angle, const uint8_t* mp_desc, float th,
                                                    int orb_dist, int check_orientation, int32_t* match_cur,
                                                    int32_t* n_matches) {
+  Cur = canon(Cur);
   if (!frame_ok(Cur) || !scale_factors || n_levels <= 0 || n < 0 || !n_matches ||
       (Cur->n > 0 && (!match_cur || !Cur->desc)) || (check_orientation && Cur->n > 0 && !Cur->angle) ||
       (n > 0 && (!valid || !u || !v || !level || !mp_desc || (check_orientation && !kf_angle))))
@@ -812,6 +1157,7 @@ extern "C" int orbfe_search_by_projection_sim3(int device, const orbfe_frame_vie
                                                int n_levels, const uint8_t* matched, int n, const uint8_t* valid,
                                                const float* u, const float* v, const int32_t* level,
                                                const uint8_t* mp_desc, float th, int32_t* match, int32_t* n_matches) {
+  KF = canon(KF);
   if (!frame_ok(KF) || !scale_factors || n_levels <= 0 || n < 0 || !n_matches || (KF->n > 0 && (!match || !KF->desc)) ||
       (n > 0 && (!valid || !u || !v || !level || !mp_desc)))
     return mfail(ORBFE_ERR_INVALID, "search_by_projection_sim3: bad argument");
@@ -849,6 +1195,8 @@ extern "C" int orbfe_search_by_projection_sim3(int device, const orbfe_frame_vie
 extern "C" int orbfe_search_for_initialization(int device, const orbfe_frame_view* F1, const orbfe_frame_view* F2,
                                                float* prev_x, float* prev_y, int window_size, float nnratio,
                                                int check_orientation, int32_t* match12, int32_t* n_matches) {
+  F1 = canon(F1);
+  F2 = canon(F2);
   if (!frame_ok(F1) || !frame_ok(F2) || !n_matches || window_size < 0 ||
       (F1->n > 0 && (!match12 || !prev_x || !prev_y || !F1->desc)) || (F2->n > 0 && !F2->desc) ||
       (check_orientation && ((F1->n > 0 && !F1->angle) || (F2->n > 0 && !F2->angle))))
@@ -907,52 +1255,105 @@ extern "C" int orbfe_search_for_initialization(int device, const orbfe_frame_vie
 
 namespace {
 // best keypoint of every window with octave in [level-1, level] (first minimum in scan order), the
-// inner search shared by Fuse x2 and SearchBySim3; gate = chi-square test of Fuse (src/ORBmatcher.cc:1029-1060)
+// inner search shared by Fuse x2 and SearchBySim3; gate = chi-square test of Fuse (src/ORBmatcher.cc:1029-1060).
+// Several (key frame, projected points) jobs of one call run as ONE window_search_multi group.
+struct BestJob {
+  const orbfe_frame_view* KF;
+  const float* sf; const float* inv_level_sigma2;
+  int n;
+  const uint8_t* valid; const float *u, *v, *ur; const int32_t* level; const uint8_t* desc;
+  int32_t* best;
+};
+int window_best_multi(const char* who, int device, BestJob* jobs, int nJobs, int n_levels, float th, bool gate, int max_dist) {
+  std::vector<std::vector<float>> qr((size_t)nJobs);
+  std::vector<std::vector<int32_t>> qmin((size_t)nJobs), qmax((size_t)nJobs);
+  std::vector<WindowResult> res((size_t)nJobs);
+  std::vector<WindowJob> wj;
+  std::vector<int> jobOf;
+  for (int j = 0; j < nJobs; j++) {
+    BestJob& J = jobs[j];
+    int rc = level_queries(who, J.n, J.valid, J.level, J.sf, n_levels, th, -1, 0, false, &qr[j], &qmin[j], &qmax[j]);
+    if (rc != ORBFE_OK) return rc;
+    for (int i = 0; i < J.n; i++) J.best[i] = -1;
+    if (J.n == 0 || J.KF->n == 0) continue;
+    wj.push_back(WindowJob{J.KF, J.n, J.u, J.v, qr[j].data(), qmin[j].data(), qmax[j].data(), J.valid, nullptr, J.desc, &res[j]});
+    jobOf.push_back(j);
+  }
+  if (wj.empty()) return ORBFE_OK;
+  int rc = window_search_multi(device, wj.data(), (int)wj.size(), 32);
+  if (rc != ORBFE_OK) return rc;
+  for (int j : jobOf) {
+    const BestJob& J = jobs[j];
+    const WindowResult& R = res[j];
+    const orbfe_frame_view* KF = J.KF;
+    for (int i = 0; i < J.n; i++) {
+      if (!J.valid[i]) continue;
+      int bestDist = 256, bestIdx = -1;
+      for (int c = 0; c < R.count[i]; c++) {
+        const uint32_t e = R.cand[(size_t)i * R.K + c];
+        const int idx = (int)(e & 0xffffu), dist = (int)(e >> 16);
+        if (gate) {
+          const int kpLevel = KF->octave[idx];
+          const float kpx = KF->x[idx], kpy = KF->y[idx];
+          if (KF->u_right && KF->u_right[idx] >= 0) {
+            const float kpr = KF->u_right[idx];
+            const float ex = J.u[i] - kpx, ey = J.v[i] - kpy, er = J.ur[i] - kpr;
+            const float e2 = ex * ex + ey * ey + er * er;
+            if (e2 * J.inv_level_sigma2[kpLevel] > 7.8) continue;
+          } else {
+            const float ex = J.u[i] - kpx, ey = J.v[i] - kpy;
+            const float e2 = ex * ex + ey * ey;
+            if (e2 * J.inv_level_sigma2[kpLevel] > 5.99) continue;
+          }
+        }
+        if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+      }
+      if (bestDist <= max_dist) J.best[i] = bestIdx;
+    }
+  }
+  return ORBFE_OK;
+}
 int window_best(const char* who, int device, const orbfe_frame_view* KF, const float* sf, int n_levels,
                 const float* inv_level_sigma2, int n, const uint8_t* valid, const float* u, const float* v,
                 const float* ur, const int32_t* level, const uint8_t* desc, float th, bool gate, int max_dist,
                 int32_t* best) {
-  std::vector<float> qr;
-  std::vector<int32_t> qmin, qmax;
-  int rc = level_queries(who, n, valid, level, sf, n_levels, th, -1, 0, false, &qr, &qmin, &qmax);
-  if (rc != ORBFE_OK) return rc;
-  for (int i = 0; i < n; i++) best[i] = -1;
-  if (n == 0 || KF->n == 0) return ORBFE_OK;
-  WindowResult res;
-  rc = window_search(device, KF, n, u, v, qr.data(), qmin.data(), qmax.data(), valid, nullptr, desc, 32, &res);
-  if (rc != ORBFE_OK) return rc;
-  for (int i = 0; i < n; i++) {
-    if (!valid[i]) continue;
-    int bestDist = 256, bestIdx = -1;
-    for (int c = 0; c < res.count[i]; c++) {
-      const uint32_t e = res.cand[(size_t)i * res.K + c];
-      const int idx = (int)(e & 0xffffu), dist = (int)(e >> 16);
-      if (gate) {
-        const int kpLevel = KF->octave[idx];
-        const float kpx = KF->x[idx], kpy = KF->y[idx];
-        if (KF->u_right && KF->u_right[idx] >= 0) {
-          const float kpr = KF->u_right[idx];
-          const float ex = u[i] - kpx, ey = v[i] - kpy, er = ur[i] - kpr;
-          const float e2 = ex * ex + ey * ey + er * er;
-          if (e2 * inv_level_sigma2[kpLevel] > 7.8) continue;
-        } else {
-          const float ex = u[i] - kpx, ey = v[i] - kpy;
-          const float e2 = ex * ex + ey * ey;
-          if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
-        }
-      }
-      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
-    }
-    if (bestDist <= max_dist) best[i] = bestIdx;
-  }
-  return ORBFE_OK;
+  BestJob j{KF, sf, inv_level_sigma2, n, valid, u, v, ur, level, desc, best};
+  return window_best_multi(who, device, &j, 1, n_levels, th, gate, max_dist);
 }
 }  // namespace
+
+// The per-point search of ORBmatcher::Fuse for the SAME map points against K key frames in one call: what
+// LocalMapping::SearchInNeighbors does neighbour by neighbour (src/LocalMapping.cc:542-549: matcher.Fuse(pKFi,
+// vpMapPointMatches) for every target key frame).  Arrays are [k * n + i]; mp_desc [n * 32] is shared.
+extern "C" int orbfe_fuse_search_multi(int device, int n_keyframes, const orbfe_frame_view* const* KF,
+                                       const float* scale_factors, const float* inv_level_sigma2, int n_levels, int n,
+                                       const uint8_t* valid, const float* u, const float* v, const float* ur,
+                                       const int32_t* level, const uint8_t* mp_desc, float th, int chi2_gate,
+                                       int32_t* best_idx) {
+  if (n_keyframes < 0 || n < 0 || !scale_factors || n_levels <= 0 || (n_keyframes > 0 && !KF) ||
+      (n_keyframes > 0 && n > 0 && (!valid || !u || !v || !level || !mp_desc || !best_idx)) || (chi2_gate && !inv_level_sigma2))
+    return mfail(ORBFE_ERR_INVALID, "fuse_search_multi: bad argument");
+  std::vector<BestJob> jobs;
+  for (int k = 0; k < n_keyframes; k++) {
+    const orbfe_frame_view* f = canon(KF[k]);
+    if (!frame_ok(f) || (f->n > 0 && !f->desc) || (chi2_gate && f->u_right && n > 0 && !ur))
+      return mfail(ORBFE_ERR_INVALID, "fuse_search_multi: bad key frame view");
+    for (int i = 0; i < f->n; i++)
+      if (chi2_gate && (f->octave[i] < 0 || f->octave[i] >= n_levels))
+        return mfail(ORBFE_ERR_INVALID, "fuse_search_multi: keypoint octave outside the pyramid");
+    const size_t o = (size_t)k * n;
+    jobs.push_back(BestJob{f, scale_factors, inv_level_sigma2, n, valid + o, u + o, v + o, ur ? ur + o : nullptr, level + o,
+                           mp_desc, best_idx + o});
+  }
+  if (jobs.empty()) return ORBFE_OK;
+  return window_best_multi("fuse_search_multi", device, jobs.data(), (int)jobs.size(), n_levels, th, chi2_gate != 0, 50 /* TH_LOW */);
+}
 
 extern "C" int orbfe_fuse_search(int device, const orbfe_frame_view* KF, const float* scale_factors,
                                  const float* inv_level_sigma2, int n_levels, int n, const uint8_t* valid,
                                  const float* u, const float* v, const float* ur, const int32_t* level,
                                  const uint8_t* mp_desc, float th, int chi2_gate, int32_t* best_idx) {
+  KF = canon(KF);
   if (!frame_ok(KF) || !scale_factors || n_levels <= 0 || n < 0 || (KF->n > 0 && !KF->desc) ||
       (n > 0 && (!valid || !u || !v || !level || !mp_desc || !best_idx)) ||
       (chi2_gate && (!inv_level_sigma2 || (KF->u_right && n > 0 && !ur))))
@@ -970,16 +1371,17 @@ extern "C" int orbfe_search_by_sim3(int device, const orbfe_frame_view* KF1, con
                                     const uint8_t* desc1, const uint8_t* valid2, const float* u2, const float* v2,
                                     const int32_t* level2, const uint8_t* desc2, float th, int32_t* match12,
                                     int32_t* n_found) {
+  KF1 = canon(KF1);
+  KF2 = canon(KF2);
   if (!frame_ok(KF1) || !frame_ok(KF2) || !scale_factors1 || !scale_factors2 || n_levels <= 0 || !n_found ||
       (KF1->n > 0 && (!valid1 || !u1 || !v1 || !level1 || !desc1 || !match12 || !KF1->desc)) ||
       (KF2->n > 0 && (!valid2 || !u2 || !v2 || !level2 || !desc2 || !KF2->desc)))
     return mfail(ORBFE_ERR_INVALID, "search_by_sim3: bad argument");
   std::vector<int32_t> m1(KF1->n ? KF1->n : 1), m2(KF2->n ? KF2->n : 1);
-  int rc = window_best("search_by_sim3", device, KF2, scale_factors2, n_levels, nullptr, KF1->n, valid1, u1, v1, nullptr,
-                       level1, desc1, th, false, 100 /* TH_HIGH */, m1.data());
-  if (rc != ORBFE_OK) return rc;
-  rc = window_best("search_by_sim3", device, KF1, scale_factors1, n_levels, nullptr, KF2->n, valid2, u2, v2, nullptr,
-                   level2, desc2, th, false, 100, m2.data());
+  // both directions (src/ORBmatcher.cc:1190-1275 and :1277-1358) as one upload / launch group / download
+  BestJob jobs[2] = {{KF2, scale_factors2, nullptr, KF1->n, valid1, u1, v1, nullptr, level1, desc1, m1.data()},
+                     {KF1, scale_factors1, nullptr, KF2->n, valid2, u2, v2, nullptr, level2, desc2, m2.data()}};
+  int rc = window_best_multi("search_by_sim3", device, jobs, 2, n_levels, th, false, 100 /* TH_HIGH */);
   if (rc != ORBFE_OK) return rc;
   int nFound = 0;
   for (int i1 = 0; i1 < KF1->n; i1++) {

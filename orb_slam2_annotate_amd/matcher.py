@@ -45,7 +45,12 @@ class FrameView:
         self.bounds = tuple(float(b) for b in bounds)  # (mnMinX, mnMaxX, mnMinY, mnMaxY)
         self.c = FrameViewC(self.N, ptr(self.x), ptr(self.y), ptr(self.octave),
                             None if self.angle is None else ptr(self.angle),
-                            None if self.u_right is None else ptr(self.u_right), ptr(self.desc), *self.bounds)
+                            None if self.u_right is None else ptr(self.u_right), ptr(self.desc), *self.bounds, None)
+
+    def upload(self, fv: "FeatureVector | None" = None, device: int = 0) -> "ResidentFrame":
+        """orbfe_frame_upload: keypoint arrays, descriptors, grid (built once) and the FeatureVector's index list move to
+        the device; the returned handle can stand in for this view in every search and feeds the *_resident / *_multi ones."""
+        return ResidentFrame(self, fv, device)
 
     @classmethod
     def from_keypoints(cls, kps, desc, width, height, u_right=None):
@@ -75,6 +80,28 @@ class FrameView:
                 continue
             check(rc)
             return [idx[q, :count[q]].copy() for q in range(nq)]
+
+
+class ResidentFrame:
+    """Device-resident operands of a Frame / KeyFrame (include/orbfe.h orbfe_frame).  `.c` is the handle's own
+    orbfe_frame_view (host copies inside the handle, `resident` set), so an instance is accepted wherever a FrameView is."""
+
+    def __init__(self, view: FrameView, fv=None, device: int = 0):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        check(self._L.orbfe_frame_upload(device, C.byref(view.c), C.byref(fv.c) if fv is not None else None, C.byref(self._h)))
+        self.c = self._L.orbfe_frame_get_view(self._h).contents
+        self.N, self.device = view.N, device
+        # the searches' Python wrappers read these for the outputs' shapes only
+        self.x, self.y, self.octave, self.angle, self.u_right, self.desc, self.bounds = (view.x, view.y, view.octave, view.angle,
+                                                                                       view.u_right, view.desc, view.bounds)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.orbfe_frame_release(self._h)
+            self._h = None
+
+    __del__ = close
 
 
 def _f32(a):
@@ -133,6 +160,60 @@ class ORBmatcher:
                                                  ptr(desc2), ptr(m2), ptr(a2), n2, C.byref(fv2.c),
                                                  self.mfNNratio, int(self.mbCheckOrientation), ptr(out)))
         return n, out[:n1]
+
+    def SearchByBoWResident(self, kf: "ResidentFrame", has_mp1, f: "ResidentFrame", has_mp2=None):
+        """SearchByBoW on frames uploaded with their FeatureVector: KF-Frame form when has_mp2 is None, else KF-KF."""
+        m1 = _u8(has_mp1)
+        if has_mp2 is None:
+            out = np.full(max(f.N, 1), -1, dtype=np.int32)
+            n = check(self._L.orbfe_search_by_bow_resident(kf._h, ptr(m1), f._h, self.mfNNratio, int(self.mbCheckOrientation), ptr(out)))
+            return n, out[:f.N]
+        m2 = _u8(has_mp2)
+        out = np.full(max(kf.N, 1), -1, dtype=np.int32)
+        n = check(self._L.orbfe_search_by_bow_kf_resident(kf._h, ptr(m1), f._h, ptr(m2), self.mfNNratio,
+                                                          int(self.mbCheckOrientation), ptr(out)))
+        return n, out[:kf.N]
+
+    def SearchForTriangulationMulti(self, kf1: "ResidentFrame", has_mp1, neighbours, has_mp2_list, F12s, epipoles,
+                                    scale_factors2, level_sigma2_2, only_stereo: bool = False):
+        """SearchForTriangulation of kf1 against every neighbour in one call (LocalMapping::CreateNewMapPoints):
+        returns (n_matches[K], match12[K, n1])."""
+        K, n1 = len(neighbours), kf1.N
+        m1 = _u8(has_mp1)
+        masks = [_u8(m) for m in has_mp2_list]
+        hs = (C.c_void_p * max(K, 1))(*[nb._h for nb in neighbours])
+        ms = (C.c_void_p * max(K, 1))(*[m.ctypes.data for m in masks])
+        F = _f32(np.asarray(F12s, dtype=np.float32).reshape(K, 9))
+        ep = _f32(np.asarray(epipoles, dtype=np.float32).reshape(K, 2))
+        ex, ey = _f32(ep[:, 0]), _f32(ep[:, 1])
+        sf, sg = _f32(scale_factors2), _f32(level_sigma2_2)
+        out = np.full((max(K, 1), max(n1, 1)), -1, dtype=np.int32)
+        cnt = np.zeros(max(K, 1), dtype=np.int32)
+        check(self._L.orbfe_search_for_triangulation_multi(kf1._h, ptr(m1), K, hs, ms, ptr(F), ptr(ex), ptr(ey), ptr(sf), ptr(sg),
+                                                           len(sf), int(bool(only_stereo)), int(self.mbCheckOrientation),
+                                                           ptr(out), ptr(cnt)))
+        return cnt[:K], out[:K, :n1]
+
+    def FuseSearchMulti(self, KFs, scale_factors, valid, u, v, level, mp_desc, th: float = 3.0, inv_level_sigma2=None,
+                        ur=None):
+        """The per-point search of Fuse for the same map points against K key frames (views or resident frames):
+        valid / u / v / level / ur are [K, n]; returns best_idx[K, n]."""
+        K = len(KFs)
+        valid = _u8(np.asarray(valid).reshape(K, -1))
+        n = valid.shape[1] if K else 0
+        u, v = _f32(np.asarray(u).reshape(K, n)), _f32(np.asarray(v).reshape(K, n))
+        level = np.ascontiguousarray(np.asarray(level).reshape(K, n), dtype=np.int32)
+        sf = _f32(scale_factors)
+        d = _u8(mp_desc).reshape(-1, 32)
+        gate = inv_level_sigma2 is not None
+        isg = _f32(inv_level_sigma2) if gate else None
+        urr = _f32(np.asarray(ur).reshape(K, n)) if ur is not None else None
+        views = (C.POINTER(FrameViewC) * max(K, 1))(*[C.pointer(k.c) for k in KFs])
+        out = np.full((max(K, 1), max(n, 1)), -1, dtype=np.int32)
+        check(self._L.orbfe_fuse_search_multi(self.device, K, views, ptr(sf), ptr(isg) if gate else None, len(sf), n, ptr(valid),
+                                              ptr(u), ptr(v), ptr(urr) if urr is not None else None, ptr(level), ptr(d),
+                                              float(th), int(gate), ptr(out)))
+        return out[:K, :n]
 
     def SearchByProjection(self, F: FrameView, scale_factors, in_view, level, view_cos, proj_x, proj_y, mp_desc,
                            th: float = 1.0, proj_xr=None, blocked=None, mp_obs_positive=None):

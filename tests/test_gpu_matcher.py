@@ -294,3 +294,72 @@ def test_stereo_then_next_async_extract_does_not_race(amd):
             assert np.array_equal(d_u[k, p, :len(kL)].cpu().numpy(), u_ref), (k, p)
             assert np.array_equal(d_d[k, p, :len(kL)].cpu().numpy(), d_ref), (k, p)
             assert int(d_ns[k, p].item()) == int((u_ref >= 0).sum())
+
+
+def _resident(amd, k, d, nodes, u_right=None):
+    v = amd.FrameView(k["x"], k["y"], k["octave"], d, (0.0, 640.0, 0.0, 480.0), angle=k["angle"], u_right=u_right)
+    return v.upload(amd.FeatureVector.from_node_of_feature(nodes))
+
+
+@pytest.mark.parametrize("seed,ori", [(31, True), (32, False)])
+def test_search_by_bow_resident_frames(amd, seed, ori):
+    """SearchByBoW (KF, F) and (KF, KF) on frames uploaded once (orbfe_frame_upload): only the shared-node list, the
+    MapPoint masks and the result travel per call -- same outputs as the oracle; the handles are reused across calls."""
+    k1, d1, k2, d2 = _two_frames(amd, seed)
+    rng = np.random.default_rng(seed)
+    n1, n2 = _nodes(d1, 13, 60), _nodes(d2, 13, 60)
+    R1, R2 = _resident(amd, k1, d1, n1), _resident(amd, k2, d2, n2)
+    m = amd.ORBmatcher(0.7, ori)
+    for rep in range(3):  # masks change between calls (map points get created), the frames stay
+        has1 = (rng.random(len(k1)) < 0.6).astype(np.uint8)
+        has2 = (rng.random(len(k2)) < 0.6).astype(np.uint8)
+        rn, r = orc.search_by_bow(d1, has1, k1["angle"], orc.FeatVec(n1), d2, k2["angle"], orc.FeatVec(n2), 0.7, ori)
+        gn, g = m.SearchByBoWResident(R1, has1, R2)
+        assert rn == gn and np.array_equal(r, g)
+        rn, r = orc.search_by_bow_kf(d1, has1, k1["angle"], orc.FeatVec(n1), d2, has2, k2["angle"], orc.FeatVec(n2), 0.7, ori)
+        gn, g = m.SearchByBoWResident(R1, has1, R2, has_mp2=has2)
+        assert rn == gn and np.array_equal(r, g)
+        assert rn > 5
+    R1.close()
+    R2.close()
+
+
+@pytest.mark.parametrize("only_stereo,ori", [(False, True), (True, False)])
+def test_search_for_triangulation_multi(amd, only_stereo, ori):
+    """One key frame against K neighbours in ONE call (LocalMapping::CreateNewMapPoints, src/LocalMapping.cc:283-315): every
+    neighbour's match array equals the oracle's single-pair SearchForTriangulation; includes an empty neighbour and one
+    sharing no vocabulary node."""
+    o = orc.Oracle()
+    sf, sg = o.scale_factors(), o.level_sigma2()
+    k1, d1, _, _ = _two_frames(amd, 40)
+    rng = np.random.default_rng(40)
+    n1 = _nodes(d1, 13, 60)
+    ur1 = np.where(rng.random(len(k1)) < 0.5, k1["x"] - 5.0, -1.0).astype(np.float32)
+    has1 = (rng.random(len(k1)) < 0.4).astype(np.uint8)
+    R1 = _resident(amd, k1, d1, n1, ur1)
+    neigh, masks, Fs, eps, refs = [], [], [], [], []
+    for k in range(6):
+        _, _, k2, d2 = _two_frames(amd, 41 + k)
+        if k == 4:
+            k2, d2 = k2[:0], d2[:0]  # a neighbour without keypoints
+        n2 = _nodes(d2, 13, 60) if len(d2) else np.zeros(0, np.int64)
+        if k == 5:
+            n2 = n2 + 1000  # no node in common
+        ur2 = np.where(rng.random(len(k2)) < 0.5, k2["x"] - 4.0, -1.0).astype(np.float32)
+        has2 = (rng.random(len(k2)) < 0.4).astype(np.uint8)
+        F12 = (np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], dtype=np.float32) * (0.01 + 0.002 * k)).astype(np.float32)
+        ex, ey = 5000.0 - 100 * k, 240.0 + k
+        neigh.append(_resident(amd, k2, d2, n2, ur2))
+        masks.append(has2); Fs.append(F12); eps.append((ex, ey))
+        if len(d2):
+            refs.append(orc.search_for_triangulation(d1, has1, k1["x"], k1["y"], k1["angle"], (ur1 >= 0).astype(np.uint8),
+                                                     orc.FeatVec(n1), d2, has2, k2["x"], k2["y"], k2["angle"], k2["octave"],
+                                                     (ur2 >= 0).astype(np.uint8), orc.FeatVec(n2), F12, ex, ey, sf, sg,
+                                                     only_stereo, ori))
+        else:
+            refs.append((0, np.full(len(k1), -1, np.int32)))
+    cnt, match = amd.ORBmatcher(0.6, ori).SearchForTriangulationMulti(R1, has1, neigh, masks, Fs, eps, sf, sg, only_stereo)
+    for k in range(6):
+        assert int(cnt[k]) == refs[k][0], k
+        assert np.array_equal(match[k], refs[k][1]), k
+    assert sum(r[0] for r in refs) > 20 and refs[4][0] == 0 and refs[5][0] == 0

@@ -29,9 +29,24 @@ def _random_frame(rng, n, stereo=False, spread=5.0):
     return x, y, octv, ang, desc, ur
 
 
+RESIDENT = False
+
+
+@pytest.fixture(autouse=True, params=["host_arrays", "resident_frame"])
+def _frame_kind(request):
+    """every search of this file runs twice: on host-array views (everything uploaded per call) and on frames made
+    resident with orbfe_frame_upload (keypoints, descriptors and the grid already on the device)"""
+    global RESIDENT
+    RESIDENT = request.param == "resident_frame"
+    yield
+    RESIDENT = False
+
+
 def _both(amd, x, y, octv, ang, desc, ur, bounds=BOUNDS):
-    return (amd.FrameView(x, y, octv, desc, bounds, angle=ang, u_right=ur),
-            orc.Frame(x, y, octv, desc, bounds, angle=ang, u_right=ur))
+    F = amd.FrameView(x, y, octv, desc, bounds, angle=ang, u_right=ur)
+    if RESIDENT:
+        F = F.upload()
+    return F, orc.Frame(x, y, octv, desc, bounds, angle=ang, u_right=ur)
 
 
 @pytest.mark.parametrize("seed,n,bounds", [(0, 1000, BOUNDS), (1, 2300, (-12.5, 655.25, -8.0, 490.5)), (2, 1, BOUNDS),
@@ -298,3 +313,34 @@ def test_search_by_sim3(amd):
     n_got, got = amd.ORBmatcher(0.75).SearchBySim3(K1, K2, SF, SF, va1, u1, v1, l1, d1, va2, u2, v2, l2, d2, 7.5)
     assert (n_got, got.tolist()) == (n_ref, ref.tolist())
     assert n_ref > 100
+
+
+def test_fuse_search_multi(amd):
+    """The per-point search of Fuse for the same map points against K key frames in one call (LocalMapping::SearchInNeighbors,
+    src/LocalMapping.cc:542-549) == K single orbfe_fuse_search calls of the oracle; a mix of resident and host-array key frames."""
+    rng = np.random.default_rng(85)
+    K, n = 5, 1800
+    inv_sigma2 = (1.0 / (SF * SF)).astype(np.float32)
+    md = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    KFs, refs, U, V, UR, LV, VA = [], [], [], [], [], [], []
+    for k in range(K):
+        x, y, octv, ang, desc, ur = _random_frame(rng, 1200 + 100 * k, True, spread=0.0)
+        ur = np.where(ur > 0, ur, -1.0).astype(np.float32)
+        src = rng.integers(0, len(x), n)
+        desc[src[: n // 2]] = md[: n // 2] ^ (rng.integers(0, 256, (n // 2, 32), dtype=np.uint8) & rng.integers(0, 256, (n // 2, 32), dtype=np.uint8) &
+                                              rng.integers(0, 256, (n // 2, 32), dtype=np.uint8))
+        KF, Ko = _both(amd, x, y, octv, ang, desc, ur)
+        if k == 2 and RESIDENT:
+            KF = amd.FrameView(x, y, octv, desc, BOUNDS, angle=ang, u_right=ur)  # one host-array frame in the group
+        u = (x[src] + rng.normal(0, 1.2, n)).astype(np.float32)
+        v = (y[src] + rng.normal(0, 1.2, n)).astype(np.float32)
+        pur = np.where(ur[src] >= 0, ur[src] + rng.normal(0, 1.0, n), u - 10).astype(np.float32)
+        level = np.clip(octv[src] + rng.integers(0, 2, n), 0, 7).astype(np.int32)
+        valid = (rng.random(n) < 0.85).astype(np.uint8)
+        refs.append(orc.fuse_search(Ko, SF, inv_sigma2, valid, u, v, pur, level, md, 3.0, True))
+        KFs.append(KF); U.append(u); V.append(v); UR.append(pur); LV.append(level); VA.append(valid)
+    got = amd.ORBmatcher(0.6).FuseSearchMulti(KFs, SF, np.stack(VA), np.stack(U), np.stack(V), np.stack(LV), md, th=3.0,
+                                              inv_level_sigma2=inv_sigma2, ur=np.stack(UR))
+    for k in range(K):
+        assert got[k].tolist() == refs[k].tolist(), k
+    assert sum(int((r >= 0).sum()) for r in refs) > 500
