@@ -864,6 +864,7 @@ def main():
                     "euroc:<cam0 dir>,<cam1 dir>,<timestamps file> | tum:<sequence dir> (image lists as the reference's example mains "
                     "read them, orb_slam2_annotate_amd/datasets.py); default: $ORBFE_DATASET, else synthetic")
     ap.add_argument("--input-cache", default=None, help="directory for the rendered synthetic batches (.npy), reused when present")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-call latency block (tools/matcher_latency.py)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-in/host-out (PCIe-inclusive) rate of each workload")
     ap.add_argument("--e2e-chunk", type=int, default=0, help="frames per chunk of the pipelined host path (0 = 256)")
     ap.add_argument("--seq-scale", type=float, default=1.0, help="kitti_seq: scale factor on the sequence lengths")
@@ -966,6 +967,15 @@ def main():
                     out[k] = head[k]
             if len(results) > 1:
                 out["secondary"] = results[1:]
+            if world == 1 and not args.no_latency and not args.no_cpu_baseline:
+                # the live system's call pattern (one call at a time): tools/matcher_latency.py, GPU next to the CPU oracle
+                sys.path.insert(0, str(ROOT / "tools"))
+                import matcher_latency
+                rows = matcher_latency.measure(reps=12, verbose=False)
+                out["latency"] = {"what": "median ms of ONE call through the class-level API on a 1241x376 / 2000-feature frame (1000 projected "
+                                          "map points), GPU next to the CPU oracle on one core; 'resident' = frames uploaded once with "
+                                          "orbfe_frame_upload; multi-neighbour rows give the per-neighbour cost of one call",
+                                  "rows": rows}
             print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -107,6 +107,8 @@ struct orbfe_extractor {
   // constant device tables
   float4* d_patternF = nullptr;
   uint4* d_momentTab = nullptr;
+  uint8_t* d_hostIn = nullptr;      // input slab of the small host-batch path (frames at the caller's pitch)
+  size_t hostInBytes = 0;
   DescTile* d_descTiles = nullptr;  // tile form of the orientation + descriptor stage (k_desc_tiles.hip)
   int nDescTiles = 0;
   int descTilesMode = -1;           // -1: $ORBFE_DESC_TILES or the default (on for batches of more than 8 frames); 0 / 1 forced
@@ -804,6 +806,7 @@ extern "C" void orbfe_extractor_destroy(orbfe_extractor* e) {
   dfree(&e->d_stereoSorted);
   dfree(&e->d_stereoRec);
   dfree(&e->d_momentTab);
+  dfree(&e->d_hostIn);
   dfree(&e->d_umax);
   for (int r = 0; r < orbfe_extractor::kEvRing; r++)
     for (int u = 0; u < orbfe_extractor::kEvSubs; u++)
@@ -1004,16 +1007,31 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* images, in
   if ((rc = ensure_outputs(e, n_frames, capacity))) return rc;
   const FrameGeom& g = e->geom;
   next_event_slot(e);
+  LevelView l0{e->d_pyr + g.lv[0].off, g.pyrBytes, g.lv[0].pitch, width, height};
+  const bool tight = frame_stride == (size_t)stride * height || n_frames == 1;
   {
     StageTimer t(e, ORBFE_STAGE_H2D, 0, 0, 0, e->stream);
-    // level 0 lives at the head of the per-frame pyramid slab (pitch-aligned copy)
-    for (int f = 0; f < n_frames; f++)
-      HIPCHK(hipMemcpy2DAsync(e->d_pyr + (size_t)f * g.pyrBytes + g.lv[0].off, g.lv[0].pitch,
-                              images + (size_t)f * frame_stride, stride, width, height,
-                              hipMemcpyHostToDevice, e->stream));
+    if (tight && stride != g.lv[0].pitch) {
+      // ONE linear copy of the frames as they lie in host memory into an input slab of the caller's pitch, which the
+      // kernels read in place at any stride (like caller-owned device frames).  A 2-D copy of rows that are not a
+      // multiple of the DMA granule degenerates into one descriptor per row: 3.0 ms for ONE 1241 x 376 frame (0.15 GB/s)
+      // against 0.1 ms this way -- the live-camera latency of a KITTI frame was that copy.
+      const size_t bytes = (size_t)(n_frames - 1) * frame_stride + (size_t)(height - 1) * stride + width;
+      if (bytes > e->hostInBytes) {
+        if ((rc = dalloc(&e->d_hostIn, bytes + 64))) return rc;
+        e->hostInBytes = bytes;
+      }
+      HIPCHK(hipMemcpyAsync(e->d_hostIn, images, bytes, hipMemcpyHostToDevice, e->stream));
+      l0 = LevelView{e->d_hostIn, frame_stride, stride, width, height};
+    } else {
+      // level 0 lives at the head of the per-frame pyramid slab (pitch-aligned copy)
+      for (int f = 0; f < n_frames; f++)
+        HIPCHK(hipMemcpy2DAsync(e->d_pyr + (size_t)f * g.pyrBytes + g.lv[0].off, g.lv[0].pitch,
+                                images + (size_t)f * frame_stride, stride, width, height,
+                                hipMemcpyHostToDevice, e->stream));
+    }
   }
   HIPCHK(hipStreamSynchronize(e->stream));  // the sub-batch streams read the uploaded frames
-  LevelView l0{e->d_pyr + g.lv[0].off, g.pyrBytes, g.lv[0].pitch, width, height};
   if ((rc = run_pipeline(e, l0, n_frames, e->d_kpOut, e->d_descOut, capacity, e->d_nOut))) return rc;
   if ((rc = sync_all(e))) return rc;
   {

@@ -102,6 +102,7 @@ class ResidentFrame:
             self._h = None
 
     __del__ = close
+    GetFeaturesInArea = FrameView.GetFeaturesInArea  # (reads self.c only: no frame data travels)
 
 
 def _f32(a):

@@ -1,9 +1,15 @@
 #!/usr/bin/env python3
-"""Per-call latency of the ORBmatcher entry points as Tracking / LocalMapping call them: ONE call on host arrays
-(H2D of the operands, kernels, D2H of the result), median of `reps` calls, next to the CPU oracle's time for the same
-call (one core).  These calls are latency-bound by construction (a few thousand descriptors per call); the batched,
-device-resident forms are what bench.py measures.
-    python tools/matcher_latency.py [reps]"""
+"""Per-call latency of the ORBmatcher entry points as Tracking / LocalMapping call them, median of `reps` calls, next to
+the CPU oracle's time for the same call (one core):
+  * ONE call on host arrays (H2D of every operand, kernels, D2H of the result) -- what a drop-in without any change to the
+    callers pays;
+  * the same call on RESIDENT frames (orbfe_frame_upload once per Frame / KeyFrame: keypoints, descriptors, grid and
+    FeatureVector indices stay on the device);
+  * the multi-neighbour patterns of LocalMapping in ONE call: SearchForTriangulation of a key frame against 20 neighbours
+    (src/LocalMapping.cc:283-315), Fuse of its map points into 10 neighbours (:542-549) -- per-neighbour cost reported;
+  * one stereo frame through the class API: operator() on L and R (two handles, two threads, src/Frame.cc:78-81) +
+    ComputeStereoMatches.
+bench.py embeds measure() as its `latency` block.     python tools/matcher_latency.py [reps]"""
 import sys
 import time
 from pathlib import Path
@@ -38,11 +44,12 @@ def nodes_of(desc, seed, n_nodes=100):
     return (x[:, None, :] != c[None, :, :]).sum(axis=2).argmin(axis=1).astype(np.uint32)
 
 
-def main():
-    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+def measure(reps=30, verbose=True):
+    """-> list of dicts {call, gpu_ms, cpu_oracle_ms, [per_neighbour_gpu_ms]}"""
+    from concurrent.futures import ThreadPoolExecutor
     rng = np.random.default_rng(1)
     w, h, nf = 1241, 376, 2000
-    left, right = synth.render_stereo(3, w, h)
+    left, right = synth.render_stereo_textured(3, w, h)
     eL, eR = amd.ORBextractor(nf, 1.2, 8, 20, 7), amd.ORBextractor(nf, 1.2, 8, 20, 7)
     kL, dL = eL(left)
     kR, dR = eR(right)
@@ -51,15 +58,31 @@ def main():
     _, _, pR = o.extract(right, want_pyramid=True)
     rows = []
 
-    def row(name, gpu, cpu):
+    def row(name, gpu, cpu, per=1):
         g, c = med(gpu, reps), med(cpu, max(3, reps // 6))
-        rows.append((name, g, c))
-        print(f"{name:44s} GPU {g:7.3f} ms   CPU oracle {c:7.3f} ms   x{c / g:5.1f}", flush=True)
+        rows.append({"call": name, "gpu_ms": g, "cpu_oracle_ms": c, "units_per_call": per, "gpu_ms_per_unit": g / per,
+                     "cpu_ms_per_unit": c / per})
+        if verbose:
+            print(f"{name:58s} GPU {g:7.3f} ms   CPU oracle {c:7.3f} ms   x{c / g:5.1f}" +
+                  (f"   ({g / per:.4f} / {c / per:.4f} ms per neighbour)" if per > 1 else ""), flush=True)
 
-    print(f"frame: {w}x{h}, {len(kL)} / {len(kR)} keypoints; map points projected: 1000")
-    # --- stereo
+    if verbose:
+        print(f"frame: {w}x{h}, {len(kL)} / {len(kR)} keypoints; map points projected: 1000")
+    # --- one stereo frame through the class API: L || R on two handles + ComputeStereoMatches
     mbf = np.float32(386.1448)
     mb = np.float32(mbf / np.float32(718.856))
+    with ThreadPoolExecutor(2) as pool:
+        def gpu_frame():
+            fl, fr = pool.submit(eL, left), pool.submit(eR, right)
+            (a1, b1), (a2, b2) = fl.result(), fr.result()
+            return amd.ComputeStereoMatches(eL, eR, a1, b1, a2, b2, float(mbf), float(mb))
+        o2 = orc.Oracle(nf, 1.2, 8, 20, 7)
+        def cpu_frame():
+            fl, fr = pool.submit(o.extract, left, None, True), pool.submit(o2.extract, right, None, True)
+            (a1, b1, p1), (a2, b2, p2) = fl.result(), fr.result()
+            return o.stereo(w, h, a1, b1, a2, b2, p1, p2, float(mbf), float(mb))
+        row("stereo Frame: operator() L || R + ComputeStereoMatches", gpu_frame, cpu_frame)
+    # --- stereo
     row("ComputeStereoMatches", lambda: amd.ComputeStereoMatches(eL, eR, kL, dL, kR, dR, float(mbf), float(mb)),
         lambda: o.stereo(w, h, kL, dL, kR, dR, pL, pR, float(mbf), float(mb)))
     # --- BoW family
@@ -84,6 +107,25 @@ def main():
                                          kR["octave"], st2, fv2, F12, 5000.0, 240.0, sf, sg, False),
         lambda: orc.search_for_triangulation(dL, h1, kL["x"], kL["y"], kL["angle"], st1, fo1, dR, h2, kR["x"], kR["y"],
                                              kR["angle"], kR["octave"], st2, fo2, F12, 5000.0, 240.0, sf, sg, False, True))
+    # the same on frames made resident once
+    R1 = amd.FrameView(kL["x"], kL["y"], kL["octave"], dL, (0.0, float(w), 0.0, float(h)), angle=kL["angle"],
+                       u_right=np.where(st1 > 0, kL["x"] - 5, -1).astype(np.float32)).upload(fv1)
+    R2 = amd.FrameView(kR["x"], kR["y"], kR["octave"], dR, (0.0, float(w), 0.0, float(h)), angle=kR["angle"],
+                       u_right=np.where(st2 > 0, kR["x"] - 5, -1).astype(np.float32)).upload(fv2)
+    row("SearchByBoW(KeyFrame, Frame), resident", lambda: M.SearchByBoWResident(R1, has1, R2),
+        lambda: orc.search_by_bow(dL, has1, kL["angle"], fo1, dR, kR["angle"], fo2, 0.7, True))
+    row("SearchByBoW(KeyFrame, KeyFrame), resident", lambda: M.SearchByBoWResident(R1, has1, R2, has_mp2=has2),
+        lambda: orc.search_by_bow_kf(dL, has1, kL["angle"], fo1, dR, has2, kR["angle"], fo2, 0.7, True))
+    row("SearchForTriangulation, resident (1 neighbour)",
+        lambda: M.SearchForTriangulationMulti(R1, h1, [R2], [h2], [F12], [(5000.0, 240.0)], sf, sg, False),
+        lambda: orc.search_for_triangulation(dL, h1, kL["x"], kL["y"], kL["angle"], st1, fo1, dR, h2, kR["x"], kR["y"],
+                                             kR["angle"], kR["octave"], st2, fo2, F12, 5000.0, 240.0, sf, sg, False, True))
+    NB = 20  # CreateNewMapPoints: 20 neighbours for monocular, 10 for stereo (src/LocalMapping.cc:256-259)
+    row(f"SearchForTriangulation x {NB} neighbours, ONE call (resident)",
+        lambda: M.SearchForTriangulationMulti(R1, h1, [R2] * NB, [h2] * NB, [F12] * NB, [(5000.0, 240.0)] * NB, sf, sg, False),
+        lambda: [orc.search_for_triangulation(dL, h1, kL["x"], kL["y"], kL["angle"], st1, fo1, dR, h2, kR["x"], kR["y"],
+                                              kR["angle"], kR["octave"], st2, fo2, F12, 5000.0, 240.0, sf, sg, False, True)
+                 for _ in range(NB)], per=NB)
     # --- projection family: 1000 map points projected into the right frame
     x, y, octv, ang = kR["x"].copy(), kR["y"].copy(), kR["octave"].astype(np.int32), kR["angle"].copy()
     bounds = (0.0, float(w), 0.0, float(h))
@@ -115,9 +157,41 @@ def main():
     inv_s2 = (1.0 / (SF * SF)).astype(np.float32)
     row("Fuse", lambda: M.FuseSearch(F, SF, valid, u, v, lv, md, th=th, inv_level_sigma2=inv_s2, ur=pxr),
         lambda: orc.fuse_search(Fo, SF, inv_s2, valid, u, v, pxr, lv, md, th, True))
-    print("| call | GPU ms | CPU oracle ms |\n|---|---|---|")
-    for name, g, c in rows:
-        print(f"| `{name}` | {g:.3f} | {c:.3f} |")
+    FR = F.upload()
+    row("SearchByProjection(Frame, MapPoints), resident", lambda: M.SearchByProjection(FR, SF, valid, lv, vc, u, v, md, th=th, proj_xr=pxr),
+        lambda: orc.search_by_projection_mappoints(Fo, SF, None, valid, lv, vc, u, v, pxr, md, None, th, 0.7))
+    row("SearchByProjection(Frame, LastFrame), resident",
+        lambda: M.SearchByProjectionLastFrame(FR, SF, valid, u, v, lv, a, md, 7.0, mode=0, mbf=40.0, invzc=invz),
+        lambda: orc.search_by_projection_lastframe(Fo, SF, 40.0, valid, u, v, invz, lv, a, md, None, 0, 7.0, True))
+    row("SearchByProjection(Frame, KeyFrame) reloc, resident", lambda: M.SearchByProjectionKeyFrame(FR, SF, valid, u, v, lv, a, md, th, 100),
+        lambda: orc.search_by_projection_reloc(Fo, SF, valid, u, v, lv, a, md, None, th, 100, True))
+    row("SearchByProjection(KeyFrame, Scw) Sim3, resident", lambda: M.SearchByProjectionSim3(FR, SF, valid, u, v, lv, md, th),
+        lambda: orc.search_by_projection_sim3(Fo, SF, valid, u, v, lv, md, None, th))
+    row("Fuse, resident", lambda: M.FuseSearch(FR, SF, valid, u, v, lv, md, th=th, inv_level_sigma2=inv_s2, ur=pxr),
+        lambda: orc.fuse_search(Fo, SF, inv_s2, valid, u, v, pxr, lv, md, th, True))
+    NK = 10  # SearchInNeighbors: the current key frame's map points fused into every neighbour (src/LocalMapping.cc:542-549)
+    st = lambda a_: np.stack([a_] * NK)  # noqa: E731
+    row(f"Fuse into {NK} neighbours, ONE call (resident)",
+        lambda: M.FuseSearchMulti([FR] * NK, SF, st(valid), st(u), st(v), st(lv), md, th=th, inv_level_sigma2=inv_s2, ur=st(pxr)),
+        lambda: [orc.fuse_search(Fo, SF, inv_s2, valid, u, v, pxr, lv, md, th, True) for _ in range(NK)], per=NK)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        F.upload(fv2).close()
+    rows.append({"call": "orbfe_frame_upload + release (2000 keypoints, FeatureVector, grid build)", "gpu_ms": 1e2 * (time.perf_counter() - t0),
+                 "cpu_oracle_ms": None, "units_per_call": 1})
+    if verbose:
+        print(f"{rows[-1]['call']:58s} GPU {rows[-1]['gpu_ms']:7.3f} ms")
+    return rows
+
+
+def main():
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    rows = measure(reps)
+    print("| call | GPU ms | CPU oracle ms | GPU ms per neighbour |\n|---|---|---|---|")
+    for r in rows:
+        c = "" if r["cpu_oracle_ms"] is None else f"{r['cpu_oracle_ms']:.3f}"
+        pn = f"{r['gpu_ms_per_unit']:.4f}" if r["units_per_call"] > 1 else ""
+        print(f"| `{r['call']}` | {r['gpu_ms']:.3f} | {c} | {pn} |")
 
 
 if __name__ == "__main__":
