@@ -147,10 +147,23 @@ class FrameArrays {
     c.u_right = uRight.empty() ? nullptr : uRight.data();
     c.desc = desc.data();
     c.min_x = mnMinX; c.max_x = mnMaxX; c.min_y = mnMinY; c.max_y = mnMaxY;
+    c.resident = nullptr;
   }
+  ~FrameArrays() { if (resident_) orbfe_frame_release(resident_); }
   FrameArrays(const FrameArrays&) = delete;
   FrameArrays& operator=(const FrameArrays&) = delete;
   int N() const { return c.n; }
+
+  // Move this frame's operands to the device ONCE (keypoint arrays, descriptors, the 64 x 48 grid, and -- for the
+  // FeatureVector searches -- mFeatVec's index list): every later search on this object uploads nothing of the frame.
+  // Call it where the reference fills the object for good: at the end of the Frame constructor / in
+  // KeyFrame::ComputeBoW (src/KeyFrame.cc:64-73).  A KeyFrame is matched against 10-20 neighbours per insertion.
+  void makeResident(const FeatureVectorCSR* mFeatVec = nullptr, int device = 0) {
+    if (resident_) { orbfe_frame_release(resident_); resident_ = nullptr; c.resident = nullptr; }
+    check(orbfe_frame_upload(device, &c, mFeatVec ? &mFeatVec->c : nullptr, &resident_), "FrameArrays::makeResident");
+    c.resident = resident_;
+  }
+  const orbfe_frame* resident() const { return resident_; }
 
   // vector<size_t> Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel) const
   std::vector<size_t> GetFeaturesInArea(float qx, float qy, float r, int minLevel = -1, int maxLevel = -1,
@@ -172,6 +185,9 @@ class FrameArrays {
   std::vector<uint8_t> desc;
   std::vector<float> uRight;
   orbfe_frame_view c;
+
+ private:
+  orbfe_frame* resident_ = nullptr;
 };
 
 class ORBmatcher {
@@ -287,6 +303,48 @@ class ORBmatcher {
     for (int i = 0; i < n1; i++)  // :920-925: ascending idx1
       if (match12[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)match12[i]));
     return rc;
+  }
+
+  // The loop of LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:283-315) in ONE call: SearchForTriangulation of
+  // pKF1 against every neighbour.  All frames resident (makeResident with their mFeatVec).  F12s[k] / epipoles[k] as the
+  // single-pair form takes them; vMatchedPairs[k] = the pairs of neighbour k (ascending idx1).
+  void SearchForTriangulationMulti(const FrameArrays& KF1, const std::vector<uint8_t>& hasMp1,
+                                   const std::vector<const FrameArrays*>& neighbours,
+                                   const std::vector<const std::vector<uint8_t>*>& hasMp2, const std::vector<float>& F12s /* 9 per neighbour */,
+                                   const std::vector<float>& ex, const std::vector<float>& ey,
+                                   const std::vector<float>& mvScaleFactors2, const std::vector<float>& mvLevelSigma2_2,
+                                   std::vector<std::vector<std::pair<size_t, size_t> > >& vMatchedPairs, bool bOnlyStereo) {
+    const int K = (int)neighbours.size(), n1 = KF1.N();
+    std::vector<const orbfe_frame*> fr(K > 0 ? K : 1, nullptr);
+    std::vector<const uint8_t*> mk(K > 0 ? K : 1, nullptr);
+    for (int k = 0; k < K; k++) { fr[k] = neighbours[k]->resident(); mk[k] = hasMp2[k]->data(); }
+    std::vector<int32_t> match((size_t)(K > 0 ? K : 1) * (n1 > 0 ? n1 : 1), -1), cnt(K > 0 ? K : 1, 0);
+    check(orbfe_search_for_triangulation_multi(KF1.resident(), hasMp1.data(), K, fr.data(), mk.data(), F12s.data(), ex.data(),
+                                               ey.data(), mvScaleFactors2.data(), mvLevelSigma2_2.data(),
+                                               (int)mvScaleFactors2.size(), bOnlyStereo, mbCheckOrientation, match.data(), cnt.data()),
+          "SearchForTriangulationMulti");
+    vMatchedPairs.assign(K, std::vector<std::pair<size_t, size_t> >());
+    for (int k = 0; k < K; k++)
+      for (int i = 0; i < n1; i++)
+        if (match[(size_t)k * n1 + i] >= 0) vMatchedPairs[k].push_back(std::make_pair((size_t)i, (size_t)match[(size_t)k * n1 + i]));
+  }
+
+  // The per-point search of Fuse for the SAME map points against K key frames in one call (LocalMapping::SearchInNeighbors,
+  // src/LocalMapping.cc:542-549): per-key-frame arrays are [k * n + i] (the caller's projection prologue per key frame,
+  // src/ORBmatcher.cc:960-1020); bestIdx[k * n + i] = keypoint of key frame k chosen for point i, or -1.
+  void FuseSearchMulti(const std::vector<const FrameArrays*>& KFs, const std::vector<float>& mvScaleFactors,
+                       const std::vector<float>& mvInvLevelSigma2, int nPoints, const std::vector<uint8_t>& valid,
+                       const std::vector<float>& u, const std::vector<float>& v, const std::vector<float>& ur,
+                       const std::vector<int32_t>& level, const std::vector<uint8_t>& mpDescriptors, float th,
+                       std::vector<int32_t>& bestIdx) {
+    const int K = (int)KFs.size();
+    std::vector<const orbfe_frame_view*> views(K > 0 ? K : 1, nullptr);
+    for (int k = 0; k < K; k++) views[k] = &KFs[k]->c;
+    bestIdx.assign((size_t)K * nPoints, -1);
+    check(orbfe_fuse_search_multi(device_, K, views.data(), mvScaleFactors.data(), mvInvLevelSigma2.data(),
+                                  (int)mvScaleFactors.size(), nPoints, valid.data(), u.data(), v.data(),
+                                  ur.empty() ? nullptr : ur.data(), level.data(), mpDescriptors.data(), th, 1, bestIdx.data()),
+          "FuseSearchMulti");
   }
 
   // int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, const float th,

@@ -91,3 +91,11 @@ def test_cpp_classes_match_oracle(tmp_path):
     n_s3, m_s3 = orc.search_by_sim3(K1, K2, sf, sf, valid, u, v, kL["octave"], dL, np.ones(len(kR), np.uint8), u2, v2,
                                     kR["octave"], dR, 12.0)
     assert int(kv["ns3"]) == n_s3 > 0 and int(kv["s3"], 16) == _fnv(m_s3.astype(np.int32).tobytes())
+    # SearchByBoW x2 through the C++ class (host arrays; the resident and threaded variants are compared with these inside
+    # the C++ program: tests/cpp/test_classes.cpp "resident frames, the multi-neighbour calls and RE-ENTRANCY")
+    n_bow, m_bow = orc.search_by_bow(dL, np.ones(len(kL), np.uint8), kL["angle"], fv1, dR, kR["angle"], fv2, 0.7, True)
+    assert int(kv["nbow"]) == n_bow > 0 and int(kv["bow"], 16) == _fnv(m_bow.astype(np.int32).tobytes())
+    n_bkf, m_bkf = orc.search_by_bow_kf(dL, has1, kL["angle"], fv1, dR, has2, kR["angle"], fv2, 0.7, True)
+    assert int(kv["nbowkf"]) == n_bkf and int(kv["bowkf"], 16) == _fnv(m_bkf.astype(np.int32).tobytes())
+    # three matcher threads + two extractor threads (+ a matcher thread that exits and is replaced): no result differed
+    assert int(kv["reentrancy_mismatches"]) == 0
