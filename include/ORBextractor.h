@@ -2,8 +2,8 @@
 // (reference: include/ORBextractor.h) for builds that have OpenCV: class
 // ORB_SLAM2::ORBextractor with the reference's exact public signatures, implemented on the
 // C-ABI of liborbfe.so.  Frame/Tracking keep calling it unchanged (src/Frame.cc:272-278).
-// This file is NOT compiled in this repository's own tests (no OpenCV in the image); the
-// OpenCV-free twin it forwards to (orbfe_classes.hpp) is.
+// No OpenCV exists in this image: tests/test_gpu_dropin.py compiles and RUNS this class against a functional
+// cv::Mat test double (tests/cpp/doubles/); the OpenCV-free twin it forwards to (orbfe_classes.hpp) is tested directly.
 #ifndef ORBFE_DROPIN_ORBEXTRACTOR_H
 #define ORBFE_DROPIN_ORBEXTRACTOR_H
 

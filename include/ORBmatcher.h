@@ -6,10 +6,10 @@
 // src/LocalMapping.cc:261,542, src/LoopClosing.cc:294,691).
 //
 // Integration: replace the reference's include/ORBmatcher.h by this file, replace src/ORBmatcher.cc by
-// src/ORBmatcher_orbfe.cc in CMakeLists.txt:54-73, add -lorbfe.  This pair is NOT compiled in this repository's
-// own tests (no OpenCV / Eigen in the image; tests/test_dropin_headers.py only parses it against declaration
-// stubs); the OpenCV-free twin it forwards to -- orbfe_cpp::ORBmatcher, include/orbfe_classes.hpp -- is compiled
-// and parity-tested through tests/cpp/test_classes.cpp.
+// src/ORBmatcher_orbfe.cc in CMakeLists.txt:54-73, add -lorbfe.  No OpenCV / Eigen exists in this image, so the
+// pair is exercised against functional test doubles instead (tests/test_gpu_dropin.py: all 12 methods run on the GPU
+// and match the oracle); the OpenCV-free twin it forwards to -- orbfe_cpp::ORBmatcher, include/orbfe_classes.hpp --
+// is compiled and parity-tested through tests/cpp/test_classes.cpp.
 #ifndef ORBFE_DROPIN_ORBMATCHER_H
 #define ORBFE_DROPIN_ORBMATCHER_H
 

@@ -509,14 +509,16 @@ int orbfe_fuse_search_multi(int device, int n_keyframes, const orbfe_frame_view 
  * the image; last_octave / last_angle are LastFrame.mvKeysUn[i]; mp_desc its map point's
  * descriptor; obs_positive[i] = Observations()>0 (NULL = all).  mode 0: levels
  * [octave-1, octave+1]; 1 (bForward): >= octave; 2 (bBackward): <= octave.  mbf / invzc are read
- * only for frames with u_right.  match_cur[i2] = last-frame index or -1. */
+ * only for frames with u_right.  blocked[i2] != 0 <=> CurrentFrame.mvpMapPoints[i2] holds a point with
+ * Observations() > 0 at entry (:1572-1574; NULL = none, which is the state Tracking::TrackWithMotionModel calls it in).
+ * match_cur[i2] = last-frame index or -1. */
 int orbfe_search_by_projection_last_frame(int device, const orbfe_frame_view *Cur,
                                           const float *scale_factors, int n_levels, float mbf,
                                           int n_last, const uint8_t *valid, const float *u,
                                           const float *v, const float *invzc,
                                           const int32_t *last_octave, const float *last_angle,
                                           const uint8_t *mp_desc, const uint8_t *obs_positive,
-                                          int mode, float th, int check_orientation,
+                                          const uint8_t *blocked, int mode, float th, int check_orientation,
                                           int32_t *match_cur, int32_t *n_matches);
 
 /* ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound,

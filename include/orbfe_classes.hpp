@@ -254,13 +254,17 @@ class ORBmatcher {
                          const std::vector<uint8_t>& valid, const std::vector<float>& u, const std::vector<float>& v,
                          const std::vector<float>& invzc, const std::vector<int32_t>& lastOctave,
                          const std::vector<float>& lastAngle, const std::vector<uint8_t>& mpDescriptors, int mode,
-                         float th, std::vector<int32_t>& matchCur) {
+                         float th, std::vector<int32_t>& matchCur,
+                         const std::vector<uint8_t>& obsPositive = std::vector<uint8_t>(),
+                         const std::vector<uint8_t>& curBlocked = std::vector<uint8_t>()) {
     matchCur.assign(CurrentFrame.N(), -1);
     int32_t n = 0;
     check(orbfe_search_by_projection_last_frame(device_, &CurrentFrame.c, mvScaleFactors.data(),
                                                 (int)mvScaleFactors.size(), mbf, (int)valid.size(), valid.data(),
                                                 u.data(), v.data(), invzc.empty() ? nullptr : invzc.data(),
-                                                lastOctave.data(), lastAngle.data(), mpDescriptors.data(), nullptr, mode,
+                                                lastOctave.data(), lastAngle.data(), mpDescriptors.data(),
+                                                obsPositive.empty() ? nullptr : obsPositive.data(),
+                                                curBlocked.empty() ? nullptr : curBlocked.data(), mode,
                                                 th, mbCheckOrientation, matchCur.data(), &n),
           "SearchByProjection(Frame,Frame)");
     return n;

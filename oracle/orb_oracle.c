@@ -1470,12 +1470,14 @@ int orc_search_by_projection_mappoints(orc_frame *F, const float *sf, const uint
 int orc_search_by_projection_lastframe(orc_frame *Cur, const float *sf, float mbf, int nLast, const uint8_t *valid,
                                        const float *u, const float *v, const float *invzc, const int32_t *last_octave,
                                        const float *last_angle, const uint8_t *mp_desc, const uint8_t *obs_positive,
-                                       int mode, float th, int check_ori, int32_t *match_cur) {
+                                       const uint8_t *blocked_at_entry, int mode, float th, int check_ori,
+                                       int32_t *match_cur) {
   int nmatches = 0;
   rothist rh;
   rh_init(&rh, nLast > Cur->N ? nLast : Cur->N);
   for (int i = 0; i < Cur->N; i++) match_cur[i] = -1;
   uint8_t *blocked = (uint8_t *)calloc((size_t)(Cur->N > 0 ? Cur->N : 1), 1);
+  if (blocked_at_entry) memcpy(blocked, blocked_at_entry, (size_t)Cur->N); /* :1572-1574 on the entry state */
   int32_t *vIdx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(Cur->N > 0 ? Cur->N : 1));
   for (int i = 0; i < nLast; i++) {
     if (!valid[i]) continue;

@@ -188,8 +188,8 @@ int orc_search_by_projection_mappoints(orc_frame *F, const float *scale_factors,
 int orc_search_by_projection_lastframe(orc_frame *Cur, const float *scale_factors, float mbf, int nLast,
                                        const uint8_t *valid, const float *u, const float *v, const float *invzc,
                                        const int32_t *last_octave, const float *last_angle, const uint8_t *mp_desc,
-                                       const uint8_t *obs_positive, int mode, float th, int check_ori,
-                                       int32_t *match_cur);
+                                       const uint8_t *obs_positive, const uint8_t *blocked_at_entry, int mode, float th,
+                                       int check_ori, int32_t *match_cur);
 
 /* SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist),
  * src/ORBmatcher.cc:1641-1775 (relocalisation), after the caller's projection: valid = map point exists, not bad,

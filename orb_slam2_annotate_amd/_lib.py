@@ -162,7 +162,7 @@ def load():
     fwp = C.POINTER(FrameViewC)
     L.orbfe_features_in_area.argtypes = [ci, fwp, ci, vp, vp, vp, vp, vp, ci, vp, vp]
     L.orbfe_search_by_projection.argtypes = [ci, fwp, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, vp, vp]
-    L.orbfe_search_by_projection_last_frame.argtypes = [ci, fwp, vp, ci, cf, ci, vp, vp, vp, vp, vp, vp, vp, vp,
+    L.orbfe_search_by_projection_last_frame.argtypes = [ci, fwp, vp, ci, cf, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                                         ci, cf, ci, vp, vp]
     L.orbfe_search_by_projection_keyframe.argtypes = [ci, fwp, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, cf, ci, ci, vp, vp]
     L.orbfe_search_by_projection_sim3.argtypes = [ci, fwp, vp, ci, vp, ci, vp, vp, vp, vp, vp, cf, vp, vp]

@@ -994,7 +994,8 @@ extern "C" int orbfe_search_by_projection_last_frame(int device, const orbfe_fra
                                                      int n_levels, float mbf, int n_last, const uint8_t* valid,
                                                      const float* u, const float* v, const float* invzc,
                                                      const int32_t* last_octave, const float* last_angle,
-                                                     const uint8_t* mp_desc, const uint8_t* obs_positive, int mode,
+                                                     const uint8_t* mp_desc, const uint8_t* obs_positive,
+                                                     const uint8_t* blocked, int mode,
                                                      float th, int check_orientation, int32_t* match_cur,
                                                      int32_t* n_matches) {
   Cur = canon(Cur);
@@ -1028,6 +1029,7 @@ extern "C" int orbfe_search_by_projection_last_frame(int device, const orbfe_fra
   std::vector<int> rotHist[HISTO_LENGTH];
   const float factor = 1.0f / HISTO_LENGTH;
   std::vector<uint8_t> blk(Cur->n, 0);
+  if (blocked) std::memcpy(blk.data(), blocked, (size_t)Cur->n);  // mvpMapPoints[i2] set with Observations() > 0 at entry (:1572-1574)
   int nmatches = 0;
   for (int i = 0; i < n_last; i++) {
     if (!valid[i]) continue;

@@ -236,7 +236,7 @@ class ORBmatcher:
 
     def SearchByProjectionLastFrame(self, Cur: FrameView, scale_factors, valid, u, v, last_octave, last_angle,
                                     mp_desc, th: float, mode: int = 0, mbf: float = 0.0, invzc=None,
-                                    obs_positive=None):
+                                    obs_positive=None, blocked=None):
         """SearchByProjection(CurrentFrame, LastFrame, th, bMono) (src/ORBmatcher.cc:1484-1633) after the
         caller's projection -> (nmatches, match_cur[Cur.N]) with match_cur[i2] = last-frame index or -1."""
         sf = _f32(scale_factors)
@@ -244,11 +244,13 @@ class ORBmatcher:
         lo, la, md = np.ascontiguousarray(last_octave, dtype=np.int32), _f32(last_angle), _u8(mp_desc).reshape(-1, 32)
         iz = None if invzc is None else _f32(invzc)
         obs = None if obs_positive is None else _u8(obs_positive)
+        blk = None if blocked is None else _u8(blocked)
         match = np.full(max(Cur.N, 1), -1, dtype=np.int32)
         n = C.c_int32(0)
         check(self._L.orbfe_search_by_projection_last_frame(
             self.device, C.byref(Cur.c), ptr(sf), len(sf), float(mbf), len(va), ptr(va), ptr(uu), ptr(vv),
-            None if iz is None else ptr(iz), ptr(lo), ptr(la), ptr(md), None if obs is None else ptr(obs), int(mode),
+            None if iz is None else ptr(iz), ptr(lo), ptr(la), ptr(md), None if obs is None else ptr(obs),
+            None if blk is None else ptr(blk), int(mode),
             float(th), int(self.mbCheckOrientation), ptr(match), C.byref(n)))
         return n.value, match[:Cur.N]
 

@@ -10,9 +10,12 @@
 //   * call: window gather, 256-bit Hamming distances, best / second-best, rotation histogram -- on the GPU;
 //   * un-flatten: index results back into MapPoint* bookkeeping (mvpMapPoints, vpMatched, Replace / AddObservation).
 //
-// NOT compiled in this repository (needs OpenCV, Eigen-free but with the reference's MapPoint.h / KeyFrame.h /
-// Frame.h); tests/test_dropin_headers.py parses it with g++ -fsyntax-only against declaration stubs.  The layer
-// below it (orbfe_cpp::ORBmatcher) is compiled and checked against the oracle in tests/cpp/test_classes.cpp.
+// A build against OpenCV and the reference's MapPoint.h / KeyFrame.h / Frame.h is not possible in this repository
+// (neither exists in the image).  What IS done: tests/test_gpu_dropin.py compiles this file (g++ -std=c++11) against
+// functional test doubles of exactly the cv::Mat / Frame / KeyFrame / MapPoint members it touches
+// (tests/cpp/doubles/, authored here) and RUNS all 12 methods on the GPU, comparing the un-flattened MapPoint*
+// results with the oracle behind an independent numpy-float32 prologue; tests/test_dropin_headers.py additionally
+// parses it against declaration stubs and compares the 12 public signatures with the reference header.
 #include "ORBmatcher.h"
 
 #include <stdint.h>
@@ -145,12 +148,16 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
     put_row(desc, i, pMP->GetDescriptor());
   }
   FrameFlat cur(CurrentFrame);
-  std::vector<int32_t> matchCur(CurrentFrame.N, -1);
+  std::vector<int32_t> matchCur(CurrentFrame.N > 0 ? CurrentFrame.N : 1, -1);
+  std::vector<uint8_t> blocked(CurrentFrame.N > 0 ? CurrentFrame.N : 1, 0);  // :1572-1574, the state at entry
+  for (int i2 = 0; i2 < CurrentFrame.N; i2++)
+    blocked[i2] = CurrentFrame.mvpMapPoints[i2] && CurrentFrame.mvpMapPoints[i2]->Observations() > 0;
   int32_t nmatches = 0;
   orbfe_cpp::check(orbfe_search_by_projection_last_frame(0, &cur.a.c, CurrentFrame.mvScaleFactors.data(),
                                                          (int)CurrentFrame.mvScaleFactors.size(), CurrentFrame.mbf, N,
                                                          valid.data(), u.data(), v.data(), invzc.data(), oct.data(),
-                                                         ang.data(), desc.data(), obs.data(), bForward ? 1 : (bBackward ? 2 : 0),
+                                                         ang.data(), desc.data(), obs.data(), blocked.data(),
+                                                         bForward ? 1 : (bBackward ? 2 : 0),
                                                          th, mbCheckOrientation, matchCur.data(), &nmatches),
                    "SearchByProjection(Frame,Frame)");
   for (int i2 = 0; i2 < CurrentFrame.N; i2++)

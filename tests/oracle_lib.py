@@ -382,17 +382,17 @@ def search_by_projection_mappoints(F: Frame, sf, blocked, in_view, level, view_c
 
 
 def search_by_projection_lastframe(Cur: Frame, sf, mbf, valid, u, v, invzc, last_octave, last_angle, mp_desc, obs,
-                                   mode, th, check_ori):
+                                   mode, th, check_ori, blocked=None):
     f = lambda a, t: None if a is None else np.ascontiguousarray(a, dtype=t)
     sf = f(sf, np.float32)
     valid = f(valid, np.uint8)
     a = [valid, f(u, np.float32), f(v, np.float32),
          f(invzc if invzc is not None else np.zeros(len(valid)), np.float32), f(last_octave, np.int32),
-         f(last_angle, np.float32), f(mp_desc, np.uint8), f(obs, np.uint8)]
+         f(last_angle, np.float32), f(mp_desc, np.uint8), f(obs, np.uint8), f(blocked, np.uint8)]
     out = np.zeros(max(Cur.N, 1), dtype=np.int32)
     L = lib()
     L.orc_search_by_projection_lastframe.argtypes = [C.POINTER(OrcFrame), C.c_void_p, C.c_float, C.c_int] + \
-        [C.c_void_p] * 8 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
+        [C.c_void_p] * 9 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
     n = L.orc_search_by_projection_lastframe(C.byref(Cur.c), _p(sf), float(mbf), len(valid), *[_p(v) for v in a],
                                              int(mode), float(th), int(check_ori), _p(out))
     return n, out[:Cur.N].copy()

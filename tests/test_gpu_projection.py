@@ -157,6 +157,13 @@ def test_search_by_projection_last_frame(amd, seed, stereo, mode, check_ori):
         assert n_got == n_ref
         assert got.tolist() == ref.tolist()
         assert n_ref > 200
+    # CurrentFrame keypoints that hold a map point with observations at entry are skipped (src/ORBmatcher.cc:1572-1574)
+    blocked = (rng.random(len(x)) < 0.3).astype(np.uint8)
+    n_ref, ref = orc.search_by_projection_lastframe(Co, SF, mbf, valid, u, v, invzc, lo, la, md, obs, mode, th, check_ori, blocked)
+    n_got, got = m.SearchByProjectionLastFrame(Cur, SF, valid, u, v, lo, la, md, th, mode=mode, mbf=mbf, invzc=invzc,
+                                               obs_positive=obs, blocked=blocked)
+    assert n_got == n_ref and got.tolist() == ref.tolist()
+    assert not (got[blocked > 0] >= 0).any() and n_ref < n_got + 1 and (ref >= 0).sum() > 100
 
 
 def test_projection_on_extracted_frames(amd):
