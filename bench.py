@@ -80,7 +80,7 @@ STAGE_KERNELS = {  # kernels (and launches per step) behind each timed stage
     "octree": [("k_gather_candidates", 1), ("k_octree", 1)], "blur": [("k_blur7", 1)],
     "orient_desc": [("k_orient_desc", 1)],
     "match": [("k_stereo_bucket", 1), ("k_stereo_match_batch", 1), ("k_stereo_median_cut", 1),
-              ("k_vocab_featvec", 1), ("k_search_by_bow_batch", 1)],
+              ("k_vocab_transform16", 1), ("k_vocab_featvec", 1), ("k_search_by_bow_batch", 1)],
 }
 
 
@@ -185,7 +185,9 @@ def _render(names, batches, rank, procs=0):
                 tasks.append(("seq", 1000 + 100000 * rank + c // 64 + (7000 if nm == "euroc" else 0), min(64, B - c),
                               wl["w"], wl["h"]))
                 owner.append(nm)
-    nproc = max(1, min(16, host_cores(), len(tasks)))
+    # every rank renders its own inputs at the same time: share the host's cores between the ranks of this node
+    world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+    nproc = max(1, min(16, host_cores() // world, len(tasks)))
     # a profiler that preloads itself has initialised the GPU runtime before main(): never fork from such a process
     # (rocprofv3 --pmc does; plain --kernel-trace --stats does not, and tools/profile_round.sh asks for the pool there)
     if procs > 0:
@@ -717,7 +719,7 @@ def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, u
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(name, frames[: min(len(frames), 256)], voc_arrays, args.cpu_seconds)
             res["vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
-        if not args.no_e2e and not g.raw:
+        if not args.no_e2e and not g.raw and world == 1:
             res["e2e"] = e2e_rate(g, args)
     del g
     torch.cuda.empty_cache()
@@ -763,6 +765,18 @@ def reduce_report(dt, units, torch, dist, use_dist, dev):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(n, op=dist.ReduceOp.SUM)
     return float(t.item()), float(n.item())
+
+
+def kitti_seq_entry(plans, lengths, pool):
+    """configs[4] figures as one JSON object (its own line for --workload kitti_seq, a `secondary` of the default line
+    when --gpus N > 1: one driver run then yields the weak-scaling headline AND the strong-scaling sequence plans)"""
+    wl = WORKLOADS["kitti"]
+    return {"key": "kitti_seq", "value": plans["sequence"]["value"], "unit": "stereo frames/s", "scaling": "strong",
+            "ms_per_step": plans["sequence"]["ms_per_step"],
+            "workload": "KITTI 00-07 (sequence lengths %s; synthetic 1241x376 stereo pairs cycled from a resident pool of %d), "
+                        "nFeatures=2000, extract L+R + ComputeStereoMatches" % (lengths, pool),
+            "sharding": "plan 'sequence': sequence s -> rank s mod N (configs[4]); plan 'round_robin': frames dealt evenly; no "
+                        "data-path collective", "per_image": wl["name"], "plans": plans}
 
 
 def run_kitti_seq(frames, args, rank, world, local_rank, torch, dist, use_dist, batches):
@@ -822,10 +836,25 @@ def stub_worker(args, rank, world):
         dist.barrier()
     dt = time.perf_counter() - t0
     dt_max, total = reduce_report(dt, float(units * args.steps), torch, dist, use_dist, torch.device("cpu"))
+    out = {"metric": "stub", "value": total / dt_max, "unit": "units/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps, "stub": True, "total_units": total}
+    if world > 1:  # the shape of the real line for --gpus N > 1: the configs[4] plans as a `secondary`
+        from orb_slam2_annotate_amd import shard
+        lengths = [max(1, int(round(n * args.seq_scale))) for n in shard.KITTI_00_07]
+        plans = {}
+        for mode in ("sequence", "round_robin"):
+            mine = shard.frames_of(shard.shard_sequences(lengths, world, mode)[rank])
+            if use_dist:
+                dist.barrier()
+            t0 = time.perf_counter()
+            time.sleep(1e-6 * mine)  # a stub "pass": 1 us per stereo frame of this rank's share
+            if use_dist:
+                dist.barrier()
+            dtm, tot = reduce_report(time.perf_counter() - t0, float(mine), torch, dist, use_dist, torch.device("cpu"))
+            plans[mode] = {"value": tot / dtm, "ms_per_step": 1e3 * dtm, "stereo_frames_per_step": tot, "frames_of_rank0": mine}
+        out["secondary"] = [kitti_seq_entry(plans, lengths, 0)]
     if rank == 0:
-        print(json.dumps({"metric": "stub", "value": total / dt_max, "unit": "units/s", "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps, "stub": True,
-                          "total_units": total}), flush=True)
+        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -930,22 +959,25 @@ def main():
     if args.workload == "kitti_seq":
         plans, lengths, check = run_kitti_seq(inputs["kitti"], args, rank, world, local_rank, torch, dist, use_dist, batches)
         if rank == 0:
-            wl = WORKLOADS["kitti"]
+            ent = kitti_seq_entry(plans, lengths, batches["kitti"])
             print(json.dumps({
                 "metric": "ORB extract+match stereo frames/sec, KITTI 00-07 sharded over the GPUs (bit-exact vs CPU oracle on checked frames)",
-                "value": plans["sequence"]["value"], "unit": "stereo frames/s", "n_gpus": world, "steps": args.steps,
-                "warmup": args.warmup, "ms_per_step": plans["sequence"]["ms_per_step"], "higher_is_better": True,
+                "value": ent["value"], "unit": "stereo frames/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": ent["ms_per_step"], "higher_is_better": True,
                 "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-                "config": {"workload": "KITTI 00-07 (sequence lengths %s; synthetic 1241x376 stereo pairs cycled from a resident pool of %d), "
-                                       "nFeatures=2000, extract L+R + ComputeStereoMatches" % (lengths, batches["kitti"]),
-                           "sharding": "plan 'sequence': sequence s -> rank s mod N (configs[4]); no data-path collective",
-                           "per_image": wl["name"]},
+                "config": {"workload": ent["workload"], "sharding": ent["sharding"], "per_image": ent["per_image"]},
                 "plans": plans, "parity_check": check}), flush=True)
     else:
         results = []
+        kitti_frames = inputs.get("kitti") if world > 1 else None  # (kept for the configs[4] plans below)
         for nm in names:
             r = run_gpu_workload(nm, inputs.pop(nm), args, rank, world, local_rank, torch, dist, use_dist, voc_arrays, batches)
             results.append(r)
+        if kitti_frames is not None:
+            # more than one GPU: the KITTI 00-07 `sequence` / `round_robin` plans (configs[4], strong scaling) ride along
+            plans, lengths, _ = run_kitti_seq(kitti_frames, args, rank, world, local_rank, torch, dist, use_dist, batches)
+            if rank == 0:
+                results.append(kitti_seq_entry(plans, lengths, batches["kitti"]))
         if rank == 0:
             head = results[0]
             out = {

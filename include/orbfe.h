@@ -117,7 +117,10 @@ int orbfe_extract_batch_pipelined(orbfe_extractor *e, const uint8_t *images, int
 
 /* Same, but `d_images`, `d_keypoints`, `d_descriptors`, `d_n_out` are DEVICE pointers
  * (HBM-resident in, HBM-resident out; nothing crosses PCIe except per-batch control words).
- * The call returns after the work is complete on the handle's stream. */
+ * The call returns after the work is complete on the handle's stream.
+ * Frames are read IN PLACE at any stride and alignment; the kernels stage whole rows with 16-byte requests bounded by
+ * the row PITCH, so every frame -- the last one included -- must be readable for stride * height bytes (a buffer that
+ * ends at the last pixel of a frame with stride > width is not enough): frame_stride >= stride * height is required. */
 int orbfe_extract_batch_device(orbfe_extractor *e, const uint8_t *d_images, int n_frames,
                                int width, int height, int stride, size_t frame_stride,
                                orbfe_keypoint *d_keypoints, uint8_t *d_descriptors, int capacity,
@@ -135,7 +138,11 @@ int orbfe_extractor_synchronize(orbfe_extractor *e);
 /* Replaces reads of the public member `mvImagePyramid[level]` (include/ORBextractor.h:86;
  * read by Frame::ComputeStereoMatches, src/Frame.cc:519,609,621,626): copies level `level`
  * of frame `frame` of the LAST extract call into `dst` (host, dst_stride bytes per row).
- * level_size gives the dimensions for any input size. */
+ * level_size gives the dimensions for any input size.
+ * `frame` always counts in the caller's batch.  The chunked host paths (orbfe_extract_batch_pipelined, and
+ * orbfe_extract_batch when it routes a large batch there) keep the intermediate data of their LAST chunk only:
+ * asking for a frame before it fails with ORBFE_ERR_INVALID ("pyramid of frame F not retained ...") -- this
+ * holds for every frame-indexed accessor below and for orbfe_compute_stereo_matches. */
 int orbfe_extractor_level_size(const orbfe_extractor *e, int width, int height, int level,
                                int *w, int *h);
 int orbfe_extractor_get_pyramid_level(orbfe_extractor *e, int frame, int level, uint8_t *dst,

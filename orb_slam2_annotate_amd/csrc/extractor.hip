@@ -170,6 +170,7 @@ struct orbfe_extractor {
   PyramidViews lastPyr = {};
   PyramidViews lastBlur = {};
   int lastFrames = 0;
+  int lastFrameBase = 0;  // index, in the caller's batch, of the first frame the retained pyramid belongs to (pipelined host path: its LAST chunk)
   bool haveLast = false;
 };
 
@@ -674,6 +675,7 @@ int run_pipeline(orbfe_extractor* e, LevelView level0, int nFrames, orbfe_keypoi
     e->consumerPending = false;
     e->chunksPending = 1;  // every sub-batch ends on `stream`: consumers there are ordered behind all of them
     e->lastFrames = nFrames;
+    e->lastFrameBase = 0;
     e->haveLast = true;
     return ORBFE_OK;
   }
@@ -698,6 +700,7 @@ int run_pipeline(orbfe_extractor* e, LevelView level0, int nFrames, orbfe_keypoi
   e->consumerPending = false;  // stream 0 is ordered behind the consumer by itself
   e->chunksPending = S;
   e->lastFrames = nFrames;
+  e->lastFrameBase = 0;
   e->haveLast = true;
   return ORBFE_OK;
 }
@@ -879,6 +882,8 @@ extern "C" int orbfe_extract_batch_device_async(orbfe_extractor* e, const uint8_
   if (n_frames == 0) return ORBFE_OK;
   if (!d_images || width <= 0 || height <= 0 || stride < width)
     return fail(ORBFE_ERR_INVALID, "extract_batch_device: bad image");
+  if (frame_stride < (size_t)stride * (size_t)height)  // rows are staged up to the PITCH (16-byte requests): see orbfe.h
+    return fail(ORBFE_ERR_INVALID, "extract_batch_device: frame_stride < stride * height (every frame must be readable for stride * height bytes)");
   HIPCHK(hipSetDevice(e->device));
   int rc;
   if (e->geom.W != width || e->geom.H != height || n_frames > e->capFrames) {
@@ -1017,9 +1022,11 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* images, in
       // multiple of the DMA granule degenerates into one descriptor per row: 3.0 ms for ONE 1241 x 376 frame (0.15 GB/s)
       // against 0.1 ms this way -- the live-camera latency of a KITTI frame was that copy.
       const size_t bytes = (size_t)(n_frames - 1) * frame_stride + (size_t)(height - 1) * stride + width;
-      if (bytes > e->hostInBytes) {
-        if ((rc = dalloc(&e->d_hostIn, bytes + 64))) return rc;
-        e->hostInBytes = bytes;
+      // the slab is readable for stride * height bytes per frame: the kernels stage rows up to the pitch, not the width
+      const size_t slab = (size_t)(n_frames - 1) * frame_stride + (size_t)stride * height + 64;
+      if (slab > e->hostInBytes) {
+        if ((rc = dalloc(&e->d_hostIn, slab))) return rc;
+        e->hostInBytes = slab;
       }
       HIPCHK(hipMemcpyAsync(e->d_hostIn, images, bytes, hipMemcpyHostToDevice, e->stream));
       l0 = LevelView{e->d_hostIn, frame_stride, stride, width, height};
@@ -1148,7 +1155,8 @@ extern "C" int orbfe_extract_batch_pipelined(orbfe_extractor* e, const uint8_t* 
     }
   }
   // device input slab: tightly packed host frames are uploaded as they are (ONE linear copy per chunk, row pitch =
-  // the caller's stride; an odd pitch is repacked on the device by run_chunk) -- a 2-D copy of 1241-byte rows
+  // the caller's stride, which the kernels read in place whatever its alignment; only $ORBFE_COPY_UNALIGNED=1 repacks
+  // an odd pitch in run_chunk) -- a 2-D copy of 1241-byte rows
   // degenerates into one DMA descriptor per row and ran at 0.1 GB/s; only batches with gaps between the frames
   // take the per-frame 2-D form into a 64-byte pitch
   const bool tight = frame_stride == (size_t)stride * height;
@@ -1201,6 +1209,7 @@ extern "C" int orbfe_extract_batch_pipelined(orbfe_extractor* e, const uint8_t* 
     if (status == ORBFE_OK) {
       rc = run_pipeline(e, l0, n, d_kp, d_de, capacity, d_n, waits, k >= 2 ? 2 : 1);
       if (rc) { status = rc; break; }
+      e->lastFrameBase = f0;  // the pyramid / blurred levels / candidates that stay behind are those of frames [f0, f0 + n)
     }
     for (int i = 1; i < e->chunksPending; i++) H(hipStreamWaitEvent(e->stream, e->evChunkDone[i], 0));  // join the sub-batches
     H(hipEventRecord(e->evComp[slot], e->stream));
@@ -1237,10 +1246,24 @@ extern "C" int orbfe_extract(orbfe_extractor* e, const uint8_t* image, int width
                              keypoints, descriptors, capacity, n_out);
 }
 
+// frame index of the LAST extract call -> index into what the handle still holds.  The chunked (pipelined) host path keeps
+// the intermediate data of its last chunk only: frames before it fail loudly instead of silently answering with another
+// frame's pyramid.
+static int retained_frame(orbfe_extractor* e, int frame, int* local) {
+  if (!e->haveLast) return fail(ORBFE_ERR_INVALID, "no extract call yet");
+  const int f = frame - e->lastFrameBase;
+  if (frame < 0 || f >= e->lastFrames) return fail(ORBFE_ERR_INVALID, "frame out of range");
+  if (f < 0)
+    return fail(ORBFE_ERR_INVALID, "pyramid of frame " + std::to_string(frame) + " not retained: the pipelined host path keeps the last chunk only (frames " +
+                                       std::to_string(e->lastFrameBase) + ".." + std::to_string(e->lastFrameBase + e->lastFrames - 1) + ")");
+  *local = f;
+  return ORBFE_OK;
+}
+
 static int copy_level_out(orbfe_extractor* e, const PyramidViews& pv, int frame, int level, uint8_t* dst, int dst_stride) {
   if (!e || !dst) return fail(ORBFE_ERR_INVALID, "NULL argument");
-  if (!e->haveLast) return fail(ORBFE_ERR_INVALID, "no extract call yet");
-  if (frame < 0 || frame >= e->lastFrames || level < 0 || level >= pv.nlevels)
+  { int rcf = retained_frame(e, frame, &frame); if (rcf) return rcf; }
+  if (level < 0 || level >= pv.nlevels)
     return fail(ORBFE_ERR_INVALID, "frame/level out of range");
   const LevelView& v = pv.lv[level];
   if (dst_stride < v.w) return fail(ORBFE_ERR_INVALID, "dst_stride too small");
@@ -1262,8 +1285,8 @@ extern "C" int orbfe_extractor_debug_blurred_level(orbfe_extractor* e, int frame
 extern "C" int orbfe_extractor_pyramid_level_device(orbfe_extractor* e, int frame, int level, const uint8_t** d_ptr,
                                                     int* pitch, int* w, int* h) {
   if (!e || !d_ptr || !pitch || !w || !h) return fail(ORBFE_ERR_INVALID, "NULL argument");
-  if (!e->haveLast || frame < 0 || frame >= e->lastFrames || level < 0 || level >= e->lastPyr.nlevels)
-    return fail(ORBFE_ERR_INVALID, "frame/level out of range");
+  { int rcf = retained_frame(e, frame, &frame); if (rcf) return rcf; }
+  if (level < 0 || level >= e->lastPyr.nlevels) return fail(ORBFE_ERR_INVALID, "frame/level out of range");
   const LevelView& v = e->lastPyr.lv[level];
   *d_ptr = v.base + (size_t)frame * v.frameStride;
   *pitch = v.pitch;
@@ -1275,8 +1298,8 @@ extern "C" int orbfe_extractor_pyramid_level_device(orbfe_extractor* e, int fram
 extern "C" int orbfe_extractor_debug_candidates(orbfe_extractor* e, int frame, int level, float* xs, float* ys,
                                                 float* resp, int cap) {
   if (!e || !xs || !ys || !resp) return fail(ORBFE_ERR_INVALID, "NULL argument");
-  if (!e->haveLast || frame < 0 || frame >= e->lastFrames || level < 0 || level >= e->geom.nlevels)
-    return fail(ORBFE_ERR_INVALID, "frame/level out of range");
+  { int rcf = retained_frame(e, frame, &frame); if (rcf) return rcf; }
+  if (level < 0 || level >= e->geom.nlevels) return fail(ORBFE_ERR_INVALID, "frame/level out of range");
   HIPCHK(hipSetDevice(e->device));
   { int rcs = sync_all(e); if (rcs) return rcs; }
   int32_t n = 0;
@@ -1389,10 +1412,13 @@ extern "C" int orbfe_gaussian_blur7_spec(int device, int spec, const uint8_t* sr
 extern "C" int orbfe_stereo_views_(orbfe_extractor* e, int frame, PyramidViews* pv, float* scale, float* invScale,
                                    int* nlevels, int* device, const float** d_scaleTab) {
   if (!e->haveLast) return fail(ORBFE_ERR_INVALID, "compute_stereo_matches: extractor has no pyramid yet");
-  if (frame < 0 || frame >= e->lastFrames) return fail(ORBFE_ERR_INVALID, "compute_stereo_matches: frame out of range");
+  int local = 0;
+  { int rcf = retained_frame(e, frame, &local); if (rcf) return rcf; }
   HIPCHK(hipSetDevice(e->device));
   { int rcs = sync_all(e); if (rcs) return rcs; }
   *pv = e->lastPyr;
+  for (int l = 0; l < pv->nlevels; l++)  // the caller indexes the views with ITS frame number
+    pv->lv[l].base -= (size_t)e->lastFrameBase * pv->lv[l].frameStride;
   for (int l = 0; l < e->tab.nlevels; l++) { scale[l] = e->tab.scale[l]; invScale[l] = e->tab.invScale[l]; }
   *nlevels = e->tab.nlevels;
   *device = e->device;

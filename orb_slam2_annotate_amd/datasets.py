@@ -62,17 +62,24 @@ def read_image(path) -> np.ndarray:
         return np.asarray(im.convert("RGBA" if "A" in im.mode else "RGB"), dtype=np.uint8)
 
 
-def read_gray(path, rgb_order: bool = True, device: int = 0) -> np.ndarray:
-    """An 8-bit gray frame as Tracking::GrabImage* hands it to the extractor: gray files as stored, colour files
-    through the library's cvtColor (mbRGB = rgb_order, src/Tracking.cc:176-201).  Pillow decodes to RGB(A) order."""
-    a = read_image(path)
+# Camera.RGB of EVERY example configuration of the reference is 1 (Examples/*/*.yaml: TUM1-3, KITTI00-12, EuRoC)
+MB_RGB = {"tum": True, "kitti": True, "euroc": True}
+
+
+def read_gray(path, mbRGB: bool = True, device: int = 0) -> np.ndarray:
+    """An 8-bit gray frame as Tracking::GrabImage* hands it to the extractor.  Gray files as stored.  Colour files the way
+    the reference processes them: the example mains call cv::imread(..., CV_LOAD_IMAGE_UNCHANGED)
+    (Examples/Monocular/mono_tum.cc:66), which delivers B, G, R(, A) byte order, and Tracking applies
+    cvtColor(CV_RGB2GRAY / CV_RGBA2GRAY) when mbRGB (= Camera.RGB) is set, else CV_BGR2GRAY (src/Tracking.cc:250-262).
+    With Camera.RGB: 1 on imread's BGR data that is gray = (4899*B + 9617*G + 1868*R + 2^13) >> 14 -- NOT the
+    luminance of the picture, but what the reference feeds its extractor (round-2 ADVICE: this function used to convert
+    Pillow's true RGB order, i.e. it extracted from different pixels than the reference)."""
+    a = read_image(path)  # Pillow: R, G, B(, A)
     if a.ndim == 2:
         return a
     from .ingest import cvtColorToGray
-    if rgb_order:
-        return cvtColorToGray(a, rgb=True, device=device)
-    bgr = a[..., ::-1] if a.shape[2] == 3 else a[..., [2, 1, 0, 3]]  # what imread would have delivered
-    return cvtColorToGray(np.ascontiguousarray(bgr), rgb=False, device=device)
+    bgr = np.ascontiguousarray(a[..., ::-1] if a.shape[2] == 3 else a[..., [2, 1, 0, 3]])  # what imread delivers
+    return cvtColorToGray(bgr, rgb=bool(mbRGB), device=device)
 
 
 def load_frames(spec: str, n_units: int, device: int = 0):
@@ -87,13 +94,13 @@ def load_frames(spec: str, n_units: int, device: int = 0):
         files, _ = load_tum(arg)
         if len(files) < n_units:
             raise ValueError(f"{spec}: {len(files)} frames, {n_units} asked")
-        return kind, [read_gray(f, True, device) for f in files[:n_units]]
+        return kind, [read_gray(f, MB_RGB[kind], device) for f in files[:n_units]]
     else:
         raise ValueError(f"unknown dataset kind {kind!r} (kitti | euroc | tum)")
     if len(left) < n_units:
         raise ValueError(f"{spec}: {len(left)} stereo frames, {n_units} asked")
     out = []
     for a, b in zip(left[:n_units], right[:n_units]):
-        out.append(read_gray(a, True, device))
-        out.append(read_gray(b, True, device))
+        out.append(read_gray(a, MB_RGB[kind], device))
+        out.append(read_gray(b, MB_RGB[kind], device))
     return kind, out

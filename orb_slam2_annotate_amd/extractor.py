@@ -143,7 +143,7 @@ class ORBextractor:
         cap = kps.shape[1]
         check(self._L.orbfe_extract_batch_pipelined(self._h, ptr(img), B, W, H, W, W * H, ptr(kps), ptr(desc), cap, ptr(n),
                                                     int(chunk_frames)))
-        self._last_shape = (min(B, chunk_frames or 256), H, W)
+        self._last_shape = (B, H, W)  # frame indices count in the caller's batch; only the last chunk's pyramids are retained
         return kps, desc, n
 
     def extract_batch_pipelined(self, images: np.ndarray, chunk_frames: int = 0, capacity: int | None = None):

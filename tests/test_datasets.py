@@ -63,5 +63,12 @@ def test_tum_colour_frames_are_converted_like_cvtcolor(tmp_path):
     _png(tmp_path / "rgb" / "a.png", rgb)
     (tmp_path / "rgb.txt").write_text("#\n#\n#\n1.0 rgb/a.png\n")
     _, frames = datasets.load_frames(f"tum:{tmp_path}", 1)
-    want = ((rgb[..., 0].astype(np.int64) * 4899 + rgb[..., 1].astype(np.int64) * 9617 + rgb[..., 2].astype(np.int64) * 1868 + 8192) >> 14)
+    # imread delivers B,G,R; TUM1.yaml has Camera.RGB: 1, so Tracking applies CV_RGB2GRAY to that BGR data
+    # (src/Tracking.cc:250-262): the first channel the conversion sees -- weight 4899 -- is BLUE
+    R_, G_, B_ = (rgb[..., k].astype(np.int64) for k in range(3))
+    want = (B_ * 4899 + G_ * 9617 + R_ * 1868 + 8192) >> 14
     assert np.array_equal(frames[0], want.astype(np.uint8))
+    # Camera.RGB: 0 (CV_BGR2GRAY on the same BGR data) is the true luminance
+    lum = (R_ * 4899 + G_ * 9617 + B_ * 1868 + 8192) >> 14
+    assert np.array_equal(datasets.read_gray(tmp_path / "rgb" / "a.png", mbRGB=False), lum.astype(np.uint8))
+    assert not np.array_equal(want, lum)

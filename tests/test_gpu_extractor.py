@@ -85,6 +85,23 @@ def test_extract_euroc_752x480(amd):
     assert _check_frame(amd, synth.render_frame(9, 752, 480), (1200, 1.2, 8, 20, 7)) > 600
 
 
+@pytest.mark.parametrize("seed", [4, 5])
+def test_extract_mono_initialisation_extractor(amd, seed):
+    """mpIniORBextractor = ORBextractor(2 * nFeatures, ...) (src/Tracking.cc:128): 2000 features on a 640 x 480 TUM frame,
+    single frame and a batch on several streams."""
+    params = (2000, 1.2, 8, 20, 7)
+    n = _check_frame(amd, synth.render_frame(seed), params)
+    assert n > 1200
+    frames = np.stack(synth.render_sequence(seed, 9, 640, 480))
+    e = amd.ORBextractor(*params)
+    e.set_streams(3)
+    o = orc.Oracle(*params)
+    for (k, d), f in zip(e.extract_batch(frames), frames):
+        kr, dr = o.extract(f)
+        _kp_equal(kr, k)
+        assert np.array_equal(dr, d)
+
+
 @pytest.mark.parametrize("kind", ["constant", "noise", "checker"])
 def test_extract_adversarial(amd, kind):
     n = _check_frame(amd, synth.adversarial(kind, 640, 480, seed=1), (1000, 1.2, 8, 20, 7))
@@ -580,3 +597,38 @@ def test_orient_desc_tile_form_matches_the_oracle(amd, shape, params):
         assert n[f] == len(kr), f
         assert np.array_equal(d_kp[f, :n[f]].cpu().numpy().view(np.uint8).reshape(-1, 28), kr.view(np.uint8).reshape(-1, 28)), f
         assert np.array_equal(d_desc[f, :n[f]].cpu().numpy(), dr), f
+
+
+def test_pipelined_host_batch_keeps_the_last_chunk_only(amd):
+    """orbfe_extract_batch routes large host batches through the chunked path, which keeps the pyramid /
+    blurred levels / candidates of its LAST chunk.  Frame-indexed accessors count in the caller's batch: a retained frame
+    answers with ITS pyramid (== oracle), an earlier one fails loudly instead of returning another frame's data."""
+    w, h, B, chunk = 160, 120, 40, 16  # chunks [0,16) [16,32) [32,40): the tail chunk is shorter
+    frames = np.stack([synth.render_frame(500 + i, w, h) for i in range(B)])
+    e = amd.ORBextractor(300, 1.2, 8, 20, 7)
+    res = e.extract_batch_pipelined(frames, chunk_frames=chunk)
+    o = orc.Oracle(300, 1.2, 8, 20, 7)
+    for f in (0, 17, 39):
+        kr, dr = o.extract(frames[f])
+        _kp_equal(kr, res[f][0])
+        assert np.array_equal(dr, res[f][1])
+    for f in (32, 39):  # retained
+        _, _, pyr = o.extract(frames[f], want_pyramid=True)
+        levels = o.split_pyramid(pyr, w, h)
+        for l in (0, 3, 7):
+            assert np.array_equal(e.pyramid_level(l, frame=f), levels[l]), (f, l)
+            assert np.array_equal(e.debug_blurred_level(l, frame=f), orc.gaussian_blur7(levels[l])), (f, l)
+    for f in (0, 16, 31):  # not retained: an error, never frame f + 32's pyramid
+        with pytest.raises(amd.OrbfeError, match="not retained"):
+            e.pyramid_level(0, frame=f)
+    with pytest.raises(amd.OrbfeError):
+        e.pyramid_level(0, frame=B)
+    # the plain host entry point with a pageable batch large enough to be routed (>= 512 frames): same contract
+    big = np.stack([frames[i % B] for i in range(520)])
+    res = e.extract_batch(big)
+    kr, dr = o.extract(big[519])
+    _kp_equal(kr, res[519][0])
+    _, _, pyr = o.extract(big[519], want_pyramid=True)
+    assert np.array_equal(e.pyramid_level(2, frame=519), o.split_pyramid(pyr, w, h)[2])
+    with pytest.raises(amd.OrbfeError, match="not retained"):
+        e.pyramid_level(0, frame=0)

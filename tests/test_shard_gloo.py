@@ -94,6 +94,14 @@ def test_bench_launcher_starts_the_ranks_itself():
     assert out["n_gpus"] == 2 and out["steps"] == 3
     assert out["total_units"] == 3 * (100 + 101)  # SUM over both ranks
     assert out["ms_per_step"] >= 4.0  # MAX over ranks: rank 1 sleeps 4 ms per step
+    # with more than one rank the line also carries the configs[4] plans (strong scaling) as a secondary
+    (seq,) = [s_ for s_ in out["secondary"] if s_["key"] == "kitti_seq"]
+    assert seq["scaling"] == "strong" and set(seq["plans"]) == {"sequence", "round_robin"}
+    total = sum(shard.KITTI_00_07)
+    for mode in ("sequence", "round_robin"):
+        assert seq["plans"][mode]["stereo_frames_per_step"] == total  # SUM over ranks: every frame exactly once
+    assert seq["plans"]["sequence"]["frames_of_rank0"] == sum(shard.KITTI_00_07[0::2])
+    assert abs(seq["plans"]["round_robin"]["frames_of_rank0"] - total / 2) <= 1
 
 
 def test_bench_launcher_reports_a_failing_rank():
