@@ -22,6 +22,8 @@
 // resident waves.  The detection rectangles tile [19, w-19) x [19, h-19); the 19-px frame around them is
 // covered by blur-only cells (no FAST phases, reflect-101 staging) appended to the cell table by
 // FrameGeom::build, so one launch writes the whole blurred level.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace orbfe {
@@ -113,7 +115,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
                                                    uint16_t* __restrict__ cellCount,
                                                    int tileRows, int scoreRows, uint32_t cellsMagic,
                                                    PyramidViews blurOut, int nFastCells,
-                                                   unsigned int* __restrict__ fallbackStat) {
+                                                   unsigned int* __restrict__ fallbackStat,
+                                                   int cutoff /* 0; $ORBFE_FAST_CUTOFF: stop after staging (1) / A (2) / B (3) / C (4) -- per-phase instruction counts */) {
   extern __shared__ uint32_t lds[];
   uint32_t* tile = lds;                                   // pixels: origin (x0-4, y0-3)
   uint32_t* score = lds + tileRows * kPitchDw;            // FAST responses: origin (x0-4, y0-1)
@@ -213,6 +216,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
     }
   }
   __syncthreads();
+  if (cutoff == 1 && !blurOnly) {  // (profiling cut-off: the cell reports no candidates, so the later kernels see a consistent state)
+    if (lane == 0) cellCount[(size_t)f * nFastCells + cellId] = 0;
+    return;
+  }
 
   if (!blurOnly) {  // wave-uniform: the FAST phases A-D of a detection cell
   // The reference calls cv::FAST(cell, iniThFAST) and only if that returns nothing cv::FAST(cell, minThFAST)
@@ -246,6 +253,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {    // the two dwords of the 8-pixel group
           const uint32_t m0 = m[hh], m1 = m[hh + 1], m2 = m[hh + 2], up = ups[hh], dn = dns[hh];
+          uint32_t p[2];
 #pragma unroll
           for (int st = 0; st < 2; st++) {  // stream 0: pixels (0,2); stream 1: pixels (1,3)
             const s16x2 c = as_s2(__builtin_amdgcn_perm(m1, m0, sel2(4 + st)));
@@ -257,9 +265,13 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
             // either <=> max(v - mD, mB - v) > t <=> sign bit of t - max(...)
             const s16x2 mD = pk_max(pk_min(rS, rN), pk_min(rE, rW));
             const s16x2 mB = pk_min(pk_max(rS, rN), pk_max(rE, rW));
-            const uint32_t p = as_u(T - pk_max(c - mD, mB - c));
-            pass |= (((p >> 15) & 1u) | ((p >> 29) & 4u)) << (st + 4 * hh);
+            p[st] = as_u(T - pk_max(c - mD, mB - c));
           }
+          // the four sign bits (pixels 0..3 = p0.lo, p1.lo, p0.hi, p1.hi) in three steps instead of six shifts / masks
+          // per stream: one v_perm lines the four sign-carrying bytes up, the multiply moves bits 7, 15, 23, 31 to
+          // 28..31 (the partial products land on distinct bits: no carries)
+          const uint32_t sg = __builtin_amdgcn_perm(p[1], p[0], 0x07030501u) & 0x80808080u;
+          pass |= ((sg * 0x00204081u) >> 28) << (4 * hh);
         }
         const int valid = cw - 8 * gx;
         if (valid < 8) pass &= (1u << valid) - 1u;
@@ -277,6 +289,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
     }
   }
   __syncthreads();
+  if (cutoff == 2) { if (lane == 0) cellCount[(size_t)f * nFastCells + cellId] = 0; return; }
 
   // ---- B: exact response of the listed pixels (cornerScore<16>: S-1, corner iff S > t); the list is
   //      compacted in place to the corners (order kept: a pass writes no further than it has read) ----
@@ -328,6 +341,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
     }
   }
   __syncthreads();
+  if (cutoff == 3) { if (lane == 0) cellCount[(size_t)f * nFastCells + cellId] = 0; return; }
 
   // ---- C: cell-local 3x3 strict NMS, one lane per corner.  Two-attempt form: survivors get bit 15 of the list entry
   //      (every listed corner has S > tcur, i.e. response S-1 >= tcur: what cv::FAST(cell, tcur) keeps after NMS).
@@ -359,6 +373,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
   // cells that needed minThFAST -- a scheduling hint only, so every 8th work item reports, spread over 64 counters
   // (one counter for all cells serialised 2 M same-address atomics per launch: 24 ms instead of 4)
   if (fallbackStat && fellBack && lane == 0 && (work & 7u) == 0) atomicAdd(&fallbackStat[(work >> 3) & 63u], 1u);
+  if (cutoff == 4) { if (lane == 0) cellCount[(size_t)f * nFastCells + cellId] = 0; return; }
 
   // ---- D: ordered compaction of the survivors (the list is in raster order, :884-893) ----
   Candidate* out = slots + (size_t)f * slotsPerFrame + cd.slotBase;
@@ -489,9 +504,10 @@ void launch_fast_cells(hipStream_t s, PyramidViews pyr, const CellDesc* d_cells,
   const dim3 grid((total + 7u) / 8u * 8u);
   const uint32_t magic = udiv_magic_multiplier((uint32_t)nWork);
   PyramidViews bo = blurOut ? *blurOut : PyramidViews{};
+  static const int kCutoff = getenv("ORBFE_FAST_CUTOFF") ? atoi(getenv("ORBFE_FAST_CUTOFF")) : 0;
 #define ORBFE_LAUNCH_FAST(P, B, L)                                                                                     \
   hipLaunchKernelGGL((k_fast_cells<P, B, L>), grid, dim3(64), ldsBytes, s, pyr, d_cells, nWork, nFrames, iniTh, minTh, \
-                     d_slots, slotsPerFrame, d_cellCount, tileRows, scoreRows, magic, bo, nCells, d_fallbackStat)
+                     d_slots, slotsPerFrame, d_cellCount, tileRows, scoreRows, magic, bo, nCells, d_fallbackStat, kCutoff)
 #define ORBFE_LAUNCH_FAST_P(B, L)            \
   do {                                       \
     if (pitch == 12) ORBFE_LAUNCH_FAST(12, B, L);      \
