@@ -28,7 +28,7 @@ def per_kernel(dirname, counter):
         raise SystemExit(f"no counter_collection.csv under {dirname}")
     acc = defaultdict(list)
     for r in csv.DictReader(open(max(files, key=lambda f: __import__('os').path.getmtime(f)))):
-        if r["Counter_Name"] == counter and "orbfe::" in r["Kernel_Name"]:
+        if r["Counter_Name"] == counter and ("orbfe::" in r["Kernel_Name"] or "k_remap" in r["Kernel_Name"] or "k_cvt" in r["Kernel_Name"]):
             acc[kname(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 

@@ -37,7 +37,7 @@ def main():
         raise SystemExit(f"no counter_collection.csv under {d}")
     acc = defaultdict(lambda: defaultdict(list))
     for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
-        if "orbfe::" in r["Kernel_Name"]:
+        if "orbfe::" in r["Kernel_Name"] or "k_remap" in r["Kernel_Name"] or "k_cvt" in r["Kernel_Name"]:
             acc[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     res = {"batch": int(images), "workload": workload,
            "unit": "VALU wave64 instructions (SQ_INSTS_VALU) per image; valu_busy = 4*SQ_ACTIVE_INST_VALU/(1024 SIMDs*GRBM_GUI_ACTIVE/8)",
