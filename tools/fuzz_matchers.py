@@ -63,6 +63,9 @@ def main():
         m = int(rng.choice([0, 1, 50, 1000, 2500]))
         x, y, octv, ang, desc, ur = frame(rng, n, w, h, stereo)
         F = amd.FrameView(x, y, octv, desc, bounds, angle=ang, u_right=ur)
+        resident = bool(rng.random() < 0.5)  # round 3: the same searches on a frame uploaded once (orbfe_frame_upload)
+        if resident:
+            F = F.upload()
         Fo = orc.Frame(x, y, octv, desc, bounds, angle=ang, u_right=ur)
         u, v, md, lv, a, src = queries(rng, x, y, octv, ang, desc, m, float(rng.choice([0.5, 3.0, 10.0])))
         valid = (rng.random(m) < 0.85).astype(np.uint8)
@@ -83,8 +86,9 @@ def main():
             tag = "lastframe"
             mode = int(rng.integers(0, 3))
             invz = rng.uniform(0.02, 0.5, m).astype(np.float32)
-            r = orc.search_by_projection_lastframe(Fo, SF, 40.0, valid, u, v, invz, lv, a, md, obs, mode, th, ori)
-            g = M.SearchByProjectionLastFrame(F, SF, valid, u, v, lv, a, md, th, mode=mode, mbf=40.0, invzc=invz, obs_positive=obs)
+            r = orc.search_by_projection_lastframe(Fo, SF, 40.0, valid, u, v, invz, lv, a, md, obs, mode, th, ori, blocked)
+            g = M.SearchByProjectionLastFrame(F, SF, valid, u, v, lv, a, md, th, mode=mode, mbf=40.0, invzc=invz, obs_positive=obs,
+                                              blocked=blocked)
             assert (g[0], g[1].tolist()) == (r[0], r[1].tolist())
             tag = "keyframe"
             od = int(rng.choice([64, 100]))
@@ -103,6 +107,12 @@ def main():
                              ur=pxr if stereo else u)
             assert g.tolist() == r.tolist()
             if n and m:
+                tag = "fuse_multi"  # the same points against 3 key frames (this one, resident or not, three times over)
+                K3 = 3
+                g3 = M.FuseSearchMulti([F] * K3, SF, np.stack([valid] * K3), np.stack([u] * K3), np.stack([v] * K3), np.stack([lv] * K3), md,
+                                       th=th, inv_level_sigma2=inv_s2 if chi else None, ur=np.stack([pxr if stereo else u] * K3))
+                assert all(g3[k].tolist() == r.tolist() for k in range(K3))
+            if n and m:
                 tag = "area"
                 q = min(m, 64)
                 rad = rng.choice(np.array([0.5, 5.0, 40.0, 500.0], np.float32), q)
@@ -112,8 +122,10 @@ def main():
                 for i in range(q):
                     assert got[i].tolist() == Fo.features_in_area(u[i], v[i], rad[i], lo[i], hi[i]).tolist()
         except AssertionError:
-            print(f"MISMATCH in {tag}: seed={seed} case={n_cases} n={n} m={m} stereo={stereo} th={th} bounds={bounds}")
+            print(f"MISMATCH in {tag}: seed={seed} case={n_cases} n={n} m={m} stereo={stereo} th={th} bounds={bounds} resident={resident}")
             sys.exit(1)
+        if resident:
+            F.close()
         n_cases += 1
     print(f"fuzz_matchers: {n_cases} random cases x 5-6 searches identical to the oracle in {time.time() - t0:.0f} s (seed {seed})")
 

@@ -64,7 +64,8 @@ def main():
         fused, lanes, piped = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
         fmode = str(rng.choice(["auto", "high", "low"]))
         pyrblur = bool(rng.integers(0, 2))
-        knobs = dict(spec=spec, fused=fused, lanes=lanes, pipelined=piped, fast=fmode, pyrblur=pyrblur)
+        tiles = bool(rng.integers(0, 2))  # round 3: orientation + descriptors per 128 x 128 tile (k_orient_desc_tiles)
+        knobs = dict(spec=spec, fused=fused, lanes=lanes, pipelined=piped, fast=fmode, pyrblur=pyrblur, desc_tiles=tiles)
         try:
             o = orc.Oracle(*params, blur_spec=spec)
             e = amd.ORBextractor(*params)
@@ -72,6 +73,7 @@ def main():
             e.set_fused(fused)
             e.set_pyramid_blur(pyrblur)
             e.set_fast_mode(fmode)
+            e.set_desc_tiles(tiles)
             if batch_mode:
                 w, h = min(w, 500), min(h, 400)
                 imgs = np.stack([content(rng, w, h) for _ in range(int(rng.integers(9, 25)))])
@@ -104,7 +106,7 @@ def main():
         if time.time() - last_report > 60:  # progress line (long runs must not look hung)
             last_report = time.time()
             print(f"  ... {n} cases so far", flush=True)
-    print(f"fuzz_parity: {n} random cases bit-exact in {time.time() - t0:.0f} s (seed {seed}; blur specs 0/1/2, fused / separate blur, pyramid+blur fused / separate, stream / lane schedule, direct / pipelined host path drawn at random)")
+    print(f"fuzz_parity: {n} random cases bit-exact in {time.time() - t0:.0f} s (seed {seed}; blur specs 0/1/2, fused / separate blur, pyramid+blur fused / separate, tile / per-keypoint descriptors, stream / lane schedule, direct / pipelined host path drawn at random)")
 
 
 if __name__ == "__main__":

@@ -40,7 +40,8 @@ def main():
         nf = int(rng.choice([300, 1000, 1200, 2000]))
         nl = int(rng.integers(1, 9))
         sf = float(rng.choice([1.2, 1.2, 1.1, 1.4]))
-        left, right = synth.render_stereo(int(rng.integers(1 << 30)), w, h)
+        scene = synth.STEREO_SCENES[str(rng.choice(["shapes", "textured"]))]  # round 3: both generators
+        left, right = scene(int(rng.integers(1 << 30)), w, h)
         if rng.random() < 0.3:  # noise on top: more ambiguous descriptors, SAD minima at the window edge
             left = np.clip(left.astype(np.int16) + rng.normal(0, 6, left.shape), 0, 255).astype(np.uint8)
             right = np.clip(right.astype(np.int16) + rng.normal(0, 6, right.shape), 0, 255).astype(np.uint8)
@@ -86,7 +87,33 @@ def main():
             if rn != gn or not np.array_equal(r, g):
                 print("BOW (KF, KF) MISMATCH", cfg, f"nodes={n_nodes} nnratio={nnr} ori={ori}")
                 sys.exit(1)
-            n_bow += 2
+            # round 3: the same two searches and a 3-neighbour triangulation on RESIDENT frames (orbfe_frame_upload)
+            b = (0.0, float(w), 0.0, float(h))
+            urL = np.where(rng.random(len(kL)) < 0.5, kL["x"] - 4.0, -1.0).astype(np.float32)
+            urR = np.where(rng.random(len(kR)) < 0.5, kR["x"] - 4.0, -1.0).astype(np.float32)
+            R1 = amd.FrameView(kL["x"], kL["y"], kL["octave"], dL, b, angle=kL["angle"], u_right=urL).upload(fv1)
+            R2 = amd.FrameView(kR["x"], kR["y"], kR["octave"], dR, b, angle=kR["angle"], u_right=urR).upload(fv2)
+            rn, r = orc.search_by_bow(dL, has1, kL["angle"], orc.FeatVec(n1), dR, kR["angle"], orc.FeatVec(n2), nnr, ori)
+            gn, g = m.SearchByBoWResident(R1, has1, R2)
+            rn2, r2 = orc.search_by_bow_kf(dL, has1, kL["angle"], orc.FeatVec(n1), dR, has2, kR["angle"], orc.FeatVec(n2), nnr, ori)
+            gn2, g2 = m.SearchByBoWResident(R1, has1, R2, has_mp2=has2)
+            if rn != gn or not np.array_equal(r, g) or rn2 != gn2 or not np.array_equal(r2, g2):
+                print("RESIDENT BOW MISMATCH", cfg, f"nodes={n_nodes} nnratio={nnr} ori={ori}")
+                sys.exit(1)
+            F12 = (np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32) * np.float32(rng.uniform(0.005, 0.02))).astype(np.float32)
+            ex, ey = float(rng.uniform(1000, 6000)), float(rng.uniform(0, h))
+            only = bool(rng.random() < 0.3)
+            tr_n, tr = orc.search_for_triangulation(dL, has1, kL["x"], kL["y"], kL["angle"], urL >= 0, orc.FeatVec(n1), dR, has2, kR["x"],
+                                                    kR["y"], kR["angle"], kR["octave"], urR >= 0, orc.FeatVec(n2), F12, ex, ey,
+                                                    o.scale_factors(), o.level_sigma2(), only, ori)
+            cnt, mt = m.SearchForTriangulationMulti(R1, has1, [R2, R2, R2], [has2] * 3, [F12] * 3, [(ex, ey)] * 3, o.scale_factors(),
+                                                    o.level_sigma2(), only)
+            if any(int(cnt[k]) != tr_n or not np.array_equal(mt[k], tr) for k in range(3)):
+                print("TRIANGULATION MULTI MISMATCH", cfg, f"nodes={n_nodes} only_stereo={only} ori={ori}")
+                sys.exit(1)
+            R1.close()
+            R2.close()
+            n_bow += 5
         if time.time() - last > 50:
             print(f"... {n_cases} frames pairs, {n_st} stereo, {n_bow} bow searches, {time.time() - t0:.0f} s", flush=True)
             last = time.time()
