@@ -59,8 +59,8 @@ __device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_ele
 __device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
 
 // Bresenham circle of radius 3 in cv::FAST's order.
-constexpr int kRingDx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
-constexpr int kRingDy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+[[maybe_unused]] constexpr int kRingDx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+[[maybe_unused]] constexpr int kRingDy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
 
 // v_perm_b32 selector that builds the packed u16 pair (byte[o], byte[o+2]) of the 8 bytes {hi,lo}
 constexpr uint32_t sel2(int o) { return (uint32_t)o | 0x0c00u | ((uint32_t)(o + 2) << 16) | 0x0c000000u; }
@@ -82,6 +82,22 @@ struct __attribute__((packed, aligned(1))) U1u { uint32_t x; };  // 4-byte store
 struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };  // 16-byte load at any byte address
 }  // namespace
 
+// packed pair (lo, hi) of two bytes; 3-input packed max / min of u16 values < 0x7c00 through the f16 instructions
+__device__ __forceinline__ uint32_t pk2(uint8_t lo, uint8_t hi) {
+  typedef unsigned short u16x2_ __attribute__((ext_vector_type(2)));
+  u16x2_ v = {(unsigned short)lo, (unsigned short)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 // 32-bit 3-input forms for the per-pixel exact score (one pixel per lane)
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
@@ -95,8 +111,10 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b)
 //      ADJACENT cardinal ring points (0,4,8,12), so a corner needs (c0|c8)&(c4|c12) in one
 //      polarity.  ~19 % of pixels pass; they are appended to an LDS work list IN RASTER ORDER
 //      (ballot prefix).
-//   B. exact cv::FAST response S-1 for the listed pixels, one pixel per lane (dense lanes), sliding
-//      min/max windows on the raw ring values; the list shrinks in place to the corners.
+//   B. exact cv::FAST response S-1 for the listed pixels, TWO pixels per lane (dense lanes) in the halves of
+//      a register, sliding min/max windows on the raw ring values with gfx950's 3-input packed
+//      v_pk_maximum3_f16 / v_pk_minimum3_f16 (bit patterns 0..255 are ordered as f16 exactly as they are as integers);
+//      the list shrinks in place to the corners.
 //   C. cell-local 3x3 strict NMS of the corners (one lane per corner) + threshold classes.
 //   D. per-cell 20->7 fallback, then ordered compaction of the survivors = emission order.
 // Dynamic LDS: tile [tileRows][24 dw] | score [scoreRows][24 dw] | queue [queueLen] u16, sized by
@@ -294,6 +312,65 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
   // ---- B: exact response of the listed pixels (cornerScore<16>: S-1, corner iff S > t); the list is
   //      compacted in place to the corners (order kept: a pass writes no further than it has read) ----
   nc = 0;
+#ifndef ORBFE_FAST_B_SCALAR
+  {
+    // TWO listed pixels per lane (entries 2i, 2i+1 of the pass: neighbours in raster order), packed in the halves of a
+    // register: the sliding windows are gfx950's 3-input packed
+    // v_pk_maximum3_f16 / v_pk_minimum3_f16 applied to the BIT PATTERNS 0..255 -- positive f16 denormals, whose order as
+    // floats is their order as integers; the instructions return one of their inputs unchanged (checked for all pairs
+    // < 0x7c00 by tools/ubench/valu_rate2.hip, profiles/r03_valu_rate2.txt).  80 window instructions per TWO pixels
+    // instead of per pixel (the 2-input v_pk_max_i16 form costs what the 32-bit v_max3_i32 form does).
+    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
+    uint8_t* sbytes = reinterpret_cast<uint8_t*>(score);
+    for (int q0 = 0; q0 < nq; q0 += 128) {
+      const int qa = q0 + 2 * lane;
+      const bool okA = qa < nq, okB = qa + 1 < nq;
+      // an idle half reads the tile's first ring (in-bounds garbage, never a corner: the ok flags gate it)
+      const uint32_t pair = okA ? *reinterpret_cast<const uint32_t*>(&queue[qa]) : 0u;  // qa is even, queueLen is even
+      const int ea = (int)(pair & 0xffffu), eb = okB ? (int)(pair >> 16) : 0;
+      const uint8_t* ca = tb + ((ea >> 8) + 3) * P + 4 + (ea & 255);
+      const uint8_t* cb = tb + ((eb >> 8) + 3) * P + 4 + (eb & 255);
+      // (ds_read_u8 x 2 + one v_perm per pair: the d16 loads that write one half of a register do NOT keep the other half
+      // on this part -- SRAM ECC -- which is why the compiler does not select them either)
+      const uint32_t v2 = pk2(ca[0], cb[0]);
+      uint32_t r[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) r[k] = pk2(ca[kRingDx[k] + kRingDy[k] * P], cb[kRingDx[k] + kRingDy[k] * P]);
+      uint32_t mx3[16], mn3[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        mx3[k] = pk_max3(r[k], r[(k + 1) & 15], r[(k + 2) & 15]);
+        mn3[k] = pk_min3(r[k], r[(k + 1) & 15], r[(k + 2) & 15]);
+      }
+      uint32_t mx9[16], mn9[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        mx9[k] = pk_max3(mx3[k], mx3[(k + 3) & 15], mx3[(k + 6) & 15]);
+        mn9[k] = pk_min3(mn3[k], mn3[(k + 3) & 15], mn3[(k + 6) & 15]);
+      }
+      uint32_t darkest = pk_min3(mx9[0], mx9[1], mx9[2]), brightest = pk_max3(mn9[0], mn9[1], mn9[2]);
+#pragma unroll
+      for (int k = 3; k < 15; k += 2) { darkest = pk_min3(darkest, mx9[k], mx9[k + 1]); brightest = pk_max3(brightest, mn9[k], mn9[k + 1]); }
+      darkest = pk_min3(darkest, mx9[15], mx9[15]);
+      brightest = pk_max3(brightest, mn9[15], mn9[15]);
+      // S = max(v - darkest, brightest - v) per half (differences in [-255, 255]: signed 16-bit)
+      const s16x2 S2 = pk_max(as_s2(v2) - as_s2(darkest), as_s2(brightest) - as_s2(v2));
+      const int Sa = S2.x, Sb = S2.y;
+      const bool cornerA = okA && Sa > tcur, cornerB = okB && Sb > tcur;
+      const unsigned long long balA = __ballot(cornerA), balB = __ballot(cornerB);
+      const int pos = nc + __popcll(balA & ltMask) + __popcll(balB & ltMask);
+      if (cornerA) {
+        sbytes[((ea >> 8) + 1) * P + 4 + (ea & 255)] = (uint8_t)(Sa - 1);
+        queue[pos] = (uint16_t)ea;
+      }
+      if (cornerB) {
+        sbytes[((eb >> 8) + 1) * P + 4 + (eb & 255)] = (uint8_t)(Sb - 1);
+        queue[pos + (cornerA ? 1 : 0)] = (uint16_t)eb;
+      }
+      nc += __popcll(balA) + __popcll(balB);
+    }
+  }
+#else
   {
     const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
     uint8_t* sbytes = reinterpret_cast<uint8_t*>(score);
@@ -340,6 +417,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
       nc += __popcll(bal);
     }
   }
+#endif
   __syncthreads();
   if (cutoff == 3) { if (lane == 0) cellCount[(size_t)f * nFastCells + cellId] = 0; return; }
 
