@@ -253,6 +253,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
   int nq = 0;  // wave-uniform
   {
     const s16x2 T = {(short)tcur, (short)tcur};
+    // the quantised pre-test is selective only while t >> 2 is well above the quantisation step (t = 7 would list 70 % of
+    // the pixels): thresholds below 16 take the exact packed-16 form
+    [[maybe_unused]] const bool quantA = tcur >= 16 && tcur <= 255;          // wave-uniform
+    [[maybe_unused]] const uint32_t biasT6 = 0x80808080u - (uint32_t)(tcur >> 2) * 0x01010101u;
     const int ng8 = (cw + 7) >> 3;          // 8-pixel groups per row
     const int ngroups8 = ng8 * ch;
     const uint32_t invG8 = kInv16[ng8];
@@ -268,6 +272,38 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
         const uint32_t* dnp = &tile[(gy + 6) * kPitchDw + 2 * gx + 1];
         const uint32_t m[4] = {mid[0], mid[1], mid[2], mid[3]};
         const uint32_t ups[2] = {upp[0], upp[1]}, dns[2] = {dnp[0], dnp[1]};
+#ifndef ORBFE_FAST_A_EXACT
+        if (quantA) {
+          // QUANTISED form of the same necessary test, four pixels per 32-bit lane-op in the full-rate instruction class
+          // (v_add / v_sub / v_or / v_bitop3: 2.6 cycles, against 4.3 for every packed-16 op and v_perm,
+          // profiles/r03_valu_rate2.txt).  Pixels become 6-bit values x6 = x >> 2 in 8-bit fields, t6 = t >> 2:
+          //   x > c + t  =>  x6 >= c6 + t6   <=>  bit 7 of the field  x6 + (128 - t6 - c6)   (field in [2, 191]: no carry)
+          //   x < c - t  =>  x6 <= c6 - t6   <=>  bit 7 of the field  (c6 + 128 - t6) - x6   (field in [2, 191]: no borrow)
+          // (floor(a + b) >= floor(a) + floor(b), floor(a - b) <= floor(a) - floor(b)).  Being a weaker necessary condition it
+          // lists a few more pixels (+2 % at t = 20 on the bench frames) and can never lose one; phase B decides exactly.
+          uint32_t q[4], qu[2], qd[2];
+#pragma unroll
+          for (int k = 0; k < 4; k++) q[k] = (m[k] >> 2) & 0x3f3f3f3fu;
+#pragma unroll
+          for (int k = 0; k < 2; k++) { qu[k] = (ups[k] >> 2) & 0x3f3f3f3fu; qd[k] = (dns[k] >> 2) & 0x3f3f3f3fu; }
+          uint32_t fl[2];
+#pragma unroll
+          for (int hh = 0; hh < 2; hh++) {
+            const uint32_t c6 = q[hh + 1];
+            const uint32_t e6 = __builtin_amdgcn_alignbyte(q[hh + 2], q[hh + 1], 3);  // bytes x+3 .. x+6
+            const uint32_t w6 = __builtin_amdgcn_alignbyte(q[hh + 1], q[hh], 1);      // bytes x-3 .. x
+            const uint32_t kb = biasT6 - c6, kd = biasT6 + c6;
+            const uint32_t bS = qd[hh] + kb, bN = qu[hh] + kb, bE = e6 + kb, bW = w6 + kb;
+            const uint32_t dS = kd - qd[hh], dN = kd - qu[hh], dE = kd - e6, dW = kd - w6;
+            fl[hh] = ((bS | bN) & (bE | bW)) | ((dS | dN) & (dE | dW));
+          }
+          // bit 7 of the eight bytes -> pass bits 0..7: dword 0's flags move to bits 3, 11, 19, 27, one multiply lines all
+          // eight up in the top byte (partial products on distinct bits: no carries)
+          const uint32_t g = ((fl[0] & 0x80808080u) >> 4) | (fl[1] & 0x80808080u);
+          pass = (g * 0x00204081u) >> 24;
+        } else
+#endif
+        {
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {    // the two dwords of the 8-pixel group
           const uint32_t m0 = m[hh], m1 = m[hh + 1], m2 = m[hh + 2], up = ups[hh], dn = dns[hh];
@@ -290,6 +326,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidViews pyr,
           // 28..31 (the partial products land on distinct bits: no carries)
           const uint32_t sg = __builtin_amdgcn_perm(p[1], p[0], 0x07030501u) & 0x80808080u;
           pass |= ((sg * 0x00204081u) >> 28) << (4 * hh);
+        }
         }
         const int valid = cw - 8 * gx;
         if (valid < 8) pass &= (1u << valid) - 1u;
