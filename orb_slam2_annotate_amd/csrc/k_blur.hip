@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
     //      (a (group, row slot) thread grid ran 73 % full).  The taps are read from LDS: the level is fetched from
     //      memory once for blur and resize together ----
     const int nItems = s_nG * (s_d1 - s_d0);
+    uint8_t* Nf = bb.next.base + (size_t)f * bb.next.frameStride;
     const uint32_t invG = 65536u / (uint32_t)(s_nG > 0 ? s_nG : 1) + 1u;  // exact i / nG for i < 4096 (nG <= 16)
     for (int i = tid; i < nItems; i += 256) {
       const int r = (int)(((uint32_t)i * invG) >> 16), g = i - r * s_nG;
@@ -198,8 +199,8 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
         const uint32_t v = (__umulhi(hA, rr.z) + __umulhi(hB, rr.w) + 2u) >> 2;
         packed |= v << (8 * k);
       }
-      uint8_t* N = bb.next.base + (size_t)f * bb.next.frameStride + (size_t)dy * bb.next.pitch + 4 * (s_g0 + g);
-      *reinterpret_cast<uint32_t*>(N) = packed;  // owned levels: pitch % 64 == 0, in-row
+      // block-uniform frame base (scalar) + 32-bit lane offset: no 64-bit multiply-add per item
+      *reinterpret_cast<uint32_t*>(Nf + ((uint32_t)dy * (uint32_t)bb.next.pitch + 4u * (uint32_t)(s_g0 + g))) = packed;  // owned levels: pitch % 64 == 0, in-row
     }
   }
   // ---- 2. vertical pass: a thread owns 4 adjacent columns x 4 output rows; the 10 source dwords are

@@ -10,7 +10,7 @@
 //   2. one THREAD per keypoint: cv::fastAtan2 and the double-precision sincos_spec, so the
 //      transcendental part is not replicated across 64 lanes;
 //   3. descriptors, one wavefront per keypoint: the 37x48-byte blurred patch is staged in LDS with
-//      16-byte requests, lane l evaluates tests l, l+64, l+128, l+192 on it (rotation in packed
+//      16-byte requests, lane l evaluates tests l, l+64, l+128, l+192 on it (rotation in plain
 //      fp32 mul/add, no FMA); a wave ballot IS 8 descriptor bytes.
 #include <cstdlib>
 
@@ -19,7 +19,6 @@
 namespace orbfe {
 
 namespace {
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct __attribute__((aligned(4))) U4 { uint32_t x, y, z, w; };  // 16-byte load at 4-byte alignment
 // blurred patch of one keypoint staged in LDS: rows y-18..y+18, 48 bytes from the 4-byte aligned
 // column ws <= x-18 (the steered pattern stays inside radius sqrt(13^2+13^2) < 18.5)
@@ -251,16 +250,18 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
         constexpr float kMagic = 12582912.0f;
         constexpr uint32_t kBias = 0x4B400000u * 49u;
         const uint32_t baseK = (uint32_t)((wave * kUD + u) * kPatchRows * kPatchDw * 4 + 18 * 4 * kPatchDw + colOff[u]) - kBias;
-        // both points of a test at once (packed fp32, no FMA): row = x*b + y*a, col = x*a - y*b
-        // (src/ORBextractor.cc:123-125 with a = cos, b = sin), P[t] = (x0, x1, y0, y1)
-        const f32x2 aa = {ca, ca}, bb = {sb, sb}, mm = {kMagic, kMagic};
+        // row = x*b + y*a, col = x*a - y*b (src/ORBextractor.cc:123-125 with a = cos, b = sin; no FMA), P[t] = (x0, x1, y0, y1).
+        // Plain fp32 v_mul / v_add: they issue at 2.4 cycles per wave, the packed v_pk_mul_f32 / v_pk_add_f32 of round 2 at
+        // 7.8 for two values (profiles/r02_valu_rate.txt, r03_valu_rate2.txt) -- fewer instructions, more VALU time
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-          const f32x2 X = {P[t].x, P[t].y}, Y = {P[t].z, P[t].w};
-          const f32x2 R = (X * bb + Y * aa) + mm;
-          const f32x2 Cc = (X * aa - Y * bb) + mm;
-          const uint32_t ir0 = __float_as_uint(R.x), ir1 = __float_as_uint(R.y);
-          const uint32_t ic0 = __float_as_uint(Cc.x), ic1 = __float_as_uint(Cc.y);
+          const float x0 = P[t].x, x1 = P[t].y, y0 = P[t].z, y1 = P[t].w;
+          const float r0 = __fadd_rn(__fadd_rn(__fmul_rn(x0, sb), __fmul_rn(y0, ca)), kMagic);
+          const float r1 = __fadd_rn(__fadd_rn(__fmul_rn(x1, sb), __fmul_rn(y1, ca)), kMagic);
+          const float c0 = __fadd_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sb)), kMagic);
+          const float c1 = __fadd_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sb)), kMagic);
+          const uint32_t ir0 = __float_as_uint(r0), ir1 = __float_as_uint(r1);
+          const uint32_t ic0 = __float_as_uint(c0), ic1 = __float_as_uint(c1);
           t0v[u][t] = pbytes[baseK + ir0 * (4u * kPatchDw) + ic0];
           t1v[u][t] = pbytes[baseK + ir1 * (4u * kPatchDw) + ic1];
         }

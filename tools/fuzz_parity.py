@@ -57,7 +57,7 @@ def main():
         if rng.random() < 0.2:
             w, h = [(640, 480), (752, 480), (1241, 376), (320, 240)][rng.integers(0, 4)]
         params = (int(rng.choice([100, 500, 1000, 2000, 3000])), float(rng.choice([1.1, 1.2, 1.3, 1.5])),
-                  int(rng.integers(1, 9)), int(rng.choice([20, 30, 12, 7])), int(rng.choice([7, 5, 10, 3])))
+                  int(rng.integers(1, 9)), int(rng.choice([20, 30, 12, 7, 16, 17, 19, 23, 64, 120, 255])), int(rng.choice([7, 5, 10, 3, 16, 24])))  # (thresholds on both sides of the FAST pre-test's exact / quantised switch at 16)
         img = content(rng, w, h)
         # round-2 knobs: GaussianBlur arithmetic variant, blur fused into the FAST kernel, lane schedule, host path
         spec = int(rng.choice([0, 0, 1, 2]))

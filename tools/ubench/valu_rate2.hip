@@ -106,6 +106,57 @@ __device__ __forceinline__ void body(uint32_t (&a)[N_ACC], uint32_t b, uint32_t 
   }
 }
 
+// 64-bit accumulators / register pairs: v_mad_u64_u32 (the compiler's choice for a 32-bit a*b+c whose operands may
+// exceed 24 bits), v_lshl_add_u64 (64-bit pointer + offset), v_pk_mul_f32 / v_pk_add_f32 (what the SLP vectoriser makes
+// of two independent fp32 operations)
+enum Op64 { MAD_U64_U32, LSHL_ADD_U64, PK_MUL_F32, PK_ADD_F32, N_OPS64 };
+static const char* kOp64Text[N_OPS64] = {"v_mad_u64_u32 %0, vcc, %1, %2, %0", "v_lshl_add_u64 %0, %0, 1, %3", "v_pk_mul_f32 %0, %0, %3",
+                                         "v_pk_add_f32 %0, %0, %3"};
+template <int OP>
+__global__ __launch_bounds__(256) void k_rate64(uint64_t* out, uint32_t seed) {
+  uint64_t a[N_ACC];
+#pragma unroll
+  for (int i = 0; i < N_ACC; i++) a[i] = (uint64_t)seed * (threadIdx.x + i + 1);
+  const uint32_t b = seed ^ 0x00120123u, c = 0x00020c00u + seed;
+  const uint64_t d = ((uint64_t)0x3f800000u << 32) | 0x3f800001u;
+  for (int it = 0; it < N_IT; it++) {
+#pragma unroll
+    for (int i = 0; i < N_ACC; i++) {
+      if (OP == MAD_U64_U32) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c), "v"(d) : "vcc");
+      if (OP == LSHL_ADD_U64) asm volatile("v_lshl_add_u64 %0, %0, 1, %3" : "+v"(a[i]) : "v"(b), "v"(c), "v"(d) : "vcc");
+      if (OP == PK_MUL_F32) asm volatile("v_pk_mul_f32 %0, %0, %3" : "+v"(a[i]) : "v"(b), "v"(c), "v"(d) : "vcc");
+      if (OP == PK_ADD_F32) asm volatile("v_pk_add_f32 %0, %0, %3" : "+v"(a[i]) : "v"(b), "v"(c), "v"(d) : "vcc");
+    }
+  }
+  uint64_t r = 0;
+#pragma unroll
+  for (int i = 0; i < N_ACC; i++) r ^= a[i];
+  out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+template <int OP>
+void run64(int nCU) {
+  const int blocks = nCU * 8;
+  uint64_t* d;
+  hipMalloc(&d, 8ull * 256 * blocks);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipLaunchKernelGGL((k_rate64<OP>), dim3(blocks), dim3(256), 0, 0, d, 7u);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((k_rate64<OP>), dim3(blocks), dim3(256), 0, 0, d, 7u);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double winst = (double)N_IT * N_ACC * 4.0 * blocks;
+  printf("%-100s %8.3f ms  %7.1f G wave-instr/s chip = %.2f cyc/wave-instr/SIMD @2.4GHz\n", kOp64Text[OP], ms, winst / ms / 1e6,
+         (double)nCU * 4 * 2.4e9 / (winst / (ms * 1e-3)));
+  hipFree(d);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+}
+
 template <int OP>
 __global__ __launch_bounds__(256) void k_rate(uint32_t* out, uint32_t seed) {
   uint32_t a[N_ACC];
@@ -207,5 +258,9 @@ int main() {
   printf("# %s  CUs=%d  (8 waves per SIMD, full EXEC, N_IT=%d x %d instr per wave)\n", p.name, nCU, N_IT, N_ACC);
   int bad = semantics(256) + semantics(1024) + semantics(0x7c00);
   RunAll<0>::go(nCU);
+  run64<MAD_U64_U32>(nCU);
+  run64<LSHL_ADD_U64>(nCU);
+  run64<PK_MUL_F32>(nCU);
+  run64<PK_ADD_F32>(nCU);
   return bad ? 1 : 0;
 }
