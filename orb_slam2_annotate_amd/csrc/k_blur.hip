@@ -69,8 +69,10 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   constexpr int kGX = kBW / 4;         // 4-pixel output groups per tile row (16 / 32)
   constexpr int kHR = 256 / kGX;       // output rows one step of the horizontal pass covers (16 / 8)
   constexpr uint32_t K0 = 18, K1 = 34, K2 = SPEC == 0 ? 48 : 49, K3 = SPEC == 0 ? 56 : 55;
-  __shared__ __attribute__((aligned(16))) uint32_t tin[kTH * kTDW];  // source bytes
-  __shared__ uint2 vbuf[kBH * kVDW];               // vertical sums, 4 u16 per entry
+  constexpr int kVR = 5;                             // output rows per vertical-pass item (see phase 2)
+  constexpr int kVB = (kBH + kVR - 1) / kVR;         // row blocks of a full tile: 13 / 7 -- the last one runs past the tile
+  __shared__ __attribute__((aligned(16))) uint32_t tin[(kVB * kVR + 6) * kTDW];  // source bytes: kTH staged rows (+ the last block's overhang)
+  __shared__ uint2 vbuf[kVB * kVR * kVDW];         // vertical sums, 4 u16 per entry
   __shared__ uint4 s_col[RESIZE ? 48 : 1];         // RESIZE: column records of the groups this tile owns
   __shared__ uint4 s_row[RESIZE ? 80 : 1];         //         and row records of the output rows it owns (<= 65 at scale >= 1)
   __shared__ int s_g0, s_nG, s_d0, s_d1;
@@ -93,8 +95,11 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   const int tyI = (int)udiv_magic(rem, (uint32_t)tilesX, bb.tilesXMagic[l]);  // rem / tilesX
   const int bx = (int)(rem - (unsigned)tyI * (unsigned)tilesX) * kBW, by = tyI * kBH;
   const int rowsValid = dst.h - by < kBH ? dst.h - by : kBH;  // output rows of this tile inside the level
-  const int rowBlocks = (rowsValid + 3) >> 2;                 // 4-row blocks the vertical pass computes
-  const int stageRows = 4 * rowBlocks + 6;                    // <= kTH
+  // the vertical pass computes kVR-row blocks: 5 rows make 13 x 18 = 234 (64 x 64 tile) / 7 x 34 = 238 (128 x 32) items, ONE
+  // trip of the 256 threads (4-row blocks were 288 / 272 items: wave 0 went round twice and the other three waited for it
+  // at the barrier)
+  const int rowBlocks = (rowsValid + kVR - 1) / kVR;
+  const int stageRows = rowsValid + 6;                        // <= kTH
   const uint8_t* S = src.base + (size_t)f * src.frameStride;
   // every staging load is ONE dword at whatever byte address the level and the tile give: global_load_dword takes
   // unaligned addresses on gfx950 (profiles/r02_unaligned.txt), so a caller-owned level 0 with an odd stride
@@ -203,23 +208,23 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
       *reinterpret_cast<uint32_t*>(Nf + ((uint32_t)dy * (uint32_t)bb.next.pitch + 4u * (uint32_t)(s_g0 + g))) = packed;  // owned levels: pitch % 64 == 0, in-row
     }
   }
-  // ---- 2. vertical pass: a thread owns 4 adjacent columns x 4 output rows; the 10 source dwords are
-  //         split into u16 pairs once and shared by the 4 rows; 8.8 sums, two pixels per lane-op ----
+  // ---- 2. vertical pass: a thread owns 4 adjacent columns x kVR output rows; the kVR + 6 source dwords are
+  //         split into u16 pairs once and shared by the rows; 8.8 sums, two pixels per lane-op ----
   for (int i = tid; i < rowBlocks * kVDW; i += 256) {
     const int rb = (int)((uint32_t)i / (uint32_t)kVDW), tj = i - rb * kVDW;
-    const uint32_t* tp = &tin[(4 * rb) * kTDW + tj];
-    u16x2 te[10], to[10];  // even bytes (0,2) and odd bytes (1,3) of each source dword
+    const uint32_t* tp = &tin[(kVR * rb) * kTDW + tj];
+    u16x2 te[kVR + 6], to[kVR + 6];  // even bytes (0,2) and odd bytes (1,3) of each source dword
 #pragma unroll
-    for (int j = 0; j < 10; j++) {
-      const uint32_t r = tp[j * kTDW];
+    for (int j = 0; j < kVR + 6; j++) {
+      const uint32_t r = tp[j * kTDW];  // (rows below the staged ones -- the last block of a tile -- hold stale bytes; their sums are never read)
       te[j] = as_u2(r & 0x00ff00ffu);
       to[j] = as_u2(__builtin_amdgcn_perm(r, r, 0x0c030c01u));
     }
     const u16x2 k18 = {(unsigned short)K0, (unsigned short)K0}, k34 = {(unsigned short)K1, (unsigned short)K1},
                 k48 = {(unsigned short)K2, (unsigned short)K2}, k56 = {(unsigned short)K3, (unsigned short)K3};
-    uint2* vo = &vbuf[(4 * rb) * kVDW + tj];
+    uint2* vo = &vbuf[(kVR * rb) * kVDW + tj];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < kVR; r++) {
       u16x2 a = (te[r] + te[r + 6]) * k18;
       a = (te[r + 1] + te[r + 5]) * k34 + a;
       a = (te[r + 2] + te[r + 4]) * k48 + a;
