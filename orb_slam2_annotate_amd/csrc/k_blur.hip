@@ -81,10 +81,11 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   // tiles one XCD's L2 sees are a contiguous raster run and share their halo rows there
   const unsigned chunk = gridDim.x >> 3;
   const unsigned work = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
-  if (work >= bb.tileStart[bb.nlevels]) return;
+  if (work >= bb.tileStart[RESIZE ? 1 : bb.nlevels]) return;
   int l = 0;
-  for (int k = 1; k < bb.nlevels; k++)
-    if (work >= bb.tileStart[k]) l = k;   // block-uniform (scalar) search
+  if (!RESIZE)  // (the fused form is launched per level: l = 0 is a constant and its fields sit at fixed argument offsets)
+    for (int k = 1; k < bb.nlevels; k++)
+      if (work >= bb.tileStart[k]) l = k;   // block-uniform (scalar) search
   const LevelView src = bb.src[l];
   const LevelViewMut dst = bb.dst[l];
   const int tilesX = bb.tilesX[l];
@@ -105,32 +106,51 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   // unaligned addresses on gfx950 (profiles/r02_unaligned.txt), so a caller-owned level 0 with an odd stride
   // (KITTI: 1241) runs the same paths as the handle's own 64-byte pitched levels
   struct __attribute__((packed, aligned(1))) U1u { uint32_t x; };
-  if (RESIZE) {  // ownership of the next level (scalar loads) and the owned groups' column records, for phase 1b
+  // ---- 1. stage.  The fused form issues ALL its memory requests before it waits for any: the two 16-byte pieces of the
+  //      tile first (their addresses need nothing but the kernel arguments), then the ownership tables (scalar), then the
+  //      column / row records -- every load unconditional on a clamped, always valid index, the LDS writes predicated
+  //      afterwards.  (Written as guarded load + store pairs the compiler waited for each request in turn: five
+  //      dependent round trips at the head of a workgroup whose arithmetic takes less than one.) ----
+  const bool interior = bx >= 4 && bx - 4 + 4 * kTDW <= src.w && by >= 3 && by + kBH + 3 <= src.h;  // block-uniform
+  const bool wideCols = RESIZE && bx >= 4 && bx - 4 + 4 * kTDW <= src.w;  // tile away from the left / right edges (block-uniform)
+  struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };
+  constexpr int kParts = kTDW / 4;  // 5 x 16 bytes per tile row
+  constexpr int kPieces = (kTH * kParts + 255) / 256;
+  U4u q[kPieces];
+  if (wideCols) {
+    // 16-byte requests (any byte address, profiles/r02_unaligned.txt) and ds_write_b128, 2 staging instructions per thread
+    // instead of 6 -- the memory instructions of a wave, not the bytes, are what the texture addresser meters; top /
+    // bottom tiles reflect the row
+    const uint8_t* T0 = S + (bx - 4);  // block-uniform (scalar)
+#pragma unroll
+    for (int k = 0; k < kPieces; k++) {
+      const int i = tid + 256 * k;
+      int row = (int)((uint32_t)i / (uint32_t)kParts);
+      const int part = i - row * kParts;
+      row = row < stageRows ? row : 0;  // (threads past the tile re-read its first row; they store nothing)
+      const int sy = interior ? by - 3 + row : reflect101c(by - 3 + row, src.h);
+      q[k] = *reinterpret_cast<const U4u*>(T0 + ((uint32_t)sy * (uint32_t)src.pitch + 16u * (uint32_t)part));
+    }
+  }
+  if (RESIZE) {  // ownership of the next level (scalar loads) and the owned groups' column / row records, for phase 1b
     const int txI = (int)(rem - (unsigned)tyI * (unsigned)tilesX);
     const int g0 = bb.tileGx[txI], nG = bb.tileGx[txI + 1] - g0;
     const int d0 = bb.tileDy[tyI], d1 = bb.tileDy[tyI + 1];
     if (tid == 0) { s_g0 = g0; s_nG = nG; s_d0 = d0; s_d1 = d1; }  // d1 - d0 <= 80 (build_resize_tables)
-    if (tid >= 256 - 48 && tid - (256 - 48) < 3 * nG) s_col[tid - (256 - 48)] = bb.colrec[3 * g0 + (tid - (256 - 48))];
-    if (tid < d1 - d0 && tid < 80) s_row[tid] = bb.rowrec[d0 + tid];
+    const int nColRec = 3 * ((bb.next.w + 3) >> 2);  // records of the level: 3 per 4-pixel group, one per output row
+    int ci = 3 * g0 + (tid - (256 - 48)), ri = d0 + tid;
+    ci = ci < 0 ? 0 : (ci < nColRec ? ci : nColRec - 1);
+    ri = ri < bb.next.h ? ri : bb.next.h - 1;
+    const uint4 rc = bb.colrec[ci], rw = bb.rowrec[ri];
+    if (tid >= 256 - 48 && tid - (256 - 48) < 3 * nG) s_col[tid - (256 - 48)] = rc;
+    if (tid < d1 - d0 && tid < 80) s_row[tid] = rw;
   }
-  // ---- 1. stage: thread (ty0, tj) = (tid / kTDW, tid % kTDW) walks down the tile kSR rows at a time ----
-  const bool interior = bx >= 4 && bx - 4 + 4 * kTDW <= src.w && by >= 3 && by + kBH + 3 <= src.h;  // block-uniform
-  if (RESIZE && bx >= 4 && bx - 4 + 4 * kTDW <= src.w) {
-    // fused form, tile away from the left / right edges (block-uniform): 16-byte requests (any byte address,
-    // profiles/r02_unaligned.txt) and ds_write_b128, 2 staging instructions per thread instead of 6 -- the memory
-    // instructions of a wave, not the bytes, are what the texture addresser meters; top / bottom tiles reflect the row
-    struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };
-    constexpr int kParts = kTDW / 4;  // 5 x 16 bytes per tile row
-    const uint8_t* T0 = S + (bx - 4);  // block-uniform (scalar)
+  if (wideCols) {
 #pragma unroll
-    for (int k = 0; k < (kTH * kParts + 255) / 256; k++) {
+    for (int k = 0; k < kPieces; k++) {
       const int i = tid + 256 * k;
       const int row = (int)((uint32_t)i / (uint32_t)kParts), part = i - row * kParts;
-      if (row < stageRows) {
-        const int sy = interior ? by - 3 + row : reflect101c(by - 3 + row, src.h);
-        const U4u q = *reinterpret_cast<const U4u*>(T0 + ((uint32_t)sy * (uint32_t)src.pitch + 16u * (uint32_t)part));
-        *reinterpret_cast<uint4*>(&tin[row * kTDW + 4 * part]) = make_uint4(q.x, q.y, q.z, q.w);
-      }
+      if (row < stageRows) *reinterpret_cast<uint4*>(&tin[row * kTDW + 4 * part]) = make_uint4(q[k].x, q[k].y, q[k].z, q[k].w);
     }
   } else if (tid < kSR * kTDW) {
     const int ty0 = (int)((uint32_t)tid / (uint32_t)kTDW), tj = tid - ty0 * kTDW;

@@ -4,7 +4,7 @@ for rep in 1 2; do
   for lib in "$A" ""; do
     for w in $WL; do
       ORBFE_LIB=$lib python bench.py --workload $w --no-e2e --no-cpu-baseline > gpurun_out/b_abl.json 2> gpurun_out/b_abl.err
-      echo "[${lib:-in-tree}] $(python tools/show_bench.py gpurun_out/b_abl.json | grep -E 'value|orient' | tr '\n' ' ' | sed -E 's/ +/ /g' | cut -c1-230)"
+      echo "[${lib:-in-tree}] $(python tools/show_bench.py gpurun_out/b_abl.json | grep -E 'value|pyramid|fast|orient' | tr '\n' ' ' | sed -E 's/ +/ /g' | sed -E 's/hbm_excl [0-9.]+ valu_frac [0-9.]+ busy [0-9.e+-]+//g' | cut -c1-260)"
     done
   done
 done
