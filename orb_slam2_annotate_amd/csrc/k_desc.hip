@@ -2,12 +2,13 @@
 // (src/ORBextractor.cc:78-106) on the UNBLURRED level, the 256-bit steered BRIEF descriptor
 // (:111-152) on the BLURRED level, and the final cv::KeyPoint record (:905-916,:1187-1195).
 //
-// A 256-thread workgroup owns 64 keypoint slots and runs three phases:
+// A 256-thread workgroup owns 64 keypoint slots, 16 per wavefront; each wavefront takes its slots through three
+// phases on its own (no workgroup barrier):
 //   1. moments, one wavefront per keypoint: lane = (disc row, left/right half); each lane loads
 //      its 16 pixels as aligned dwords and folds them with v_dot4_u32_u8 against per-row weight
 //      bytes ((dx+16) inside the disc, 0 outside) and mask bytes -> m10 = sum(w*I) - 16*sum(I),
 //      m01 = dy*sum(I); integer, order-free, DPP reduction across the 62 lanes;
-//   2. one THREAD per keypoint: cv::fastAtan2 and the double-precision sincos_spec, so the
+//   2. one LANE per keypoint of the wave: cv::fastAtan2 and the double-precision sincos_spec, so the
 //      transcendental part is not replicated across 64 lanes;
 //   3. descriptors, one wavefront per keypoint: the 37x48-byte blurred patch is staged in LDS with
 //      16-byte requests, lane l evaluates tests l, l+64, l+128, l+192 on it (rotation in plain
@@ -34,6 +35,12 @@ __device__ __forceinline__ int wave_sum(int x) {
   x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1, 3
   x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2, 3
   return __builtin_amdgcn_readlane(x, 63);
+}
+// LDS written by some lanes of a wave, read by others of the SAME wave: order and visibility without a workgroup barrier
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 }  // namespace
 
@@ -77,9 +84,15 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
   const int slot0 = (int)(work - (unsigned)f * (unsigned)blocksPerFrame) * kKpPerBlock;
   const int32_t* cnt = levelCount + (size_t)f * a.nlevels;
 
-  // ---- slot -> (level, index, output row); thread t < 64 resolves slot0 + t ----
-  if (tid < kKpPerBlock) {
-    const int slot = slot0 + tid;
+  // ---- slot -> (level, index, output row).  A wave owns the kKpPerBlock / 4 consecutive slots it also takes through
+  //      phases 1-3, and its first lanes resolve them: nothing in the kernel crosses a wave, so there is no workgroup
+  //      barrier -- the four waves of a workgroup drift apart and one's transcendental chain (phase 2) overlaps the
+  //      others' memory phases (round 2 resolved all slots and all angles on wave 0 between __syncthreads: three waves
+  //      waited through both serial sections) ----
+  constexpr int kKpPerWave = kKpPerBlock / 4;
+  const int myKp = wave * kKpPerWave + lane;  // the keypoint this lane resolves (phase 0) and rotates (phase 2) when lane < kKpPerWave
+  if (lane < kKpPerWave) {
+    const int slot = slot0 + myKp;
     int out = -1, l = 0;
     if (slot < a.kpSlotsPerFrame) {
       int base = 0;
@@ -91,20 +104,20 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
       if (i < cnt[l]) {
         const LevelKp kp = levelKp[(size_t)f * a.kpSlotsPerFrame + slot];
         if (base + (int)kp.rank < a.outCapacity) out = base + (int)kp.rank;
-        s_x[tid] = kp.x;
-        s_y[tid] = kp.y;
-        s_score[tid] = kp.score;
+        s_x[myKp] = kp.x;
+        s_y[myKp] = kp.y;
+        s_score[myKp] = kp.score;
       }
     }
-    s_level[tid] = l;
-    s_out[tid] = out;
+    s_level[myKp] = l;
+    s_out[myKp] = out;
     if (slot == 0) {
       int tot = 0;
       for (int k = 0; k < a.nlevels; k++) tot += cnt[k];
       nOut[f] = tot;  // the host reports ORBFE_ERR_CAPACITY when this exceeds the capacity
     }
   }
-  __syncthreads();
+  wave_sync_lds();
 
   // ---- 1. intensity-centroid moments over the 749-pixel disc ----
   {
@@ -120,7 +133,6 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
     }
     // 16 keypoints per wave, 4 at a time: the 4 x 5 row loads are issued back to back so one
     // memory latency covers four keypoints (the kernel is latency-bound, not VALU-bound)
-    constexpr int kKpPerWave = kKpPerBlock / 4;
     for (int j0 = wave * kKpPerWave; j0 < wave * kKpPerWave + kKpPerWave; j0 += kUM) {
       uint32_t dw[kUM][5];
       uint32_t mis[kUM];
@@ -175,19 +187,19 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
       }
     }
   }
-  __syncthreads();
+  wave_sync_lds();
 
-  // ---- 2. angle and rotation, one thread per keypoint ----
-  if (tid < kKpPerBlock && s_out[tid] >= 0) {
-    const float angle = fast_atan2((float)s_m01[tid], (float)s_m10[tid]);
+  // ---- 2. angle and rotation, one lane per keypoint of the wave ----
+  if (lane < kKpPerWave && s_out[myKp] >= 0) {
+    const float angle = fast_atan2((float)s_m01[myKp], (float)s_m10[myKp]);
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     float ca, sb;
     sincos_spec(__fmul_rn(angle, factorPI), &ca, &sb);
-    s_angle[tid] = angle;
-    s_cos[tid] = ca;
-    s_sin[tid] = sb;
+    s_angle[myKp] = angle;
+    s_cos[myKp] = ca;
+    s_sin[myKp] = sb;
   }
-  __syncthreads();
+  wave_sync_lds();
 
   // ---- 3. steered BRIEF + output record ----
   {
@@ -300,7 +312,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
       }
     }
   }
-  __syncthreads();  // the next item reuses the slot arrays
+  wave_sync_lds();  // the next item reuses the wave's part of the slot arrays
   }  // work items of this workgroup
 }
 
