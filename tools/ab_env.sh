@@ -1,7 +1,18 @@
-# same-box A/B of environment knobs over the three workloads: tools/ab_env.sh "A=1 B=2" "A=0" ...   (each argument = one configuration)
-for cfg in "$@"; do
-  for w in kitti tum euroc; do
-    env $cfg python bench.py --workload $w --no-e2e --no-cpu-baseline > gpurun_out/b_ab.json 2> gpurun_out/b_ab.err
-    echo "[$cfg] $(python tools/show_bench.py gpurun_out/b_ab.json | grep -E 'value' | sed -E 's/.*(KITTI|TUM|EuRoC|tum|euroc).* value ([0-9]+) .*ms\/step ([0-9.]+).*/\1 \2 \3/')"
+#!/bin/bash
+# same-box A/B of environment knobs: tools/ab_env.sh "kitti tum" "A=1 B=2" "A=0" ...   (first argument = workloads, each
+# further argument = one configuration; two rounds, configurations alternating)
+WL=$1; shift
+for rep in 1 2; do
+  for cfg in "$@"; do
+    for w in $WL; do
+      env $cfg python bench.py --workload $w --no-e2e --no-cpu-baseline --no-latency > gpurun_out/b_ab.json 2> gpurun_out/b_ab.err
+      python - "$w" "$cfg" <<'PY'
+import json, sys
+j = json.loads(open("gpurun_out/b_ab.json").read().strip().splitlines()[-1])
+st = j["roofline"]["stages"]
+print("[%-22s %-7s] value %8.0f  ms/step %7.3f | excl " % (sys.argv[2][:22], sys.argv[1], j["value"], j["ms_per_step"]) +
+      "  ".join("%s %.3f" % (k, v["ms_per_step_exclusive"]) for k, v in st.items()))
+PY
+    done
   done
 done
