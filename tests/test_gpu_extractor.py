@@ -116,6 +116,19 @@ def test_extract_other_params(amd):
     _check_frame(amd, img, (2000, 1.1, 6, 30, 10))
 
 
+@pytest.mark.parametrize("ini,mn", [(15, 7), (16, 7), (17, 16), (19, 3), (40, 24), (120, 16), (255, 7), (7, 20)])
+def test_fast_pretest_forms_at_the_threshold_switch(amd, ini, mn):
+    """k_fast_cells phase A takes the quantised 4-pixels-per-op pre-test for thresholds >= 16 and the exact packed-16 form
+    below (csrc/k_fast.hip); the candidates in emission order, their responses and everything downstream must not depend
+    on which one listed the pixels -- thresholds on both sides of the switch, for the first attempt (iniThFAST) and for
+    the fallback (minThFAST), incl. minThFAST > iniThFAST, on a textured and on a low-contrast frame."""
+    _check_frame(amd, synth.render_frame(40 + ini, 400, 300), (800, 1.2, 5, ini, mn))
+    rng = np.random.default_rng(ini * 256 + mn)
+    y, x = np.mgrid[0:240, 0:320]
+    soft = ((x * 0.31 + y * 0.17) % 256 + rng.normal(0, 6, (240, 320))).clip(0, 255).astype(np.uint8)  # few cells reach iniThFAST
+    _check_frame(amd, soft, (500, 1.2, 4, ini, mn))
+
+
 def test_extract_strided_and_batch(amd):
     imgs = np.stack([synth.render_frame(30 + i, 320, 240) for i in range(5)])
     o = orc.Oracle(500, 1.2, 8, 20, 7)
