@@ -604,12 +604,13 @@ def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, u
     #     The K-step block is repeated until >= --min-seconds have been timed (each block barrier-bracketed, max over
     #     ranks): `value` is the MEDIAN block, min / max / repeats are reported beside it.
     ext.profile([dom])
-    blocks = []
+    blocks, enq = [], []
     while True:
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             g.step()
+        enq.append(time.perf_counter() - t0)  # the host is done ENQUEUEING here; the device still runs
         barrier()
         dt = time.perf_counter() - t0
         dt_blk, total_units = reduce_report(dt, float(B * args.steps), torch, dist, use_dist, g.dev)  # same on every rank
@@ -619,6 +620,14 @@ def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, u
     prof = ext.profile_get()
     ext.profile(False)
     dt_max = float(np.median(blocks))
+    # the same enqueue with EMPTY device queues (4 steps from a synchronised state): what the launching thread needs on its
+    # own, without any back-pressure from full queues
+    g.sync()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        g.step()
+    enq_idle = (time.perf_counter() - t0) / 4
+    g.sync()
 
     n_kp = float(g.d_n.float().mean().item())
     n_st = float(g.d_ns.float().mean().item()) if g.stereo else 0.0
@@ -712,7 +721,11 @@ def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, u
                "unit": "stereo frames/s" if g.stereo else "frames/s", "ms_per_step": 1e3 * dt_max / args.steps,
                "repeats": {"blocks_of_K_steps": len(blocks), "timed_seconds": float(sum(blocks)), "value_is": "median block",
                            "value_min": total_units / max(blocks), "value_max": total_units / min(blocks),
-                           "spread_pct": 100.0 * (max(blocks) - min(blocks)) / dt_max},
+                           "spread_pct": 100.0 * (max(blocks) - min(blocks)) / dt_max,
+                           # host time to ENQUEUE a step (all HIP calls of the step issued, nothing waited for): well below
+                           # ms_per_step = the device, not the launching thread, sets the rate
+                           "host_enqueue_ms_per_step": 1e3 * float(np.median(enq)) / args.steps,
+                           "host_enqueue_ms_per_step_idle_queues": 1e3 * enq_idle},
                "units_per_gpu_per_step": B, "images_per_gpu_per_step": NI, "keypoints_per_image": n_kp,
                "stereo_matches_per_frame": n_st if g.stereo else None, "matching_work": work, "roofline": roof,
                "parity_check": check}

@@ -10,7 +10,7 @@ for rep in 1 2; do
 import json, sys
 j = json.loads(open("gpurun_out/b_ab.json").read().strip().splitlines()[-1])
 st = j["roofline"]["stages"]
-print("[%-22s %-7s] value %8.0f  ms/step %7.3f | excl " % (sys.argv[2][:22], sys.argv[1], j["value"], j["ms_per_step"]) +
+print("[%-22s %-7s] value %8.0f  ms/step %7.3f (host enqueue %.3f, on idle queues %.3f) | excl " % (sys.argv[2][:22], sys.argv[1], j["value"], j["ms_per_step"], j.get("repeats", {}).get("host_enqueue_ms_per_step", float("nan")), j.get("repeats", {}).get("host_enqueue_ms_per_step_idle_queues", float("nan"))) +
       "  ".join("%s %.3f" % (k, v["ms_per_step_exclusive"]) for k, v in st.items()))
 PY
     done

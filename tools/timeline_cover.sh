@@ -55,6 +55,14 @@ for s, e, k in ev:
         per[k].append((s, e))
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]):
     print("  %-26s sum of durations %.3f of the span, at least one running %.3f, mean duration %.1f us" % (k, v / span, union(per[k]) / span, v / len(per[k]) / 1e3))
+qcol0 = [c for c in rows[0].keys() if "Queue" in c]
+if qcol0:
+    perq = collections.defaultdict(list)
+    for r in rows:
+        s_, e_ = max(int(r["Start_Timestamp"]), lo), min(int(r["End_Timestamp"]), hi)
+        if e_ > s_:
+            perq[r[qcol0[0]]].append((s_, e_))
+    print("hardware queues busy:", "  ".join("q%s: %.3f" % (q, union(v) / span) for q, v in sorted(perq.items())))
 # an excerpt of the timeline: 70 consecutive dispatches from the middle, start / end in us relative to the first, queue
 qcol = [c for c in rows[0].keys() if "Queue" in c]
 mid = len(rows) // 2
