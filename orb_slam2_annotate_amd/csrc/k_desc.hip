@@ -343,6 +343,9 @@ void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d
     // blurred levels per frame) want ONE frame's workgroups per XCD in flight: 1 per CU measured 100.1 k vs 94.7 k
     // stereo frames/s on 8 streams, while 640 x 480 / 1000 features lose 5 % that way (same-box A/B)
     if (blocksPerFrame >= 24 && concurrentLaunches >= 8) kGridPerCu = 1;
+    // a launch that has the device to itself (one stream): no cap -- round 3, with the barrier-free kernel: 1.37 vs 1.59 ms
+    // per 1024 KITTI frames, 2.89 vs 3.45 per 4096 TUM frames, 1.76 vs 1.97 per 2048 EuRoC frames against 4 per CU
+    if (concurrentLaunches <= 1) kGridPerCu = 0;
   }
   // Round 2 measured the wider form <64, 8, 4> (twice the row / patch loads in flight per wave, 106 VGPRs, same 4
   // workgroups per CU): stage 3.36 vs 3.38 ms per 4096 VGA frames, pipeline unchanged, so <64, 4, 2> stays.

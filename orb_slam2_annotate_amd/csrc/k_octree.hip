@@ -624,7 +624,11 @@ hipError_t launch_octree(hipStream_t s, const OctreeArgs& args, int nlevels, int
   }
   if (latencyForm) hipLaunchKernelGGL(k_octree_reg, dim3(nlevels, nFrames), dim3(256), lds, s, a);
   else {
-    static const int perCu = getenv("ORBFE_OCTREE_GRID") ? atoi(getenv("ORBFE_OCTREE_GRID")) : 4;
+    // workgroups per CU of the persistent grid; 0 = one workgroup per (frame, level).  Round 2 capped it at 4; with the
+    // round-3 kernels the pipelines measure the same with any cap (KITTI 105.6 k vs 104.0 k, TUM 379.9 k vs 382.9 k, EuRoC
+    // 262.0 k vs 260.0 k stereo frames / frames per second for 0 vs 4) and the stage alone is 22 % faster without one
+    // (0.62 vs 0.81 ms per 1024 KITTI frames): no cap by default
+    static const int perCu = getenv("ORBFE_OCTREE_GRID") ? atoi(getenv("ORBFE_OCTREE_GRID")) : 0;
     unsigned grid = (unsigned)nlevels * (unsigned)nFrames;
     if (perCu > 0 && (unsigned)perCu * 256u < grid) grid = (unsigned)perCu * 256u;
     hipLaunchKernelGGL(k_octree, dim3(grid), dim3(256), lds, s, a);
