@@ -412,8 +412,8 @@ def cpu_baseline(wlname, frames, voc_arrays, seconds):
             "euroc": "operator() + vocabulary transform + SearchByBoW(t-1,t)",
             "euroc_stereo": "cv::remap L and R + operator() on L and R + ComputeStereoMatches + vocabulary transform + SearchByBoW(t-1,t)"}[wlname]
     return dict(value=variants[ref]["value"], unit=unit, cores=variants[ref]["cores"], kind="port",
-                sample=f"{variants[ref]['units']} units of the same synthetic {wl['w']}x{wl['h']} workload ({what}) through "
-                       f"oracle/orb_oracle.c (scalar C port, gcc -O3); threading of the reference for this workload: {ref}",
+                sample=f"{variants[ref]['units']} units of the same synthetic {wl['w']}x{wl['h']} workload ({what}), "
+                       f"oracle/orb_oracle.c (scalar C, gcc -O3), the reference's threading: {ref}",
                 mean_ms=variants[ref]["mean_ms"], median_ms=variants[ref]["median_ms"], variants=variants)
 
 
@@ -677,6 +677,10 @@ def run_gpu_workload(name, frames, args, rank, world, local_rank, torch, dist, u
             "traffic": pmc_traffic(dom, name, dom_imgs, stage_kernels),
             "algorithmic_bytes_per_launch_group": stage_bytes(dom, dom_imgs), "ms_per_launch_group": dom_ms,
             "images_per_launch": dom_imgs, "launch_groups_timed": n_groups, "streams": S, "schedule": args.schedule,
+            # the same kernel ALONE on the chip (1-stream warm-up pass, HIP events): the co-resident `frac` above shares the GPU
+            # with the other sub-batches' kernels
+            "exclusive": {"ms_per_step": excl[dom], "achieved": stage_bytes(dom, per_launch_units[dom] if dom != "match" else NI) / (excl[dom] * 1e-3) / 1e9 if excl[dom] > 0 else None,
+                          "frac": stages.get(dom, {}).get("hbm_frac_exclusive")},
             "stages": stages, "fused_pyramid_blur": fused_pyramid_blur,
             "pipeline": {"algorithmic_bytes_per_unit": pipe_bytes, "achieved": pipe_bytes * value / world / 1e9,
                          "frac": pipe_bytes * value / world / 1e9 / HBM_PEAK_GBS,
@@ -803,7 +807,8 @@ def run_kitti_seq(frames, args, rank, world, local_rank, torch, dist, use_dist, 
     lengths = [max(1, int(round(n * args.seq_scale))) for n in shard.KITTI_00_07]
     out = {}
     for mode in ("sequence", "round_robin"):
-        mine = shard.frames_of(shard.shard_sequences(lengths, world, mode)[rank])
+        plan = shard.shard_sequences(lengths, world, mode)
+        mine, longest = shard.frames_of(plan[rank]), max(shard.frames_of(p) for p in plan)
 
         def one_pass():
             left = mine
@@ -825,10 +830,125 @@ def run_kitti_seq(frames, args, rank, world, local_rank, torch, dist, use_dist, 
         dt = time.perf_counter() - t0
         dt_max, total = reduce_report(dt, float(mine * args.steps), torch, dist, use_dist, g.dev)
         out[mode] = {"value": total / dt_max, "ms_per_step": 1e3 * dt_max / args.steps, "stereo_frames_per_step": total / args.steps,
-                     "frames_of_rank0": mine}
+                     "frames_of_rank0": mine, "max_frames_of_a_rank": longest}
     check = g.check(None)[0] if rank == 0 else None
     del g
     return out, lengths, check
+
+
+
+# ------------------------------------------------------------------------------------------------
+# the ONE stdout line: compact (< 4 KB); everything else goes to the detail file
+# ------------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096  # bytes; the driver keeps an 8 KB tail of stdout and parses the LAST line (round 3 printed 31 KB: unparsed)
+
+
+def _r(x, sig=6):
+    """floats to `sig` significant digits (the detail file keeps full precision)"""
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}")
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and d.get(k) is not None}
+
+
+def compact_line(full, detail_path=None):
+    """The contract line from the full result dict: metric / value / config / roofline (dominant kernel + pipeline +
+    per-stage exclusive ms) / cpu_baseline / parity_check / repeats, one short object per secondary workload.  Stage
+    tables, CPU variants, e2e, matching work and the latency rows stay in the detail file named by `detail`."""
+    out = _pick(full, ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling"])
+    out["vs_baseline"] = full.get("vs_baseline")
+    out.update(_pick(full, ["dtype", "data", "vs_cpu_baseline", "stereo_matches_per_frame"]))
+    cfg = dict(full.get("config", {}))
+    if len(str(cfg.get("workload", ""))) > 200:
+        cfg["workload"] = cfg["workload"][:197] + "..."
+    out["config"] = cfg
+    rf = full.get("roofline")
+    if rf:
+        c = _pick(rf, ["bound", "bound_closest", "kernel", "stage", "achieved", "peak", "unit", "frac", "traffic",
+                       "algorithmic_bytes_per_launch_group", "ms_per_launch_group", "images_per_launch", "streams"])
+        if len(str(c.get("kernel", ""))) > 120:
+            c["kernel"] = c["kernel"][:117] + "..."
+        c.setdefault("traffic", None)
+        if rf.get("exclusive"):
+            c["exclusive"] = rf["exclusive"]
+        if rf.get("pipeline"):
+            c["pipeline"] = rf["pipeline"]
+        if rf.get("valu_issue"):
+            c["valu_issue"] = _pick(rf["valu_issue"], ["pipeline_frac", "max_stage_frac"])
+        if rf.get("stages"):
+            c["stages_exclusive_ms"] = {k: v["ms_per_step_exclusive"] for k, v in rf["stages"].items()}
+        out["roofline"] = c
+    cb = full.get("cpu_baseline")
+    if cb:
+        c = _pick(cb, ["value", "unit", "cores", "kind", "sample", "mean_ms", "median_ms"])
+        if len(str(c.get("sample", ""))) > 300:
+            c["sample"] = c["sample"][:297] + "..."
+        out["cpu_baseline"] = c
+    if full.get("parity_check"):
+        out["parity_check"] = _pick(full["parity_check"], ["ok", "units_checked", "skipped"])
+    if full.get("repeats"):
+        out["repeats"] = _pick(full["repeats"], ["blocks_of_K_steps", "timed_seconds", "value_is", "value_min", "value_max", "spread_pct"])
+    sec = []
+    for s_ in full.get("secondary") or []:
+        e = _pick(s_, ["key", "value", "unit", "ms_per_step", "vs_cpu_baseline", "scaling"])
+        pf = (s_.get("roofline") or {}).get("pipeline") or {}
+        if pf.get("frac") is not None:
+            e["pipeline_frac"] = pf["frac"]
+        if (s_.get("parity_check") or {}).get("ok") is not None:
+            e["parity_ok"] = s_["parity_check"]["ok"]
+        if s_.get("plans"):  # configs[4]: both sharding plans, value + the longest share
+            e["plans"] = {m: _pick(p, ["value", "ms_per_step", "stereo_frames_per_step", "frames_of_rank0", "max_frames_of_a_rank"])
+                          for m, p in s_["plans"].items()}
+        sec.append(e)
+    if sec:
+        out["secondary"] = sec
+    for k in ("stub", "total_units", "plans"):
+        if k in full:
+            out[k] = full[k]
+    if full.get("latency"):
+        out["latency_rows"] = len(full["latency"].get("rows", []))
+    if detail_path:
+        out["detail"] = str(detail_path)
+    out = _r(out)
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) >= LINE_LIMIT:  # never again an unparseable line: shed the optional parts, largest first
+        for k in ("secondary", "repeats", "stereo_matches_per_frame"):
+            out.pop(k, None)
+            line = json.dumps(out, separators=(",", ":"))
+            if len(line) < LINE_LIMIT:
+                break
+    return line
+
+
+def emit(full, args):
+    """Write the full result to the detail file and print the compact line LAST on stdout (`--full-line`: the full dict
+    on stdout instead, what the tools/ scripts parse)."""
+    path = None
+    if not args.no_detail:
+        path = Path(args.detail_out) if args.detail_out else ROOT / "gpurun_out" / "bench_detail.json"
+        try:
+            path.parent.mkdir(parents=True, exist_ok=True)
+            path.write_text(json.dumps(full, indent=1))
+        except OSError as e:
+            print(f"bench.py: could not write the detail file {path}: {e}", file=sys.stderr)
+            path = None
+    if args.full_line:
+        print(json.dumps(full), flush=True)
+        return
+    rel = path
+    if path is not None:
+        try:
+            rel = path.resolve().relative_to(ROOT)
+        except ValueError:
+            pass
+    print(compact_line(full, rel), flush=True)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -856,7 +976,8 @@ def stub_worker(args, rank, world):
         lengths = [max(1, int(round(n * args.seq_scale))) for n in shard.KITTI_00_07]
         plans = {}
         for mode in ("sequence", "round_robin"):
-            mine = shard.frames_of(shard.shard_sequences(lengths, world, mode)[rank])
+            plan = shard.shard_sequences(lengths, world, mode)
+            mine, longest = shard.frames_of(plan[rank]), max(shard.frames_of(p) for p in plan)
             if use_dist:
                 dist.barrier()
             t0 = time.perf_counter()
@@ -864,10 +985,11 @@ def stub_worker(args, rank, world):
             if use_dist:
                 dist.barrier()
             dtm, tot = reduce_report(time.perf_counter() - t0, float(mine), torch, dist, use_dist, torch.device("cpu"))
-            plans[mode] = {"value": tot / dtm, "ms_per_step": 1e3 * dtm, "stereo_frames_per_step": tot, "frames_of_rank0": mine}
+            plans[mode] = {"value": tot / dtm, "ms_per_step": 1e3 * dtm, "stereo_frames_per_step": tot, "frames_of_rank0": mine,
+                           "max_frames_of_a_rank": longest}
         out["secondary"] = [kitti_seq_entry(plans, lengths, 0)]
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out, args)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -883,7 +1005,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0, help="units (frames / stereo pairs) resident per GPU and processed "
                     "per step; 0 = per-workload default (tum 4096, kitti 512, euroc 2048)")
-    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["all", "kitti_seq"], default="all")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["all", "auto", "kitti_seq"], default="auto",
+                    help="auto (default) = all four workloads on ONE GPU; with --gpus N > 1 the headline only (kitti, the fast path: "
+                         "a rank renders and runs one workload) plus the configs[4] kitti_seq plans; 'all' forces the secondaries on N > 1 too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="CPU-baseline budget per variant and workload")
     ap.add_argument("--streams", type=int, default=0,
@@ -913,6 +1037,10 @@ def main():
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for 1 rank")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--full-line", action="store_true", help="print the FULL result dict as the stdout line (tens of KB: stage tables, "
+                    "CPU variants, e2e, latency rows) instead of the compact contract line; what the tools/ scripts parse")
+    ap.add_argument("--detail-out", default=None, help="file for the full result dict (default: gpurun_out/bench_detail.json)")
+    ap.add_argument("--no-detail", action="store_true", help="do not write the detail file")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -926,6 +1054,8 @@ def main():
     if args.stub:
         return stub_worker(args, rank, world)
 
+    if args.workload == "auto":
+        args.workload = "all" if world == 1 else "kitti"
     names = ["kitti", "tum", "euroc", "euroc_stereo"] if args.workload == "all" else (["kitti"] if args.workload == "kitti_seq" else [args.workload])
     batches = {nm: (args.batch if args.batch > 0 else WORKLOADS[nm]["batch"]) for nm in names}
     global SINGLE_SCENE, STEREO_SCENE, VOC_SHAPE
@@ -973,13 +1103,13 @@ def main():
         plans, lengths, check = run_kitti_seq(inputs["kitti"], args, rank, world, local_rank, torch, dist, use_dist, batches)
         if rank == 0:
             ent = kitti_seq_entry(plans, lengths, batches["kitti"])
-            print(json.dumps({
+            emit({
                 "metric": "ORB extract+match stereo frames/sec, KITTI 00-07 sharded over the GPUs (bit-exact vs CPU oracle on checked frames)",
                 "value": ent["value"], "unit": "stereo frames/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": ent["ms_per_step"], "higher_is_better": True,
                 "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                 "config": {"workload": ent["workload"], "sharding": ent["sharding"], "per_image": ent["per_image"]},
-                "plans": plans, "parity_check": check}), flush=True)
+                "plans": plans, "parity_check": check}, args)
     else:
         results = []
         kitti_frames = inputs.get("kitti") if world > 1 else None  # (kept for the configs[4] plans below)
@@ -997,9 +1127,9 @@ def main():
                 "metric": "ORB extract+match frames/sec (kp/desc/matches bit-exact vs CPU oracle on the checked frames of every run)",
                 "value": head["value"], "unit": head["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-                # BASELINE.md publishes no number (the reference has none): the baseline is the CPU oracle timed in this run, in
-                # the reference's own threading for the workload (cpu_baseline below)
-                "vs_baseline": head.get("vs_cpu_baseline"),
+                # BASELINE.md publishes no number (the reference has none) -> null; the CPU oracle timed in this run, in the
+                # reference's own threading for the workload, is `cpu_baseline` and the ratio to it `vs_cpu_baseline`
+                "vs_baseline": None,
                 "dtype": "u8", "data": data_tag,
                 "config": {"workload": head["workload"] + (" [single-scene round-1 input]" if args.single_scene else ""), "units_per_gpu_per_step": head["units_per_gpu_per_step"],
                            "images_per_gpu_per_step": head["images_per_gpu_per_step"],
@@ -1021,7 +1151,7 @@ def main():
                                           "map points), GPU next to the CPU oracle on one core; 'resident' = frames uploaded once with "
                                           "orbfe_frame_upload; multi-neighbour rows give the per-neighbour cost of one call",
                                   "rows": rows}
-            print(json.dumps(out), flush=True)
+            emit(out, args)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

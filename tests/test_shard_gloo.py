@@ -114,3 +114,29 @@ def test_bench_launcher_reports_a_failing_rank():
     p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--stub", "--workload", "nope"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert p.returncode != 0
+
+
+def test_bench_launcher_world8_keeps_the_compact_line():
+    """configs[4] rehearsed without hardware: `--gpus 8 --stub` through the real launcher (8 gloo ranks): ONE compact
+    line (< 4 KB, the driver parses the last stdout line) that still carries the kitti_seq plans; the `sequence` plan is
+    bounded by the longest sequence (4661 frames of KITTI 02), `round_robin` is balanced."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "8", "--stub", "--steps", "2", "--no-detail"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = p.stdout.strip().splitlines()
+    assert len(lines[-1]) < 4096
+    out = json.loads(lines[-1])
+    assert out["n_gpus"] == 8 and out["total_units"] == 2 * sum(100 + r for r in range(8))
+    (seq,) = [s_ for s_ in out["secondary"] if s_["key"] == "kitti_seq"]
+    total = sum(shard.KITTI_00_07)
+    assert seq["plans"]["sequence"]["max_frames_of_a_rank"] == 4661
+    assert seq["plans"]["sequence"]["frames_of_rank0"] == shard.KITTI_00_07[0]
+    assert seq["plans"]["round_robin"]["max_frames_of_a_rank"] - total // 8 <= 1
+    for mode in ("sequence", "round_robin"):
+        assert seq["plans"][mode]["stereo_frames_per_step"] == total

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Builds a second copy of the library with extra compiler flags for same-box A/B runs of compile-time variants:
 #   tools/ab_build.sh exp -DORBFE_RESIZE_WAVES=8      -> orb_slam2_annotate_amd/liborbfe_exp.so
-#   ORBFE_LIB=$PWD/orb_slam2_annotate_amd/liborbfe_exp.so python bench.py ...
+#   ORBFE_LIB=$PWD/orb_slam2_annotate_amd/liborbfe_exp.so python bench.py --full-line --no-detail ...
 set -e
 TAG=$1; shift
 cd "$(dirname "$0")/../orb_slam2_annotate_amd/csrc"

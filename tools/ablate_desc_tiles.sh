@@ -9,7 +9,7 @@ OUT=gpurun_out/ablate_desc_tiles_$WL.txt
 : > $OUT
 run() {  # label, env...
   local label=$1; shift
-  env "$@" ORBFE_BENCH_NO_CHECK=1 timeout -k 10 200 python bench.py --workload $WL --steps 10 --min-seconds 0.2 --no-cpu-baseline --no-e2e \
+  env "$@" ORBFE_BENCH_NO_CHECK=1 timeout -k 10 200 python bench.py --full-line --no-detail --workload $WL --steps 10 --min-seconds 0.2 --no-cpu-baseline --no-e2e \
       --input-cache /tmp/orbfe_cache > gpurun_out/_abl.json 2>> gpurun_out/_abl.err
   python - "$label" >> $OUT <<'PY'
 import json, sys

@@ -4,7 +4,7 @@ cd "$(dirname "$0")/.."
 W=${1:-kitti}; BB=${2:-"512 1024 2048"}
 for B in $BB; do
   t0=$(date +%s)
-  python bench.py --workload $W --no-e2e --no-cpu-baseline --no-latency --batch $B > gpurun_out/b_bs.json 2> gpurun_out/b_bs.err
+  python bench.py --full-line --no-detail --workload $W --no-e2e --no-cpu-baseline --no-latency --batch $B > gpurun_out/b_bs.json 2> gpurun_out/b_bs.err
   t1=$(date +%s)
   python - $B $((t1 - t0)) <<'PY'
 import json, sys

@@ -8,11 +8,11 @@ W=${1:-tum}; B=${2:-256}; TAG=${3:-}
 OUT=gpurun_out/fast_phase_split_$W${TAG:+_$TAG}
 mkdir -p gpurun_out
 : > $OUT.txt
-timeout -k 10 300 python3 bench.py --workload $W --steps 1 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-e2e --no-latency --batch $B --input-cache /tmp/orbfe_cache_fps > /dev/null 2>&1
+timeout -k 10 300 python3 bench.py --full-line --no-detail --workload $W --steps 1 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-e2e --no-latency --batch $B --input-cache /tmp/orbfe_cache_fps > /dev/null 2>&1
 for C in 1 2 3 4 0; do
   rm -rf ${OUT}_c$C
   ORBFE_FAST_CUTOFF=$C ORBFE_BENCH_NO_CHECK=1 timeout -k 10 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d ${OUT}_c$C -- \
-    python3 bench.py --workload $W --steps 3 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-e2e --no-latency --render-procs 1 --streams 1 --batch $B --input-cache /tmp/orbfe_cache_fps > /dev/null 2>${OUT}_c$C.err
+    python3 bench.py --full-line --no-detail --workload $W --steps 3 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-e2e --no-latency --render-procs 1 --streams 1 --batch $B --input-cache /tmp/orbfe_cache_fps > /dev/null 2>${OUT}_c$C.err
   echo "cutoff $C rc=$? $(date +%T)" >> $OUT.progress
   python3 - $C ${OUT}_c$C >> $OUT.txt <<'PY'
 import csv, glob, sys, collections

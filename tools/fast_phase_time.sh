@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.."
 W=${1:-tum}
 for C in 1 2 3 4 0; do
-  ORBFE_FAST_CUTOFF=$C ORBFE_BENCH_NO_CHECK=1 python bench.py --workload $W --no-e2e --no-cpu-baseline --no-latency --min-seconds 0.5 --input-cache /tmp/orbfe_cache_fpt > gpurun_out/b_fpt.json 2> gpurun_out/b_fpt.err
+  ORBFE_FAST_CUTOFF=$C ORBFE_BENCH_NO_CHECK=1 python bench.py --full-line --no-detail --workload $W --no-e2e --no-cpu-baseline --no-latency --min-seconds 0.5 --input-cache /tmp/orbfe_cache_fpt > gpurun_out/b_fpt.json 2> gpurun_out/b_fpt.err
   python - $C $W <<'PY'
 import json, sys
 j = json.loads(open("gpurun_out/b_fpt.json").read().strip().splitlines()[-1])

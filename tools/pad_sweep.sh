@@ -1,4 +1,4 @@
-run() { echo "== $*"; env "$@" python bench.py --workload tum --no-cpu-baseline --no-e2e --input-cache /tmp/ic 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); rf=j['roofline']; print(round(j['value']), round(j['ms_per_step'],3), {s:round(v['ms_per_step_exclusive'],2) for s,v in rf['stages'].items()})"; }
+run() { echo "== $*"; env "$@" python bench.py --full-line --no-detail --workload tum --no-cpu-baseline --no-e2e --input-cache /tmp/ic 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); rf=j['roofline']; print(round(j['value']), round(j['ms_per_step'],3), {s:round(v['ms_per_step_exclusive'],2) for s,v in rf['stages'].items()})"; }
 run A=1
 run ORBFE_PAD_RESIZE=40
 run ORBFE_PAD_OCTREE=28

@@ -10,9 +10,9 @@ OUT=gpurun_out/pmc_busy_$W${TAG:+_$TAG}
 mkdir -p gpurun_out
 rm -rf ${OUT}_a ${OUT}_b ${OUT}_c
 ARGS="--workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --render-procs 1 --streams 1 --batch $B"
-timeout -k 10 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d ${OUT}_a -- python3 bench.py $ARGS > /dev/null 2>${OUT}_a.err; echo "pass a done rc=$? $(date +%T)" >> ${OUT}.progress
-timeout -k 10 240 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d ${OUT}_b -- python3 bench.py $ARGS > /dev/null 2>${OUT}_b.err; echo "pass b done rc=$? $(date +%T)" >> ${OUT}.progress
-timeout -k 10 240 rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d ${OUT}_c -- python3 bench.py $ARGS > /dev/null 2>${OUT}_c.err; echo "pass c done rc=$? $(date +%T)" >> ${OUT}.progress
+timeout -k 10 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d ${OUT}_a -- python3 bench.py --full-line --no-detail $ARGS > /dev/null 2>${OUT}_a.err; echo "pass a done rc=$? $(date +%T)" >> ${OUT}.progress
+timeout -k 10 240 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d ${OUT}_b -- python3 bench.py --full-line --no-detail $ARGS > /dev/null 2>${OUT}_b.err; echo "pass b done rc=$? $(date +%T)" >> ${OUT}.progress
+timeout -k 10 240 rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d ${OUT}_c -- python3 bench.py --full-line --no-detail $ARGS > /dev/null 2>${OUT}_c.err; echo "pass c done rc=$? $(date +%T)" >> ${OUT}.progress
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]

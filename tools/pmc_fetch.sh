@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 rm -rf gpurun_out/pmcf
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmcf -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1 --batch 256 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmcf -- python3 bench.py --full-line --no-detail --steps 3 --warmup 1 --no-cpu-baseline --streams 1 --batch 256 > /dev/null 2>&1
 python3 - <<'PY'
 import csv, glob, collections
 f=glob.glob('gpurun_out/pmcf/*/*counter_collection.csv')[0]

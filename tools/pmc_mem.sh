@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 W=${1:-tum}; B=${2:-256}
 OUT=gpurun_out/pmc_mem_$W
 rm -rf ${OUT}_p*
-python3 bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --batch $B --input-cache /tmp/ic_mem > /dev/null 2>&1
+python3 bench.py --full-line --no-detail --workload $W --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --batch $B --input-cache /tmp/ic_mem > /dev/null 2>&1
 ARGS="--workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --render-procs 1 --input-cache /tmp/ic_mem --streams 1 --batch $B"
 PASSES=(
   "TCP_PENDING_STALL_CYCLES TCP_TOTAL_CACHE_ACCESSES"
@@ -20,7 +20,7 @@ PASSES=(
 )
 i=0
 for P in "${PASSES[@]}"; do
-  timeout -k 10 150 rocprofv3 --kernel-trace --pmc $P GRBM_GUI_ACTIVE --output-format csv -d ${OUT}_p$i -- python3 bench.py $ARGS > /dev/null 2>${OUT}_p$i.err
+  timeout -k 10 150 rocprofv3 --kernel-trace --pmc $P GRBM_GUI_ACTIVE --output-format csv -d ${OUT}_p$i -- python3 bench.py --full-line --no-detail $ARGS > /dev/null 2>${OUT}_p$i.err
   echo "pass $i ($P) rc=$?" | tee -a ${OUT}_progress.log
   i=$((i+1))
 done

@@ -4,8 +4,8 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 W=${1:-tum}; B=${2:-256}
 rm -rf gpurun_out/pmcq
-timeout -k 10 300 python3 bench.py --workload $W --steps 1 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-e2e --no-latency --batch $B --input-cache /tmp/orbfe_cache_q > /dev/null 2>&1
-timeout -k 10 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmcq -- python3 bench.py --workload $W --steps 3 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-e2e --no-latency --render-procs 1 --streams 1 --batch $B --input-cache /tmp/orbfe_cache_q > /dev/null 2>&1
+timeout -k 10 300 python3 bench.py --full-line --no-detail --workload $W --steps 1 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-e2e --no-latency --batch $B --input-cache /tmp/orbfe_cache_q > /dev/null 2>&1
+timeout -k 10 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmcq -- python3 bench.py --full-line --no-detail --workload $W --steps 3 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-e2e --no-latency --render-procs 1 --streams 1 --batch $B --input-cache /tmp/orbfe_cache_q > /dev/null 2>&1
 echo "pmc pass rc=$?"
 python3 - <<'PY'
 import csv, glob, collections

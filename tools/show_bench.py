@@ -30,7 +30,13 @@ def show(r, name):
     print("    parity", r["parity_check"]["units_checked"])
 
 
-j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+txt = open(sys.argv[1]).read().strip()
+try:
+    j = json.loads(txt)  # the detail file (bench.py --detail-out): one pretty-printed object
+except ValueError:
+    j = json.loads(txt.splitlines()[-1])  # a stdout capture of `bench.py --full-line`
+if "stages" not in j.get("roofline", {}):
+    raise SystemExit("this is the compact contract line; pass the detail file (gpurun_out/bench_detail.json) or a --full-line capture")
 show(j, "HEAD " + j["config"]["workload"][:40])
 for r in j.get("secondary", []):
     show(r, r["key"])

@@ -3,9 +3,9 @@
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 W=${1:-kitti}
-python3 bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --input-cache /tmp/ic_sq > /dev/null 2>&1
+python3 bench.py --full-line --no-detail --workload $W --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --input-cache /tmp/ic_sq > /dev/null 2>&1
 rm -rf gpurun_out/sq_$W
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/sq_$W -- python3 bench.py --workload $W --no-cpu-baseline --no-e2e --render-procs 1 --input-cache /tmp/ic_sq > gpurun_out/sq_$W.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/sq_$W -- python3 bench.py --full-line --no-detail --workload $W --no-cpu-baseline --no-e2e --render-procs 1 --input-cache /tmp/ic_sq > gpurun_out/sq_$W.json 2>/dev/null
 cp gpurun_out/sq_$W/*/*kernel_stats.csv gpurun_out/sq_${W}_kernel_stats.csv
 python3 - gpurun_out/sq_${W}_kernel_stats.csv <<'PY'
 import csv, sys

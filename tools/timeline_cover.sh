@@ -7,8 +7,8 @@ export TMPDIR=/tmp
 W=${1:-kitti}
 OUT=gpurun_out/timeline_$W
 rm -rf ${OUT}_trace
-timeout -k 10 300 python3 bench.py --workload $W --steps 1 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-e2e --no-latency --input-cache /tmp/orbfe_cache_tl > /dev/null 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d ${OUT}_trace -- python3 bench.py --workload $W --steps 40 --warmup 2 --min-seconds 0 --no-cpu-baseline --no-e2e --no-latency --render-procs 1 --input-cache /tmp/orbfe_cache_tl > ${OUT}_bench.json 2>/dev/null
+timeout -k 10 300 python3 bench.py --full-line --no-detail --workload $W --steps 1 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-e2e --no-latency --input-cache /tmp/orbfe_cache_tl > /dev/null 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d ${OUT}_trace -- python3 bench.py --full-line --no-detail --workload $W --steps 40 --warmup 2 --min-seconds 0 --no-cpu-baseline --no-e2e --no-latency --render-procs 1 --input-cache /tmp/orbfe_cache_tl > ${OUT}_bench.json 2>/dev/null
 python3 - ${OUT}_trace $W > $OUT.txt <<'PY'
 import csv, glob, sys, collections
 fs = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")
