@@ -1085,6 +1085,7 @@ int orc_compute_stereo_matches(const orc_extractor *e, int W, int H, const orc_k
   for (int pass = 0; pass < 2; pass++) {
     for (int iR = 0; iR < Nr; iR++) {
       const float kpY = kpR[iR].y;
+      if (kpR[iR].octave < 0 || kpR[iR].octave >= e->nlevels || !(fabsf(kpY) < 3.0e38f)) continue; /* not a keypoint of this pyramid */
       const float r = 2.0f * e->mvScaleFactor[kpR[iR].octave];
       const int maxr = (int)ceilf(kpY + r);
       const int minr = (int)floorf(kpY - r);
@@ -1106,6 +1107,8 @@ int orc_compute_stereo_matches(const orc_extractor *e, int W, int H, const orc_k
     const orc_keypoint *kl = &kpL[iL];
     const int levelL = kl->octave;
     const float vL = kl->y, uL = kl->x;
+    /* records no extractor writes: the reference indexes its tables out of range with them; here "no stereo" */
+    if (levelL < 0 || levelL >= e->nlevels || !(fabsf(uL) < 3.0e38f) || !(fabsf(vL) < 3.0e38f)) continue;
     const int row = (int)vL;
     if (row < 0 || row >= nRows) continue;
     if (rowCnt[row] == 0) continue;
@@ -1141,6 +1144,9 @@ int orc_compute_stereo_matches(const orc_extractor *e, int W, int H, const orc_k
       const float iniu = scaleduR0 + L - w;
       const float endu = scaleduR0 + L + w + 1;
       if (iniu < 0 || endu >= (float)lw[lv]) continue;
+      /* rowRange / colRange (:609-610, :626) assert 0 <= start <= end <= size: a patch that leaves the level throws in
+         the reference; "no stereo" here */
+      if (cy < w || cy + w >= lh[lv] || cxL < w || cxL + w >= lw[lv] || (int)scaleduR0 < L + w) continue;
       g_stereo_sad++;
       const int cL = IL[(size_t)cy * st + cxL];
       for (int incR = -L; incR <= +L; incR++) {

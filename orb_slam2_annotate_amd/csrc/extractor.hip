@@ -111,7 +111,7 @@ struct orbfe_extractor {
   size_t hostInBytes = 0;
   DescTile* d_descTiles = nullptr;  // tile form of the orientation + descriptor stage (k_desc_tiles.hip)
   int nDescTiles = 0;
-  int descTilesMode = -1;           // -1: $ORBFE_DESC_TILES or the default (on for batches of more than 8 frames); 0 / 1 forced
+  int descTilesMode = -1;           // -1: $ORBFE_DESC_TILES (default 0 = the per-keypoint form); 0 / 1 forced by orbfe_extractor_set_desc_tiles
   int32_t* d_umax = nullptr;
   CellDesc* d_cells = nullptr;
   LevelGeom* d_lvgeom = nullptr;
@@ -1025,6 +1025,10 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* images, in
       // the slab is readable for stride * height bytes per frame: the kernels stage rows up to the pitch, not the width
       const size_t slab = (size_t)(n_frames - 1) * frame_stride + (size_t)stride * height + 64;
       if (slab > e->hostInBytes) {
+        // dalloc frees the old slab first: until the new one exists nothing may still point at it (the last result's
+        // level-0 view lives in it: get_pyramid_level / compute_stereo_matches of the PREVIOUS call would read freed memory)
+        e->hostInBytes = 0;
+        e->haveLast = false;
         if ((rc = dalloc(&e->d_hostIn, slab))) return rc;
         e->hostInBytes = slab;
       }

@@ -234,11 +234,19 @@ __global__ __launch_bounds__(256) void k_orient_desc_tiles(OrientDescArgs a, con
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       {
         const int j = wave + 4 * lane;
-        if (j < n && !(ablate & 2)) {
-          const float angle = fast_atan2((float)s_m01[j], (float)s_m10[j]);
-          const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-          float ca, sb;
-          sincos_spec(__fmul_rn(angle, factorPI), &ca, &sb);
+        if (j < n) {
+          // (ablation bits 1 / 2, timing experiments: no moments / no atan2 + sincos -- the lists still get DEFINED values, so
+          // the descriptor loop samples inside the tile and downstream kernels read real records)
+          float angle = 0.f, ca = 1.f, sb = 0.f;
+          if (!(ablate & 3)) {
+            angle = fast_atan2((float)s_m01[j], (float)s_m10[j]);
+            const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+            sincos_spec(__fmul_rn(angle, factorPI), &ca, &sb);
+          } else if (!(ablate & 2)) {  // bit 1 only: the arithmetic on a fixed moment pair
+            angle = fast_atan2(1.0f, 1.0f);
+            const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+            sincos_spec(__fmul_rn(angle, factorPI), &ca, &sb);
+          }
           s_angle[j] = angle;
           s_cos[j] = ca;
           s_sin[j] = sb;
@@ -252,7 +260,10 @@ __global__ __launch_bounds__(256) void k_orient_desc_tiles(OrientDescArgs a, con
       // ---- 3. steered BRIEF from the LDS tile + output records, two keypoints in flight ----
       const uint8_t* tbytes = reinterpret_cast<const uint8_t*>(s_tile);
       const float sc = a.scale[l], ksz = a.kpSize[l];
-      for (int j0 = wave; j0 < ((ablate & 4) ? 0 : n); j0 += 8) {
+      // (ablation bit 4 removes the 512 samples of a keypoint, NOT the loop: it also writes the cv::KeyPoint records that
+      // k_stereo_match_batch / the BoW matcher read behind this kernel -- round 3's three memory-access faults were this
+      // loop skipped as a whole, the records left at the caller's zeros and the stereo SAD reading rows -5.. of level 0)
+      for (int j0 = wave; j0 < n; j0 += 8) {
         uint32_t xy[2], sr[2];
         float ca[2], sb[2];
         int v0[2][4], v1[2][4];
@@ -280,8 +291,8 @@ __global__ __launch_bounds__(256) void k_orient_desc_tiles(OrientDescArgs a, con
             const float r1 = __fadd_rn(__fadd_rn(__fmul_rn(P[t4].y, sb[u]), __fmul_rn(P[t4].w, ca[u])), kMagic);
             const float c0 = __fadd_rn(__fsub_rn(__fmul_rn(P[t4].x, ca[u]), __fmul_rn(P[t4].z, sb[u])), kMagic);
             const float c1 = __fadd_rn(__fsub_rn(__fmul_rn(P[t4].y, ca[u]), __fmul_rn(P[t4].w, sb[u])), kMagic);
-            v0[u][t4] = tbytes[__umul24(__float_as_uint(r0), (uint32_t)kPitch) + __float_as_uint(c0) + baseK];
-            v1[u][t4] = tbytes[__umul24(__float_as_uint(r1), (uint32_t)kPitch) + __float_as_uint(c1) + baseK];
+            v0[u][t4] = (ablate & 4) ? 0 : tbytes[__umul24(__float_as_uint(r0), (uint32_t)kPitch) + __float_as_uint(c0) + baseK];
+            v1[u][t4] = (ablate & 4) ? 0 : tbytes[__umul24(__float_as_uint(r1), (uint32_t)kPitch) + __float_as_uint(c1) + baseK];
           }
         }
 #pragma unroll

@@ -398,10 +398,14 @@ __device__ __forceinline__ void stereo_row16(const StereoArgs& a, const StereoLd
     const float* kl = pp.kpL + (size_t)iL * 7;
     uL = kl[0]; vL = kl[1];
     levelL = reinterpret_cast<const int32_t*>(kl)[5];
+    // a record no extractor writes (device operands are the caller's: zeroed / stale / foreign buffers): an octave that is
+    // not a pyramid level or a non-finite position is "no stereo" (-1), never an index.  The reference would index
+    // mvInvScaleFactor / mvImagePyramid out of range there (src/Frame.cc:600-609)
+    if ((unsigned)levelL >= (unsigned)a.pyrL.nlevels || !(fabsf(uL) < 3.0e38f) || !(fabsf(vL) < 3.0e38f)) { alive = false; levelL = 0; uL = vL = 0.f; }
   }
   const int row = (int)vL;
   const float minU = __fsub_rn(uL, a.maxD), maxU = uL;  // minD = 0
-  bool live = alive && !(maxU < 0);
+  bool live = alive && !(maxU < 0) && row >= 0 && row < a.rows;  // vRowIndices[vL] (:560) has nRows entries
   int pBeg = 0, pEnd = live ? pp.Nr : 0;
   if (pp.rowStart && live) {
     // rows that can hold a candidate: a right keypoint of octave o covers image rows floor(y - r) .. ceil(y + r) with
@@ -439,6 +443,7 @@ __device__ __forceinline__ void stereo_row16(const StereoArgs& a, const StereoLd
         yR = kr[1];
         uR = kr[0];
       }
+      if ((unsigned)octR >= (unsigned)a.pyrL.nlevels || !(fabsf(yR) < 3.0e38f)) continue;  // not a record of this pyramid: never a candidate
       const float r = __fmul_rn(2.0f, lv.scale[octR]);
       const int maxr = (int)ceilf(__fadd_rn(yR, r));
       const int minr = (int)floorf(__fsub_rn(yR, r));
@@ -468,6 +473,10 @@ __device__ __forceinline__ void stereo_row16(const StereoArgs& a, const StereoLd
   const float endu = scaleduR0 + 5 + 5 + 1;
   if (iniu < 0 || endu >= (float)R.w) live = false;
   const int cy = (int)scaledvL, cxL = (int)scaleduL, cxR0 = (int)scaleduR0;
+  // the reference takes the patches with cv::Mat::rowRange / colRange (:609-610, :626), which assert
+  // 0 <= start <= end <= size: a window that leaves the level is an exception there and "no stereo" here.  Every byte
+  // the SAD reads below lies inside rows cy-5 .. cy+5, columns cxL-5 .. cxL+5 (left) / cxR0-10 .. cxR0+10 (right).
+  if (cy < 5 || cy + 5 >= L.h || cy + 5 >= R.h || cxL < 5 || cxL + 5 >= L.w || cxR0 < 10) live = false;
   // lane r < 11 of the row holds patch row cy-5+r: left bytes cxL-5 .. cxL+5 in ql[0..2], right bytes cxR0-10 .. cxR0+10 in
   // qr[0..5].  Keypoints of the extractor lie >= 19 px inside their level, so the 16- and 24-byte requests stay inside the
   // image row; any other caller's keypoints take byte loads of exactly the pixels the reference reads

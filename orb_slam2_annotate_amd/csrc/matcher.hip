@@ -433,11 +433,14 @@ extern "C" int orbfe_frame_upload(int device, const orbfe_frame_view* v, const o
   size_t nIdx = 0;
   if (fv) {
     f->haveFv = true;
-    f->nodeIds.assign(fv->node_ids, fv->node_ids + fv->n_nodes);
-    f->offsets.assign(fv->offsets, fv->offsets + fv->n_nodes + 1);
-    nIdx = fv->n_nodes ? (size_t)fv->offsets[fv->n_nodes] : 0;
-    f->hindices.assign(fv->indices, fv->indices + nIdx);
-    if (f->offsets.empty()) f->offsets.push_back(0);
+    if (fv->n_nodes > 0) {  // (an EMPTY FeatureVector may come with NULL arrays: nothing is read from them)
+      f->nodeIds.assign(fv->node_ids, fv->node_ids + fv->n_nodes);
+      f->offsets.assign(fv->offsets, fv->offsets + fv->n_nodes + 1);
+      nIdx = (size_t)fv->offsets[fv->n_nodes];
+      f->hindices.assign(fv->indices, fv->indices + nIdx);
+    } else {
+      f->offsets.assign(1, 0);
+    }
     f->fv.n_nodes = fv->n_nodes; f->fv.node_ids = f->nodeIds.data(); f->fv.offsets = f->offsets.data(); f->fv.indices = f->hindices.data();
   }
   orbfe_frame_view& c = f->view;
@@ -656,10 +659,17 @@ extern "C" int orbfe_compute_stereo_matches(orbfe_extractor* left, int frameL, o
   for (int l = 0; l < nlL; l++)
     if (a.pyrL.lv[l].w != a.pyrR.lv[l].w || a.pyrL.lv[l].h != a.pyrR.lv[l].h)
       return mfail(ORBFE_ERR_INVALID, "compute_stereo_matches: left/right pyramids differ in size");
-  for (int i = 0; i < N; i++)
-    if (kpL[i].octave < 0 || kpL[i].octave >= nlL) return mfail(ORBFE_ERR_INVALID, "compute_stereo_matches: octave out of range");
-  for (int i = 0; i < Nr; i++)
-    if (kpR[i].octave < 0 || kpR[i].octave >= nlL) return mfail(ORBFE_ERR_INVALID, "compute_stereo_matches: octave out of range");
+  // host operands are checked here (the reference indexes mvInvScaleFactor / mvImagePyramid / vRowIndices with them
+  // unchecked, src/Frame.cc:537-538,560,600-610); the device-operand form cannot look and answers "no stereo" instead
+  const float W0 = (float)a.pyrL.lv[0].w, H0 = (float)a.pyrL.lv[0].h;
+  for (int side = 0; side < 2; side++) {
+    const orbfe_keypoint* kp = side ? kpR : kpL;
+    for (int i = 0, n = side ? Nr : N; i < n; i++) {
+      if (kp[i].octave < 0 || kp[i].octave >= nlL) return mfail(ORBFE_ERR_INVALID, "compute_stereo_matches: octave out of range");
+      if (!(kp[i].x >= 0.f && kp[i].x < W0 && kp[i].y >= 0.f && kp[i].y < H0))  // (false for NaN too)
+        return mfail(ORBFE_ERR_INVALID, "compute_stereo_matches: keypoint outside the image (or not finite)");
+    }
+  }
   Arena* ar;
   const int rows = a.pyrL.lv[0].h;
   MHIP(arena_begin(devL, pad((size_t)N * 60) + pad((size_t)Nr * 60) + 3 * pad((size_t)N * 4) + pad((size_t)Nr * 4) +

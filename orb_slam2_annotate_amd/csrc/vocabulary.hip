@@ -349,9 +349,9 @@ extern "C" int orbfe_vocabulary_load_text(const char* path, int device, orbfe_vo
     while ((got = fread(buf, 1, sizeof buf, fp)) > 0) txt.append(buf, got);
     fclose(fp);
   }
-  const char* p = txt.c_str();
-  const char* const end = p + txt.size();
-  auto line_end = [&](const char* q) { while (q < end && *q != '\n') q++; return q; };
+  char* p = &txt[0];
+  char* const end = p + txt.size();  // (*end is the string's own NUL)
+  auto line_end = [&](char* q) { while (q < end && *q != '\n') q++; return q; };
   if (p == end) return vfail(ORBFE_ERR_INVALID, "vocabulary_load_text: empty file");
   int k = -1, L = -1, n1 = -1, n2 = -1;
   {
@@ -370,10 +370,14 @@ extern "C" int orbfe_vocabulary_load_text(const char* path, int device, orbfe_vo
   p = line_end(p);
   while (p < end) {
     p++;  // the '\n'
-    const char* le = line_end(p);
+    char* le = line_end(p);
     const char* q = p;
     while (q < le && (*q == ' ' || *q == '\t' || *q == '\r')) q++;
     if (q < le) {  // see orbfe.h: empty lines are ignored
+      // A node is ONE line (the reference parses each through its own getline + stringstream, :1374-1417): the line is
+      // NUL-terminated in place so that strtol / strtod -- which skip '\n' as white space -- cannot run on into the next
+      // node's tokens; the fields a short line lacks read as 0, like the reference's failed `>>` extractions
+      *le = 0;
       char* r;
       const long pid = strtol(q, &r, 10);
       const long leaf = strtol(r, &r, 10);

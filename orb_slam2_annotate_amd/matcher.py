@@ -88,18 +88,37 @@ class ResidentFrame:
 
     def __init__(self, view: FrameView, fv=None, device: int = 0):
         self._L = _lib.load()
-        self._h = C.c_void_p()
-        check(self._L.orbfe_frame_upload(device, C.byref(view.c), C.byref(fv.c) if fv is not None else None, C.byref(self._h)))
-        self.c = self._L.orbfe_frame_get_view(self._h).contents
+        self._handle = C.c_void_p()
+        check(self._L.orbfe_frame_upload(device, C.byref(view.c), C.byref(fv.c) if fv is not None else None, C.byref(self._handle)))
+        self._view = self._L.orbfe_frame_get_view(self._handle).contents  # aliases memory INSIDE the handle
         self.N, self.device = view.N, device
         # the searches' Python wrappers read these for the outputs' shapes only
         self.x, self.y, self.octave, self.angle, self.u_right, self.desc, self.bounds = (view.x, view.y, view.octave, view.angle,
                                                                                        view.u_right, view.desc, view.bounds)
 
+    # `.c` (the view) and `._h` (the handle) are what every wrapper hands to the library: after close() they point into
+    # freed memory, so they raise instead (round-3 ADVICE: a closed frame was a use-after-free, not a Python error)
+    @property
+    def c(self):
+        if self._view is None:
+            raise ValueError("ResidentFrame is closed")
+        return self._view
+
+    @property
+    def _h(self):
+        if self._handle is None:
+            raise ValueError("ResidentFrame is closed")
+        return self._handle
+
+    @property
+    def closed(self):
+        return self._handle is None
+
     def close(self):
-        if getattr(self, "_h", None):
-            self._L.orbfe_frame_release(self._h)
-            self._h = None
+        if getattr(self, "_handle", None):
+            self._L.orbfe_frame_release(self._handle)
+        self._handle = None
+        self._view = None
 
     __del__ = close
     GetFeaturesInArea = FrameView.GetFeaturesInArea  # (reads self.c only: no frame data travels)

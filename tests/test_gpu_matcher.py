@@ -252,6 +252,125 @@ def test_stereo_batch_device_resident(amd):
             assert int(d_ns[p].item()) == int((u_ref >= 0).sum()) > 30
 
 
+def _poison_records(kp, desc, rng, W, H):
+    """records no extractor writes, planted in copies of real keypoint arrays: (index, field values) -> what a zeroed /
+    stale / foreign device buffer looks like to the stereo kernels"""
+    bad = {
+        3: dict(x=0.0, y=0.0, octave=0),                       # a zeroed record (torch.zeros: round 3's three GPU faults)
+        5: dict(x=np.nan, y=50.0, octave=1),
+        7: dict(x=100.0, y=np.inf, octave=0),
+        11: dict(x=120.0, y=60.0, octave=9),                   # not a pyramid level
+        13: dict(x=120.0, y=60.0, octave=-3),
+        17: dict(x=1.0e9, y=60.0, octave=0),                   # far outside the image
+        19: dict(x=200.0, y=-40.0, octave=2),
+        23: dict(x=300.0, y=1.0e6, octave=0),
+        29: dict(x=float(W - 2), y=float(H - 2), octave=0),    # inside the image, the 11 x 11 patch is not
+        31: dict(x=2.0, y=2.0, octave=0),
+    }
+    kp, desc = kp.copy(), desc.copy()
+    names = kp.dtype.names
+    for i, f in bad.items():
+        kp[names[0]][i], kp[names[1]][i], kp[names[5]][i] = np.float32(f["x"]), np.float32(f["y"]), f["octave"]
+    return kp, desc, sorted(bad)
+
+
+def test_stereo_device_operands_are_not_trusted(amd):
+    """`orbfe_stereo_match_batch_device` takes arbitrary device keypoint records.  Zeroed / NaN /
+    octave-9 / out-of-image / border records (left AND right side) must give "no stereo" (-1) -- the reference's own guards
+    are `iniu < 0 || endu >= cols` (src/Frame.cc:619-622) and the rowRange / colRange asserts (:609-610, :626) -- never a
+    read outside a pyramid level; every other keypoint keeps the oracle's result."""
+    torch = pytest.importorskip("torch")
+    w, h, nf = 640, 240, 800
+    pairs = [synth.render_stereo(60 + p, w, h, n_shapes=300, max_disp=48) for p in range(2)]
+    imgs = np.stack([im for pr in pairs for im in pr])
+    e = amd.ORBextractor(nf, 1.2, 8, 20, 7)
+    cap = e.max_keypoints()
+    dev = torch.device("cuda", 0)
+    d_img = torch.from_numpy(imgs).to(dev)
+    B = len(imgs)
+    d_kp = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros((B,), dtype=torch.int32, device=dev)
+    d_u = torch.zeros((B // 2, cap), dtype=torch.float32, device=dev)
+    d_d = torch.zeros((B // 2, cap), dtype=torch.float32, device=dev)
+    d_ns = torch.zeros((B // 2,), dtype=torch.int32, device=dev)
+    e.extract_batch_device(d_img.data_ptr(), B, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(), wait=True)
+    mbf = np.float32(120.0)
+    mb = np.float32(mbf / np.float32(400.0))
+    o = orc.Oracle(nf, 1.2, 8, 20, 7)
+    rng = np.random.default_rng(5)
+    n = d_n.cpu().numpy()
+    kps = d_kp.cpu().numpy()
+    descs = d_desc.cpu().numpy()
+    from orb_slam2_annotate_amd import _lib
+    host = []
+    for fi in range(B):  # poison the left frame of pair 0, the right frame of pair 1, and both frames' twins of a border match
+        k = np.ascontiguousarray(kps[fi, :n[fi]]).view(_lib.KP_DTYPE).reshape(-1)
+        dsc = descs[fi, :n[fi]].copy()
+        if fi in (0, 3):
+            k, dsc, _ = _poison_records(k, dsc, rng, w, h)
+        host.append([k, dsc])
+    # a border PAIR that really matches (distance 0, right keypoint left of the left one): without the window guard the SAD
+    # would read rows -3.. of level 0
+    nm = host[0][0].dtype.names
+    for fi, x in ((0, 2.0), (1, 1.0)):
+        host[fi][0][nm[0]][31], host[fi][0][nm[1]][31], host[fi][0][nm[5]][31] = x, 2.0, 0
+        host[fi][1][31] = 0xA5
+    for fi in range(B):
+        kps[fi, :n[fi]] = host[fi][0].view(np.float32).reshape(-1, 7)
+        descs[fi, :n[fi]] = host[fi][1]
+    d_kp.copy_(torch.from_numpy(kps))
+    d_desc.copy_(torch.from_numpy(descs))
+    # all-zero records for a whole pair as well: counts say 700 keypoints, the buffers hold nothing
+    e.stereo_match_batch_device(B // 2, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, float(mbf), float(mb),
+                                d_u.data_ptr(), d_d.data_ptr(), d_ns.data_ptr())
+    e.synchronize()
+    pyr = [o.extract(imgs[fi], want_pyramid=True)[2] for fi in range(B)]
+    for p in range(B // 2):
+        (kL, dL), (kR, dR) = host[2 * p], host[2 * p + 1]
+        u_ref, d_ref = o.stereo(w, h, kL, dL, kR, dR, pyr[2 * p], pyr[2 * p + 1], float(mbf), float(mb))
+        u, dd = d_u[p].cpu().numpy()[: len(kL)], d_d[p].cpu().numpy()[: len(kL)]
+        assert np.array_equal(u, u_ref) and np.array_equal(dd, d_ref)
+        assert (u >= 0).sum() > 30
+    bad = _poison_records(host[0][0], host[0][1], rng, w, h)[2]
+    assert (d_u[0].cpu().numpy()[bad] == -1).all() and (d_d[0].cpu().numpy()[bad] == -1).all()
+    # buffers that hold NOTHING (zeros) while the counts say hundreds of keypoints
+    d_kp.zero_()
+    e.stereo_match_batch_device(B // 2, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, float(mbf), float(mb),
+                                d_u.data_ptr(), d_d.data_ptr(), d_ns.data_ptr())
+    e.synchronize()
+    assert (d_u.cpu().numpy() == -1).all() and (d_ns.cpu().numpy() == 0).all()
+
+
+def test_compute_stereo_matches_rejects_bad_host_records(amd):
+    """the host-operand form can look at its operands: ORBFE_ERR_INVALID for an octave that is no pyramid level, a
+    non-finite or out-of-image position (left or right); a border record inside the image is "no stereo" like the oracle"""
+    from orb_slam2_annotate_amd import _lib
+    w, h, nf = 640, 240, 800
+    left, right = synth.render_stereo(61, w, h, n_shapes=300, max_disp=48)
+    eL, eR = amd.ORBextractor(nf, 1.2, 8, 20, 7), amd.ORBextractor(nf, 1.2, 8, 20, 7)
+    (kL, dL), (kR, dR) = eL(left), eR(right)
+    mbf = np.float32(120.0)
+    mb = np.float32(mbf / np.float32(400.0))
+    nm = kL.dtype.names
+    for side in (0, 1):
+        for field, val in ((nm[5], 9), (nm[5], -1), (nm[0], np.nan), (nm[1], np.inf), (nm[0], float(w)), (nm[1], -1.0)):
+            a, b = kL.copy(), kR.copy()
+            (b if side else a)[field][10] = val
+            with pytest.raises(_lib.OrbfeError):
+                amd.ComputeStereoMatches(eL, eR, a, dL, b, dR, float(mbf), float(mb))
+    a, b, da, db = kL.copy(), kR.copy(), dL.copy(), dR.copy()
+    for k_, d_, x in ((a, da, 2.0), (b, db, 1.0)):
+        k_[nm[0]][31], k_[nm[1]][31], k_[nm[5]][31] = x, 2.0, 0
+        d_[31] = 0x5A
+    a[nm[0]][40], a[nm[1]][40] = w - 1.0, h - 1.0
+    o = orc.Oracle(nf, 1.2, 8, 20, 7)
+    pL, pR = o.extract(left, want_pyramid=True)[2], o.extract(right, want_pyramid=True)[2]
+    u_ref, d_ref = o.stereo(w, h, a, da, b, db, pL, pR, float(mbf), float(mb))
+    u, d = amd.ComputeStereoMatches(eL, eR, a, da, b, db, float(mbf), float(mb))
+    assert np.array_equal(u, u_ref) and np.array_equal(d, d_ref) and u[31] == -1 and u[40] == -1 and (u >= 0).sum() > 30
+
+
 def test_stereo_then_next_async_extract_does_not_race(amd):
     """async extract(A) on 4 sub-batch streams, stereo(A), async extract(B != A) enqueued
     right behind it without any host wait -- stereo(A) must still equal the oracle (the sub-batch streams
@@ -322,6 +441,37 @@ def test_search_by_bow_resident_frames(amd, seed, ori):
         assert rn > 5
     R1.close()
     R2.close()
+
+
+def test_resident_frame_closed_and_empty_featvec(amd):
+    """round-3 ADVICE: (1) a closed ResidentFrame raises instead of handing the library a dangling view / handle;
+    (2) orbfe_frame_upload with an EMPTY FeatureVector given as NULL arrays (n_nodes = 0) must not read through them."""
+    import ctypes as C
+    from orb_slam2_annotate_amd import _lib
+    from orb_slam2_annotate_amd._lib import FeatVecC
+    k1, d1, k2, d2 = _two_frames(amd, 33)
+    n1, n2 = _nodes(d1, 13, 60), _nodes(d2, 13, 60)
+    R1, R2 = _resident(amd, k1, d1, n1), _resident(amd, k2, d2, n2)
+    m = amd.ORBmatcher(0.7, True)
+    has1 = np.ones(len(k1), np.uint8)
+    gn, _ = m.SearchByBoWResident(R1, has1, R2)
+    assert gn > 5 and not R2.closed
+    R2.close()
+    assert R2.closed
+    with pytest.raises(ValueError):
+        m.SearchByBoWResident(R1, has1, R2)
+    with pytest.raises(ValueError):
+        R2.GetFeaturesInArea(100.0, 100.0, 20.0)
+    R2.close()  # idempotent
+    v = amd.FrameView(k2["x"], k2["y"], k2["octave"], d2, (0.0, 640.0, 0.0, 480.0), angle=k2["angle"])
+    empty = FeatVecC(0, None, None, None)
+    h = C.c_void_p()
+    _lib.check(_lib.load().orbfe_frame_upload(0, C.byref(v.c), C.byref(empty), C.byref(h)))
+    out = np.full(len(k2), 7, dtype=np.int32)
+    n = _lib.check(_lib.load().orbfe_search_by_bow_resident(R1._h, _lib.ptr(has1), h, C.c_float(0.7), 1, _lib.ptr(out)))
+    assert n == 0 and (out == -1).all()  # no node in common with an empty FeatureVector
+    _lib.load().orbfe_frame_release(h)
+    R1.close()
 
 
 @pytest.mark.parametrize("only_stereo,ori", [(False, True), (True, False)])

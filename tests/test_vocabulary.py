@@ -291,3 +291,52 @@ def test_gpu_euroc_composite_extract_then_search_by_bow(tmp_path):
         kr, dr = o.extract(seqs[1][f])
         assert n[f] == len(kr)
         assert np.array_equal(d_desc[f, :n[f]].cpu().numpy(), dr)
+
+
+def _short_line_vocabulary(tmp_path):
+    """A text vocabulary with two TRUNCATED leaf lines (no weight token; no weight and two descriptor bytes missing) and
+    the arrays the reference's per-line `getline` + `>>` parsing turns them into: the missing fields read as 0 and the
+    FOLLOWING nodes keep their own tokens (TemplatedVocabulary.h:1374-1417)."""
+    k, L, parent, leaf, desc, weight = synthetic_vocabulary_arrays(4, 3, seed=9)
+    desc, weight = desc.copy(), np.round(weight, 6)
+    path = tmp_path / "short.txt"
+    write_vocabulary_text(path, (k, L, parent, leaf, desc, weight))
+    lines = open(path).read().split("\n")
+    leaves = np.flatnonzero(leaf)
+    a, b = int(leaves[3]), int(leaves[17])
+    lines[1 + a] = " ".join(lines[1 + a].split()[:-1])   # weight token gone
+    lines[1 + b] = " ".join(lines[1 + b].split()[:-3])   # weight and the last two descriptor bytes gone
+    open(path, "w").write("\n".join(lines))
+    weight[a] = 0.0
+    weight[b] = 0.0
+    desc[b, 30:] = 0
+    return path, (k, L, parent, leaf, desc, weight)
+
+
+def test_oracle_vocabulary_short_lines_do_not_shift_later_nodes(tmp_path):
+    path, arrays = _short_line_vocabulary(tmp_path)
+    vt, va = orc.Vocabulary(path), orc.Vocabulary.from_arrays(arrays)
+    assert vt.info() == va.info()
+    desc = np.random.default_rng(4).integers(0, 256, size=(500, 32), dtype=np.uint8)
+    desc[:64] = arrays[4][np.flatnonzero(arrays[3])[:64]]  # the leaves' own descriptors: every early word is hit
+    for levelsup in (0, 1):
+        rt, ra = vt.transform(desc, levelsup), va.transform(desc, levelsup)
+        assert rt[0] == ra[0] and all(np.array_equal(x, y) for x, y in zip(rt[1:], ra[1:]))
+
+
+@pytest.mark.gpu
+def test_gpu_vocabulary_short_lines_do_not_shift_later_nodes(tmp_path):
+    """round-3 ADVICE: strtol / strtod skip '\\n', so a short node line used to swallow the next node's tokens and shift
+    every later node.  Each line is now parsed on its own, like the reference's stringstream per getline."""
+    import orb_slam2_annotate_amd as amd
+    path, arrays = _short_line_vocabulary(tmp_path)
+    va = orc.Vocabulary.from_arrays(arrays)
+    voc = amd.ORBVocabulary()
+    assert voc.loadFromTextFile(path)
+    assert voc.info() == va.info()
+    desc = np.random.default_rng(4).integers(0, 256, size=(500, 32), dtype=np.uint8)
+    desc[:64] = arrays[4][np.flatnonzero(arrays[3])[:64]]
+    for levelsup in (0, 1):
+        word, weight, node = voc.transform_features(desc, levelsup)
+        _, w_ref, wt_ref, n_ref = va.transform(desc, levelsup)
+        assert np.array_equal(word, w_ref) and np.array_equal(weight, wt_ref) and np.array_equal(node, n_ref)
