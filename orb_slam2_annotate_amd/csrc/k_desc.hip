@@ -134,15 +134,13 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
     // 16 keypoints per wave, 4 at a time: the 4 x 5 row loads are issued back to back so one
     // memory latency covers four keypoints (the kernel is latency-bound, not VALU-bound)
     for (int j0 = wave * kKpPerWave; j0 < wave * kKpPerWave + kKpPerWave; j0 += kUM) {
-      uint32_t dw[kUM][5];
-      uint32_t mis[kUM];
+      uint32_t dw[kUM][4];
       int kout[kUM];  // per-keypoint values are wave-uniform: kept in scalar registers (readfirstlane)
 #pragma unroll
       for (int u = 0; u < kUM; u++) {
         const int j = j0 + u;
-        mis[u] = 0;
 #pragma unroll
-        for (int k = 0; k < 5; k++) dw[u][k] = 0;
+        for (int k = 0; k < 4; k++) dw[u][k] = 0;
         kout[u] = __builtin_amdgcn_readfirstlane(s_out[j]);
         if (kout[u] >= 0) {
           const int kl = __builtin_amdgcn_readfirstlane(s_level[j]);
@@ -155,8 +153,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
             {
               // one byte-aligned 16-byte request per (row, half) whatever the level's pitch and the keypoint's column
               // (global_load_dwordx4 takes any address on gfx950, profiles/r02_unaligned.txt): no fifth dword, no
-              // v_alignbyte (mis stays 0) -- stage -5 % in a same-box A/B; columns x-15 .. x+16 are inside the row for
-              // every keypoint (19 <= x <= w-20)
+              // v_alignbyte -- stage -5 % in a same-box A/B; columns x-15 .. x+16 are inside the row for every keypoint
+              // (19 <= x <= w-20)
               struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };
               const U4u q = *reinterpret_cast<const U4u*>(p);
               dw[u][0] = q.x; dw[u][1] = q.y; dw[u][2] = q.z; dw[u][3] = q.w;
@@ -168,10 +166,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
       for (int u = 0; u < kUM; u++) {
         const int j = j0 + u;
         if (kout[u] < 0) continue;  // scalar branch
-        const uint32_t q0 = __builtin_amdgcn_alignbyte(dw[u][1], dw[u][0], mis[u]);
-        const uint32_t q1 = __builtin_amdgcn_alignbyte(dw[u][2], dw[u][1], mis[u]);
-        const uint32_t q2 = __builtin_amdgcn_alignbyte(dw[u][3], dw[u][2], mis[u]);
-        const uint32_t q3 = __builtin_amdgcn_alignbyte(dw[u][4], dw[u][3], mis[u]);
+        const uint32_t q0 = dw[u][0], q1 = dw[u][1], q2 = dw[u][2], q3 = dw[u][3];
         unsigned w = __builtin_amdgcn_udot4(q0, wt.x, 0u, false);
         w = __builtin_amdgcn_udot4(q1, wt.y, w, false);
         w = __builtin_amdgcn_udot4(q2, wt.z, w, false);
@@ -356,6 +351,14 @@ void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d
   } else {
     unsigned grid = full;
     if (kGridPerCu > 0 && (unsigned)kGridPerCu * 256u < full) grid = (unsigned)kGridPerCu * 256u;  // 256 CUs, multiple of 8
+    static const int kWide = getenv("ORBFE_ORIENT_WIDE") ? atoi(getenv("ORBFE_ORIENT_WIDE")) : 0;
+    if (kWide == 2)
+      hipLaunchKernelGGL((k_orient_desc<64, 16, 8>), dim3(grid), dim3(256), kPad, s, a, d_levelKp, d_levelCount,
+                         d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic);
+    else if (kWide == 1)
+      hipLaunchKernelGGL((k_orient_desc<64, 8, 4>), dim3(grid), dim3(256), kPad, s, a, d_levelKp, d_levelCount,
+                         d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic);
+    else
     hipLaunchKernelGGL((k_orient_desc<64, 4, 2>), dim3(grid), dim3(256), kPad, s, a, d_levelKp, d_levelCount,
                        d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic);
   }

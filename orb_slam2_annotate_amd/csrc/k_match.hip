@@ -394,6 +394,7 @@ __device__ __forceinline__ void stereo_row16(const StereoArgs& a, const StereoLd
   const int sub = lane & 15, rowBase = lane & 48;
   float uL = 0.f, vL = 0.f;
   int levelL = 0;
+  bool record = true;  // (`alive` = the slot holds a left keypoint and gets an output; `record` = its fields are usable)
   if (alive) {
     const float* kl = pp.kpL + (size_t)iL * 7;
     uL = kl[0]; vL = kl[1];
@@ -401,11 +402,11 @@ __device__ __forceinline__ void stereo_row16(const StereoArgs& a, const StereoLd
     // a record no extractor writes (device operands are the caller's: zeroed / stale / foreign buffers): an octave that is
     // not a pyramid level or a non-finite position is "no stereo" (-1), never an index.  The reference would index
     // mvInvScaleFactor / mvImagePyramid out of range there (src/Frame.cc:600-609)
-    if ((unsigned)levelL >= (unsigned)a.pyrL.nlevels || !(fabsf(uL) < 3.0e38f) || !(fabsf(vL) < 3.0e38f)) { alive = false; levelL = 0; uL = vL = 0.f; }
+    if ((unsigned)levelL >= (unsigned)a.pyrL.nlevels || !(fabsf(uL) < 3.0e38f) || !(fabsf(vL) < 3.0e38f)) { record = false; levelL = 0; uL = vL = 0.f; }
   }
   const int row = (int)vL;
   const float minU = __fsub_rn(uL, a.maxD), maxU = uL;  // minD = 0
-  bool live = alive && !(maxU < 0) && row >= 0 && row < a.rows;  // vRowIndices[vL] (:560) has nRows entries
+  bool live = alive && record && !(maxU < 0) && row >= 0 && row < a.rows;  // vRowIndices[vL] (:560) has nRows entries
   int pBeg = 0, pEnd = live ? pp.Nr : 0;
   if (pp.rowStart && live) {
     // rows that can hold a candidate: a right keypoint of octave o covers image rows floor(y - r) .. ceil(y + r) with

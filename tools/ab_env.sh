@@ -5,7 +5,7 @@ WL=$1; shift
 for rep in 1 2; do
   for cfg in "$@"; do
     for w in $WL; do
-      env $cfg python bench.py --full-line --no-detail --workload $w --no-e2e --no-cpu-baseline --no-latency > gpurun_out/b_ab.json 2> gpurun_out/b_ab.err
+      env $cfg python bench.py --full-line --no-detail --workload $w --no-e2e --no-cpu-baseline --no-latency --input-cache /tmp/orbfe_ab_cache > gpurun_out/b_ab.json 2> gpurun_out/b_ab.err
       python - "$w" "$cfg" <<'PY'
 import json, sys
 j = json.loads(open("gpurun_out/b_ab.json").read().strip().splitlines()[-1])

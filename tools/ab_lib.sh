@@ -5,7 +5,7 @@ A=$1; WL=${2:-"kitti tum euroc"}
 for rep in 1 2; do
   for lib in "$A" ""; do
     for w in $WL; do
-      ORBFE_LIB=$lib python bench.py --full-line --no-detail --workload $w --no-e2e --no-cpu-baseline --no-latency > gpurun_out/b_abl.json 2> gpurun_out/b_abl.err
+      ORBFE_LIB=$lib python bench.py --full-line --no-detail --workload $w --no-e2e --no-cpu-baseline --no-latency --input-cache /tmp/orbfe_ab_cache > gpurun_out/b_abl.json 2> gpurun_out/b_abl.err
       python - "$w" "${lib:-in-tree}" <<'PY'
 import json, sys, os
 j = json.loads(open("gpurun_out/b_abl.json").read().strip().splitlines()[-1])
