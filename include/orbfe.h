@@ -460,6 +460,27 @@ void orbfe_frame_release(orbfe_frame *f);
  * taken.  Valid until orbfe_frame_release. */
 const orbfe_frame_view *orbfe_frame_get_view(const orbfe_frame *f);
 
+/* Frame::Frame (src/Frame.cc:61-117) is ExtractORB -> UndistortKeyPoints -> ComputeStereoMatches -> AssignFeaturesToGrid:
+ * when the Frame is built the extractor's keypoint records and descriptors are still in HBM.  These two build the
+ * resident operands FROM THEM -- records split into the x / y / angle / octave arrays, descriptors copied device to device,
+ * grid built on the device -- so of a frame's 60 bytes per keypoint only mvuRight (and, with ORBFE_FRAME_XY_FROM_VIEW, the
+ * caller's undistorted positions) cross PCIe.  `view` holds the host arrays the claim loops and chi-square gates read
+ * (mvKeysUn / mvuRight / mDescriptors as the caller has them after its own constructor steps); view->n records are taken.
+ *   orbfe_frame_from_extractor: frame `frame` of the handle's last orbfe_extract / small orbfe_extract_batch call
+ *       (ORBFE_ERR_INVALID after a device-batch or pipelined call: those outputs are the caller's);
+ *   orbfe_frame_from_device:    any device arrays in the extractor's output layout (orbfe_extract_batch_device outputs at
+ *       d_keypoints + frame * capacity, d_descriptors + frame * capacity * 32), complete when the call is made.
+ * Like orbfe_frame_upload neither waits for the device: searches are ordered behind the build by the frame's own event.
+ * Released slabs are pooled (no hipMalloc / hipFree -- which waits for the whole device -- per key frame). */
+#define ORBFE_FRAME_XY_FROM_VIEW 1 /* x / y come from `view` (undistorted by the caller: cameras with distortion) */
+int orbfe_frame_from_extractor(orbfe_extractor *e, int frame, const orbfe_frame_view *view, const orbfe_featvec *fv,
+                               int flags, orbfe_frame **out);
+int orbfe_frame_from_device(int device, const orbfe_keypoint *d_keypoints, const uint8_t *d_descriptors,
+                            const orbfe_frame_view *view, const orbfe_featvec *fv, int flags, orbfe_frame **out);
+/* Frame::ComputeBoW runs after the constructor (src/Tracking.cc:836-843, src/Frame.cc:433-440): attach the FeatureVector
+ * to a frame made resident without one.  Call it before other threads use the handle. */
+int orbfe_frame_set_featvec(orbfe_frame *f, const orbfe_featvec *fv);
+
 /* Frame::AssignFeaturesToGrid + Frame::GetFeaturesInArea (src/Frame.cc:246-267, 358-427) for
  * n_queries windows at once: count[q] features lie in the window of query q; the first
  * min(count[q], capacity) of them -- in the reference's order (grid column, grid row, feature
@@ -490,6 +511,20 @@ int orbfe_search_by_bow_resident(const orbfe_frame *kf, const uint8_t *has_mp_kf
                                  int check_orientation, int32_t *match_f);
 int orbfe_search_by_bow_kf_resident(const orbfe_frame *kf1, const uint8_t *has_mp1, const orbfe_frame *kf2,
                                     const uint8_t *has_mp2, float nnratio, int check_orientation, int32_t *match12);
+/* SearchByBoW against n_keyframes candidates in ONE call (one upload of the K shared-node lists and masks, K + 1
+ * launches on one stream, one download):
+ *   orbfe_search_by_bow_multi:    Tracking::Relocalization, src/Tracking.cc:1478-1498 -- SearchByBoW(pKF_k, mCurrentFrame,
+ *       vvpMapPointMatches[k]) for every candidate key frame; match_f [k * f->n + i2] = feature of key frame k matched to
+ *       feature i2 of the frame, or -1; n_matches [k];
+ *   orbfe_search_by_bow_kf_multi: LoopClosing::ComputeSim3, src/LoopClosing.cc:294-321 -- SearchByBoW(mpCurrentKF, pKF_k,
+ *       vvpMapPointMatches[k]); match12 [k * kf1->n + i1] = feature of candidate k matched to feature i1 of kf1, or -1.
+ * Every output equals the corresponding single-pair call. */
+int orbfe_search_by_bow_multi(int n_keyframes, const orbfe_frame *const *kf, const uint8_t *const *has_mp_kf,
+                              const orbfe_frame *f, float nnratio, int check_orientation, int32_t *match_f,
+                              int32_t *n_matches);
+int orbfe_search_by_bow_kf_multi(const orbfe_frame *kf1, const uint8_t *has_mp1, int n_keyframes,
+                                 const orbfe_frame *const *kf2, const uint8_t *const *has_mp2, float nnratio,
+                                 int check_orientation, int32_t *match12, int32_t *n_matches);
 /* ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:754-928) of ONE key frame against n_neighbours key frames in
  * one call -- the loop of LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:283-315): F12[9*k ..], ex[k], ey[k]
  * the fundamental matrix and epipole of neighbour k, has_mp2[k] its MapPoint mask; the stereo flags come from the
@@ -541,6 +576,20 @@ int orbfe_search_by_projection_keyframe(int device, const orbfe_frame_view *Cur,
                                         const float *kf_angle, const uint8_t *mp_desc, float th,
                                         int orb_dist, int check_orientation, int32_t *match_cur,
                                         int32_t *n_matches);
+
+/* The same search of ONE current frame against the projected map points of n_candidates key frames in one call
+ * (Tracking::Relocalization, src/Tracking.cc:1577,1595: per candidate whose PnP pose survived, th = 10 then 3, ORBdist = 100
+ * then 64).  Candidate k brings n[k] points and its own arrays valid[k] / u[k] / v[k] / level[k] / kf_angle[k] / mp_desc[k] /
+ * blocked[k] (blocked, or blocked[k], may be NULL), window th[k] and bound orb_dist[k].  One upload of all query lists, one
+ * launch group, one download; the frame itself goes up once (or not at all when resident).
+ * match_cur [k * Cur->n + i2], n_matches [k]; every output equals the single call. */
+int orbfe_search_by_projection_keyframe_multi(int device, const orbfe_frame_view *Cur, const float *scale_factors,
+                                              int n_levels, int n_candidates, const uint8_t *const *blocked,
+                                              const int32_t *n, const uint8_t *const *valid, const float *const *u,
+                                              const float *const *v, const int32_t *const *level,
+                                              const float *const *kf_angle, const uint8_t *const *mp_desc,
+                                              const float *th, const int32_t *orb_dist, int check_orientation,
+                                              int32_t *match_cur, int32_t *n_matches);
 
 /* ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints,
  * vector<MapPoint*> &vpMatched, int th) (src/ORBmatcher.cc:335-449, loop closing) after the caller's

@@ -163,6 +163,18 @@ class FrameArrays {
     check(orbfe_frame_upload(device, &c, mFeatVec ? &mFeatVec->c : nullptr, &resident_), "FrameArrays::makeResident");
     c.resident = resident_;
   }
+  // The same from the extractor's OWN device records -- Frame::Frame is ExtractORB -> UndistortKeyPoints ->
+  // ComputeStereoMatches -> AssignFeaturesToGrid (src/Frame.cc:61-117): the keypoints and descriptors operator() just
+  // returned are still in HBM, so only mvuRight (and, for cameras with distortion, the undistorted positions:
+  // undistorted = true) travel.  `e` = the extractor whose last operator() produced this frame's keypoints.
+  void makeResidentFromExtractor(const orbfe_extractor* e, bool undistorted = false, const FeatureVectorCSR* mFeatVec = nullptr) {
+    if (resident_) { orbfe_frame_release(resident_); resident_ = nullptr; c.resident = nullptr; }
+    check(orbfe_frame_from_extractor(const_cast<orbfe_extractor*>(e), 0, &c, mFeatVec ? &mFeatVec->c : nullptr,
+                                     undistorted ? ORBFE_FRAME_XY_FROM_VIEW : 0, &resident_), "FrameArrays::makeResidentFromExtractor");
+    c.resident = resident_;
+  }
+  // Frame::ComputeBoW (src/Frame.cc:433-440) runs after the constructor: attach mFeatVec to the resident frame
+  void setFeatVec(const FeatureVectorCSR& mFeatVec) { check(orbfe_frame_set_featvec(resident_, &mFeatVec.c), "FrameArrays::setFeatVec"); }
   const orbfe_frame* resident() const { return resident_; }
 
   // vector<size_t> Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel) const
@@ -331,6 +343,73 @@ class ORBmatcher {
     for (int k = 0; k < K; k++)
       for (int i = 0; i < n1; i++)
         if (match[(size_t)k * n1 + i] >= 0) vMatchedPairs[k].push_back(std::make_pair((size_t)i, (size_t)match[(size_t)k * n1 + i]));
+  }
+
+  // The loop of Tracking::Relocalization (src/Tracking.cc:1478-1498) in ONE call: SearchByBoW(pKF_k, mCurrentFrame,
+  // vvpMapPointMatches[k]) for every candidate key frame.  All frames resident with their mFeatVec.  vnMatches[k][i2] =
+  // feature of key frame k whose MapPoint goes to feature i2 of the frame, or -1; returns the counts.
+  std::vector<int> SearchByBoWMulti(const std::vector<const FrameArrays*>& vpCandidateKFs,
+                                    const std::vector<const std::vector<uint8_t>*>& hasMp, const FrameArrays& F,
+                                    std::vector<std::vector<int32_t> >& vnMatches) {
+    const int K = (int)vpCandidateKFs.size(), n = F.N();
+    std::vector<const orbfe_frame*> fr(K > 0 ? K : 1, nullptr);
+    std::vector<const uint8_t*> mk(K > 0 ? K : 1, nullptr);
+    for (int k = 0; k < K; k++) { fr[k] = vpCandidateKFs[k]->resident(); mk[k] = hasMp[k]->data(); }
+    std::vector<int32_t> match((size_t)(K > 0 ? K : 1) * (n > 0 ? n : 1), -1), cnt(K > 0 ? K : 1, 0);
+    check(orbfe_search_by_bow_multi(K, fr.data(), mk.data(), F.resident(), mfNNratio, mbCheckOrientation, match.data(), cnt.data()),
+          "SearchByBoWMulti");
+    vnMatches.assign(K, std::vector<int32_t>());
+    for (int k = 0; k < K; k++) vnMatches[k].assign(match.begin() + (size_t)k * n, match.begin() + (size_t)(k + 1) * n);
+    return std::vector<int>(cnt.begin(), cnt.begin() + K);
+  }
+  // The loop of LoopClosing::ComputeSim3 (src/LoopClosing.cc:294-321): SearchByBoW(mpCurrentKF, pKF_k, vvpMapPointMatches[k]).
+  // vnMatches12[k][i1] = feature of candidate k matched to feature i1 of the current key frame, or -1.
+  std::vector<int> SearchByBoWMulti(const FrameArrays& KF1, const std::vector<uint8_t>& hasMp1,
+                                    const std::vector<const FrameArrays*>& vpCandidateKFs,
+                                    const std::vector<const std::vector<uint8_t>*>& hasMp2,
+                                    std::vector<std::vector<int32_t> >& vnMatches12) {
+    const int K = (int)vpCandidateKFs.size(), n = KF1.N();
+    std::vector<const orbfe_frame*> fr(K > 0 ? K : 1, nullptr);
+    std::vector<const uint8_t*> mk(K > 0 ? K : 1, nullptr);
+    for (int k = 0; k < K; k++) { fr[k] = vpCandidateKFs[k]->resident(); mk[k] = hasMp2[k]->data(); }
+    std::vector<int32_t> match((size_t)(K > 0 ? K : 1) * (n > 0 ? n : 1), -1), cnt(K > 0 ? K : 1, 0);
+    check(orbfe_search_by_bow_kf_multi(KF1.resident(), hasMp1.data(), K, fr.data(), mk.data(), mfNNratio, mbCheckOrientation,
+                                       match.data(), cnt.data()),
+          "SearchByBoWMulti(KF,KF)");
+    vnMatches12.assign(K, std::vector<int32_t>());
+    for (int k = 0; k < K; k++) vnMatches12[k].assign(match.begin() + (size_t)k * n, match.begin() + (size_t)(k + 1) * n);
+    return std::vector<int>(cnt.begin(), cnt.begin() + K);
+  }
+
+  // SearchByProjection(mCurrentFrame, vpCandidateKFs[k], sFound, th_k, ORBdist_k) (src/Tracking.cc:1577,1595) for several
+  // candidates in ONE call; one ProjectedKeyFrame per candidate = the caller's projection prologue (:1657-1700).
+  struct ProjectedKeyFrame {
+    std::vector<uint8_t> valid, mpDescriptors, curHasMapPoint /* may be empty */;
+    std::vector<float> u, v, kfAngle;
+    std::vector<int32_t> level;
+    float th; int ORBdist;
+  };
+  std::vector<int> SearchByProjectionMulti(const FrameArrays& CurrentFrame, const std::vector<float>& mvScaleFactors,
+                                           const std::vector<ProjectedKeyFrame>& cands, std::vector<std::vector<int32_t> >& matchCur) {
+    const int K = (int)cands.size(), n = CurrentFrame.N(), K1 = K > 0 ? K : 1;
+    std::vector<const uint8_t*> blk(K1, nullptr), va(K1, nullptr), md(K1, nullptr);
+    std::vector<const float*> u(K1, nullptr), v(K1, nullptr), ka(K1, nullptr);
+    std::vector<const int32_t*> lv(K1, nullptr);
+    std::vector<int32_t> nk(K1, 0), od(K1, 0), match((size_t)K1 * (n > 0 ? n : 1), -1), cnt(K1, 0);
+    std::vector<float> th(K1, 0.f);
+    for (int k = 0; k < K; k++) {
+      const ProjectedKeyFrame& c = cands[k];
+      blk[k] = c.curHasMapPoint.empty() ? nullptr : c.curHasMapPoint.data();
+      va[k] = c.valid.data(); md[k] = c.mpDescriptors.data(); u[k] = c.u.data(); v[k] = c.v.data(); ka[k] = c.kfAngle.data();
+      lv[k] = c.level.data(); nk[k] = (int32_t)c.valid.size(); od[k] = c.ORBdist; th[k] = c.th;
+    }
+    check(orbfe_search_by_projection_keyframe_multi(device_, &CurrentFrame.c, mvScaleFactors.data(), (int)mvScaleFactors.size(), K,
+                                                    blk.data(), nk.data(), va.data(), u.data(), v.data(), lv.data(), ka.data(), md.data(),
+                                                    th.data(), od.data(), mbCheckOrientation, match.data(), cnt.data()),
+          "SearchByProjectionMulti");
+    matchCur.assign(K, std::vector<int32_t>());
+    for (int k = 0; k < K; k++) matchCur[k].assign(match.begin() + (size_t)k * n, match.begin() + (size_t)(k + 1) * n);
+    return std::vector<int>(cnt.begin(), cnt.begin() + K);
   }
 
   // The per-point search of Fuse for the SAME map points against K key frames in one call (LocalMapping::SearchInNeighbors,

@@ -55,7 +55,7 @@ EXPORTS = [
     "orbfe_debug_resize_tables", "orbfe_debug_resize_tiles", "orbfe_extractor_set_streams", "orbfe_extractor_set_fused", "orbfe_extractor_set_pyramid_blur", "orbfe_extractor_set_fast_mode", "orbfe_extractor_set_schedule", "orbfe_extractor_set_desc_tiles", "orbfe_extractor_set_blur_spec", "orbfe_gaussian_blur7_spec", "orbfe_extractor_profile", "orbfe_extractor_profile_get",
     "orbfe_stage_name", "orbfe_resize_linear", "orbfe_gaussian_blur7", "orbfe_descriptor_distance",
     "orbfe_hamming_matrix", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",
-    "orbfe_search_for_triangulation", "orbfe_frame_upload", "orbfe_frame_release", "orbfe_frame_get_view", "orbfe_search_by_bow_resident", "orbfe_search_by_bow_kf_resident", "orbfe_search_for_triangulation_multi", "orbfe_fuse_search_multi", "orbfe_compute_stereo_matches", "orbfe_stereo_match_batch_device", "orbfe_vocabulary_load_text", "orbfe_vocabulary_create", "orbfe_vocabulary_destroy",
+    "orbfe_search_for_triangulation", "orbfe_frame_upload", "orbfe_frame_release", "orbfe_frame_get_view", "orbfe_search_by_bow_resident", "orbfe_search_by_bow_kf_resident", "orbfe_search_for_triangulation_multi", "orbfe_fuse_search_multi", "orbfe_search_by_bow_multi", "orbfe_search_by_bow_kf_multi", "orbfe_search_by_projection_keyframe_multi", "orbfe_frame_from_extractor", "orbfe_frame_from_device", "orbfe_frame_set_featvec", "orbfe_compute_stereo_matches", "orbfe_stereo_match_batch_device", "orbfe_vocabulary_load_text", "orbfe_vocabulary_create", "orbfe_vocabulary_destroy",
     "orbfe_vocabulary_info", "orbfe_vocabulary_transform", "orbfe_vocabulary_featvec_batch_device",
     "orbfe_bow_match_consecutive_batch_device", "orbfe_bow_match_consecutive_batch_device_async", "orbfe_bow_match_consecutive_stereo_batch_device_async", "orbfe_cvt_gray", "orbfe_cvt_gray_batch_device",
     "orbfe_distinctive_descriptors", "orbfe_features_in_area", "orbfe_search_by_projection",
@@ -178,6 +178,12 @@ def load():
     L.orbfe_search_by_bow_kf_resident.argtypes = [vp, vp, vp, vp, cf, ci, vp]
     L.orbfe_search_for_triangulation_multi.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp]
     L.orbfe_fuse_search_multi.argtypes = [ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, cf, ci, vp]
+    L.orbfe_search_by_bow_multi.argtypes = [ci, vp, vp, vp, cf, ci, vp, vp]
+    L.orbfe_search_by_bow_kf_multi.argtypes = [vp, vp, ci, vp, vp, cf, ci, vp, vp]
+    L.orbfe_search_by_projection_keyframe_multi.argtypes = [ci, fwp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp]
+    L.orbfe_frame_from_extractor.argtypes = [vp, ci, fwp, vp, ci, C.POINTER(C.c_void_p)]
+    L.orbfe_frame_from_device.argtypes = [ci, vp, vp, fwp, vp, ci, C.POINTER(C.c_void_p)]
+    L.orbfe_frame_set_featvec.argtypes = [vp, vp]
     L.orbfe_rectifier_create.argtypes = [ci, vp, vp, ci, ci, ci, C.POINTER(C.c_void_p)]
     L.orbfe_rectifier_destroy.argtypes = [vp]
     L.orbfe_rectifier_destroy.restype = None

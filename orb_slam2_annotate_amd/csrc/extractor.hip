@@ -152,6 +152,10 @@ struct orbfe_extractor {
   orbfe_keypoint* d_kpOut = nullptr;
   uint8_t* d_descOut = nullptr;
   int32_t* d_nOut = nullptr;
+  // the handle's own output block still holds the records of the last HOST-buffer call (orbfe_extract / small
+  // orbfe_extract_batch): orbfe_frame_from_extractor builds resident frames from it without the features travelling again
+  int outLastFrames = 0, outLastCapacity = 0;
+  std::vector<int32_t> outLastCount;
   uint8_t* h_outStage = nullptr;  // pinned
   size_t outStageBytes = 0;
   int outCap = 0;
@@ -229,6 +233,7 @@ void free_outputs(orbfe_extractor* e) {
   dfree(&e->d_outBlock);
   e->d_kpOut = nullptr; e->d_descOut = nullptr; e->d_nOut = nullptr;
   e->outCap = 0;
+  e->outLastFrames = 0;
 }
 
 int ensure_geometry(orbfe_extractor* e, int W, int H) {
@@ -1007,6 +1012,7 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* images, in
   HIPCHK(hipSetDevice(e->device));
   int rc;
   if ((rc = sync_all(e))) return rc;  // an earlier asynchronous call may still use the workspace
+  e->outLastFrames = 0;
   if ((rc = ensure_geometry(e, width, height))) return rc;
   if ((rc = ensure_workspace(e, n_frames))) return rc;
   if ((rc = ensure_outputs(e, n_frames, capacity))) return rc;
@@ -1092,7 +1098,25 @@ extern "C" int orbfe_extract_batch(orbfe_extractor* e, const uint8_t* images, in
     }
     if (overflow) return fail(ORBFE_ERR_CAPACITY, "keypoint capacity too small");
   }
+  e->outLastCount.assign(n_out, n_out + n_frames);
+  e->outLastCapacity = capacity;
+  e->outLastFrames = n_frames;
   resolve_stage_times(e);
+  return ORBFE_OK;
+}
+
+// internal (matcher.hip, orbfe_frame_from_extractor): device records of frame `frame` of the last host-buffer call
+extern "C" int orbfe_extractor_output_device_(orbfe_extractor* e, int frame, const orbfe_keypoint** d_kp, const uint8_t** d_desc,
+                                              int* n, int* device) {
+  if (!e || !d_kp || !d_desc || !n || !device) return fail(ORBFE_ERR_INVALID, "frame_from_extractor: NULL argument");
+  if (e->outLastFrames <= 0)
+    return fail(ORBFE_ERR_INVALID, "frame_from_extractor: the handle holds no output block (the last call was not orbfe_extract / a small "
+                                   "orbfe_extract_batch; device-batch callers own their outputs: orbfe_frame_from_device)");
+  if (frame < 0 || frame >= e->outLastFrames) return fail(ORBFE_ERR_INVALID, "frame_from_extractor: frame out of range");
+  *d_kp = e->d_kpOut + (size_t)frame * e->outLastCapacity;
+  *d_desc = e->d_descOut + (size_t)frame * e->outLastCapacity * 32;
+  *n = e->outLastCount[(size_t)frame];
+  *device = e->device;
   return ORBFE_OK;
 }
 

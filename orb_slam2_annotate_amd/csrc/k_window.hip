@@ -139,6 +139,33 @@ void launch_grid_build(hipStream_t s, const GridFrame& f, uint32_t* sortedKey, i
   hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(1024), (size_t)sortN * 4, s, f, sortN, sortedKey, cellOff);
 }
 
+// orbfe_frame_from_device: the extractor's 28-byte cv::KeyPoint records -> the resident frame's arrays, descriptors copied
+// device to device.  Thread t < n splits record t; the whole grid moves the n x 32 descriptor bytes as 16-byte pieces.
+__global__ __launch_bounds__(256) void k_frame_from_records(const float* __restrict__ kp, const uint8_t* __restrict__ desc, int n,
+                                                            float* __restrict__ x, float* __restrict__ y,
+                                                            float* __restrict__ angle, int32_t* __restrict__ octave,
+                                                            uint8_t* __restrict__ descOut, uint8_t* __restrict__ stereoZero) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < n) {
+    const float* r = kp + (size_t)t * 7;
+    if (x) x[t] = r[0];
+    if (y) y[t] = r[1];
+    angle[t] = r[3];
+    octave[t] = reinterpret_cast<const int32_t*>(r)[5];
+    if (stereoZero) stereoZero[t] = 0;  // monocular frame: no mvuRight
+  }
+  const uint4* src = reinterpret_cast<const uint4*>(desc);  // (rows of 32 bytes in buffers the library or torch allocated: 16-byte aligned)
+  uint4* dst = reinterpret_cast<uint4*>(descOut);
+  for (int i = t; i < 2 * n; i += gridDim.x * 256) dst[i] = src[i];
+}
+
+void launch_frame_from_records(hipStream_t s, const float* d_kp, const uint8_t* d_desc, int n, float* x, float* y, float* angle,
+                               int32_t* octave, uint8_t* descOut, uint8_t* stereoZero) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_frame_from_records, dim3((n + 255) / 256), dim3(256), 0, s, d_kp, d_desc, n, x, y, angle, octave, descOut,
+                     stereoZero);
+}
+
 void launch_window_search(hipStream_t s, const GridFrame& f, const uint32_t* sortedKey, const int32_t* cellOff,
                           const WindowQueries& q, int32_t* count, uint32_t* cand) {
   if (q.n <= 0) return;

@@ -107,6 +107,8 @@ struct WindowQueries {
   const uint8_t* desc /* NULL: indices only */; int n; int K;
 };
 void launch_grid_build(hipStream_t s, const GridFrame& f, uint32_t* sortedKey, int32_t* cellOff);
+void launch_frame_from_records(hipStream_t s, const float* d_kp, const uint8_t* d_desc, int n, float* x, float* y, float* angle,
+                               int32_t* octave, uint8_t* descOut, uint8_t* stereoZero);
 void launch_window_search(hipStream_t s, const GridFrame& f, const uint32_t* sortedKey, const int32_t* cellOff,
                           const WindowQueries& q, int32_t* count, uint32_t* cand);
 

@@ -4,10 +4,12 @@
 // on three threads concurrently, src/LocalMapping.cc:261, src/LoopClosing.cc:294).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -161,6 +163,7 @@ void shared_nodes(const orbfe_featvec* f1, const orbfe_featvec* f2, std::vector<
 // pinned staging of the calling thread (defined with the window searches below)
 hipError_t staging_reserve_(size_t bytes);
 uint8_t* staging_ptr_();
+hipError_t staging_mark_pending_(hipStream_t s);
 
 bool featvec_ok(const orbfe_featvec* f, int n) {
   if (!f || f->n_nodes < 0) return false;
@@ -390,7 +393,10 @@ struct orbfe_frame {
   std::vector<uint32_t> hindices;
   orbfe_featvec fv = {};
   bool haveFv = false;
-  uint8_t* slab = nullptr;                  // one device allocation
+  uint8_t* slab = nullptr;                  // one device allocation (from the slab pool)
+  size_t slabCap = 0;
+  hipEvent_t ready = nullptr;               // recorded behind the upload + grid build; consumers on other streams wait for it
+  mutable std::atomic<bool> settled{false}; // a consumer has synchronised behind `ready`: no further waits needed
   float *dx = nullptr, *dy = nullptr, *dangle = nullptr, *dur = nullptr;
   int32_t* doct = nullptr;
   uint8_t *ddesc = nullptr, *dstereo = nullptr;
@@ -404,23 +410,105 @@ namespace {
 inline const orbfe_frame_view* canon(const orbfe_frame_view* f) { return (f && f->resident) ? &f->resident->view : f; }
 }
 
+namespace {
+// Slabs and events of released frames are kept for the next upload: hipMalloc / hipFree cost tens of microseconds and
+// hipFree waits for the whole device -- in a live system every key-frame insertion would stall the extractor's streams.
+struct FramePool {
+  std::mutex m;
+  struct Slab { int device; uint8_t* p; size_t cap; };
+  std::vector<Slab> slabs;
+  std::vector<std::pair<int, hipEvent_t>> events;
+  static constexpr size_t kKeep = 64;
+  ~FramePool() {}  // (process exit: the runtime reclaims device memory; no HIP calls from static destructors)
+};
+FramePool g_framePool;
+
+hipError_t slab_get(int device, size_t bytes, uint8_t** p, size_t* cap) {
+  {
+    std::lock_guard<std::mutex> lk(g_framePool.m);
+    auto& v = g_framePool.slabs;
+    int best = -1;
+    for (size_t i = 0; i < v.size(); i++)
+      if (v[i].device == device && v[i].cap >= bytes && v[i].cap <= 4 * bytes + (1u << 16) && (best < 0 || v[i].cap < v[(size_t)best].cap))
+        best = (int)i;
+    if (best >= 0) {
+      *p = v[(size_t)best].p; *cap = v[(size_t)best].cap;
+      v.erase(v.begin() + best);
+      return hipSuccess;
+    }
+  }
+  const size_t want = (bytes + (1u << 16) - 1) & ~(size_t)((1u << 16) - 1);  // 64 KB classes: frames of similar size share slabs
+  hipError_t e = hipMalloc((void**)p, want);
+  if (e == hipSuccess) *cap = want;
+  return e;
+}
+void slab_put(int device, uint8_t* p, size_t cap) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(g_framePool.m);
+    if (g_framePool.slabs.size() < FramePool::kKeep) { g_framePool.slabs.push_back({device, p, cap}); return; }
+  }
+  (void)hipFree(p);
+}
+hipError_t event_get(int device, hipEvent_t* e) {
+  {
+    std::lock_guard<std::mutex> lk(g_framePool.m);
+    auto& v = g_framePool.events;
+    for (size_t i = 0; i < v.size(); i++)
+      if (v[i].first == device) { *e = v[i].second; v.erase(v.begin() + (long)i); return hipSuccess; }
+  }
+  return hipEventCreateWithFlags(e, hipEventDisableTiming);
+}
+void event_put(int device, hipEvent_t e) {
+  if (!e) return;
+  {
+    std::lock_guard<std::mutex> lk(g_framePool.m);
+    if (g_framePool.events.size() < 4 * FramePool::kKeep) { g_framePool.events.push_back({device, e}); return; }
+  }
+  (void)hipEventDestroy(e);
+}
+
+// A search that reads a resident frame on ITS stream: ordered behind the frame's upload + grid build (which ran on the
+// uploading thread's stream) by the frame's event -- the upload itself does not wait for the device.  Once any consumer
+// has synchronised behind the event the frame is settled and nothing waits any more.
+thread_local std::vector<const orbfe_frame*> t_unsettled;
+hipError_t frame_use(Arena* ar, const orbfe_frame* f) {
+  if (!f || f->settled.load(std::memory_order_acquire)) return hipSuccess;
+  hipError_t e = hipStreamWaitEvent(ar->stream, f->ready, 0);
+  if (e == hipSuccess) t_unsettled.push_back(f);
+  return e;
+}
+void frames_settle() {  // call after the stream of the call has been synchronised
+  for (const orbfe_frame* f : t_unsettled) f->settled.store(true, std::memory_order_release);
+  t_unsettled.clear();
+}
+}  // namespace
+
 extern "C" void orbfe_frame_release(orbfe_frame* f) {
   if (!f) return;
   (void)hipSetDevice(f->device);
-  if (f->slab) (void)hipFree(f->slab);
+  // a frame whose own upload may still be in flight (released before any search used it): its slab must not be handed
+  // to the next upload until then
+  if (f->ready && !f->settled.load(std::memory_order_acquire)) (void)hipEventSynchronize(f->ready);
+  for (size_t i = 0; i < t_unsettled.size();)
+    if (t_unsettled[i] == f) t_unsettled.erase(t_unsettled.begin() + (long)i); else i++;
+  slab_put(f->device, f->slab, f->slabCap);
+  event_put(f->device, f->ready);
   delete f;
 }
 
 extern "C" const orbfe_frame_view* orbfe_frame_get_view(const orbfe_frame* f) { return f ? &f->view : nullptr; }
 
-extern "C" int orbfe_frame_upload(int device, const orbfe_frame_view* v, const orbfe_featvec* fv, orbfe_frame** out) {
-  if (!out) return mfail(ORBFE_ERR_INVALID, "frame_upload: NULL argument");
-  *out = nullptr;
+namespace {
+// host side of a resident frame: copies of what the claim loops / gates read, the canonical view, the slab layout
+struct FrameLayout { size_t oX, oY, oA, oU, oO, oK, oC, oI, oD, oS, total; };
+int frame_host_init(const char* who, int device, const orbfe_frame_view* v, const orbfe_featvec* fv, orbfe_frame** outF,
+                    FrameLayout* L, size_t* nIdxOut) {
   if (!v || v->n < 0 || v->n > GRID_MAX_FEATURES || !(v->max_x > v->min_x) || !(v->max_y > v->min_y) ||
       (v->n > 0 && (!v->x || !v->y || !v->octave || !v->desc)))
-    return mfail(ORBFE_ERR_INVALID, "frame_upload: bad frame view (x, y, octave, desc and the image bounds are required)");
+    return mfail(ORBFE_ERR_INVALID, std::string(who) + ": bad frame view (x, y, octave, desc and the image bounds are required)");
   const int n = v->n;
-  if (fv && !featvec_ok(fv, n)) return mfail(ORBFE_ERR_INVALID, "frame_upload: malformed FeatureVector");
+  if (fv && !featvec_ok(fv, n)) return mfail(ORBFE_ERR_INVALID, std::string(who) + ": malformed FeatureVector");
   orbfe_frame* f = new (std::nothrow) orbfe_frame();
   if (!f) return mfail(ORBFE_ERR_NOMEM, "out of memory");
   f->device = device; f->n = n;
@@ -450,49 +538,176 @@ extern "C" int orbfe_frame_upload(int device, const orbfe_frame_view* v, const o
   c.desc = f->hdesc.data();
   c.min_x = v->min_x; c.max_x = v->max_x; c.min_y = v->min_y; c.max_y = v->max_y;
   c.resident = f;
-  // one slab: x y angle u_right | octave | key | cell | indices | desc | stereo
+  // one slab: x y angle u_right | octave | key | cell | indices | desc | stereo.  The index list gets room for one index per
+  // feature even when no FeatureVector comes with the upload: orbfe_frame_set_featvec may attach it later (Frame::ComputeBoW
+  // runs after the constructor, src/Tracking.cc:836-843)
   const size_t N = (size_t)(n ? n : 1);
   size_t off = 0;
   auto place = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-  const size_t oX = place(N * 4), oY = place(N * 4), oA = place(N * 4), oU = place(N * 4), oO = place(N * 4), oK = place(N * 4),
-               oC = place(3073 * 4), oI = place((nIdx ? nIdx : 1) * 4), oD = place(N * 32), oS = place(N);
+  L->oX = place(N * 4); L->oY = place(N * 4); L->oA = place(N * 4); L->oU = place(N * 4); L->oO = place(N * 4); L->oK = place(N * 4);
+  L->oC = place(3073 * 4); L->oI = place((nIdx > N ? nIdx : N) * 4); L->oD = place(N * 32); L->oS = place(N);
+  L->total = off;
   hipError_t err = hipSetDevice(device);
-  if (err == hipSuccess) err = hipMalloc((void**)&f->slab, off);
-  if (err != hipSuccess) { delete f; return mfail(err == hipErrorOutOfMemory ? ORBFE_ERR_NOMEM : ORBFE_ERR_HIP, std::string("frame_upload: ") + hipGetErrorString(err)); }
+  if (err == hipSuccess) err = slab_get(device, off, &f->slab, &f->slabCap);
+  if (err == hipSuccess) err = event_get(device, &f->ready);
+  if (err != hipSuccess) {
+    const int code = err == hipErrorOutOfMemory ? ORBFE_ERR_NOMEM : ORBFE_ERR_HIP;
+    orbfe_frame_release(f);
+    return mfail(code, std::string(who) + ": " + hipGetErrorString(err));
+  }
+  f->settled.store(false);
   uint8_t* b = f->slab;
-  f->dx = (float*)(b + oX); f->dy = (float*)(b + oY); f->dangle = (float*)(b + oA); f->dur = (float*)(b + oU);
-  f->doct = (int32_t*)(b + oO); f->dkey = (uint32_t*)(b + oK); f->dcell = (int32_t*)(b + oC); f->dindices = (uint32_t*)(b + oI);
-  f->ddesc = b + oD; f->dstereo = b + oS;
+  f->dx = (float*)(b + L->oX); f->dy = (float*)(b + L->oY); f->dangle = (float*)(b + L->oA); f->dur = (float*)(b + L->oU);
+  f->doct = (int32_t*)(b + L->oO); f->dkey = (uint32_t*)(b + L->oK); f->dcell = (int32_t*)(b + L->oC); f->dindices = (uint32_t*)(b + L->oI);
+  f->ddesc = b + L->oD; f->dstereo = b + L->oS;
+  *outF = f;
+  *nIdxOut = nIdx;
+  return ORBFE_OK;
+}
+
+// grid build behind whatever filled the slab, then the ready event: NO host wait (frame_use orders the consumers)
+hipError_t frame_finish(Arena* ar, orbfe_frame* f, const orbfe_frame_view* v) {
+  GridFrame g{};
+  g.x = f->dx; g.y = f->dy; g.octave = f->doct; g.uRight = v->u_right ? f->dur : nullptr; g.desc = f->ddesc; g.n = f->n;
+  g.minX = v->min_x; g.minY = v->min_y;
+  g.wInv = 64.0f / (v->max_x - v->min_x);
+  g.hInv = 48.0f / (v->max_y - v->min_y);
+  launch_grid_build(ar->stream, g, f->dkey, f->dcell);
+  hipError_t err = hipGetLastError();
+  if (err == hipSuccess) err = hipEventRecord(f->ready, ar->stream);
+  return err;
+}
+}  // namespace
+
+extern "C" int orbfe_frame_upload(int device, const orbfe_frame_view* v, const orbfe_featvec* fv, orbfe_frame** out) {
+  if (!out) return mfail(ORBFE_ERR_INVALID, "frame_upload: NULL argument");
+  *out = nullptr;
+  orbfe_frame* f = nullptr;
+  FrameLayout L;
+  size_t nIdx = 0;
+  int rc = frame_host_init("frame_upload", device, v, fv, &f, &L, &nIdx);
+  if (rc != ORBFE_OK) return rc;
+  const int n = f->n;
+  // only what the searches read goes up: the key / cell arrays are written by the grid build, the rest of the slab is padding
+  const size_t upBytes = L.oS + (size_t)(n ? n : 1);
   Arena* ar;
   // staged through the thread's pinned mirror: one copy up, then the grid build (Frame::AssignFeaturesToGrid, once)
-  err = arena_begin(device, 1024, &ar);
-  if (err == hipSuccess) err = staging_reserve_(off);
+  hipError_t err = arena_begin(device, 1024, &ar);
+  if (err == hipSuccess) err = staging_reserve_(upBytes);
   if (err == hipSuccess) {
     uint8_t* h = staging_ptr_();
-    std::memset(h, 0, off);
     if (n) {
-      std::memcpy(h + oX, f->hx.data(), (size_t)n * 4); std::memcpy(h + oY, f->hy.data(), (size_t)n * 4);
-      if (v->angle) std::memcpy(h + oA, f->hangle.data(), (size_t)n * 4);
-      if (v->u_right) std::memcpy(h + oU, f->hur.data(), (size_t)n * 4);
-      std::memcpy(h + oO, f->hoct.data(), (size_t)n * 4);
-      std::memcpy(h + oD, f->hdesc.data(), (size_t)n * 32);
-      std::memcpy(h + oS, f->hstereo.data(), (size_t)n);
+      std::memcpy(h + L.oX, f->hx.data(), (size_t)n * 4); std::memcpy(h + L.oY, f->hy.data(), (size_t)n * 4);
+      if (v->angle) std::memcpy(h + L.oA, f->hangle.data(), (size_t)n * 4); else std::memset(h + L.oA, 0, (size_t)n * 4);
+      if (v->u_right) std::memcpy(h + L.oU, f->hur.data(), (size_t)n * 4); else std::memset(h + L.oU, 0, (size_t)n * 4);
+      std::memcpy(h + L.oO, f->hoct.data(), (size_t)n * 4);
+      std::memcpy(h + L.oD, f->hdesc.data(), (size_t)n * 32);
+      std::memcpy(h + L.oS, f->hstereo.data(), (size_t)n);
     }
-    if (nIdx) std::memcpy(h + oI, f->hindices.data(), nIdx * 4);
-    err = hipMemcpyAsync(b, h, off, hipMemcpyHostToDevice, ar->stream);
+    if (nIdx) std::memcpy(h + L.oI, f->hindices.data(), nIdx * 4);
+    // three ranges instead of one slab-sized copy with a memset in front: keypoint arrays | index list | descriptors + flags
+    err = hipMemcpyAsync(f->slab, h, L.oK, hipMemcpyHostToDevice, ar->stream);
+    if (err == hipSuccess && nIdx) err = hipMemcpyAsync(f->slab + L.oI, h + L.oI, nIdx * 4, hipMemcpyHostToDevice, ar->stream);
+    if (err == hipSuccess) err = hipMemcpyAsync(f->slab + L.oD, h + L.oD, upBytes - L.oD, hipMemcpyHostToDevice, ar->stream);
+    if (err == hipSuccess) err = staging_mark_pending_(ar->stream);  // the next use of the staging buffer waits for these copies
   }
-  if (err == hipSuccess) {
-    GridFrame g{};
-    g.x = f->dx; g.y = f->dy; g.octave = f->doct; g.uRight = v->u_right ? f->dur : nullptr; g.desc = f->ddesc; g.n = n;
-    g.minX = v->min_x; g.minY = v->min_y;
-    g.wInv = 64.0f / (v->max_x - v->min_x);
-    g.hInv = 48.0f / (v->max_y - v->min_y);
-    launch_grid_build(ar->stream, g, f->dkey, f->dcell);
-    err = hipGetLastError();
-  }
-  if (err == hipSuccess) err = hipStreamSynchronize(ar->stream);
+  if (err == hipSuccess) err = frame_finish(ar, f, v);
   if (err != hipSuccess) { orbfe_frame_release(f); return mfail(ORBFE_ERR_HIP, std::string("frame_upload: ") + hipGetErrorString(err)); }
   *out = f;
+  return ORBFE_OK;
+}
+
+// Frame::Frame (src/Frame.cc:61-117) is extract -> undistort -> stereo -> grid: the keypoint records and descriptors the
+// extractor produced are still in HBM when the Frame is built.  orbfe_frame_from_device makes the resident operands from
+// THOSE (28-byte records -> x / y / angle / octave arrays, descriptors device to device, grid built on the device): of
+// the frame's 60 bytes per keypoint only mvuRight (and, with ORBFE_FRAME_XY_FROM_VIEW, the undistorted positions) travel
+// over PCIe.  `view` holds the host arrays the claim loops read (what orbfe_extract returned to the caller, after its own
+// UndistortKeyPoints); view->n records are taken.
+extern "C" int orbfe_frame_from_device(int device, const orbfe_keypoint* d_keypoints, const uint8_t* d_descriptors,
+                                       const orbfe_frame_view* view, const orbfe_featvec* fv, int flags, orbfe_frame** out) {
+  if (!out) return mfail(ORBFE_ERR_INVALID, "frame_from_device: NULL argument");
+  *out = nullptr;
+  if (view && view->n > 0 && (!d_keypoints || !d_descriptors)) return mfail(ORBFE_ERR_INVALID, "frame_from_device: NULL device arrays");
+  orbfe_frame* f = nullptr;
+  FrameLayout L;
+  size_t nIdx = 0;
+  int rc = frame_host_init("frame_from_device", device, view, fv, &f, &L, &nIdx);
+  if (rc != ORBFE_OK) return rc;
+  const int n = f->n;
+  const bool xyFromView = (flags & ORBFE_FRAME_XY_FROM_VIEW) != 0;
+  Arena* ar;
+  hipError_t err = arena_begin(device, 1024, &ar);
+  // host part: mvuRight + stereo flags (+ positions) + the FeatureVector's index list, through the pinned staging
+  const size_t hostBytes = (view->u_right ? 5 : 0) * (size_t)n + (xyFromView ? 8 : 0) * (size_t)n + nIdx * 4 + 1024;
+  if (err == hipSuccess) err = staging_reserve_(hostBytes);
+  if (err == hipSuccess && n) {
+    uint8_t* h = staging_ptr_();
+    size_t o = 0;
+    auto send = [&](void* dst, const void* src, size_t bytes) {
+      if (err != hipSuccess || bytes == 0) return;
+      std::memcpy(h + o, src, bytes);
+      err = hipMemcpyAsync(dst, h + o, bytes, hipMemcpyHostToDevice, ar->stream);
+      o += (bytes + 255) & ~(size_t)255;
+    };
+    if (view->u_right) { send(f->dur, f->hur.data(), (size_t)n * 4); send(f->dstereo, f->hstereo.data(), (size_t)n); }
+    if (xyFromView) { send(f->dx, f->hx.data(), (size_t)n * 4); send(f->dy, f->hy.data(), (size_t)n * 4); }
+    if (nIdx) send(f->dindices, f->hindices.data(), nIdx * 4);
+    if (err == hipSuccess && o) err = staging_mark_pending_(ar->stream);
+  }
+  if (err == hipSuccess && n) {
+    launch_frame_from_records(ar->stream, reinterpret_cast<const float*>(d_keypoints), d_descriptors, n, xyFromView ? nullptr : f->dx,
+                              xyFromView ? nullptr : f->dy, f->dangle, f->doct, f->ddesc, view->u_right ? nullptr : f->dstereo);
+    err = hipGetLastError();
+  }
+  if (err == hipSuccess) err = frame_finish(ar, f, view);
+  if (err != hipSuccess) { orbfe_frame_release(f); return mfail(ORBFE_ERR_HIP, std::string("frame_from_device: ") + hipGetErrorString(err)); }
+  *out = f;
+  return ORBFE_OK;
+}
+
+// implemented in extractor.hip: device pointers of frame `frame` of the handle's own output block (the host-buffer calls)
+extern "C" int orbfe_extractor_output_device_(orbfe_extractor* e, int frame, const orbfe_keypoint** d_kp, const uint8_t** d_desc,
+                                              int* n, int* device);
+
+extern "C" int orbfe_frame_from_extractor(orbfe_extractor* e, int frame, const orbfe_frame_view* view, const orbfe_featvec* fv,
+                                          int flags, orbfe_frame** out) {
+  if (!out) return mfail(ORBFE_ERR_INVALID, "frame_from_extractor: NULL argument");
+  *out = nullptr;
+  const orbfe_keypoint* dkp = nullptr;
+  const uint8_t* ddesc = nullptr;
+  int n = 0, device = 0;
+  int rc = orbfe_extractor_output_device_(e, frame, &dkp, &ddesc, &n, &device);
+  if (rc != ORBFE_OK) return rc;
+  if (!view || view->n > n) return mfail(ORBFE_ERR_INVALID, "frame_from_extractor: the view holds more keypoints than the extractor produced for this frame");
+  return orbfe_frame_from_device(device, dkp, ddesc, view, fv, flags, out);
+}
+
+// Frame::ComputeBoW runs after the constructor (src/Tracking.cc:836-843, src/Frame.cc:433-440): attach the FeatureVector
+// to a frame that was made resident without one.  Call it before the handle is shared with other threads.
+extern "C" int orbfe_frame_set_featvec(orbfe_frame* f, const orbfe_featvec* fv) {
+  if (!f || !fv) return mfail(ORBFE_ERR_INVALID, "frame_set_featvec: NULL argument");
+  if (!featvec_ok(fv, f->n)) return mfail(ORBFE_ERR_INVALID, "frame_set_featvec: malformed FeatureVector");
+  const size_t nIdx = fv->n_nodes > 0 ? (size_t)fv->offsets[fv->n_nodes] : 0;
+  if (nIdx > (size_t)(f->n ? f->n : 1)) return mfail(ORBFE_ERR_INVALID, "frame_set_featvec: more indices than features");
+  if (fv->n_nodes > 0) {
+    f->nodeIds.assign(fv->node_ids, fv->node_ids + fv->n_nodes);
+    f->offsets.assign(fv->offsets, fv->offsets + fv->n_nodes + 1);
+    f->hindices.assign(fv->indices, fv->indices + nIdx);
+  } else {
+    f->nodeIds.clear(); f->hindices.clear(); f->offsets.assign(1, 0);
+  }
+  f->fv.n_nodes = fv->n_nodes; f->fv.node_ids = f->nodeIds.data(); f->fv.offsets = f->offsets.data(); f->fv.indices = f->hindices.data();
+  f->haveFv = true;
+  if (nIdx == 0) return ORBFE_OK;
+  Arena* ar;
+  hipError_t err = arena_begin(f->device, 1024, &ar);
+  if (err == hipSuccess) err = staging_reserve_(nIdx * 4);
+  if (err == hipSuccess) {
+    std::memcpy(staging_ptr_(), f->hindices.data(), nIdx * 4);
+    err = hipMemcpyAsync(f->dindices, staging_ptr_(), nIdx * 4, hipMemcpyHostToDevice, ar->stream);
+  }
+  if (err == hipSuccess) err = hipStreamSynchronize(ar->stream);  // (the handle may be in use on other streams afterwards)
+  if (err != hipSuccess) return mfail(ORBFE_ERR_HIP, std::string("frame_set_featvec: ") + hipGetErrorString(err));
   return ORBFE_OK;
 }
 
@@ -515,6 +730,8 @@ static int bow_resident(const orbfe_frame* k1, const uint8_t* has_mp1, const orb
   if (maxCnt2 > 65535) return mfail(ORBFE_ERR_INVALID, "search_by_bow: more than 65535 features in one node");
   Arena* ar;
   MHIP(arena_begin(k1->device, pad(pairs.size() * sizeof(NodePair)) + pad(n1) + pad(n2) + 2 * pad((size_t)nOut * 4) + 4096, &ar));
+  MHIP(frame_use(ar, k1));
+  MHIP(frame_use(ar, k2));
   NodePair* dp;
   uint8_t *dm1, *dm2 = nullptr;
   MHIP(up(ar, &dp, pairs.data(), pairs.size()));
@@ -536,6 +753,7 @@ static int bow_resident(const orbfe_frame* k1, const uint8_t* has_mp1, const orb
   MHIP(hipGetLastError());
   MHIP(down_range(ar, dmatch, dcount + 1));
   MHIP(hipStreamSynchronize(ar->stream));
+  frames_settle();
   std::memcpy(match, mirror_of(ar, dmatch), (size_t)nOut * 4);
   return *mirror_of(ar, dcount);
 }
@@ -548,6 +766,93 @@ extern "C" int orbfe_search_by_bow_kf_resident(const orbfe_frame* kf1, const uin
                                                const uint8_t* has_mp2, float nnratio, int check_orientation,
                                                int32_t* match12) {
   return bow_resident(kf1, has_mp1, kf2, has_mp2, nnratio, check_orientation, 1, match12);
+}
+
+// ORBmatcher::SearchByBoW of ONE frame / key frame against K candidate key frames in one call: Tracking::Relocalization
+// runs SearchByBoW(pKF_k, mCurrentFrame, ...) over every candidate (src/Tracking.cc:1478-1498), LoopClosing::ComputeSim3
+// SearchByBoW(mpCurrentKF, pKF_k, ...) (src/LoopClosing.cc:294-321).  A single resident call is a round trip of ~0.16 ms
+// whatever it computes; here the K shared-node lists and masks go up in ONE copy, K + 1 launches run back to back on one
+// stream, and the K match arrays with their counts come back in ONE copy.
+//   kfkf = 0: (KF_k, F):   key frame k on the `1` side (mask has_mp_k[k]), `one` = the frame; match [k * one->n + i2]
+//   kfkf = 1: (KF, KF_k):  `one` = the current key frame on the `1` side (mask has_mp_one), candidate k on the `2` side
+//                          (mask has_mp_k[k]); match [k * one->n + i1]
+static int bow_multi(const orbfe_frame* one, const uint8_t* has_mp_one, int K, const orbfe_frame* const* many,
+                     const uint8_t* const* has_mp_k, float nnratio, int check_ori, int kfkf, int32_t* match,
+                     int32_t* n_matches) {
+  if (!one || K < 0 || (K > 0 && (!many || !has_mp_k || !match || !n_matches)))
+    return mfail(ORBFE_ERR_INVALID, "search_by_bow_multi: bad argument");
+  const int nOut = one->n;
+  for (size_t i = 0; i < (size_t)K * nOut; i++) match[i] = -1;
+  for (int k = 0; k < K; k++) n_matches[k] = 0;
+  if (K == 0 || nOut == 0) return ORBFE_OK;
+  if (!one->haveFv || one->hangle.empty() || (kfkf && !has_mp_one))
+    return mfail(ORBFE_ERR_INVALID, "search_by_bow_multi: frame uploaded without FeatureVector / angles, or NULL mask");
+  std::vector<std::vector<NodePair>> pairs((size_t)K);
+  std::vector<int> maxCnt2((size_t)K, 0);
+  size_t bytes = pad((size_t)nOut) + 2 * pad((size_t)K * nOut * 4) + pad((size_t)K * 4) + 8192;
+  for (int k = 0; k < K; k++) {
+    const orbfe_frame* c = many[k];
+    if (!c || (c->n > 0 && !has_mp_k[k])) return mfail(ORBFE_ERR_INVALID, "search_by_bow_multi: NULL candidate or mask");
+    if (c->device != one->device) return mfail(ORBFE_ERR_INVALID, "search_by_bow_multi: frames on different devices");
+    if (c->n == 0) continue;
+    if (!c->haveFv || c->hangle.empty())
+      return mfail(ORBFE_ERR_INVALID, "search_by_bow_multi: candidate uploaded without FeatureVector / angles");
+    if (kfkf) shared_nodes(&one->fv, &c->fv, &pairs[k]); else shared_nodes(&c->fv, &one->fv, &pairs[k]);
+    for (const NodePair& p : pairs[k]) maxCnt2[k] = p.cnt2 > maxCnt2[k] ? p.cnt2 : maxCnt2[k];
+    if (maxCnt2[k] > 65535) return mfail(ORBFE_ERR_INVALID, "search_by_bow: more than 65535 features in one node");
+    bytes += pad(pairs[k].size() * sizeof(NodePair)) + pad((size_t)c->n);
+  }
+  Arena* ar;
+  MHIP(arena_begin(one->device, bytes, &ar));
+  MHIP(frame_use(ar, one));
+  for (int k = 0; k < K; k++) MHIP(frame_use(ar, many[k]));
+  std::vector<NodePair*> dp((size_t)K, nullptr);
+  std::vector<uint8_t*> dmk((size_t)K, nullptr);
+  uint8_t* dmOne = nullptr;
+  if (kfkf) MHIP(up(ar, &dmOne, has_mp_one, (size_t)nOut));
+  for (int k = 0; k < K; k++) {
+    if (pairs[k].empty()) continue;
+    MHIP(up(ar, &dp[k], pairs[k].data(), pairs[k].size()));
+    MHIP(up(ar, &dmk[k], has_mp_k[k], (size_t)many[k]->n));
+  }
+  int32_t* dmatch;
+  int8_t* dbin;
+  MHIP(up_fill(ar, &dmatch, (size_t)K * nOut, 0xff));  // match arrays and counts adjacent: one copy back
+  int32_t* dcount;
+  MHIP(up_fill(ar, &dcount, (size_t)K, 0));
+  MHIP(up_fill(ar, &dbin, (size_t)K * nOut, 0));
+  MHIP(flush(ar));
+  for (int k = 0; k < K; k++) {
+    if (pairs[k].empty()) continue;
+    const orbfe_frame* c = many[k];
+    const orbfe_frame *f1 = kfkf ? one : c, *f2 = kfkf ? c : one;
+    BowArgs a = {};
+    a.pairs = dp[k];
+    a.desc1 = f1->ddesc; a.hasMp1 = kfkf ? dmOne : dmk[k]; a.angle1 = f1->dangle; a.indices1 = f1->dindices;
+    a.desc2 = f2->ddesc; a.hasMp2 = kfkf ? dmk[k] : nullptr; a.angle2 = f2->dangle; a.indices2 = f2->dindices;
+    a.angleStride = 1;
+    a.nnratio = nnratio; a.strictLow = kfkf; a.match = dmatch + (size_t)k * nOut; a.bin = dbin + (size_t)k * nOut;
+    launch_search_by_bow(ar->stream, a, (int)pairs[k].size(), maxCnt2[k]);
+  }
+  launch_rot_prune_batch(ar->stream, dmatch, dbin, nOut, K, check_ori, dcount);  // all K histograms in one launch
+  MHIP(hipGetLastError());
+  MHIP(down_range(ar, dmatch, dcount + K));
+  MHIP(hipStreamSynchronize(ar->stream));
+  frames_settle();
+  std::memcpy(match, mirror_of(ar, dmatch), (size_t)K * nOut * 4);
+  std::memcpy(n_matches, mirror_of(ar, dcount), (size_t)K * 4);
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_search_by_bow_multi(int n_keyframes, const orbfe_frame* const* kf, const uint8_t* const* has_mp_kf,
+                                         const orbfe_frame* f, float nnratio, int check_orientation, int32_t* match_f,
+                                         int32_t* n_matches) {
+  return bow_multi(f, nullptr, n_keyframes, kf, has_mp_kf, nnratio, check_orientation, 0, match_f, n_matches);
+}
+extern "C" int orbfe_search_by_bow_kf_multi(const orbfe_frame* kf1, const uint8_t* has_mp1, int n_keyframes,
+                                            const orbfe_frame* const* kf2, const uint8_t* const* has_mp2, float nnratio,
+                                            int check_orientation, int32_t* match12, int32_t* n_matches) {
+  return bow_multi(kf1, has_mp1, n_keyframes, kf2, has_mp2, nnratio, check_orientation, 1, match12, n_matches);
 }
 
 // ORBmatcher::SearchForTriangulation of ONE key frame against K neighbours (LocalMapping::CreateNewMapPoints,
@@ -595,6 +900,8 @@ extern "C" int orbfe_search_for_triangulation_multi(const orbfe_frame* kf1, cons
   }
   Arena* ar;
   MHIP(arena_begin(kf1->device, bytes, &ar));
+  MHIP(frame_use(ar, kf1));
+  for (int k = 0; k < K; k++) MHIP(frame_use(ar, kf2[k]));
   float *dF, *dsf, *dsg;
   MHIP(up(ar, &dF, F12, (size_t)K * 9));
   MHIP(up(ar, &dsf, scale_factors2, (size_t)n_levels2));
@@ -629,6 +936,7 @@ extern "C" int orbfe_search_for_triangulation_multi(const orbfe_frame* kf1, cons
   MHIP(hipGetLastError());
   MHIP(down_range(ar, dmatch, dcount + K));
   MHIP(hipStreamSynchronize(ar->stream));
+  frames_settle();
   std::memcpy(match12, mirror_of(ar, dmatch), (size_t)K * n1 * 4);
   std::memcpy(n_matches, mirror_of(ar, dcount), (size_t)K * 4);
   return ORBFE_OK;
@@ -731,7 +1039,12 @@ bool frame_ok(const orbfe_frame_view* f) {
 struct Staging {
   uint8_t* h = nullptr;
   size_t cap = 0;
-  ~Staging() { if (h) (void)hipHostFree(h); }
+  hipEvent_t pending = nullptr;  // an asynchronous copy OUT of the buffer that nobody waited for (orbfe_frame_upload): the
+  bool isPending = false;        // next use of the buffer waits for it first
+  ~Staging() {
+    if (h) (void)hipHostFree(h);
+    if (pending) (void)hipEventDestroy(pending);
+  }
 };
 thread_local Staging t_staging;
 
@@ -740,7 +1053,21 @@ hipError_t staging_reserve(size_t bytes);
 namespace {
 hipError_t staging_reserve_(size_t bytes) { return staging_reserve(bytes); }
 uint8_t* staging_ptr_() { return t_staging.h; }
+hipError_t staging_mark_pending_(hipStream_t s) {
+  if (!t_staging.pending) {
+    hipError_t e = hipEventCreateWithFlags(&t_staging.pending, hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+  }
+  hipError_t e = hipEventRecord(t_staging.pending, s);
+  if (e == hipSuccess) t_staging.isPending = true;
+  return e;
+}
 hipError_t staging_reserve(size_t bytes) {
+  if (t_staging.isPending) {  // (normally long done: the copy took microseconds, the caller's next call comes later)
+    hipError_t e = hipEventSynchronize(t_staging.pending);
+    if (e != hipSuccess) return e;
+    t_staging.isPending = false;
+  }
   if (bytes <= t_staging.cap) return hipSuccess;
   if (t_staging.h) (void)hipHostFree(t_staging.h);
   t_staging.h = nullptr;
@@ -768,7 +1095,7 @@ struct WindowJob {
 // grids, search every window; grows K until every list fits.
 int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
   int K = K0 < 8 ? 8 : K0;
-  struct Lay { size_t oX, oY, oOct, oUr, oDesc, oQx, oQy, oQr, oQmin, oQmax, oQact, oQur, oQdesc, oOut; bool withDesc, withUr, res; };
+  struct Lay { size_t oX, oY, oOct, oUr, oDesc, oQx, oQy, oQr, oQmin, oQmax, oQact, oQur, oQdesc, oOut; bool withDesc, withUr, res; int frameOf; };
   std::vector<Lay> lay((size_t)nJobs);
   size_t off = 0;
   auto place = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -781,7 +1108,14 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
     L.withDesc = J.f->desc && J.qdesc;
     L.withUr = J.qur && J.f->u_right;
     L.oX = L.oY = L.oOct = L.oUr = L.oDesc = 0;
-    if (!L.res) {
+    L.frameOf = j;  // several jobs on the SAME host-array frame (one frame against K candidates): one upload, one grid
+    if (!L.res)
+      for (int k = 0; k < j; k++)
+        if (!lay[k].res && jobs[k].f == J.f && lay[k].withDesc == L.withDesc) { L.frameOf = lay[k].frameOf; break; }
+    if (!L.res && L.frameOf != j) {
+      const Lay& F = lay[L.frameOf];
+      L.oX = F.oX; L.oY = F.oY; L.oOct = F.oOct; L.oUr = F.oUr; L.oDesc = F.oDesc;
+    } else if (!L.res) {
       L.oX = place(n * 4); L.oY = place(n * 4); L.oOct = place(n * 4);
       L.oUr = J.f->u_right ? place(n * 4) : 0;
       L.oDesc = L.withDesc ? place(n * 32) : 0;
@@ -804,16 +1138,18 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
     for (int j = 0; j < nJobs; j++) {
       lay[j].oOut = outBytes;
       outBytes += pad((size_t)jobs[j].nq * 4) + pad((size_t)jobs[j].nq * (size_t)K * 4);
-      if (!lay[j].res) gridBytes += pad((size_t)jobs[j].f->n * 4) + pad(3073 * 4);
+      if (!lay[j].res && lay[j].frameOf == j) gridBytes += pad((size_t)jobs[j].f->n * 4) + pad(3073 * 4);
     }
     MHIP(arena_begin(device, pad(inBytes) + gridBytes + outBytes + 1024, &ar));
+    for (int j = 0; j < nJobs; j++)
+      if (lay[j].res) MHIP(frame_use(ar, jobs[j].f->resident));
     MHIP(staging_reserve(inBytes > outBytes ? inBytes : outBytes));
     uint8_t* h = t_staging.h;
     for (int j = 0; j < nJobs; j++) {
       const WindowJob& J = jobs[j];
       const Lay& L = lay[j];
       const size_t n = (size_t)J.f->n, q = (size_t)J.nq;
-      if (!L.res && n) {
+      if (!L.res && L.frameOf == j && n) {
         std::memcpy(h + L.oX, J.f->x, n * 4); std::memcpy(h + L.oY, J.f->y, n * 4); std::memcpy(h + L.oOct, J.f->octave, n * 4);
         if (J.f->u_right) std::memcpy(h + L.oUr, J.f->u_right, n * 4);
         if (L.withDesc) std::memcpy(h + L.oDesc, J.f->desc, n * 32);
@@ -831,6 +1167,8 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
     uint8_t* dgrid = carve<uint8_t>(ar, gridBytes ? gridBytes : 1);
     uint8_t* dout = carve<uint8_t>(ar, outBytes ? outBytes : 1);
     size_t goff = 0;
+    std::vector<const uint32_t*> keyOf((size_t)nJobs, nullptr);
+    std::vector<const int32_t*> cellOf((size_t)nJobs, nullptr);
     for (int j = 0; j < nJobs; j++) {
       const WindowJob& J = jobs[j];
       const Lay& L = lay[j];
@@ -853,7 +1191,9 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
       g.minX = J.f->min_x; g.minY = J.f->min_y;
       g.wInv = 64.0f / (J.f->max_x - J.f->min_x);  // src/Frame.cc:109-110 (FRAME_GRID_COLS / ROWS)
       g.hInv = 48.0f / (J.f->max_y - J.f->min_y);
-      if (!L.res) {
+      if (!L.res && L.frameOf != j) {
+        dkey = keyOf[L.frameOf]; dcell = cellOf[L.frameOf];
+      } else if (!L.res) {
         uint32_t* k = reinterpret_cast<uint32_t*>(dgrid + goff);
         goff += pad(n * 4);
         int32_t* c = reinterpret_cast<int32_t*>(dgrid + goff);
@@ -861,6 +1201,7 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
         launch_grid_build(ar->stream, g, k, c);
         MHIP(hipGetLastError());
         dkey = k; dcell = c;
+        keyOf[j] = k; cellOf[j] = c;
       }
       WindowQueries wq{};
       wq.x = reinterpret_cast<const float*>(din + L.oQx); wq.y = reinterpret_cast<const float*>(din + L.oQy);
@@ -878,6 +1219,7 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
     }
     if (outBytes) MHIP(hipMemcpyAsync(h, dout, outBytes, hipMemcpyDeviceToHost, ar->stream));
     MHIP(hipStreamSynchronize(ar->stream));
+    frames_settle();
     int mx = 0;
     for (int j = 0; j < nJobs; j++) {
       const size_t q = (size_t)jobs[j].nq;
@@ -1111,28 +1453,10 @@ struct RotHist {
 
 }  // namespace
 
-extern "C" int orbfe_search_by_projection_keyframe(int device, const orbfe_frame_view* Cur, const float* scale_factors,
-                                                   int n_levels, const uint8_t* blocked, int n, const uint8_t* valid,
-                                                   const float* u, const float* v, const int32_t* level,
-                                                   const float* kf_angle, const uint8_t* mp_desc, float th,
-                                                   int orb_dist, int check_orientation, int32_t* match_cur,
-                                                   int32_t* n_matches) {
-  Cur = canon(Cur);
-  if (!frame_ok(Cur) || !scale_factors || n_levels <= 0 || n < 0 || !n_matches ||
-      (Cur->n > 0 && (!match_cur || !Cur->desc)) || (check_orientation && Cur->n > 0 && !Cur->angle) ||
-      (n > 0 && (!valid || !u || !v || !level || !mp_desc || (check_orientation && !kf_angle))))
-    return mfail(ORBFE_ERR_INVALID, "search_by_projection_keyframe: bad argument");
-  std::vector<float> qr;
-  std::vector<int32_t> qmin, qmax;
-  int rc = level_queries("search_by_projection_keyframe", n, valid, level, scale_factors, n_levels, th, -1, +1, false,
-                         &qr, &qmin, &qmax);
-  if (rc != ORBFE_OK) return rc;
-  for (int i = 0; i < Cur->n; i++) match_cur[i] = -1;
-  *n_matches = 0;
-  if (n == 0 || Cur->n == 0) return ORBFE_OK;
-  WindowResult res;
-  rc = window_search(device, Cur, n, u, v, qr.data(), qmin.data(), qmax.data(), valid, nullptr, mp_desc, 32, &res);
-  if (rc != ORBFE_OK) return rc;
+namespace {
+// the claim loop of SearchByProjection(CurrentFrame, pKF, ...) (src/ORBmatcher.cc:1700-1770) over the window lists of one job
+void keyframe_claim(const orbfe_frame_view* Cur, const WindowResult& res, const uint8_t* blocked, int n, const uint8_t* valid,
+                    const float* kf_angle, int orb_dist, int check_orientation, int32_t* match_cur, int32_t* n_matches) {
   std::vector<uint8_t> blk(Cur->n, 0);
   if (blocked) std::memcpy(blk.data(), blocked, (size_t)Cur->n);
   RotHist rh;
@@ -1162,6 +1486,77 @@ extern "C" int orbfe_search_by_projection_keyframe(int device, const orbfe_frame
     }
   }
   *n_matches = nmatches;
+}
+}  // namespace
+
+extern "C" int orbfe_search_by_projection_keyframe(int device, const orbfe_frame_view* Cur, const float* scale_factors,
+                                                   int n_levels, const uint8_t* blocked, int n, const uint8_t* valid,
+                                                   const float* u, const float* v, const int32_t* level,
+                                                   const float* kf_angle, const uint8_t* mp_desc, float th,
+                                                   int orb_dist, int check_orientation, int32_t* match_cur,
+                                                   int32_t* n_matches) {
+  Cur = canon(Cur);
+  if (!frame_ok(Cur) || !scale_factors || n_levels <= 0 || n < 0 || !n_matches ||
+      (Cur->n > 0 && (!match_cur || !Cur->desc)) || (check_orientation && Cur->n > 0 && !Cur->angle) ||
+      (n > 0 && (!valid || !u || !v || !level || !mp_desc || (check_orientation && !kf_angle))))
+    return mfail(ORBFE_ERR_INVALID, "search_by_projection_keyframe: bad argument");
+  std::vector<float> qr;
+  std::vector<int32_t> qmin, qmax;
+  int rc = level_queries("search_by_projection_keyframe", n, valid, level, scale_factors, n_levels, th, -1, +1, false,
+                         &qr, &qmin, &qmax);
+  if (rc != ORBFE_OK) return rc;
+  for (int i = 0; i < Cur->n; i++) match_cur[i] = -1;
+  *n_matches = 0;
+  if (n == 0 || Cur->n == 0) return ORBFE_OK;
+  WindowResult res;
+  rc = window_search(device, Cur, n, u, v, qr.data(), qmin.data(), qmax.data(), valid, nullptr, mp_desc, 32, &res);
+  if (rc != ORBFE_OK) return rc;
+  keyframe_claim(Cur, res, blocked, n, valid, kf_angle, orb_dist, check_orientation, match_cur, n_matches);
+  return ORBFE_OK;
+}
+
+// The same search of ONE current frame against the projected map points of K candidate key frames in one call
+// (Tracking::Relocalization, src/Tracking.cc:1577,1595: matcher2.SearchByProjection(mCurrentFrame, vpCandidateKFs[i],
+// sFound, 10 | 3, 100 | 64) per candidate whose PnP pose survived).  Candidate k brings n[k] points: valid[k] / u[k] / v[k]
+// / level[k] / kf_angle[k] / mp_desc[k] / blocked[k] (may be NULL) are its arrays; th[k] / orb_dist[k] its window and
+// distance bound.  The K window searches share ONE upload of the queries, one launch group and one download
+// (window_search_multi); a resident Cur uploads nothing of the frame.  match_cur [k * Cur->n + i2], n_matches [k].
+extern "C" int orbfe_search_by_projection_keyframe_multi(int device, const orbfe_frame_view* Cur, const float* scale_factors,
+                                                         int n_levels, int n_candidates, const uint8_t* const* blocked,
+                                                         const int32_t* n, const uint8_t* const* valid, const float* const* u,
+                                                         const float* const* v, const int32_t* const* level,
+                                                         const float* const* kf_angle, const uint8_t* const* mp_desc,
+                                                         const float* th, const int32_t* orb_dist, int check_orientation,
+                                                         int32_t* match_cur, int32_t* n_matches) {
+  Cur = canon(Cur);
+  const int K = n_candidates;
+  if (!frame_ok(Cur) || !scale_factors || n_levels <= 0 || K < 0 ||
+      (K > 0 && (!n || !valid || !u || !v || !level || !mp_desc || !th || !orb_dist || !n_matches || (check_orientation && !kf_angle))) ||
+      (Cur->n > 0 && K > 0 && (!match_cur || !Cur->desc)) || (check_orientation && Cur->n > 0 && !Cur->angle))
+    return mfail(ORBFE_ERR_INVALID, "search_by_projection_keyframe_multi: bad argument");
+  std::vector<std::vector<float>> qr((size_t)K);
+  std::vector<std::vector<int32_t>> qmin((size_t)K), qmax((size_t)K);
+  std::vector<WindowResult> res((size_t)K);
+  std::vector<WindowJob> wj;
+  std::vector<int> jobOf;
+  for (int k = 0; k < K; k++) {
+    if (n[k] < 0 || (n[k] > 0 && (!valid[k] || !u[k] || !v[k] || !level[k] || !mp_desc[k] || (check_orientation && !kf_angle[k]))))
+      return mfail(ORBFE_ERR_INVALID, "search_by_projection_keyframe_multi: NULL array of a candidate");
+    int rc = level_queries("search_by_projection_keyframe_multi", n[k], valid[k], level[k], scale_factors, n_levels, th[k], -1, +1,
+                           false, &qr[k], &qmin[k], &qmax[k]);
+    if (rc != ORBFE_OK) return rc;
+    for (int i = 0; i < Cur->n; i++) match_cur[(size_t)k * Cur->n + i] = -1;
+    n_matches[k] = 0;
+    if (n[k] == 0 || Cur->n == 0) continue;
+    wj.push_back(WindowJob{Cur, n[k], u[k], v[k], qr[k].data(), qmin[k].data(), qmax[k].data(), valid[k], nullptr, mp_desc[k], &res[k]});
+    jobOf.push_back(k);
+  }
+  if (wj.empty()) return ORBFE_OK;
+  int rc = window_search_multi(device, wj.data(), (int)wj.size(), 32);
+  if (rc != ORBFE_OK) return rc;
+  for (int k : jobOf)
+    keyframe_claim(Cur, res[k], blocked ? blocked[k] : nullptr, n[k], valid[k], check_orientation ? kf_angle[k] : nullptr, orb_dist[k],
+                   check_orientation, match_cur + (size_t)k * Cur->n, &n_matches[k]);
   return ORBFE_OK;
 }
 

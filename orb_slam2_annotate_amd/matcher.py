@@ -86,10 +86,23 @@ class ResidentFrame:
     """Device-resident operands of a Frame / KeyFrame (include/orbfe.h orbfe_frame).  `.c` is the handle's own
     orbfe_frame_view (host copies inside the handle, `resident` set), so an instance is accepted wherever a FrameView is."""
 
-    def __init__(self, view: FrameView, fv=None, device: int = 0):
+    XY_FROM_VIEW = 1  # ORBFE_FRAME_XY_FROM_VIEW
+
+    def __init__(self, view: FrameView, fv=None, device: int = 0, extractor=None, frame: int = 0, d_keypoints: int = 0,
+                 d_descriptors: int = 0, flags: int = 0):
+        """default: orbfe_frame_upload (everything from the host arrays of `view`).  extractor=...: orbfe_frame_from_extractor
+        (records and descriptors of frame `frame` of the handle's last host-buffer call, still in HBM); d_keypoints /
+        d_descriptors (device addresses in the extractor's output layout): orbfe_frame_from_device."""
         self._L = _lib.load()
         self._handle = C.c_void_p()
-        check(self._L.orbfe_frame_upload(device, C.byref(view.c), C.byref(fv.c) if fv is not None else None, C.byref(self._handle)))
+        fvp = C.byref(fv.c) if fv is not None else None
+        if extractor is not None:
+            check(self._L.orbfe_frame_from_extractor(extractor._h, int(frame), C.byref(view.c), fvp, int(flags), C.byref(self._handle)))
+        elif d_keypoints:
+            check(self._L.orbfe_frame_from_device(device, C.c_void_p(d_keypoints), C.c_void_p(d_descriptors), C.byref(view.c), fvp,
+                                                  int(flags), C.byref(self._handle)))
+        else:
+            check(self._L.orbfe_frame_upload(device, C.byref(view.c), fvp, C.byref(self._handle)))
         self._view = self._L.orbfe_frame_get_view(self._handle).contents  # aliases memory INSIDE the handle
         self.N, self.device = view.N, device
         # the searches' Python wrappers read these for the outputs' shapes only
@@ -113,6 +126,10 @@ class ResidentFrame:
     @property
     def closed(self):
         return self._handle is None
+
+    def set_featvec(self, fv):
+        """Frame::ComputeBoW after the constructor (src/Tracking.cc:836-843): attach the FeatureVector."""
+        check(self._L.orbfe_frame_set_featvec(self._h, C.byref(fv.c)))
 
     def close(self):
         if getattr(self, "_handle", None):
@@ -193,6 +210,68 @@ class ORBmatcher:
         n = check(self._L.orbfe_search_by_bow_kf_resident(kf._h, ptr(m1), f._h, ptr(m2), self.mfNNratio,
                                                           int(self.mbCheckOrientation), ptr(out)))
         return n, out[:kf.N]
+
+    def SearchByBoWMulti(self, kfs, has_mp_kfs, f: "ResidentFrame"):
+        """Tracking::Relocalization (src/Tracking.cc:1478-1498): SearchByBoW(pKF_k, mCurrentFrame) for every candidate key
+        frame in ONE call -> (n_matches[K], match_f[K, f.N])."""
+        K = len(kfs)
+        masks = [_u8(m) for m in has_mp_kfs]
+        hs = (C.c_void_p * max(K, 1))(*[k._h for k in kfs])
+        ms = (C.c_void_p * max(K, 1))(*[m.ctypes.data for m in masks])
+        out = np.full((max(K, 1), max(f.N, 1)), -1, dtype=np.int32)
+        cnt = np.zeros(max(K, 1), dtype=np.int32)
+        check(self._L.orbfe_search_by_bow_multi(K, hs, ms, f._h, self.mfNNratio, int(self.mbCheckOrientation), ptr(out), ptr(cnt)))
+        return cnt[:K], out[:K, :f.N]
+
+    def SearchByBoWKFMulti(self, kf1: "ResidentFrame", has_mp1, kf2s, has_mp2s):
+        """LoopClosing::ComputeSim3 (src/LoopClosing.cc:294-321): SearchByBoW(mpCurrentKF, pKF_k) for every candidate in ONE
+        call -> (n_matches[K], match12[K, kf1.N])."""
+        K = len(kf2s)
+        m1 = _u8(has_mp1)
+        masks = [_u8(m) for m in has_mp2s]
+        hs = (C.c_void_p * max(K, 1))(*[k._h for k in kf2s])
+        ms = (C.c_void_p * max(K, 1))(*[m.ctypes.data for m in masks])
+        out = np.full((max(K, 1), max(kf1.N, 1)), -1, dtype=np.int32)
+        cnt = np.zeros(max(K, 1), dtype=np.int32)
+        check(self._L.orbfe_search_by_bow_kf_multi(kf1._h, ptr(m1), K, hs, ms, self.mfNNratio, int(self.mbCheckOrientation),
+                                                   ptr(out), ptr(cnt)))
+        return cnt[:K], out[:K, :kf1.N]
+
+    def SearchByProjectionKeyFrameMulti(self, Cur: FrameView, scale_factors, candidates):
+        """SearchByProjection(CurrentFrame, pKF_k, sFound, th_k, ORBdist_k) (src/Tracking.cc:1577,1595) for K candidates in ONE
+        call.  candidates: list of dicts with valid, u, v, level, kf_angle, mp_desc, th, ORBdist and optionally blocked ->
+        (n_matches[K], match_cur[K, Cur.N])."""
+        K = len(candidates)
+        sf = _f32(scale_factors)
+        keep = []  # the arrays must outlive the call
+
+        def col(key, conv, optional=False):
+            arr = []
+            for c in candidates:
+                a = c.get(key)
+                if a is None:
+                    if not optional:
+                        raise ValueError(key)
+                    arr.append(None)
+                else:
+                    a = conv(a)
+                    keep.append(a)
+                    arr.append(a.ctypes.data)
+            return (C.c_void_p * max(K, 1))(*arr)
+
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)  # noqa: E731
+        va, uu, vv, lv = col("valid", _u8), col("u", _f32), col("v", _f32), col("level", i32)
+        ka, md = col("kf_angle", _f32), col("mp_desc", lambda a: _u8(a).reshape(-1, 32))
+        blk = col("blocked", _u8, optional=True)
+        n = np.array([len(_u8(c["valid"])) for c in candidates] or [0], dtype=np.int32)
+        th = np.array([c["th"] for c in candidates] or [0], dtype=np.float32)
+        od = np.array([c["ORBdist"] for c in candidates] or [0], dtype=np.int32)
+        match = np.full((max(K, 1), max(Cur.N, 1)), -1, dtype=np.int32)
+        cnt = np.zeros(max(K, 1), dtype=np.int32)
+        check(self._L.orbfe_search_by_projection_keyframe_multi(
+            self.device, C.byref(Cur.c), ptr(sf), len(sf), K, blk, ptr(n), va, uu, vv, lv, ka, md, ptr(th), ptr(od),
+            int(self.mbCheckOrientation), ptr(match), ptr(cnt)))
+        return cnt[:K], match[:K, :Cur.N]
 
     def SearchForTriangulationMulti(self, kf1: "ResidentFrame", has_mp1, neighbours, has_mp2_list, F12s, epipoles,
                                     scale_factors2, level_sigma2_2, only_stereo: bool = False):

@@ -162,6 +162,36 @@ int main(int argc, char** argv) {
       for (int k = 0; k < 3; k++) Fs.insert(Fs.end(), F12, F12 + 9);
       tri.SearchForTriangulationMulti(K1, has1, nb, mk, Fs, exs, eys, sf, sig2, multi, false);
       for (int k = 0; k < 3; k++) expect(multi[k] == refTri, "triangulation multi");
+      // round 4: one frame / key frame against K candidates in ONE call (src/Tracking.cc:1478-1498, src/LoopClosing.cc:294-321)
+      {
+        std::vector<std::vector<int32_t> > mm;
+        std::vector<const FrameArrays*> cands(3, &K1);
+        std::vector<const std::vector<uint8_t>*> cm(3, &all1);
+        std::vector<int> c = bow.SearchByBoWMulti(cands, cm, K2, mm);
+        for (int k = 0; k < 3; k++) expect(c[k] == nBow && mm[k] == refBow, "bow multi (KF_k, F)");
+        std::vector<const FrameArrays*> cands2(3, &K2);
+        std::vector<const std::vector<uint8_t>*> cm2(3, &has2);
+        c = bow.SearchByBoWMulti(K1, has1, cands2, cm2, mm);
+        for (int k = 0; k < 3; k++) expect(c[k] == nBowKF && mm[k] == refBowKF, "bow multi (KF, KF_k)");
+        ORBmatcher::ProjectedKeyFrame pk;
+        pk.valid = valid; pk.mpDescriptors = dL; pk.u = u; pk.v = v; pk.kfAngle = H1.angle; pk.level = lev; pk.th = 12.0f; pk.ORBdist = 100;
+        std::vector<ORBmatcher::ProjectedKeyFrame> pks(3, pk);
+        c = prj.SearchByProjectionMulti(K2, sf, pks, mm);
+        for (int k = 0; k < 3; k++) expect(c[k] == nRel && mm[k] == refReloc, "reloc multi resident");
+        c = prj.SearchByProjectionMulti(H2, sf, pks, mm);
+        for (int k = 0; k < 3; k++) expect(c[k] == nRel && mm[k] == refReloc, "reloc multi host arrays");
+        // Frame::Frame without the features travelling twice: eL's output block still holds kL / dL
+        FrameArrays X1(kL, dL, 0.0f, (float)W, 0.0f, (float)H, urL);
+        X1.makeResidentFromExtractor(eL.handle());
+        X1.setFeatVec(fv1);  // Frame::ComputeBoW afterwards
+        std::vector<int32_t> m;
+        expect(orbfe_search_by_bow_resident(X1.resident(), all1.data(), K2.resident(), 0.7f, 1, (m.assign(K2.N(), -1), m.data())) == nBow && m == refBow, "bow on a frame built from the extractor's records");
+        std::vector<int32_t> fx;
+        prj.Fuse(X1, sf, isig2, valid, u, v, urp, lev, dL, fx, 12.0f);
+        std::vector<int32_t> fh;
+        prj.Fuse(H1, sf, isig2, valid, u, v, urp, lev, dL, fh, 12.0f);
+        expect(fx == fh, "fuse on a frame built from the extractor's records");
+      }
       std::vector<int32_t> mr, fu, fum;
       expect(prj.SearchByProjection(K2, sf, none, valid, u, v, lev, H1.angle, dL, 12.0f, 100, mr) == nRel && mr == refReloc, "reloc resident");
       prj.Fuse(K2, sf, isig2, valid, u, v, urp, lev, dL, fu, 12.0f);

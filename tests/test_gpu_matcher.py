@@ -474,6 +474,113 @@ def test_resident_frame_closed_and_empty_featvec(amd):
     R1.close()
 
 
+@pytest.mark.parametrize("ori", [True, False])
+def test_search_by_bow_multi(amd, ori):
+    """SearchByBoW of one frame / key frame against K candidate key frames in ONE call (Tracking::Relocalization,
+    src/Tracking.cc:1478-1498; LoopClosing::ComputeSim3, src/LoopClosing.cc:294-321): every candidate's match array and
+    count equal the oracle's single-pair call; includes an empty candidate and one sharing no vocabulary node."""
+    fr = synth.render_sequence(45, 7, 640, 480, step=1.5)
+    e = amd.ORBextractor(1000, 1.2, 8, 20, 7)
+    ext = e.extract_batch(np.stack(fr))
+    rng = np.random.default_rng(45)
+    kF, dF = ext[0]
+    nF = _nodes(dF, 13, 60)
+    RF = _resident(amd, kF, dF, nF)
+    hasF = (rng.random(len(kF)) < 0.6).astype(np.uint8)
+    cands, masks, ref_f, ref_kf = [], [], [], []
+    for k in range(6):
+        k2, d2 = ext[1 + k]
+        if k == 3:
+            k2, d2 = k2[:0], d2[:0]
+        n2 = _nodes(d2, 13, 60) if len(d2) else np.zeros(0, np.int64)
+        if k == 4:
+            n2 = n2 + 1000
+        has2 = (rng.random(len(k2)) < 0.6).astype(np.uint8)
+        cands.append(_resident(amd, k2, d2, n2))
+        masks.append(has2)
+        if len(d2):
+            # (KF_k, F): the candidate is the key-frame side; (KF, KF_k): the current key frame is side 1
+            ref_f.append(orc.search_by_bow(d2, has2, k2["angle"], orc.FeatVec(n2), dF, kF["angle"], orc.FeatVec(nF), 0.75, ori))
+            ref_kf.append(orc.search_by_bow_kf(dF, hasF, kF["angle"], orc.FeatVec(nF), d2, has2, k2["angle"], orc.FeatVec(n2), 0.75, ori))
+        else:
+            ref_f.append((0, np.full(len(kF), -1, np.int32)))
+            ref_kf.append((0, np.full(len(kF), -1, np.int32)))
+    m = amd.ORBmatcher(0.75, ori)
+    cnt, got = m.SearchByBoWMulti(cands, masks, RF)
+    for k in range(6):
+        assert (int(cnt[k]), got[k].tolist()) == (int(ref_f[k][0]), ref_f[k][1].tolist()), k
+    cnt, got = m.SearchByBoWKFMulti(RF, hasF, cands, masks)
+    for k in range(6):
+        assert (int(cnt[k]), got[k].tolist()) == (int(ref_kf[k][0]), ref_kf[k][1].tolist()), k
+    assert sum(int(r[0]) for r in ref_f) > 50 and sum(int(r[0]) for r in ref_kf) > 50
+    cnt, got = m.SearchByBoWMulti([], [], RF)
+    assert len(cnt) == 0
+    for r in cands + [RF]:
+        r.close()
+
+
+def test_frame_from_extractor_and_device(amd):
+    """orbfe_frame_from_extractor / orbfe_frame_from_device: the resident frame built from the extractor's OWN device
+    records (no re-upload of keypoints and descriptors) behaves exactly like the uploaded one -- grid (GetFeaturesInArea),
+    SearchByBoW after set_featvec, and with ORBFE_FRAME_XY_FROM_VIEW for caller-undistorted positions."""
+    torch = pytest.importorskip("torch")
+    fr = synth.render_sequence(46, 2, 640, 480, step=2.0)
+    e1, e2 = amd.ORBextractor(1000, 1.2, 8, 20, 7), amd.ORBextractor(1000, 1.2, 8, 20, 7)
+    k1, d1 = e1(fr[0])
+    k2, d2 = e2(fr[1])
+    n1, n2 = _nodes(d1, 13, 60), _nodes(d2, 13, 60)
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    v1 = amd.FrameView(k1["x"], k1["y"], k1["octave"], d1, bounds, angle=k1["angle"])
+    v2 = amd.FrameView(k2["x"], k2["y"], k2["octave"], d2, bounds, angle=k2["angle"])
+    from orb_slam2_annotate_amd.matcher import ResidentFrame
+    A = ResidentFrame(v1, amd.FeatureVector.from_node_of_feature(n1), extractor=e1, frame=0)
+    B = ResidentFrame(v2, None, extractor=e2, frame=0)              # Frame::Frame first ...
+    B.set_featvec(amd.FeatureVector.from_node_of_feature(n2))        # ... Frame::ComputeBoW later
+    U1, U2 = _resident(amd, k1, d1, n1), _resident(amd, k2, d2, n2)  # the uploaded twins
+    rng = np.random.default_rng(46)
+    qx, qy = rng.uniform(0, 640, 300).astype(np.float32), rng.uniform(0, 480, 300).astype(np.float32)
+    qr = rng.uniform(5, 60, 300).astype(np.float32)
+    for X, Y in ((A, U1), (B, U2)):
+        for a, b in zip(X.GetFeaturesInArea(qx, qy, qr), Y.GetFeaturesInArea(qx, qy, qr)):
+            assert a.tolist() == b.tolist()
+    m = amd.ORBmatcher(0.7, True)
+    has1 = (rng.random(len(k1)) < 0.7).astype(np.uint8)
+    rn, r = orc.search_by_bow(d1, has1, k1["angle"], orc.FeatVec(n1), d2, k2["angle"], orc.FeatVec(n2), 0.7, True)
+    gn, g = m.SearchByBoWResident(A, has1, B)
+    assert rn == gn and np.array_equal(r, g) and rn > 20
+    # a frame that is released before anything used it (its build may still be in flight), then the slab reused at once
+    for _ in range(3):
+        ResidentFrame(v1, None, extractor=e1, frame=0).close()
+    C_ = ResidentFrame(v1, amd.FeatureVector.from_node_of_feature(n1), extractor=e1, frame=0)
+    gn, g = m.SearchByBoWResident(C_, has1, B)
+    assert rn == gn and np.array_equal(r, g)
+    # caller-undistorted positions: x / y from the view, descriptors / angles / octaves still from the device records
+    xs, ys = (k1["x"] + 0.37).astype(np.float32), (k1["y"] - 0.21).astype(np.float32)
+    vs = amd.FrameView(xs, ys, k1["octave"], d1, bounds, angle=k1["angle"])
+    S = ResidentFrame(vs, None, extractor=e1, frame=0, flags=ResidentFrame.XY_FROM_VIEW)
+    T = vs.upload()
+    for a, b in zip(S.GetFeaturesInArea(qx, qy, qr), T.GetFeaturesInArea(qx, qy, qr)):
+        assert a.tolist() == b.tolist()
+    # device-batch outputs are the caller's: orbfe_frame_from_device on (d_kp + f * cap, d_desc + f * cap * 32)
+    cap = e1.max_keypoints()
+    dev = torch.device("cuda", 0)
+    d_img = torch.from_numpy(np.stack(fr)).to(dev)
+    d_kp = torch.zeros((2, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros((2,), dtype=torch.int32, device=dev)
+    e1.extract_batch_device(d_img.data_ptr(), 2, 640, 480, 640, 640 * 480, d_kp.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(), wait=True)
+    with pytest.raises(Exception):  # the handle's own output block is gone after a device-batch call
+        ResidentFrame(v1, None, extractor=e1, frame=0)
+    D = ResidentFrame(v2, amd.FeatureVector.from_node_of_feature(n2), d_keypoints=d_kp[1].data_ptr(), d_descriptors=d_desc[1].data_ptr())
+    gn, g = m.SearchByBoWResident(A, has1, D)
+    assert rn == gn and np.array_equal(r, g)
+    with pytest.raises(Exception):  # more keypoints in the view than the extractor produced
+        big = amd.FrameView(np.tile(k2["x"], 2), np.tile(k2["y"], 2), np.tile(k2["octave"], 2), np.tile(d2, (2, 1)), bounds)
+        ResidentFrame(big, None, extractor=e2, frame=0)
+    for r_ in (A, B, U1, U2, C_, S, T, D):
+        r_.close()
+
+
 @pytest.mark.parametrize("only_stereo,ori", [(False, True), (True, False)])
 def test_search_for_triangulation_multi(amd, only_stereo, ori):
     """One key frame against K neighbours in ONE call (LocalMapping::CreateNewMapPoints, src/LocalMapping.cc:283-315): every

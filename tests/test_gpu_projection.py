@@ -351,3 +351,28 @@ def test_fuse_search_multi(amd):
     for k in range(K):
         assert got[k].tolist() == refs[k].tolist(), k
     assert sum(int((r >= 0).sum()) for r in refs) > 500
+
+
+def test_search_by_projection_keyframe_multi(amd):
+    """ONE current frame against the projected map points of K candidate key frames in one call (Tracking::Relocalization,
+    src/Tracking.cc:1577,1595: th = 10 / ORBdist = 100, then th = 3 / ORBdist = 64) == K single calls of the oracle;
+    candidates of different sizes, one empty, one without `blocked`."""
+    rng = np.random.default_rng(90)
+    x, y, octv, ang, desc, _ = _random_frame(rng, 1600, spread=0.0)
+    Cur, Co = _both(amd, x, y, octv, ang, desc, None)
+    cands, refs = [], []
+    for k, (nk, th, od) in enumerate([(1400, 10.0, 100), (900, 3.0, 64), (0, 10.0, 100), (1200, 10.0, 100), (300, 3.0, 64)]):
+        if nk:
+            src, u, v, md, level, valid, ka = _projected(rng, x, y, octv, ang, desc, nk)
+        else:
+            u = v = ka = np.zeros(0, np.float32); level = np.zeros(0, np.int32); valid = np.zeros(0, np.uint8); md = np.zeros((0, 32), np.uint8)
+        blocked = None if k == 3 else (rng.random(1600) < 0.3).astype(np.uint8)
+        cands.append(dict(valid=valid, u=u, v=v, level=level, kf_angle=ka, mp_desc=md, th=th, ORBdist=od, blocked=blocked))
+        if nk:
+            refs.append(orc.search_by_projection_reloc(Co, SF, valid, u, v, level, ka, md, blocked, th, od, True))
+        else:
+            refs.append((0, np.full(1600, -1, np.int32)))
+    cnt, got = amd.ORBmatcher(0.9, True).SearchByProjectionKeyFrameMulti(Cur, SF, cands)
+    for k, (n_ref, ref) in enumerate(refs):
+        assert (int(cnt[k]), got[k].tolist()) == (n_ref, ref.tolist()), k
+    assert sum(r[0] for r in refs) > 400

@@ -120,6 +120,13 @@ def measure(reps=30, verbose=True):
         lambda: M.SearchForTriangulationMulti(R1, h1, [R2], [h2], [F12], [(5000.0, 240.0)], sf, sg, False),
         lambda: orc.search_for_triangulation(dL, h1, kL["x"], kL["y"], kL["angle"], st1, fo1, dR, h2, kR["x"], kR["y"],
                                              kR["angle"], kR["octave"], st2, fo2, F12, 5000.0, 240.0, sf, sg, False, True))
+    NC = 10  # Relocalization / ComputeSim3: the candidate key frames DetectRelocalizationCandidates / the covisibility groups return
+    row(f"SearchByBoW(KeyFrame_k, Frame) x {NC} candidates, ONE call (resident)",
+        lambda: M.SearchByBoWMulti([R1] * NC, [has1] * NC, R2),
+        lambda: [orc.search_by_bow(dL, has1, kL["angle"], fo1, dR, kR["angle"], fo2, 0.7, True) for _ in range(NC)], per=NC)
+    row(f"SearchByBoW(KeyFrame, KeyFrame_k) x {NC} candidates, ONE call (resident)",
+        lambda: M.SearchByBoWKFMulti(R1, has1, [R2] * NC, [has2] * NC),
+        lambda: [orc.search_by_bow_kf(dL, has1, kL["angle"], fo1, dR, has2, kR["angle"], fo2, 0.7, True) for _ in range(NC)], per=NC)
     NB = 20  # CreateNewMapPoints: 20 neighbours for monocular, 10 for stereo (src/LocalMapping.cc:256-259)
     row(f"SearchForTriangulation x {NB} neighbours, ONE call (resident)",
         lambda: M.SearchForTriangulationMulti(R1, h1, [R2] * NB, [h2] * NB, [F12] * NB, [(5000.0, 240.0)] * NB, sf, sg, False),
@@ -174,13 +181,32 @@ def measure(reps=30, verbose=True):
     row(f"Fuse into {NK} neighbours, ONE call (resident)",
         lambda: M.FuseSearchMulti([FR] * NK, SF, st(valid), st(u), st(v), st(lv), md, th=th, inv_level_sigma2=inv_s2, ur=st(pxr)),
         lambda: [orc.fuse_search(Fo, SF, inv_s2, valid, u, v, pxr, lv, md, th, True) for _ in range(NK)], per=NK)
-    t0 = time.perf_counter()
-    for _ in range(10):
-        F.upload(fv2).close()
-    rows.append({"call": "orbfe_frame_upload + release (2000 keypoints, FeatureVector, grid build)", "gpu_ms": 1e2 * (time.perf_counter() - t0),
-                 "cpu_oracle_ms": None, "units_per_call": 1})
-    if verbose:
-        print(f"{rows[-1]['call']:58s} GPU {rows[-1]['gpu_ms']:7.3f} ms")
+    NR = 5  # Relocalization: SearchByProjection(mCurrentFrame, pKF_k, sFound, 10, 100) per surviving candidate (src/Tracking.cc:1577)
+    cand = [dict(valid=valid, u=u, v=v, level=lv, kf_angle=a, mp_desc=md, th=th, ORBdist=100)] * NR
+    row(f"SearchByProjection(Frame, KeyFrame_k) reloc x {NR} candidates, ONE call (resident)",
+        lambda: M.SearchByProjectionKeyFrameMulti(FR, SF, cand),
+        lambda: [orc.search_by_projection_reloc(Fo, SF, valid, u, v, lv, a, md, None, th, 100, True) for _ in range(NR)], per=NR)
+
+    def timed(name, fn, n=20):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        rows.append({"call": name, "gpu_ms": 1e3 * (time.perf_counter() - t0) / n, "cpu_oracle_ms": None, "units_per_call": 1})
+        if verbose:
+            print(f"{name:58s} GPU {rows[-1]['gpu_ms']:7.3f} ms", flush=True)
+
+    timed("orbfe_frame_upload + release (2000 keypoints, FeatureVector, grid build; pooled slab, no host wait)",
+          lambda: F.upload(fv2).close())
+    # Frame::Frame without the features travelling twice: resident operands from the extractor's own device records
+    from orb_slam2_annotate_amd.matcher import ResidentFrame
+    eR(right)  # (the handle's output block = this frame)
+    VR = amd.FrameView(kR["x"], kR["y"], kR["octave"], dR, bounds, angle=kR["angle"])
+    timed("orbfe_frame_from_extractor + release (records and descriptors stay in HBM)", lambda: ResidentFrame(VR, fv2, extractor=eR, frame=0).close())
+    keep = []
+    timed("orbfe_frame_upload alone (no release: what a new key frame costs)", lambda: keep.append(F.upload(fv2)), n=10)
+    for k_ in keep:
+        k_.close()
     return rows
 
 
