@@ -895,6 +895,7 @@ extern "C" int orbfe_extract_batch_device_async(orbfe_extractor* e, const uint8_
     int rcs = sync_all(e);  // the workspace is about to be re-allocated
     if (rcs) return rcs;
   }
+  e->outLastFrames = 0;  // "the frame this handle produced last" is no longer the one in its own output block
   if ((rc = ensure_geometry(e, width, height))) return rc;
   if ((rc = ensure_workspace(e, n_frames))) return rc;
   next_event_slot(e);

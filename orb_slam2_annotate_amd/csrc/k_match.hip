@@ -129,62 +129,121 @@ __device__ __forceinline__ void bow_node(const BowArgs& a, const NodePair np, in
   }
 }
 
-// The common case -- both sides of the node hold at most 64 features (k = 10, level 2: ~1 % of a frame each) -- without
-// a memory access inside the sequential query loop: lane p keeps candidate p's descriptor, index, angle and its
-// "claimed" flag in registers, lane q keeps query q's, a query is handed to the wave with v_readlane (q is the loop
-// counter).  bow_node's chain per query was index -> descriptor -> candidate descriptors (three dependent round trips,
-// ~40 us per node); here a node is two round trips plus ~100 ALU cycles per query.  Same scan order, same claims.
-__device__ __forceinline__ void bow_node_small(const BowArgs& a, const NodePair np, int lane) {
-  uint32_t idx1 = 0, idx2 = 0;
-  bool ok1 = false, free2 = false;
-  if (lane < np.cnt1) { idx1 = a.indices1[np.off1 + lane]; ok1 = !(a.hasMp1 && !a.hasMp1[idx1]); }
-  if (lane < np.cnt2) { idx2 = a.indices2[np.off2 + lane]; free2 = !(a.hasMp2 && !a.hasMp2[idx2]); }
-  Desc D1 = {}, D2 = {};
-  float ang1 = 0.f, ang2 = 0.f;
-  if (lane < np.cnt1) { D1 = load_desc(a.desc1, idx1); ang1 = a.angle1[(size_t)idx1 * a.angleStride]; }
-  if (lane < np.cnt2) { D2 = load_desc(a.desc2, idx2); ang2 = a.angle2[(size_t)idx2 * a.angleStride]; }
-  const unsigned long long okMask = __ballot(ok1);
-  for (int q = 0; q < np.cnt1; q++) {
-    if (!((okMask >> q) & 1ull)) continue;  // wave-uniform
-    Desc d1;
+// The common case -- a node holds a few dozen features on either side (k = 10, level 2: ~1 % of a frame each; a skewed
+// vocabulary: a few hundred) -- without a memory access inside the sequential query loop: lane p keeps candidates p,
+// p + 64, ... (NC per lane: up to 64 * NC candidates) with their descriptor, index, angle and "claimed" flag in
+// registers, the queries pass through the wave 64 at a time (lane q keeps query q's), a query is handed to the wave with
+// v_readlane (q is the loop counter).  bow_node's chain per query was index -> descriptor -> candidate descriptors
+// (three dependent round trips, ~40 us per node -- and the LARGEST node of a pair decides how long the launch takes);
+// here a node is two round trips plus ~100 ALU cycles per query.  Same scan order, same claims: the key carries the
+// candidate's position in the node, so the minimum over lanes and slots is the reference's first minimum.
+template <int NC>
+__device__ __forceinline__ void bow_node_regs(const BowArgs& a, const NodePair np, int lane) {
+  uint32_t idx2[NC];
+  bool free2[NC];
+  Desc D2[NC];
+  float ang2[NC];
 #pragma unroll
-    for (int i = 0; i < 8; i++) d1.w[i] = (uint32_t)__builtin_amdgcn_readlane((int)D1.w[i], q);
-    uint32_t key1 = (256u << 16) | 0xffffu;  // (bestDist1, position) -- first minimum wins
-    uint32_t best2 = 256u;
-    if (free2) key1 = ((uint32_t)hdist(d1, D2) << 16) | (uint32_t)lane;
+  for (int c = 0; c < NC; c++) {
+    const int p = lane + 64 * c;
+    idx2[c] = 0; free2[c] = false; ang2[c] = 0.f; D2[c] = Desc{};
+    if (p < np.cnt2) { idx2[c] = a.indices2[np.off2 + p]; free2[c] = !(a.hasMp2 && !a.hasMp2[idx2[c]]); }
+  }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const uint32_t ok1k = (uint32_t)__shfl_xor((int)key1, o, 64);
-      const uint32_t ob2 = (uint32_t)__shfl_xor((int)best2, o, 64);
-      const uint32_t lo = ok1k < key1 ? ok1k : key1, hi = ok1k < key1 ? key1 : ok1k;
-      const uint32_t m2 = ob2 < best2 ? ob2 : best2;
-      key1 = lo;
-      best2 = (hi >> 16) < m2 ? (hi >> 16) : m2;
+  for (int c = 0; c < NC; c++)
+    if (lane + 64 * c < np.cnt2) { D2[c] = load_desc(a.desc2, idx2[c]); ang2[c] = a.angle2[(size_t)idx2[c] * a.angleStride]; }
+  for (int q0 = 0; q0 < np.cnt1; q0 += 64) {  // (wave-uniform trip count)
+    uint32_t idx1 = 0;
+    bool ok1 = false;
+    Desc D1 = {};
+    float ang1 = 0.f;
+    if (q0 + lane < np.cnt1) {
+      idx1 = a.indices1[np.off1 + q0 + lane];
+      ok1 = !(a.hasMp1 && !a.hasMp1[idx1]);
+      D1 = load_desc(a.desc1, idx1);
+      ang1 = a.angle1[(size_t)idx1 * a.angleStride];
     }
-    key1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)key1);
-    best2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)best2);
-    const uint32_t bestDist1 = key1 >> 16, pos = key1 & 0xffffu;
-    const bool pass1 = a.strictLow ? (bestDist1 < 50u) : (bestDist1 <= 50u);  // :263 vs :686
-    if (pass1 && (float)bestDist1 < __fmul_rn(a.nnratio, (float)best2)) {  // wave-uniform; pos < cnt2 here
-      if ((uint32_t)lane == pos) free2 = false;  // :267 / :691
-      const uint32_t i1 = (uint32_t)__builtin_amdgcn_readlane((int)idx1, q);
-      const uint32_t i2 = (uint32_t)__builtin_amdgcn_readlane((int)idx2, (int)pos);
-      const float a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ang1), q));
-      const float a2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ang2), (int)pos));
-      if (lane == 0) {
-        const int bin = rot_bin(a1, a2);
-        if (a.strictLow) { a.match[i1] = (int32_t)i2; a.bin[i1] = (int8_t)bin; }
-        else { a.match[i2] = (int32_t)i1; a.bin[i2] = (int8_t)bin; }
+    const unsigned long long okMask = __ballot(ok1);
+    const int nq = np.cnt1 - q0 < 64 ? np.cnt1 - q0 : 64;
+    for (int q = 0; q < nq; q++) {
+      if (!((okMask >> q) & 1ull)) continue;  // wave-uniform
+      Desc d1;
+#pragma unroll
+      for (int i = 0; i < 8; i++) d1.w[i] = (uint32_t)__builtin_amdgcn_readlane((int)D1.w[i], q);
+      uint32_t key1 = (256u << 16) | 0xffffu;  // (bestDist1, position) -- first minimum wins
+      uint32_t best2 = 256u;
+#pragma unroll
+      for (int c = 0; c < NC; c++)
+        if (free2[c]) {  // ascending position inside the lane: strict < keeps the earlier of two equal distances
+          const uint32_t dist = (uint32_t)hdist(d1, D2[c]);
+          if (dist < (key1 >> 16)) { best2 = key1 >> 16; key1 = (dist << 16) | (uint32_t)(lane + 64 * c); }
+          else if (dist < best2) best2 = dist;
+        }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t ok1k = (uint32_t)__shfl_xor((int)key1, o, 64);
+        const uint32_t ob2 = (uint32_t)__shfl_xor((int)best2, o, 64);
+        const uint32_t lo = ok1k < key1 ? ok1k : key1, hi = ok1k < key1 ? key1 : ok1k;
+        const uint32_t m2 = ob2 < best2 ? ob2 : best2;
+        key1 = lo;
+        best2 = (hi >> 16) < m2 ? (hi >> 16) : m2;
+      }
+      key1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)key1);
+      best2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)best2);
+      const uint32_t bestDist1 = key1 >> 16, pos = key1 & 0xffffu;
+      const bool pass1 = a.strictLow ? (bestDist1 < 50u) : (bestDist1 <= 50u);  // :263 vs :686
+      if (pass1 && (float)bestDist1 < __fmul_rn(a.nnratio, (float)best2)) {  // wave-uniform; pos < cnt2 here
+        const int pl = (int)(pos & 63u), pc = (int)(pos >> 6);                // the winner's lane and slot (wave-uniform)
+        uint32_t i2 = 0;
+        float a2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+          if (c == pc) {  // scalar branch
+            if (lane == pl) free2[c] = false;  // :267 / :691
+            i2 = (uint32_t)__builtin_amdgcn_readlane((int)idx2[c], pl);
+            a2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ang2[c]), pl));
+          }
+        const uint32_t i1 = (uint32_t)__builtin_amdgcn_readlane((int)idx1, q);
+        const float a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ang1), q));
+        if (lane == 0) {
+          const int bin = rot_bin(a1, a2);
+          if (a.strictLow) { a.match[i1] = (int32_t)i2; a.bin[i1] = (int8_t)bin; }
+          else { a.match[i2] = (int32_t)i1; a.bin[i2] = (int8_t)bin; }
+        }
       }
     }
   }
 }
 
+// NCMAX = candidate slots per lane the launch was built for (the host knows the largest node of the call): nodes beyond
+// 64 * NCMAX candidates take the LDS-claim path
+template <int NCMAX>
+__device__ __forceinline__ void bow_node_any(const BowArgs& a, const NodePair np, int lane, uint8_t* claimed) {
+  if (np.cnt2 <= 64) bow_node_regs<1>(a, np, lane);
+  else if (NCMAX >= 2 && np.cnt2 <= 128) bow_node_regs<2>(a, np, lane);
+  else if (NCMAX >= 4 && np.cnt2 <= 256) bow_node_regs<4>(a, np, lane);
+  else bow_node(a, np, lane, claimed);
+}
+
+template <int NCMAX>
 __global__ __launch_bounds__(64) void k_search_by_bow(BowArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t claimed[];  // per position in node 2
-  const NodePair np = a.pairs[blockIdx.x];
-  if (np.cnt1 <= 64 && np.cnt2 <= 64) bow_node_small(a, np, threadIdx.x);
-  else bow_node(a, np, threadIdx.x, claimed);
+  bow_node_any<NCMAX>(a, a.pairs[blockIdx.x], threadIdx.x, claimed);
+}
+
+// K (frame, frame) problems in ONE launch (orbfe_search_by_bow_multi: one frame against K candidate key frames): the
+// node pairs of all problems are numbered through, pairStart[k] = first pair of problem k, args[k] its operands
+template <int NCMAX>
+__global__ __launch_bounds__(64) void k_search_by_bow_multi(const BowArgs* __restrict__ args, const int32_t* __restrict__ pairStart, int K) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t claimed[];
+  const int g = blockIdx.x;
+  int lo = 0, hi = K;  // last k with pairStart[k] <= g (block-uniform: scalar loads)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (pairStart[mid] <= g) lo = mid; else hi = mid;
+  }
+  const BowArgs a = args[lo];
+  bow_node_any<NCMAX>(a, a.pairs[g - pairStart[lo]], threadIdx.x, claimed);
 }
 
 // Device-resident batch: pair p = SearchByBoW(KF = frame p, F = frame p+1) with the FeatureVectors
@@ -221,8 +280,7 @@ __global__ __launch_bounds__(64) void k_search_by_bow_batch(BowBatch b) {
   a.match = b.match + (size_t)p * c;
   a.bin = b.bin + (size_t)p * c;
   const NodePair np = {off1[i], off1[i + 1] - off1[i], off2[lo], off2[lo + 1] - off2[lo]};
-  if (np.cnt1 <= 64 && np.cnt2 <= 64) bow_node_small(a, np, lane);
-  else bow_node(a, np, lane, claimed);
+  bow_node_any<1>(a, np, lane, claimed);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -326,7 +384,16 @@ __global__ __launch_bounds__(256) void k_rot_prune(int32_t* __restrict__ match, 
 void launch_search_by_bow(hipStream_t s, const BowArgs& a, int nPairs, int maxCnt2) {
   if (nPairs <= 0) return;
   const size_t lds = (size_t)((maxCnt2 + 15) & ~15);
-  hipLaunchKernelGGL(k_search_by_bow, dim3(nPairs), dim3(64), lds, s, a);
+  if (maxCnt2 <= 64) hipLaunchKernelGGL((k_search_by_bow<1>), dim3(nPairs), dim3(64), lds, s, a);
+  else if (maxCnt2 <= 128) hipLaunchKernelGGL((k_search_by_bow<2>), dim3(nPairs), dim3(64), lds, s, a);
+  else hipLaunchKernelGGL((k_search_by_bow<4>), dim3(nPairs), dim3(64), lds, s, a);
+}
+void launch_search_by_bow_multi(hipStream_t s, const BowArgs* d_args, const int32_t* d_pairStart, int K, int nPairsTotal, int maxCnt2) {
+  if (nPairsTotal <= 0 || K <= 0) return;
+  const size_t lds = (size_t)((maxCnt2 + 15) & ~15);
+  if (maxCnt2 <= 64) hipLaunchKernelGGL((k_search_by_bow_multi<1>), dim3(nPairsTotal), dim3(64), lds, s, d_args, d_pairStart, K);
+  else if (maxCnt2 <= 128) hipLaunchKernelGGL((k_search_by_bow_multi<2>), dim3(nPairsTotal), dim3(64), lds, s, d_args, d_pairStart, K);
+  else hipLaunchKernelGGL((k_search_by_bow_multi<4>), dim3(nPairsTotal), dim3(64), lds, s, d_args, d_pairStart, K);
 }
 void launch_search_triangulation(hipStream_t s, const TriArgs& a) {
   if (a.nQueries <= 0) return;

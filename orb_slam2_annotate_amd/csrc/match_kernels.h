@@ -113,6 +113,7 @@ void launch_window_search(hipStream_t s, const GridFrame& f, const uint32_t* sor
                           const WindowQueries& q, int32_t* count, uint32_t* cand);
 
 void launch_search_by_bow(hipStream_t s, const BowArgs& a, int nPairs, int maxCnt2);
+void launch_search_by_bow_multi(hipStream_t s, const BowArgs* d_args, const int32_t* d_pairStart, int K, int nPairsTotal, int maxCnt2);
 void launch_search_by_bow_batch(hipStream_t s, const BowBatch& b, int nPairs, int checkOri, int32_t* d_nMatches,
                                 int maxNodes /* bound on FeatureVector entries per frame, 0: capacity */);
 void launch_search_triangulation(hipStream_t s, const TriArgs& a);

@@ -605,10 +605,9 @@ extern "C" int orbfe_frame_upload(int device, const orbfe_frame_view* v, const o
       std::memcpy(h + L.oS, f->hstereo.data(), (size_t)n);
     }
     if (nIdx) std::memcpy(h + L.oI, f->hindices.data(), nIdx * 4);
-    // three ranges instead of one slab-sized copy with a memset in front: keypoint arrays | index list | descriptors + flags
-    err = hipMemcpyAsync(f->slab, h, L.oK, hipMemcpyHostToDevice, ar->stream);
-    if (err == hipSuccess && nIdx) err = hipMemcpyAsync(f->slab + L.oI, h + L.oI, nIdx * 4, hipMemcpyHostToDevice, ar->stream);
-    if (err == hipSuccess) err = hipMemcpyAsync(f->slab + L.oD, h + L.oD, upBytes - L.oD, hipMemcpyHostToDevice, ar->stream);
+    // ONE copy (every further hipMemcpyAsync costs the host ~5 us): the key / cell arrays in the middle of the range receive
+    // whatever the staging buffer held -- the grid build behind the copy overwrites them
+    err = hipMemcpyAsync(f->slab, h, upBytes, hipMemcpyHostToDevice, ar->stream);
     if (err == hipSuccess) err = staging_mark_pending_(ar->stream);  // the next use of the staging buffer waits for these copies
   }
   if (err == hipSuccess) err = frame_finish(ar, f, v);
@@ -789,7 +788,7 @@ static int bow_multi(const orbfe_frame* one, const uint8_t* has_mp_one, int K, c
     return mfail(ORBFE_ERR_INVALID, "search_by_bow_multi: frame uploaded without FeatureVector / angles, or NULL mask");
   std::vector<std::vector<NodePair>> pairs((size_t)K);
   std::vector<int> maxCnt2((size_t)K, 0);
-  size_t bytes = pad((size_t)nOut) + 2 * pad((size_t)K * nOut * 4) + pad((size_t)K * 4) + 8192;
+  size_t bytes = pad((size_t)nOut) + 2 * pad((size_t)K * nOut * 4) + pad((size_t)K * 4) + pad((size_t)K * sizeof(BowArgs)) + pad((size_t)K * 4) + 8192;
   for (int k = 0; k < K; k++) {
     const orbfe_frame* c = many[k];
     if (!c || (c->n > 0 && !has_mp_k[k])) return mfail(ORBFE_ERR_INVALID, "search_by_bow_multi: NULL candidate or mask");
@@ -821,7 +820,10 @@ static int bow_multi(const orbfe_frame* one, const uint8_t* has_mp_one, int K, c
   int32_t* dcount;
   MHIP(up_fill(ar, &dcount, (size_t)K, 0));
   MHIP(up_fill(ar, &dbin, (size_t)K * nOut, 0));
-  MHIP(flush(ar));
+  // the K problems as ONE launch: operands of problem k in hargs[k], its node pairs numbered from pairStart[k]
+  std::vector<BowArgs> hargs;
+  std::vector<int32_t> pairStart;
+  int total = 0, maxAll = 0;
   for (int k = 0; k < K; k++) {
     if (pairs[k].empty()) continue;
     const orbfe_frame* c = many[k];
@@ -832,8 +834,19 @@ static int bow_multi(const orbfe_frame* one, const uint8_t* has_mp_one, int K, c
     a.desc2 = f2->ddesc; a.hasMp2 = kfkf ? dmk[k] : nullptr; a.angle2 = f2->dangle; a.indices2 = f2->dindices;
     a.angleStride = 1;
     a.nnratio = nnratio; a.strictLow = kfkf; a.match = dmatch + (size_t)k * nOut; a.bin = dbin + (size_t)k * nOut;
-    launch_search_by_bow(ar->stream, a, (int)pairs[k].size(), maxCnt2[k]);
+    hargs.push_back(a);
+    pairStart.push_back(total);
+    total += (int)pairs[k].size();
+    maxAll = maxCnt2[k] > maxAll ? maxCnt2[k] : maxAll;
   }
+  BowArgs* dargs = nullptr;
+  int32_t* dstart = nullptr;
+  if (!hargs.empty()) {
+    MHIP(up(ar, &dargs, hargs.data(), hargs.size()));
+    MHIP(up(ar, &dstart, pairStart.data(), pairStart.size()));
+  }
+  MHIP(flush(ar));
+  launch_search_by_bow_multi(ar->stream, dargs, dstart, (int)hargs.size(), total, maxAll);
   launch_rot_prune_batch(ar->stream, dmatch, dbin, nOut, K, check_ori, dcount);  // all K histograms in one launch
   MHIP(hipGetLastError());
   MHIP(down_range(ar, dmatch, dcount + K));

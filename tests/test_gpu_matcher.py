@@ -59,20 +59,32 @@ def test_search_by_bow_frame(amd, seed, nnratio, ori):
     assert ref_n > 20
 
 
-@pytest.mark.parametrize("n_nodes", [3, 12])
+@pytest.mark.parametrize("n_nodes", [3, 7, 12, 20])
 def test_search_by_bow_large_nodes(amd, n_nodes):
-    """Few vocabulary nodes -> hundreds of features per node: the node no longer fits the register-resident path
-    (64 x 64) and the LDS-claim path runs; 12 nodes mixes both in one call."""
+    """Few vocabulary nodes -> hundreds of features per node.  Round 4: nodes of up to 256 candidates stay in registers
+    (1, 2 or 4 candidates per lane, the queries pass through the wave 64 at a time); beyond that the LDS-claim path runs.
+    3 nodes: > 256 per node (LDS path); 7: 128..256 (4 slots); 12 and 20 mix 1 / 2 / 4 slots in one call.  Both SearchByBoW
+    forms, and the resident / multi entry points on the same nodes."""
     k1, d1, k2, d2 = _two_frames(amd, 6)
     n1, n2 = _nodes(d1, 13, n_nodes), _nodes(d2, 13, n_nodes)
     assert np.bincount(n1).max() > 64
+    rng = np.random.default_rng(n_nodes)
     has1 = np.ones(len(k1), np.uint8)
     ref_n, ref = orc.search_by_bow(d1, has1, k1["angle"], orc.FeatVec(n1), d2, k2["angle"], orc.FeatVec(n2), 0.7, True)
     m = amd.ORBmatcher(0.7, True)
-    got_n, got = m.SearchByBoW(d1, has1, k1["angle"], amd.FeatureVector.from_node_of_feature(n1), d2, k2["angle"],
-                               amd.FeatureVector.from_node_of_feature(n2))
+    fv1, fv2 = amd.FeatureVector.from_node_of_feature(n1), amd.FeatureVector.from_node_of_feature(n2)
+    got_n, got = m.SearchByBoW(d1, has1, k1["angle"], fv1, d2, k2["angle"], fv2)
     assert ref_n == got_n and np.array_equal(ref, got)
     assert ref_n > 20
+    h1, h2 = (rng.random(len(k1)) < 0.6).astype(np.uint8), (rng.random(len(k2)) < 0.6).astype(np.uint8)
+    ref_n, ref = orc.search_by_bow_kf(d1, h1, k1["angle"], orc.FeatVec(n1), d2, h2, k2["angle"], orc.FeatVec(n2), 0.7, True)
+    got_n, got = m.SearchByBoW(d1, h1, k1["angle"], fv1, d2, k2["angle"], fv2, has_mp2=h2)
+    assert ref_n == got_n and np.array_equal(ref, got)
+    R1, R2 = _resident(amd, k1, d1, n1), _resident(amd, k2, d2, n2)
+    cnt, multi = m.SearchByBoWKFMulti(R1, h1, [R2, R2], [h2, h2])
+    assert cnt.tolist() == [ref_n, ref_n] and np.array_equal(multi[0], ref) and np.array_equal(multi[1], ref)
+    R1.close()
+    R2.close()
 
 
 @pytest.mark.parametrize("seed", [4, 5])

@@ -203,8 +203,16 @@ def measure(reps=30, verbose=True):
     eR(right)  # (the handle's output block = this frame)
     VR = amd.FrameView(kR["x"], kR["y"], kR["octave"], dR, bounds, angle=kR["angle"])
     timed("orbfe_frame_from_extractor + release (records and descriptors stay in HBM)", lambda: ResidentFrame(VR, fv2, extractor=eR, frame=0).close())
+    # what a NEW key frame costs in steady state: the pool holds slabs and events of released key frames (culling), the
+    # upload does not wait for the device (the first search on another stream is ordered behind it by the frame's event)
+    warm = [F.upload(fv2) for _ in range(24)]
+    M.SearchByBoWMulti(warm, [has2] * len(warm), R1)  # (settles them: releasing an unused frame waits for its own build)
+    for k_ in warm:
+        k_.close()
     keep = []
-    timed("orbfe_frame_upload alone (no release: what a new key frame costs)", lambda: keep.append(F.upload(fv2)), n=10)
+    timed("orbfe_frame_upload alone, warm pool (what a new key frame costs)", lambda: keep.append(F.upload(fv2)), n=10)
+    timed("orbfe_frame_from_extractor alone, warm pool", lambda: keep.append(ResidentFrame(VR, fv2, extractor=eR, frame=0)), n=10)
+    M.SearchByBoWMulti(keep, [has2] * len(keep), R1)
     for k_ in keep:
         k_.close()
     return rows
