@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void k_window_search(GridFrame f, const uint32
   const bool empty = nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0 ||
                      (q.active && !q.active[qi]);
   int n = 0;
+  uint32_t bestKey = 0xffffffffu, bestId = 0;
   if (!empty) {
     const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
     uint32_t qd[8];
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(256) void k_window_search(GridFrame f, const uint32
       qd[0] = a.x; qd[1] = a.y; qd[2] = a.z; qd[3] = a.w; qd[4] = b.x; qd[5] = b.y; qd[6] = b.z; qd[7] = b.w;
     }
     const float ur = q.ur ? q.ur[qi] : 0.0f;
+    const float gur = (q.best && q.gate && q.gateUr) ? q.gateUr[qi] : 0.0f;
     uint32_t* out = cand + (size_t)qi * q.K;
     for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
       const int s = cellOff[ix * GRID_ROWS + nMinCellY], e = cellOff[ix * GRID_ROWS + nMaxCellY + 1];
@@ -114,7 +116,33 @@ __global__ __launch_bounds__(256) void k_window_search(GridFrame f, const uint32
         }
         const unsigned long long m = __ballot(ok);
         const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-        if (ok && pos < q.K) {
+        if (q.best) {  // wave-uniform
+          if (ok) {
+            bool pass = true;
+            if (q.gate) {  // Fuse: src/ORBmatcher.cc:1036-1058 -- fp32 like the reference, the compare in double
+              const float kpx = f.x[id], kpy = f.y[id];
+              const float inv = q.invSigma2[f.octave[id]];
+              const float ex = __fsub_rn(x, kpx), ey = __fsub_rn(y, kpy);
+              const float u2 = f.uRight ? f.uRight[id] : -1.0f;
+              if (u2 >= 0) {
+                const float er = __fsub_rn(gur, u2);
+                const float e2 = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(er, er));
+                if ((double)__fmul_rn(e2, inv) > 7.8) pass = false;
+              } else {
+                const float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+                if ((double)__fmul_rn(e2, inv) > 5.99) pass = false;
+              }
+            }
+            if (pass) {
+              const uint4* p = reinterpret_cast<const uint4*>(f.desc + (size_t)id * 32);
+              const uint4 a = p[0], b = p[1];
+              const uint32_t dist = __popc(qd[0] ^ a.x) + __popc(qd[1] ^ a.y) + __popc(qd[2] ^ a.z) + __popc(qd[3] ^ a.w) +
+                                    __popc(qd[4] ^ b.x) + __popc(qd[5] ^ b.y) + __popc(qd[6] ^ b.z) + __popc(qd[7] ^ b.w);
+              const uint32_t key = (dist << 16) | (uint32_t)pos;  // pos < 16384: first minimum in scan order = smallest key
+              if (key < bestKey) { bestKey = key; bestId = id; }
+            }
+          }
+        } else if (ok && pos < q.K) {
           uint32_t dist = 0;
           if (q.desc) {
             const uint4* p = reinterpret_cast<const uint4*>(f.desc + (size_t)id * 32);
@@ -127,6 +155,18 @@ __global__ __launch_bounds__(256) void k_window_search(GridFrame f, const uint32
         n += __popcll(m);
       }
     }
+  }
+  if (q.best) {
+    uint32_t k = bestKey;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t t = (uint32_t)__shfl_xor((int)k, o, 64);
+      k = t < k ? t : k;
+    }
+    // (keys are unique: they carry the scan position) the owner of the minimum writes its keypoint
+    if (k == 0xffffffffu) { if (lane == 0) q.best[qi] = -1; }
+    else if (bestKey == k) q.best[qi] = (int)(k >> 16) <= q.maxDist ? (int32_t)bestId : -1;
+    return;
   }
   if (lane == 0) count[qi] = n;
 }

@@ -105,6 +105,10 @@ struct WindowQueries {
   const float* x; const float* y; const float* r; const int32_t* minLevel; const int32_t* maxLevel;
   const uint8_t* active /* NULL: all */; const float* ur /* NULL: no stereo check */;
   const uint8_t* desc /* NULL: indices only */; int n; int K;
+  // BEST mode (best != NULL; Fuse x2 / SearchBySim3, src/ORBmatcher.cc:1029-1075, 1217-1260): no list leaves the device --
+  // per query the keypoint with the smallest distance in scan order (first minimum), optionally behind Fuse's chi-square
+  // gate (gateUr = the projected ur of every query, invSigma2 = mvInvLevelSigma2), kept when its distance <= maxDist
+  int32_t* best; const float* gateUr; const float* invSigma2; int gate; int maxDist;
 };
 void launch_grid_build(hipStream_t s, const GridFrame& f, uint32_t* sortedKey, int32_t* cellOff);
 void launch_frame_from_records(hipStream_t s, const float* d_kp, const uint8_t* d_desc, int n, float* x, float* y, float* angle,

@@ -544,8 +544,11 @@ int frame_host_init(const char* who, int device, const orbfe_frame_view* v, cons
   const size_t N = (size_t)(n ? n : 1);
   size_t off = 0;
   auto place = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-  L->oX = place(N * 4); L->oY = place(N * 4); L->oA = place(N * 4); L->oU = place(N * 4); L->oO = place(N * 4); L->oK = place(N * 4);
-  L->oC = place(3073 * 4); L->oI = place((nIdx > N ? nIdx : N) * 4); L->oD = place(N * 32); L->oS = place(N);
+  // what always comes from the host first (mvuRight, stereo flags, index list, then the positions), what the device can
+  // supply behind it (angles, octaves, descriptors), what the grid build writes last: an upload is ONE copy of [0, oK), a
+  // frame built from the extractor's records ONE copy of [0, oX) (or [0, oA) with caller-undistorted positions)
+  L->oU = place(N * 4); L->oS = place(N); L->oI = place((nIdx > N ? nIdx : N) * 4); L->oX = place(N * 4); L->oY = place(N * 4);
+  L->oA = place(N * 4); L->oO = place(N * 4); L->oD = place(N * 32); L->oK = place(N * 4); L->oC = place(3073 * 4);
   L->total = off;
   hipError_t err = hipSetDevice(device);
   if (err == hipSuccess) err = slab_get(device, off, &f->slab, &f->slabCap);
@@ -588,8 +591,8 @@ extern "C" int orbfe_frame_upload(int device, const orbfe_frame_view* v, const o
   int rc = frame_host_init("frame_upload", device, v, fv, &f, &L, &nIdx);
   if (rc != ORBFE_OK) return rc;
   const int n = f->n;
-  // only what the searches read goes up: the key / cell arrays are written by the grid build, the rest of the slab is padding
-  const size_t upBytes = L.oS + (size_t)(n ? n : 1);
+  // only what the searches read goes up: the key / cell arrays behind it are written by the grid build
+  const size_t upBytes = L.oK;
   Arena* ar;
   // staged through the thread's pinned mirror: one copy up, then the grid build (Frame::AssignFeaturesToGrid, once)
   hipError_t err = arena_begin(device, 1024, &ar);
@@ -605,8 +608,7 @@ extern "C" int orbfe_frame_upload(int device, const orbfe_frame_view* v, const o
       std::memcpy(h + L.oS, f->hstereo.data(), (size_t)n);
     }
     if (nIdx) std::memcpy(h + L.oI, f->hindices.data(), nIdx * 4);
-    // ONE copy (every further hipMemcpyAsync costs the host ~5 us): the key / cell arrays in the middle of the range receive
-    // whatever the staging buffer held -- the grid build behind the copy overwrites them
+    // ONE copy (every further hipMemcpyAsync costs the host ~5 us)
     err = hipMemcpyAsync(f->slab, h, upBytes, hipMemcpyHostToDevice, ar->stream);
     if (err == hipSuccess) err = staging_mark_pending_(ar->stream);  // the next use of the staging buffer waits for these copies
   }
@@ -636,26 +638,23 @@ extern "C" int orbfe_frame_from_device(int device, const orbfe_keypoint* d_keypo
   const bool xyFromView = (flags & ORBFE_FRAME_XY_FROM_VIEW) != 0;
   Arena* ar;
   hipError_t err = arena_begin(device, 1024, &ar);
-  // host part: mvuRight + stereo flags (+ positions) + the FeatureVector's index list, through the pinned staging
-  const size_t hostBytes = (view->u_right ? 5 : 0) * (size_t)n + (xyFromView ? 8 : 0) * (size_t)n + nIdx * 4 + 1024;
-  if (err == hipSuccess) err = staging_reserve_(hostBytes);
-  if (err == hipSuccess && n) {
+  // host part: mvuRight + stereo flags + the FeatureVector's index list (+ positions), adjacent at the head of the slab:
+  // ONE copy through the pinned staging
+  const size_t hostBytes = xyFromView ? L.oA : L.oX;
+  const bool anyHost = view->u_right || nIdx || xyFromView;
+  if (err == hipSuccess && anyHost) err = staging_reserve_(hostBytes);
+  if (err == hipSuccess && n && anyHost) {
     uint8_t* h = staging_ptr_();
-    size_t o = 0;
-    auto send = [&](void* dst, const void* src, size_t bytes) {
-      if (err != hipSuccess || bytes == 0) return;
-      std::memcpy(h + o, src, bytes);
-      err = hipMemcpyAsync(dst, h + o, bytes, hipMemcpyHostToDevice, ar->stream);
-      o += (bytes + 255) & ~(size_t)255;
-    };
-    if (view->u_right) { send(f->dur, f->hur.data(), (size_t)n * 4); send(f->dstereo, f->hstereo.data(), (size_t)n); }
-    if (xyFromView) { send(f->dx, f->hx.data(), (size_t)n * 4); send(f->dy, f->hy.data(), (size_t)n * 4); }
-    if (nIdx) send(f->dindices, f->hindices.data(), nIdx * 4);
-    if (err == hipSuccess && o) err = staging_mark_pending_(ar->stream);
+    if (view->u_right) { std::memcpy(h + L.oU, f->hur.data(), (size_t)n * 4); std::memcpy(h + L.oS, f->hstereo.data(), (size_t)n); }
+    else { std::memset(h + L.oU, 0, (size_t)n * 4); std::memset(h + L.oS, 0, (size_t)n); }
+    if (nIdx) std::memcpy(h + L.oI, f->hindices.data(), nIdx * 4);
+    if (xyFromView) { std::memcpy(h + L.oX, f->hx.data(), (size_t)n * 4); std::memcpy(h + L.oY, f->hy.data(), (size_t)n * 4); }
+    err = hipMemcpyAsync(f->slab, h, hostBytes, hipMemcpyHostToDevice, ar->stream);
+    if (err == hipSuccess) err = staging_mark_pending_(ar->stream);
   }
   if (err == hipSuccess && n) {
     launch_frame_from_records(ar->stream, reinterpret_cast<const float*>(d_keypoints), d_descriptors, n, xyFromView ? nullptr : f->dx,
-                              xyFromView ? nullptr : f->dy, f->dangle, f->doct, f->ddesc, view->u_right ? nullptr : f->dstereo);
+                              xyFromView ? nullptr : f->dy, f->dangle, f->doct, f->ddesc, anyHost ? nullptr : f->dstereo);
     err = hipGetLastError();
   }
   if (err == hipSuccess) err = frame_finish(ar, f, view);
@@ -1102,13 +1101,19 @@ struct WindowJob {
   const float* qur;
   const uint8_t* qdesc;  // jobs that pass the SAME pointer share one device copy
   WindowResult* res;
+  // BEST mode (bestOut != NULL): no candidate lists come back -- the device keeps the first minimum of every window, behind
+  // Fuse's chi-square gate when gate != 0 (gur / invSigma2), and writes the keypoint or -1 (WindowQueries::best)
+  int32_t* bestOut = nullptr;
+  const float* gur = nullptr;
+  const float* invSigma2 = nullptr;
+  int nLevels = 0, gate = 0, maxDist = 256;
 };
 
 // Upload frames (unless resident: keypoint arrays, descriptors and grid are on the device already) + queries, build the
 // grids, search every window; grows K until every list fits.
 int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
   int K = K0 < 8 ? 8 : K0;
-  struct Lay { size_t oX, oY, oOct, oUr, oDesc, oQx, oQy, oQr, oQmin, oQmax, oQact, oQur, oQdesc, oOut; bool withDesc, withUr, res; int frameOf; };
+  struct Lay { size_t oX, oY, oOct, oUr, oDesc, oQx, oQy, oQr, oQmin, oQmax, oQact, oQur, oQdesc, oOut, oGur, oSig; bool withDesc, withUr, res; int frameOf; };
   std::vector<Lay> lay((size_t)nJobs);
   size_t off = 0;
   auto place = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -1136,6 +1141,8 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
     L.oQx = place(q * 4); L.oQy = place(q * 4); L.oQr = place(q * 4); L.oQmin = place(q * 4); L.oQmax = place(q * 4);
     L.oQact = J.qactive ? place(q) : 0;
     L.oQur = L.withUr ? place(q * 4) : 0;
+    L.oGur = (J.bestOut && J.gate && J.gur) ? place(q * 4) : 0;
+    L.oSig = (J.bestOut && J.gate) ? place((size_t)J.nLevels * 4) : 0;
     L.oQdesc = 0;
     if (L.withDesc) {
       int shared = -1;
@@ -1150,7 +1157,7 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
     size_t outBytes = 0, gridBytes = 0;
     for (int j = 0; j < nJobs; j++) {
       lay[j].oOut = outBytes;
-      outBytes += pad((size_t)jobs[j].nq * 4) + pad((size_t)jobs[j].nq * (size_t)K * 4);
+      outBytes += pad((size_t)jobs[j].nq * 4) + (jobs[j].bestOut ? 0 : pad((size_t)jobs[j].nq * (size_t)K * 4));
       if (!lay[j].res && lay[j].frameOf == j) gridBytes += pad((size_t)jobs[j].f->n * 4) + pad(3073 * 4);
     }
     MHIP(arena_begin(device, pad(inBytes) + gridBytes + outBytes + 1024, &ar));
@@ -1173,6 +1180,8 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
         if (J.qactive) std::memcpy(h + L.oQact, J.qactive, q);
         if (L.withUr) std::memcpy(h + L.oQur, J.qur, q * 4);
         if (L.withDesc) std::memcpy(h + L.oQdesc, J.qdesc, q * 32);
+        if (J.bestOut && J.gate && J.gur) std::memcpy(h + L.oGur, J.gur, q * 4);
+        if (J.bestOut && J.gate) std::memcpy(h + L.oSig, J.invSigma2, (size_t)J.nLevels * 4);
       }
     }
     uint8_t* din = carve<uint8_t>(ar, inBytes);
@@ -1224,6 +1233,12 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
       wq.ur = L.withUr ? reinterpret_cast<const float*>(din + L.oQur) : nullptr;
       wq.desc = L.withDesc ? din + L.oQdesc : nullptr;
       wq.n = J.nq; wq.K = K;
+      if (J.bestOut) {
+        wq.best = reinterpret_cast<int32_t*>(dout + L.oOut);  // (the job's output block holds the nq keypoint indices)
+        wq.gate = J.gate; wq.maxDist = J.maxDist;
+        wq.gateUr = (J.gate && J.gur) ? reinterpret_cast<const float*>(din + L.oGur) : nullptr;
+        wq.invSigma2 = J.gate ? reinterpret_cast<const float*>(din + L.oSig) : nullptr;
+      }
       // counts and candidate lists of a job are adjacent, the jobs' blocks too: one copy back
       int32_t* dcount = reinterpret_cast<int32_t*>(dout + L.oOut);
       uint32_t* dcand = reinterpret_cast<uint32_t*>(dout + L.oOut + pad(q * 4));
@@ -1236,6 +1251,10 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
     int mx = 0;
     for (int j = 0; j < nJobs; j++) {
       const size_t q = (size_t)jobs[j].nq;
+      if (jobs[j].bestOut) {
+        if (q) std::memcpy(jobs[j].bestOut, h + lay[j].oOut, q * 4);
+        continue;
+      }
       WindowResult* res = jobs[j].res;
       res->count.assign(q, 0);
       res->cand.resize(q * (size_t)K);
@@ -1687,51 +1706,27 @@ struct BestJob {
 int window_best_multi(const char* who, int device, BestJob* jobs, int nJobs, int n_levels, float th, bool gate, int max_dist) {
   std::vector<std::vector<float>> qr((size_t)nJobs);
   std::vector<std::vector<int32_t>> qmin((size_t)nJobs), qmax((size_t)nJobs);
-  std::vector<WindowResult> res((size_t)nJobs);
   std::vector<WindowJob> wj;
-  std::vector<int> jobOf;
   for (int j = 0; j < nJobs; j++) {
     BestJob& J = jobs[j];
     int rc = level_queries(who, J.n, J.valid, J.level, J.sf, n_levels, th, -1, 0, false, &qr[j], &qmin[j], &qmax[j]);
     if (rc != ORBFE_OK) return rc;
     for (int i = 0; i < J.n; i++) J.best[i] = -1;
     if (J.n == 0 || J.KF->n == 0) continue;
-    wj.push_back(WindowJob{J.KF, J.n, J.u, J.v, qr[j].data(), qmin[j].data(), qmax[j].data(), J.valid, nullptr, J.desc, &res[j]});
-    jobOf.push_back(j);
+    // The whole inner search runs on the device (round 4): the window scan, the octave filter, Fuse's chi-square gate
+    // (src/ORBmatcher.cc:1036-1058) and the first minimum with its distance bound -- a point's best keypoint depends on no
+    // other point, so there is no claim loop to replay: 4 bytes per point come back instead of a 32-entry candidate list
+    WindowJob w{J.KF, J.n, J.u, J.v, qr[j].data(), qmin[j].data(), qmax[j].data(), J.valid, nullptr, J.desc, nullptr};
+    w.bestOut = J.best;
+    w.gate = gate ? 1 : 0;
+    w.gur = (gate && J.KF->u_right) ? J.ur : nullptr;
+    w.invSigma2 = J.inv_level_sigma2;
+    w.nLevels = n_levels;
+    w.maxDist = max_dist;
+    wj.push_back(w);
   }
   if (wj.empty()) return ORBFE_OK;
-  int rc = window_search_multi(device, wj.data(), (int)wj.size(), 32);
-  if (rc != ORBFE_OK) return rc;
-  for (int j : jobOf) {
-    const BestJob& J = jobs[j];
-    const WindowResult& R = res[j];
-    const orbfe_frame_view* KF = J.KF;
-    for (int i = 0; i < J.n; i++) {
-      if (!J.valid[i]) continue;
-      int bestDist = 256, bestIdx = -1;
-      for (int c = 0; c < R.count[i]; c++) {
-        const uint32_t e = R.cand[(size_t)i * R.K + c];
-        const int idx = (int)(e & 0xffffu), dist = (int)(e >> 16);
-        if (gate) {
-          const int kpLevel = KF->octave[idx];
-          const float kpx = KF->x[idx], kpy = KF->y[idx];
-          if (KF->u_right && KF->u_right[idx] >= 0) {
-            const float kpr = KF->u_right[idx];
-            const float ex = J.u[i] - kpx, ey = J.v[i] - kpy, er = J.ur[i] - kpr;
-            const float e2 = ex * ex + ey * ey + er * er;
-            if (e2 * J.inv_level_sigma2[kpLevel] > 7.8) continue;
-          } else {
-            const float ex = J.u[i] - kpx, ey = J.v[i] - kpy;
-            const float e2 = ex * ex + ey * ey;
-            if (e2 * J.inv_level_sigma2[kpLevel] > 5.99) continue;
-          }
-        }
-        if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
-      }
-      if (bestDist <= max_dist) J.best[i] = bestIdx;
-    }
-  }
-  return ORBFE_OK;
+  return window_search_multi(device, wj.data(), (int)wj.size(), 8);
 }
 int window_best(const char* who, int device, const orbfe_frame_view* KF, const float* sf, int n_levels,
                 const float* inv_level_sigma2, int n, const uint8_t* valid, const float* u, const float* v,
