@@ -111,6 +111,7 @@ struct orbfe_extractor {
   size_t hostInBytes = 0;
   DescTile* d_descTiles = nullptr;  // tile form of the orientation + descriptor stage (k_desc_tiles.hip)
   int nDescTiles = 0;
+  int knockoutChunks = 0;
   int descTilesMode = -1;           // -1: $ORBFE_DESC_TILES (default 0 = the per-keypoint form); 0 / 1 forced by orbfe_extractor_set_desc_tiles
   int32_t* d_umax = nullptr;
   CellDesc* d_cells = nullptr;
@@ -141,6 +142,7 @@ struct orbfe_extractor {
   int32_t* d_stereoRowStart = nullptr;
   int32_t* d_stereoSorted = nullptr;
   float4* d_stereoRec = nullptr;   // (uR, yR, octave, index) of the right keypoints in row order
+  uint8_t* d_stereoDesc = nullptr; // their descriptors in the same order
   size_t stereoSadCap = 0, stereoRowCap = 0;
   LevelKp* d_levelKp = nullptr;
   int32_t* d_levelCount = nullptr;
@@ -436,6 +438,18 @@ int run_host_octree(orbfe_extractor* e, int nFrames) {
 }
 
 // The device pipeline for frames [f0, f0+nFrames) of a call, enqueued on stream `s`.
+// $ORBFE_KNOCKOUT = bit mask of stages whose launches are SKIPPED once the handle has run $ORBFE_KNOCKOUT_AFTER (default 4)
+// chunks in full (1 pyramid + blur, 2 FAST, 4 gather + octree, 8 orientation + descriptors, 16 stereo matcher): a timing
+// experiment -- how much does a stage add to the PIPELINED step? (tools/knockout.sh; the skipped stage's outputs are
+// the previous step's, so everything downstream still runs on real data; results unchecked, ORBFE_BENCH_NO_CHECK)
+static int knockout_mask(orbfe_extractor* e, bool count) {
+  static const int kMask = getenv("ORBFE_KNOCKOUT") ? atoi(getenv("ORBFE_KNOCKOUT")) : 0;
+  static const int kAfter = getenv("ORBFE_KNOCKOUT_AFTER") ? atoi(getenv("ORBFE_KNOCKOUT_AFTER")) : 4;
+  if (!kMask) return 0;
+  if (count) e->knockoutChunks++;
+  return e->knockoutChunks > kAfter ? kMask : 0;
+}
+
 // level0: view of the call's input frames in HBM (frame 0 of the call).
 int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int f0, int nFrames,
               orbfe_keypoint* d_kp, uint8_t* d_desc, int capacity, int32_t* d_nOut, PyramidViews* pyrOut,
@@ -444,6 +458,7 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
   // for everything when sV is NULL
   const bool lanes = sV != nullptr;
   if (!lanes) { sV = s; sT = s; }
+  const int ko = knockout_mask(e, true);
   const FrameGeom& g = e->geom;
   const size_t F = (size_t)f0;
   const int nCells = g.nFastCells;
@@ -488,7 +503,7 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
   const bool pyrBlur = e->pyrBlur && !fused && !lanes && nFrames > 8;
   {  // ComputePyramid, :1203-1234
     StageTimer t(e, ORBFE_STAGE_PYRAMID, pyrBlur ? g.nlevels : g.nlevels - 1, nFrames, sub, s);
-    for (int l = 1; l <= g.nlevels; l++) {
+    for (int l = 1; l <= g.nlevels && !(ko & 1); l++) {
       if (pyrBlur) {
         LevelViewMut bdst{const_cast<uint8_t*>(blur.lv[l - 1].base), g.pyrBytes, g.lv[l - 1].pitch, g.lv[l - 1].w, g.lv[l - 1].h};
         if (l < g.nlevels && e->d_tileGx[l]) {
@@ -543,7 +558,7 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
       stat = e->d_fastStat + sub * orbfe_extractor::kStatSlots;
       HIPCHK(hipMemsetAsync(stat, 0, sizeof(unsigned int) * orbfe_extractor::kStatSlots, sV));
     }
-    {
+    if (!(ko & 2)) {
       StageTimer t(e, ORBFE_STAGE_FAST, 1, nFrames, sub, sV);
       launch_fast_cells(sV, pyr, e->d_cells, nCells, nFrames, e->tab.iniThFAST, e->tab.minThFAST, slots, g.totalSlots,
                         cellCount, g.maxCellW, g.maxCellH, fused ? &blur : nullptr, (int)g.cells.size(), lowFirst, stat);
@@ -562,7 +577,8 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
     if (!fused && !pyrBlur) do_blur();
     HIPCHK(hipEventRecord(e->evBlur[sub], sV));
   }
-  if (!e->hostOctree) {  // candidate ordering + DistributeOctTree, :566-808, one workgroup per (frame, level)
+  if (ko & 4) {
+  } else if (!e->hostOctree) {  // candidate ordering + DistributeOctTree, :566-808, one workgroup per (frame, level)
     StageTimer t(e, ORBFE_STAGE_OCTREE, 2, nFrames, sub, sT);
     launch_gather_candidates(sT, e->d_cells, e->d_lvgeom, g.nlevels, nFrames, slots, g.totalSlots, cellCount,
                              nCells, cand, candCount, cellPrefix);
@@ -589,7 +605,7 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
   if (!lanes && !blurFirst && !fused && !pyrBlur) do_blur();
   if (lanes) HIPCHK(hipStreamWaitEvent(sT, e->evBlur[sub], 0));
 
-  {  // computeOrientation + computeDescriptors + output records
+  if (!(ko & 8)) {  // computeOrientation + computeDescriptors + output records
     StageTimer t(e, ORBFE_STAGE_ORIENT_DESC, 1, nFrames, sub, sT);
     OrientDescArgs a = {};
     a.pyr = pyr;
@@ -813,6 +829,7 @@ extern "C" void orbfe_extractor_destroy(orbfe_extractor* e) {
   dfree(&e->d_stereoRowStart);
   dfree(&e->d_stereoSorted);
   dfree(&e->d_stereoRec);
+  dfree(&e->d_stereoDesc);
   dfree(&e->d_momentTab);
   dfree(&e->d_hostIn);
   dfree(&e->d_umax);
@@ -1615,6 +1632,7 @@ extern "C" int orbfe_stereo_match_batch_device(orbfe_extractor* e, int n_pairs, 
     int rc = dalloc(&e->d_stereoSad, need);
     if (!rc) rc = dalloc(&e->d_stereoSorted, need);
     if (!rc) rc = dalloc(&e->d_stereoRec, need);
+    if (!rc) rc = dalloc(&e->d_stereoDesc, need * 32);
     if (!rc) rc = dalloc(&e->d_stereoRowStart, needRows);
     if (rc) return rc;
     e->stereoSadCap = need;
@@ -1630,6 +1648,8 @@ extern "C" int orbfe_stereo_match_batch_device(orbfe_extractor* e, int n_pairs, 
     a.rowStart = e->d_stereoRowStart;
     a.sortedIdx = e->d_stereoSorted;
     a.sortedRec = e->d_stereoRec;
+    static const bool kSortedDesc = !(getenv("ORBFE_STEREO_SORTED_DESC") && atoi(getenv("ORBFE_STEREO_SORTED_DESC")) == 0);
+    a.sortedDesc = kSortedDesc ? e->d_stereoDesc : nullptr;
     a.rows = rows;
     a.bandR = (int)std::ceil(2.0f * e->tab.scale[e->tab.nlevels - 1]) + 2;
   }
@@ -1650,12 +1670,14 @@ extern "C" int orbfe_stereo_match_batch_device(orbfe_extractor* e, int n_pairs, 
       aa.pyrR.lv[l].base += (size_t)(2 * p0) * aa.pyrR.lv[l].frameStride;
     }
     if (aa.rowStart) { aa.rowStart += (size_t)p0 * (rows + 1); aa.sortedIdx += (size_t)p0 * capacity; aa.sortedRec += (size_t)p0 * capacity; }
+    if (aa.sortedDesc) aa.sortedDesc += (size_t)p0 * capacity * 32;
     bb.kp += (size_t)(2 * p0) * capacity * 7;
     bb.desc += (size_t)(2 * p0) * capacity * 32;
     bb.n += 2 * p0;
     bb.uRight += (size_t)p0 * capacity;
     bb.depth += (size_t)p0 * capacity;
     bb.sad += (size_t)p0 * capacity;
+    if (knockout_mask(e, false) & 16) return;
     StageTimer t(e, ORBFE_STAGE_MATCH, 1, 2 * np, sub, st);
     launch_stereo_batch(st, aa, bb, np, d_n_stereo + p0);
   };

@@ -58,7 +58,9 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
                                                      float* __restrict__ kpOut,
                                                      uint8_t* __restrict__ descOut,
                                                      int32_t* __restrict__ nOut, int blocksPerFrame,
-                                                     int nFrames, uint32_t blocksMagic) {
+                                                     int nFrames, uint32_t blocksMagic,
+                                                     int ablate /* 0; $ORBFE_ORIENT_ABLATE, timing experiments: 1 no moment loads, 2 no patch loads, 4 no sampling */,
+                                                     int interleave) {
   __shared__ int s_m10[kKpPerBlock], s_m01[kKpPerBlock];
   __shared__ int s_x[kKpPerBlock], s_y[kKpPerBlock], s_level[kKpPerBlock], s_out[kKpPerBlock];
   __shared__ unsigned s_score[kKpPerBlock];
@@ -92,7 +94,12 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
   constexpr int kKpPerWave = kKpPerBlock / 4;
   const int myKp = wave * kKpPerWave + lane;  // the keypoint this lane resolves (phase 0) and rotates (phase 2) when lane < kKpPerWave
   if (lane < kKpPerWave) {
-    const int slot = slot0 + myKp;
+    // slot order = spatial order (k_octree: 128-byte column strip, then row).  INTERLEAVED over the waves (round 4): wave w
+    // takes slots w, w + 4, w + 8, ... so the four waves of the workgroup work on four NEIGHBOURING keypoints at the same
+    // time -- their patches overlap in the same cache lines, and the CU's 32 KB L1 (one patch pair pulls ~11 KB of lines
+    // through it) serves the second to fourth request for a line.  With 16 consecutive slots per wave a wave came back to a
+    // neighbourhood only after the other three had pushed it out of L1.  ($ORBFE_ORIENT_INTERLEAVE=0: the old order)
+    const int slot = slot0 + (interleave ? wave + 4 * lane : myKp);
     int out = -1, l = 0;
     if (slot < a.kpSlotsPerFrame) {
       int base = 0;
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
           const LevelView lv = a.pyr.lv[kl];
           // scalar patch origin (row y-15, column x-15); the lane adds its 32-bit (row, half) offset
           const uint8_t* origin = lv.base + (size_t)f * lv.frameStride + (size_t)(ky - 15) * lv.pitch + (kx - 15);
-          if (active) {
+          if (active && !(ablate & 1)) {
             const uint8_t* p = origin + (uint32_t)(row * lv.pitch + (half ? 16 : 0));
             {
               // one byte-aligned 16-byte request per (row, half) whatever the level's pitch and the keypoint's column
@@ -207,32 +214,45 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
     // per lane per sample (8 x 64 per keypoint) and was the slowest part of the kernel.
     uint32_t* myPatch = &s_patch[wave * kUD * kPatchRows * kPatchDw];
     constexpr int kKpPerWave3 = kKpPerBlock / 4;
-    for (int j0 = wave * kKpPerWave3; j0 < wave * kKpPerWave3 + kKpPerWave3; j0 += kUD) {
-      int t0v[kUD][4], t1v[kUD][4];
-      U4 stage[kUD][2];
-      int colOff[kUD], kout[kUD];  // per-keypoint values are wave-uniform: scalar registers, scalar branches
+    const int jBeg = wave * kKpPerWave3, jEnd = jBeg + kKpPerWave3;
+    // SOFTWARE PIPELINE (round 4): the patch rows of the NEXT kUD keypoints are requested as soon as the current ones have
+    // been written to LDS -- their memory round trip runs under the 512 LDS samples, the ballots and the stores of the
+    // current keypoints instead of at the head of the next iteration.  No extra registers (the staging registers are
+    // free once the patch is in LDS), no extra LDS: with ONE workgroup per CU in flight (the pipelined configuration) a
+    // wave has nobody to hide its latency behind but itself.
+    U4 stage[kUD][2];
+    int colOffN[kUD], koutN[kUD];  // per-keypoint values are wave-uniform: scalar registers, scalar branches
+    auto request = [&](int j0) {
 #pragma unroll
       for (int u = 0; u < kUD; u++) {
         const int j = j0 + u;
-        colOff[u] = 0;
-        kout[u] = __builtin_amdgcn_readfirstlane(s_out[j]);
-        if (kout[u] < 0) continue;
+        colOffN[u] = 0;
+        koutN[u] = __builtin_amdgcn_readfirstlane(s_out[j]);
+        if (koutN[u] < 0) continue;
         const int kl = __builtin_amdgcn_readfirstlane(s_level[j]);
         const int kx = __builtin_amdgcn_readfirstlane(s_x[j]), ky = __builtin_amdgcn_readfirstlane(s_y[j]);
         const LevelView bl = a.blur.lv[kl];
         int ws = (kx - 18) & ~3;
         if (ws > bl.pitch - 4 * kPatchDw) ws = bl.pitch - 4 * kPatchDw;  // stay inside the row pitch
-        colOff[u] = kx - ws;
+        colOffN[u] = kx - ws;
         const uint8_t* pb = bl.base + (size_t)f * bl.frameStride + (size_t)(ky - 18) * bl.pitch + ws;  // scalar
 #pragma unroll
         for (int h = 0; h < 2; h++) {
           const int idx = lane + 64 * h;
           const int row = (idx * 43) >> 7, part = idx - 3 * row;  // idx / 3 for idx < 128
-          if (idx < 3 * kPatchRows) stage[u][h] = *reinterpret_cast<const U4*>(pb + (uint32_t)(row * bl.pitch + 16 * part));
+          if (idx < 3 * kPatchRows && !(ablate & 2)) stage[u][h] = *reinterpret_cast<const U4*>(pb + (uint32_t)(row * bl.pitch + 16 * part));
+          else stage[u][h] = U4{0u, 0u, 0u, 0u};
         }
       }
+    };
+    request(jBeg);
+    for (int j0 = jBeg; j0 < jEnd; j0 += kUD) {
+      int t0v[kUD][4], t1v[kUD][4];
+      int colOff[kUD], kout[kUD];
 #pragma unroll
       for (int u = 0; u < kUD; u++) {
+        colOff[u] = colOffN[u];
+        kout[u] = koutN[u];
         if (kout[u] < 0) continue;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -242,6 +262,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
                 make_uint4(stage[u][h].x, stage[u][h].y, stage[u][h].z, stage[u][h].w);
         }
       }
+      if (j0 + kUD < jEnd) request(j0 + kUD);  // (wave-uniform) in flight during everything below
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -269,8 +290,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
           const float c1 = __fadd_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sb)), kMagic);
           const uint32_t ir0 = __float_as_uint(r0), ir1 = __float_as_uint(r1);
           const uint32_t ic0 = __float_as_uint(c0), ic1 = __float_as_uint(c1);
-          t0v[u][t] = pbytes[baseK + ir0 * (4u * kPatchDw) + ic0];
-          t1v[u][t] = pbytes[baseK + ir1 * (4u * kPatchDw) + ic1];
+          t0v[u][t] = (ablate & 4) ? (int)(ir0 & 255u) : pbytes[baseK + ir0 * (4u * kPatchDw) + ic0];
+          t1v[u][t] = (ablate & 4) ? (int)(ic1 & 255u) : pbytes[baseK + ir1 * (4u * kPatchDw) + ic1];
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -345,22 +366,24 @@ void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d
   // Round 2 measured the wider form <64, 8, 4> (twice the row / patch loads in flight per wave, 106 VGPRs, same 4
   // workgroups per CU): stage 3.36 vs 3.38 ms per 4096 VGA frames, pipeline unchanged, so <64, 4, 2> stays.
   const unsigned full = (total + 7u) / 8u * 8u;
+  static const int kAblate = getenv("ORBFE_ORIENT_ABLATE") ? atoi(getenv("ORBFE_ORIENT_ABLATE")) : 0;
+  static const int kInterleave = getenv("ORBFE_ORIENT_INTERLEAVE") ? atoi(getenv("ORBFE_ORIENT_INTERLEAVE")) : 1;
   if (latencyForm) {
     hipLaunchKernelGGL((k_orient_desc<16, 4, 2>), dim3(full), dim3(256), 0, s, a, d_levelKp, d_levelCount,
-                       d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic);
+                       d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic, kAblate, kInterleave);
   } else {
     unsigned grid = full;
     if (kGridPerCu > 0 && (unsigned)kGridPerCu * 256u < full) grid = (unsigned)kGridPerCu * 256u;  // 256 CUs, multiple of 8
     static const int kWide = getenv("ORBFE_ORIENT_WIDE") ? atoi(getenv("ORBFE_ORIENT_WIDE")) : 0;
     if (kWide == 2)
       hipLaunchKernelGGL((k_orient_desc<64, 16, 8>), dim3(grid), dim3(256), kPad, s, a, d_levelKp, d_levelCount,
-                         d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic);
+                         d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic, kAblate, kInterleave);
     else if (kWide == 1)
       hipLaunchKernelGGL((k_orient_desc<64, 8, 4>), dim3(grid), dim3(256), kPad, s, a, d_levelKp, d_levelCount,
-                         d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic);
+                         d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic, kAblate, kInterleave);
     else
     hipLaunchKernelGGL((k_orient_desc<64, 4, 2>), dim3(grid), dim3(256), kPad, s, a, d_levelKp, d_levelCount,
-                       d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic);
+                       d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic, kAblate, kInterleave);
   }
 }
 

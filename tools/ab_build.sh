@@ -5,4 +5,4 @@
 set -e
 TAG=$1; shift
 cd "$(dirname "$0")/../orb_slam2_annotate_amd/csrc"
-make -j8 OBJDIR=build_$TAG LIB=../liborbfe_$TAG.so CXXFLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wall -Wno-unused-result $*"
+make -j8 OBJDIR=build_$TAG LIB=../liborbfe_$TAG.so CXXFLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fdenormal-fp-math=ieee -Wall -Wno-unused-result $*"
