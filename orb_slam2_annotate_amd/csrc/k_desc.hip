@@ -215,11 +215,11 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
     uint32_t* myPatch = &s_patch[wave * kUD * kPatchRows * kPatchDw];
     constexpr int kKpPerWave3 = kKpPerBlock / 4;
     const int jBeg = wave * kKpPerWave3, jEnd = jBeg + kKpPerWave3;
-    // SOFTWARE PIPELINE (round 4): the patch rows of the NEXT kUD keypoints are requested as soon as the current ones have
-    // been written to LDS -- their memory round trip runs under the 512 LDS samples, the ballots and the stores of the
-    // current keypoints instead of at the head of the next iteration.  No extra registers (the staging registers are
-    // free once the patch is in LDS), no extra LDS: with ONE workgroup per CU in flight (the pipelined configuration) a
-    // wave has nobody to hide its latency behind but itself.
+    // (round 4, measured and NOT kept -- -DORBFE_DESC_PIPELINE builds it: requesting the patch rows of the NEXT kUD keypoints as
+    // soon as the current ones are in LDS, so that their round trip runs under the 512 samples, the ballots and the stores.
+    // Same registers, same LDS; exclusive stage 1.37 -> 1.42 ms per 1024 KITTI frames, pipeline unchanged (100.2 k vs 100.2 k)
+    // in a same-box A/B: the wave is not waiting for THESE loads -- with the loads removed altogether the stage still takes
+    // 0.88 ms, tools/ablate_orient.sh)
     U4 stage[kUD][2];
     int colOffN[kUD], koutN[kUD];  // per-keypoint values are wave-uniform: scalar registers, scalar branches
     auto request = [&](int j0) {
@@ -245,8 +245,13 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
         }
       }
     };
+#ifdef ORBFE_DESC_PIPELINE
     request(jBeg);
+#endif
     for (int j0 = jBeg; j0 < jEnd; j0 += kUD) {
+#ifndef ORBFE_DESC_PIPELINE
+      request(j0);
+#endif
       int t0v[kUD][4], t1v[kUD][4];
       int colOff[kUD], kout[kUD];
 #pragma unroll
@@ -262,7 +267,9 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
                 make_uint4(stage[u][h].x, stage[u][h].y, stage[u][h].z, stage[u][h].w);
         }
       }
+#ifdef ORBFE_DESC_PIPELINE
       if (j0 + kUD < jEnd) request(j0 + kUD);  // (wave-uniform) in flight during everything below
+#endif
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
