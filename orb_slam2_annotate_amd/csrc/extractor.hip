@@ -142,7 +142,6 @@ struct orbfe_extractor {
   int32_t* d_stereoRowStart = nullptr;
   int32_t* d_stereoSorted = nullptr;
   float4* d_stereoRec = nullptr;   // (uR, yR, octave, index) of the right keypoints in row order
-  uint8_t* d_stereoDesc = nullptr; // their descriptors in the same order
   size_t stereoSadCap = 0, stereoRowCap = 0;
   LevelKp* d_levelKp = nullptr;
   int32_t* d_levelCount = nullptr;
@@ -579,6 +578,9 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
   }
   if (ko & 4) {
   } else if (!e->hostOctree) {  // candidate ordering + DistributeOctTree, :566-808, one workgroup per (frame, level)
+    // (round 4, measured and not kept: the candidate ordering INSIDE the octree kernel, in front of each (frame, level) item --
+    // one launch and one global round trip fewer per chain; KITTI 100.6 k vs 101.4 k, TUM 361.9 k vs 360.1 k stereo frames /
+    // frames per second for separate vs fused in a same-box A/B: the launch is not what the chain waits for)
     StageTimer t(e, ORBFE_STAGE_OCTREE, 2, nFrames, sub, sT);
     launch_gather_candidates(sT, e->d_cells, e->d_lvgeom, g.nlevels, nFrames, slots, g.totalSlots, cellCount,
                              nCells, cand, candCount, cellPrefix);
@@ -829,7 +831,6 @@ extern "C" void orbfe_extractor_destroy(orbfe_extractor* e) {
   dfree(&e->d_stereoRowStart);
   dfree(&e->d_stereoSorted);
   dfree(&e->d_stereoRec);
-  dfree(&e->d_stereoDesc);
   dfree(&e->d_momentTab);
   dfree(&e->d_hostIn);
   dfree(&e->d_umax);
@@ -1632,7 +1633,6 @@ extern "C" int orbfe_stereo_match_batch_device(orbfe_extractor* e, int n_pairs, 
     int rc = dalloc(&e->d_stereoSad, need);
     if (!rc) rc = dalloc(&e->d_stereoSorted, need);
     if (!rc) rc = dalloc(&e->d_stereoRec, need);
-    if (!rc) rc = dalloc(&e->d_stereoDesc, need * 32);
     if (!rc) rc = dalloc(&e->d_stereoRowStart, needRows);
     if (rc) return rc;
     e->stereoSadCap = need;
@@ -1648,8 +1648,6 @@ extern "C" int orbfe_stereo_match_batch_device(orbfe_extractor* e, int n_pairs, 
     a.rowStart = e->d_stereoRowStart;
     a.sortedIdx = e->d_stereoSorted;
     a.sortedRec = e->d_stereoRec;
-    static const bool kSortedDesc = !(getenv("ORBFE_STEREO_SORTED_DESC") && atoi(getenv("ORBFE_STEREO_SORTED_DESC")) == 0);
-    a.sortedDesc = kSortedDesc ? e->d_stereoDesc : nullptr;
     a.rows = rows;
     a.bandR = (int)std::ceil(2.0f * e->tab.scale[e->tab.nlevels - 1]) + 2;
   }
@@ -1670,7 +1668,6 @@ extern "C" int orbfe_stereo_match_batch_device(orbfe_extractor* e, int n_pairs, 
       aa.pyrR.lv[l].base += (size_t)(2 * p0) * aa.pyrR.lv[l].frameStride;
     }
     if (aa.rowStart) { aa.rowStart += (size_t)p0 * (rows + 1); aa.sortedIdx += (size_t)p0 * capacity; aa.sortedRec += (size_t)p0 * capacity; }
-    if (aa.sortedDesc) aa.sortedDesc += (size_t)p0 * capacity * 32;
     bb.kp += (size_t)(2 * p0) * capacity * 7;
     bb.desc += (size_t)(2 * p0) * capacity * 32;
     bb.n += 2 * p0;

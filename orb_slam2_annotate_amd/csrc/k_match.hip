@@ -424,7 +424,7 @@ struct StereoPair {  // per-pair operands (kept apart from the kernel argument s
   const float* kpR; const uint8_t* descR; int Nr;
   int frameL, frameR;
   float* uRight; float* depth; int32_t* sad;
-  const int32_t* rowStart; const int32_t* sortedIdx; const float4* sortedRec; const uint8_t* sortedDesc;
+  const int32_t* rowStart; const int32_t* sortedIdx; const float4* sortedRec;
 };
 
 // ---- 16 lanes per left keypoint (one DPP row), four keypoints per wavefront ----
@@ -517,7 +517,7 @@ __device__ __forceinline__ void stereo_row16(const StereoArgs& a, const StereoLd
       const int minr = (int)floorf(__fsub_rn(yR, r));
       const bool cand = row >= minr && row <= maxr && octR >= levelL - 1 && octR <= levelL + 1 && uR >= minU && uR <= maxU;
       if (cand) {
-        const uint32_t dist = (uint32_t)hdist(dL, pp.sortedDesc ? load_desc(pp.sortedDesc, p) : load_desc(pp.descR, iR));
+        const uint32_t dist = (uint32_t)hdist(dL, load_desc(pp.descR, iR));
         const uint32_t key = (dist << 20) | (uint32_t)iR;
         if (dist < 100u && key < best) { best = key; bestU = uR; }  // bestDist starts at TH_HIGH, strict <
       }
@@ -629,8 +629,7 @@ __device__ __forceinline__ void stereo_row16(const StereoArgs& a, const StereoLd
 __global__ __launch_bounds__(256) void k_stereo_bucket(const float* __restrict__ kpBase, const int32_t* __restrict__ nArr,
                                                        int nFixed, int capacity, int rows,
                                                        int32_t* __restrict__ rowStartBase,
-                                                       int32_t* __restrict__ sortedBase, float4* __restrict__ recBase,
-                                                       const uint8_t* __restrict__ descBase, uint8_t* __restrict__ sortedDescBase) {
+                                                       int32_t* __restrict__ sortedBase, float4* __restrict__ recBase) {
   extern __shared__ int cnt[];  // rows + 1
   __shared__ int waveTot[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = blockIdx.x;
@@ -640,8 +639,6 @@ __global__ __launch_bounds__(256) void k_stereo_bucket(const float* __restrict__
   int32_t* rowStart = rowStartBase + (size_t)p * (rows + 1);
   int32_t* sorted = sortedBase + (size_t)p * capacity;
   float4* rec = recBase ? recBase + (size_t)p * capacity : nullptr;
-  const uint4* descR = (descBase && sortedDescBase) ? reinterpret_cast<const uint4*>(nArr ? descBase + (size_t)(2 * p + 1) * capacity * 32 : descBase) : nullptr;
-  uint4* sdesc = descR ? reinterpret_cast<uint4*>(sortedDescBase + (size_t)p * capacity * 32) : nullptr;
   for (int i = tid; i <= rows; i += 256) cnt[i] = 0;
   __syncthreads();
   for (int i = tid; i < Nr; i += 256) {
@@ -675,7 +672,6 @@ __global__ __launch_bounds__(256) void k_stereo_bucket(const float* __restrict__
     sorted[pos] = i;
     if (rec) rec[pos] = make_float4(kpR[(size_t)i * 7], kpR[(size_t)i * 7 + 1], __int_as_float(reinterpret_cast<const int32_t*>(kpR)[(size_t)i * 7 + 5]),
                                     __int_as_float(i));
-    if (sdesc) { sdesc[2 * pos] = descR[2 * i]; sdesc[2 * pos + 1] = descR[2 * i + 1]; }
   }
 }
 
@@ -694,7 +690,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a) {
   const int lane = threadIdx.x & 63;
   const int iL = blockIdx.x * 16 + (threadIdx.x >> 4);
   StereoPair pp = {a.kpL, a.descL, a.N, a.kpR, a.descR, a.Nr, a.frameL, a.frameR, a.uRight, a.depth, a.sad,
-                   a.rowStart, a.sortedIdx, a.rowStart ? a.sortedRec : nullptr, (a.rowStart && a.sortedRec) ? a.sortedDesc : nullptr};
+                   a.rowStart, a.sortedIdx, a.rowStart ? a.sortedRec : nullptr};
   stereo_row16(a, lv, pp, iL, iL < a.N, lane);
 }
 
@@ -722,7 +718,6 @@ __global__ __launch_bounds__(256) void k_stereo_match_batch(const StereoArgs a, 
   pp.rowStart = a.rowStart ? a.rowStart + (size_t)p * (a.rows + 1) : nullptr;
   pp.sortedIdx = a.rowStart ? a.sortedIdx + (size_t)p * b.capacity : nullptr;
   pp.sortedRec = (a.rowStart && a.sortedRec) ? a.sortedRec + (size_t)p * b.capacity : nullptr;
-  pp.sortedDesc = (pp.sortedRec && a.sortedDesc) ? a.sortedDesc + (size_t)p * b.capacity * 32 : nullptr;
   stereo_row16(a, lv, pp, iL, iL < N, lane);
 }
 
@@ -737,6 +732,7 @@ __global__ __launch_bounds__(256) void k_stereo_median_cut(int N, const int32_t*
   nStereo += blockIdx.x;
   __shared__ int hist[256];
   __shared__ int sel[3];  // hi bin, remaining k, total
+  __shared__ int waveTot[4];
   const int tid = threadIdx.x;
   hist[tid] = 0;
   if (tid == 0) sel[2] = 0;
@@ -750,12 +746,26 @@ __global__ __launch_bounds__(256) void k_stereo_median_cut(int N, const int32_t*
   __syncthreads();
   const int total = sel[2];
   if (total == 0) { if (tid == 0) *nStereo = 0; return; }
-  if (tid == 0) {
-    int k = total / 2, b = 0;
-    while (k >= hist[b]) { k -= hist[b]; b++; }
-    sel[0] = b; sel[1] = k;
-  }
-  __syncthreads();
+  // the bin that holds the element of rank k: the 256 threads scan the 256 bins together (thread 0 walking them one LDS
+  // round trip at a time took ~13 us of the kernel's 34)
+  auto pick = [&](int k) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int v = hist[tid];
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) waveTot[wave] = x;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; w++) base += waveTot[w];
+    const int incl = base + x;
+    if (v > 0 && incl - v <= k && k < incl) { sel[0] = tid; sel[1] = k - (incl - v); }
+    __syncthreads();
+  };
+  pick(total / 2);
   const int hi = sel[0];
   __syncthreads();
   hist[tid] = 0;
@@ -765,14 +775,11 @@ __global__ __launch_bounds__(256) void k_stereo_median_cut(int N, const int32_t*
     if (s >= 0 && (s >> 8) == hi) atomicAdd(&hist[s & 255], 1);
   }
   __syncthreads();
-  if (tid == 0) {
-    int k = sel[1], b = 0;
-    while (k >= hist[b]) { k -= hist[b]; b++; }
-    sel[0] = (hi << 8) | b;
-    sel[1] = 0;
-  }
+  pick(sel[1]);
+  const float median = (float)((hi << 8) | sel[0]);
   __syncthreads();
-  const float median = (float)sel[0];
+  if (tid == 0) sel[1] = 0;
+  __syncthreads();
   const float thDist = __fmul_rn(1.5f * 1.4f, median);
   int kept = 0;
   for (int i = tid; i < N; i += 256) {
@@ -791,7 +798,7 @@ void launch_stereo(hipStream_t s, const StereoArgs& a, int32_t* d_nStereo) {
   if (a.rowStart)
     hipLaunchKernelGGL(k_stereo_bucket, dim3(1), dim3(256), (size_t)(a.rows + 1) * sizeof(int), s, a.kpR,
                        (const int32_t*)nullptr, a.Nr, a.Nr, a.rows, const_cast<int32_t*>(a.rowStart),
-                       const_cast<int32_t*>(a.sortedIdx), const_cast<float4*>(a.sortedRec), a.descR, const_cast<uint8_t*>(a.sortedDesc));
+                       const_cast<int32_t*>(a.sortedIdx), const_cast<float4*>(a.sortedRec));
   hipLaunchKernelGGL(k_stereo_match, dim3((a.N + 15) / 16), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_stereo_median_cut, dim3(1), dim3(256), 0, s, a.N, a.sad, a.uRight, a.depth, d_nStereo, 0);
 }
@@ -801,7 +808,7 @@ void launch_stereo_batch(hipStream_t s, const StereoArgs& a, const StereoBatch& 
   if (a.rowStart)
     hipLaunchKernelGGL(k_stereo_bucket, dim3(nPairs), dim3(256), (size_t)(a.rows + 1) * sizeof(int), s, b.kp, b.n, 0,
                        b.capacity, a.rows, const_cast<int32_t*>(a.rowStart), const_cast<int32_t*>(a.sortedIdx),
-                       const_cast<float4*>(a.sortedRec), b.desc, const_cast<uint8_t*>(a.sortedDesc));
+                       const_cast<float4*>(a.sortedRec));
   hipLaunchKernelGGL(k_stereo_match_batch, dim3((b.capacity + 15) / 16, nPairs), dim3(256), 0, s, a, b);
   hipLaunchKernelGGL(k_stereo_median_cut, dim3(nPairs), dim3(256), 0, s, b.capacity, b.sad, b.uRight, b.depth,
                      d_nStereo, b.capacity);

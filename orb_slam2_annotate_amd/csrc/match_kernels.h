@@ -48,10 +48,6 @@ struct StereoArgs {
   // to sortedIdx): the candidate scan reads ONE 16-byte record instead of the index and then three fields of the
   // 28-byte keypoint, i.e. one dependent memory round trip less per left keypoint
   const float4* sortedRec;
-  // sortedDesc[p] = the 32-byte descriptor of that keypoint, in the same row order: the candidates of a left keypoint are
-  // a contiguous band of the sorted arrays, so their descriptors share cache lines (gathered from descR by index, every
-  // 32-byte descriptor cost a 128-byte line: 2.2 x the stage's algorithmic HBM bytes in round 3)
-  const uint8_t* sortedDesc;
 };
 
 struct StereoBatch {  // frames 2p / 2p+1 of an extractor batch are the left / right image of pair p

@@ -2,7 +2,8 @@
 # Regenerates the judged profile artefacts of a round on the GPU box (run through gpurun):
 #   tools/profile_round.sh r03 [workloads...]          (default: kitti tum euroc euroc_stereo)
 # per workload W -> gpurun_out/<tag>_W_{valu,traffic}.json (PMC summaries, separate passes) and
-#   <tag>_W_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --workload W`, the timed multi-stream run);
+#   <tag>_W_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --workload W`, the timed multi-stream run) and
+#   <tag>_W_kernel_stats_exclusive.csv (the same on ONE stream: every kernel alone on the chip);
 # then <tag>_bench.json = the default bench.py line (all workloads; reads the PMC summaries from profiles/).
 # Copy the files into profiles/.
 # Every profiler pass runs under `timeout -k 10` and appends a line to gpurun_out/<tag>_progress.txt when it ends: a pass
@@ -17,6 +18,7 @@ OUT=gpurun_out
 mkdir -p $OUT
 PROG=$OUT/${TAG}_progress.txt
 : > $PROG
+echo "commit $(cat .profile_commit 2>/dev/null || echo unknown) liborbfe.so sha256 $(sha256sum orb_slam2_annotate_amd/liborbfe.so | cut -c1-16)" >> $PROG
 note() { echo "$(date +%T) $*" | tee -a $PROG; }
 CACHE=/tmp/orbfe_inputs_$$
 pbatch() { case $1 in kitti|euroc_stereo) echo 64;; *) echo 256;; esac; }
@@ -43,6 +45,13 @@ for W in $WLS; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_${W}_stats -- python3 bench.py --full-line --no-detail --workload $W --no-cpu-baseline --no-e2e --no-latency --render-procs 1 --input-cache $CACHE > $OUT/${TAG}_${W}_stats_bench.json 2>/dev/null
   note "kernel stats $W rc=$?"
   cp $OUT/${TAG}_${W}_stats/*/*kernel_stats.csv $OUT/${TAG}_${W}_kernel_stats.csv
+  # the same command on ONE stream: every kernel alone on the chip -> the exclusive durations behind roofline.exclusive and
+  # the per-stage exclusive fractions, reproducible from profiles/ without trusting bench-printed HIP events
+  rm -rf $OUT/${TAG}_${W}_stats1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_${W}_stats1 -- python3 bench.py --full-line --no-detail --workload $W --streams 1 --steps 20 --min-seconds 0 --no-cpu-baseline --no-e2e --no-latency --render-procs 1 --input-cache $CACHE > /dev/null 2>&1
+  note "kernel stats, 1 stream $W rc=$?"
+  cp $OUT/${TAG}_${W}_stats1/*/*kernel_stats.csv $OUT/${TAG}_${W}_kernel_stats_exclusive.csv
+  rm -rf $OUT/${TAG}_${W}_stats1
   rm -rf $OUT/${TAG}_${W}_pmc_valu $OUT/${TAG}_${W}_pmc_fetch $OUT/${TAG}_${W}_pmc_write $OUT/${TAG}_${W}_stats   # (raw traces: tens of MB)
 done
 # the default run: stdout = the compact contract line (what the driver parses), --detail-out = the full result dict
