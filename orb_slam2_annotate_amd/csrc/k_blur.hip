@@ -56,6 +56,7 @@ struct BlurBatch {
   // pyramid level whose bilinear taps start inside it (ResizeTables::tileGx / tileDy give the ownership)
   LevelViewMut next;
   const uint4* colrec; const uint4* rowrec; const int32_t* tileGx; const int32_t* tileDy;
+  int ablate;  // 0; $ORBFE_BLUR_ABLATE, timing experiments (tools/ablate_blur.sh): 1 no blur stores, 2 no next-level stores, 4 no staging loads, 8 no resize at all
 };
 
 template <int SPEC, int kBW, int kBH, bool RESIZE>
@@ -116,8 +117,8 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };
   constexpr int kParts = kTDW / 4;  // 5 x 16 bytes per tile row
   constexpr int kPieces = (kTH * kParts + 255) / 256;
-  U4u q[kPieces];
-  if (wideCols) {
+  U4u q[kPieces] = {};
+  if (wideCols && !(bb.ablate & 4)) {
     // 16-byte requests (any byte address, profiles/r02_unaligned.txt) and ds_write_b128, 2 staging instructions per thread
     // instead of 6 -- the memory instructions of a wave, not the bytes, are what the texture addresser meters; top /
     // bottom tiles reflect the row
@@ -199,33 +200,45 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
     //      columns, scale >= 1; ~14 x 54 at 1.2); the items are numbered flat, row-major, so the 256 threads stay busy
     //      (a (group, row slot) thread grid ran 73 % full).  The taps are read from LDS: the level is fetched from
     //      memory once for blur and resize together ----
-    const int nItems = s_nG * (s_d1 - s_d0);
+    // Thread = (column group g, row slot): g and everything that depends on it alone -- the group's column record (4 v_perm
+    // selectors, 4 coefficient pairs), its window in the tile, the store column -- are fixed for the thread; a trip of the loop
+    // moves rowsPerPass = 256 / nG output rows down (round 3 numbered the items flat, i -> (i / nG, i % nG), and paid the
+    // division, three 16-byte record reads and three 64-bit multiply-adds of index arithmetic per item: 75 VALU per 4 pixels,
+    // now 58).  256 - nG * rowsPerPass < nG threads idle (nG = 13, 14: 9, 4).
+    const int nG = s_nG, nRows = s_d1 - s_d0;
     uint8_t* Nf = bb.next.base + (size_t)f * bb.next.frameStride;
-    const uint32_t invG = 65536u / (uint32_t)(s_nG > 0 ? s_nG : 1) + 1u;  // exact i / nG for i < 4096 (nG <= 16)
-    for (int i = tid; i < nItems; i += 256) {
-      const int r = (int)(((uint32_t)i * invG) >> 16), g = i - r * s_nG;
-      const int dy = s_d0 + r;
-      const uint4 s4 = s_col[3 * g], a4 = s_col[3 * g + 1];
-      const int wofs = (int)s_col[3 * g + 2].x - (bx - 4);  // window start, tile-local byte column (>= 4)
-      const uint32_t mis = (uint32_t)wofs & 3u;
-      const uint32_t* tw = &tin[wofs >> 2];
-      const uint32_t sel[4] = {s4.x, s4.y, s4.z, s4.w}, al[4] = {a4.x, a4.y, a4.z, a4.w};
-      const uint4 rr = s_row[r];  // source rows r0, r1 (clamped), b0 << 16, b1 << 16
-      const uint32_t* pa = tw + ((int)rr.x - (by - 3)) * kTDW;
-      const uint32_t* pb = tw + ((int)rr.y - (by - 3)) * kTDW;
-      const uint32_t a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
-      const uint32_t loA = __builtin_amdgcn_alignbyte(a1, a0, mis), hiA = __builtin_amdgcn_alignbyte(a2, a1, mis);
-      const uint32_t loB = __builtin_amdgcn_alignbyte(b1, b0, mis), hiB = __builtin_amdgcn_alignbyte(b2, b1, mis);
-      uint32_t packed = 0;
+    if (nG > 0 && nRows > 0 && !(bb.ablate & 8)) {
+      const uint32_t invG = 65536u / (uint32_t)nG + 1u;      // exact t / nG for t < 4096 (nG <= 16)
+      const int rowsPerPass = (int)((256u * invG) >> 16);   // 256 / nG (block-uniform)
+      int r = (int)(((uint32_t)tid * invG) >> 16);
+      const int g = tid - r * nG;
+      if (r < rowsPerPass) {
+        const uint4 s4 = s_col[3 * g], a4 = s_col[3 * g + 1];
+        const int wofs = (int)s_col[3 * g + 2].x - (bx - 4);  // window start, tile-local byte column (>= 4)
+        const uint32_t mis = (uint32_t)wofs & 3u;
+        const uint32_t* tw = &tin[wofs >> 2];
+        const uint32_t sel[4] = {s4.x, s4.y, s4.z, s4.w}, al[4] = {a4.x, a4.y, a4.z, a4.w};
+        // block-uniform frame base (scalar) + 32-bit lane offset, stepped by rowsPerPass rows per trip
+        uint32_t off = (uint32_t)(s_d0 + r) * (uint32_t)bb.next.pitch + 4u * (uint32_t)(s_g0 + g);  // owned levels: pitch % 64 == 0, in-row
+        const uint32_t offStep = (uint32_t)rowsPerPass * (uint32_t)bb.next.pitch;
+        for (; r < nRows; r += rowsPerPass, off += offStep) {
+          const uint4 rr = s_row[r];  // source rows r0, r1 (clamped), b0 << 16, b1 << 16
+          const uint32_t* pa = tw + __mul24((int)rr.x - (by - 3), kTDW);  // (rows of the tile: 24-bit multiply, not the 64-bit mad)
+          const uint32_t* pb = tw + __mul24((int)rr.y - (by - 3), kTDW);
+          const uint32_t a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
+          const uint32_t loA = __builtin_amdgcn_alignbyte(a1, a0, mis), hiA = __builtin_amdgcn_alignbyte(a2, a1, mis);
+          const uint32_t loB = __builtin_amdgcn_alignbyte(b1, b0, mis), hiB = __builtin_amdgcn_alignbyte(b2, b1, mis);
+          uint32_t packed = 0;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t hA = __builtin_amdgcn_udot2(as_u2(__builtin_amdgcn_perm(hiA, loA, sel[k])), as_u2(al[k]), 0u, false) >> 4;
-        const uint32_t hB = __builtin_amdgcn_udot2(as_u2(__builtin_amdgcn_perm(hiB, loB, sel[k])), as_u2(al[k]), 0u, false) >> 4;
-        const uint32_t v = (__umulhi(hA, rr.z) + __umulhi(hB, rr.w) + 2u) >> 2;
-        packed |= v << (8 * k);
+          for (int k = 0; k < 4; k++) {
+            const uint32_t hA = __builtin_amdgcn_udot2(as_u2(__builtin_amdgcn_perm(hiA, loA, sel[k])), as_u2(al[k]), 0u, false) >> 4;
+            const uint32_t hB = __builtin_amdgcn_udot2(as_u2(__builtin_amdgcn_perm(hiB, loB, sel[k])), as_u2(al[k]), 0u, false) >> 4;
+            const uint32_t v = (__umulhi(hA, rr.z) + __umulhi(hB, rr.w) + 2u) >> 2;
+            packed |= v << (8 * k);
+          }
+          if (!(bb.ablate & 2) || packed == 0x12345678u) *reinterpret_cast<uint32_t*>(Nf + off) = packed;
+        }
       }
-      // block-uniform frame base (scalar) + 32-bit lane offset: no 64-bit multiply-add per item
-      *reinterpret_cast<uint32_t*>(Nf + ((uint32_t)dy * (uint32_t)bb.next.pitch + 4u * (uint32_t)(s_g0 + g))) = packed;  // owned levels: pitch % 64 == 0, in-row
     }
   }
   // ---- 2. vertical pass: a thread owns 4 adjacent columns x kVR output rows; the kVR + 6 source dwords are
@@ -307,7 +320,8 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
     const bool colIn = bx + 4 * gx < dst.w;
     for (int row = tid / kGX; row < rowsValid; row += kHR, off += (uint32_t)kHR * (uint32_t)dst.pitch, vp += kHR * kVDW) {
       if (!colIn) continue;
-      *reinterpret_cast<uint32_t*>(D + off) = hgroup(vp[0], vp[1], vp[2], SPEC == 2 && bx + 4 * gx < (dst.w & ~3));
+      const uint32_t hv = hgroup(vp[0], vp[1], vp[2], SPEC == 2 && bx + 4 * gx < (dst.w & ~3));
+      if (!(bb.ablate & 1) || hv == 0x12345678u) *reinterpret_cast<uint32_t*>(D + off) = hv;
     }
   }
 }
@@ -369,6 +383,8 @@ void launch_blur7_resize(hipStream_t s, LevelView src, LevelViewMut dst, LevelVi
   bb.rowrec = reinterpret_cast<const uint4*>(d_rowrec);
   bb.tileGx = d_tileGx;
   bb.tileDy = d_tileDy;
+  static const int kAblate = getenv("ORBFE_BLUR_ABLATE") ? atoi(getenv("ORBFE_BLUR_ABLATE")) : 0;
+  bb.ablate = kAblate;
   const dim3 grid((total + 7u) / 8u * 8u);
   if (spec == kBlurSpecCv2Scalar) hipLaunchKernelGGL((k_blur7<1, 64, 64, true>), grid, dim3(256), 0, s, bb);
   else if (spec == kBlurSpecCv2Sse2) hipLaunchKernelGGL((k_blur7<2, 64, 64, true>), grid, dim3(256), 0, s, bb);
