@@ -69,7 +69,7 @@ def main():
                 sys.exit(1)
             n_st += 1
         if len(kL) > 4 and len(kR) > 4:
-            n_nodes = int(rng.choice([1, 2, 5, 20, 100, 150]))
+            n_nodes = int(rng.choice([1, 2, 5, 8, 12, 20, 100, 150]))  # round 4: 8 / 12 / 20 land in the 2- and 4-slot register paths
             n1, n2 = nodes_of(dL, rng, n_nodes), nodes_of(dR, rng, n_nodes)
             has1 = (rng.random(len(kL)) < rng.uniform(0.3, 1.0)).astype(np.uint8)
             has2 = (rng.random(len(kR)) < rng.uniform(0.3, 1.0)).astype(np.uint8)
@@ -111,9 +111,26 @@ def main():
             if any(int(cnt[k]) != tr_n or not np.array_equal(mt[k], tr) for k in range(3)):
                 print("TRIANGULATION MULTI MISMATCH", cfg, f"nodes={n_nodes} only_stereo={only} ori={ori}")
                 sys.exit(1)
+            # round 4: one frame / key frame against K candidates in ONE call, and a frame built from the extractor's own
+            # device records (orbfe_frame_from_extractor; eR's output block still holds kR / dR)
+            from orb_slam2_annotate_amd.matcher import ResidentFrame
+            X2 = ResidentFrame(amd.FrameView(kR["x"], kR["y"], kR["octave"], dR, b, angle=kR["angle"], u_right=urR), None, extractor=eR, frame=0)
+            X2.set_featvec(fv2)
+            K = int(rng.integers(1, 5))
+            cands = [R2, X2, R2, X2][:K]
+            cnt, mm = m.SearchByBoWKFMulti(R1, has1, cands, [has2] * K)
+            if any(int(cnt[k]) != rn2 or not np.array_equal(mm[k], r2) for k in range(K)):
+                print("BOW MULTI (KF, KF_k) MISMATCH", cfg, f"nodes={n_nodes} nnratio={nnr} ori={ori} K={K}")
+                sys.exit(1)
+            rn3, r3 = orc.search_by_bow(dR, has2, kR["angle"], orc.FeatVec(n2), dL, kL["angle"], orc.FeatVec(n1), nnr, ori)
+            cnt, mm = m.SearchByBoWMulti(cands, [has2] * K, R1)
+            if any(int(cnt[k]) != rn3 or not np.array_equal(mm[k], r3) for k in range(K)):
+                print("BOW MULTI (KF_k, F) MISMATCH", cfg, f"nodes={n_nodes} nnratio={nnr} ori={ori} K={K}")
+                sys.exit(1)
+            X2.close()
             R1.close()
             R2.close()
-            n_bow += 5
+            n_bow += 5 + 2 * K
         if time.time() - last > 50:
             print(f"... {n_cases} frames pairs, {n_st} stereo, {n_bow} bow searches, {time.time() - t0:.0f} s", flush=True)
             last = time.time()
