@@ -345,7 +345,13 @@ void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d
                         int32_t* d_nOut, int concurrentLaunches) {
   if (nFrames <= 0 || a.kpSlotsPerFrame <= 0) return;
   const bool latencyForm = nFrames <= 8;
-  const int kpb = latencyForm ? 16 : 64;
+  // keypoints per workgroup: 16 for a few frames; 64 for batches ($ORBFE_ORIENT_KPB = 128 | 256: measured, not faster).  Phase 2 --
+  // fastAtan2 and the double-precision sincos, ~600 instructions -- runs one LANE per keypoint of the wave: with 16 keypoints
+  // per wave three quarters of its lanes idle, 64 per wave (256 per workgroup) fill them and save 15 % of the kernel's VALU
+  // instructions -- but the wave's serial chain is four times as long: KITTI 100.2 k (64) / 98.4 k (128) / 95.9 k (256), TUM
+  // 362.7 k / 363.9 k / 355.2 k in a same-box A/B (round 4).  Instruction count is not what this kernel waits for.
+  static const int kKpbEnv = getenv("ORBFE_ORIENT_KPB") ? atoi(getenv("ORBFE_ORIENT_KPB")) : 64;
+  const int kpb = latencyForm ? 16 : (kKpbEnv == 256 ? 256 : (kKpbEnv == 128 ? 128 : 64));
   const int blocksPerFrame = (a.kpSlotsPerFrame + kpb - 1) / kpb;
   const unsigned total = (unsigned)blocksPerFrame * (unsigned)nFrames;
   const uint32_t blocksMagic = udiv_magic_multiplier((uint32_t)blocksPerFrame);
@@ -365,13 +371,16 @@ void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d
     // frames with many keypoints on a large pyramid (1241 x 376 / 2000 features: 32 workgroups and 2.9 MB of pyramid +
     // blurred levels per frame) want ONE frame's workgroups per XCD in flight: 1 per CU measured 100.1 k vs 94.7 k
     // stereo frames/s on 8 streams, while 640 x 480 / 1000 features lose 5 % that way (same-box A/B)
-    if (blocksPerFrame >= 24 && concurrentLaunches >= 8) kGridPerCu = 1;
+    if (a.kpSlotsPerFrame >= 24 * 64 && concurrentLaunches >= 8) kGridPerCu = 1;
     // a launch that has the device to itself (one stream): no cap -- round 3, with the barrier-free kernel: 1.37 vs 1.59 ms
     // per 1024 KITTI frames, 2.89 vs 3.45 per 4096 TUM frames, 1.76 vs 1.97 per 2048 EuRoC frames against 4 per CU
     if (concurrentLaunches <= 1) kGridPerCu = 0;
   }
   // Round 2 measured the wider form <64, 8, 4> (twice the row / patch loads in flight per wave, 106 VGPRs, same 4
-  // workgroups per CU): stage 3.36 vs 3.38 ms per 4096 VGA frames, pipeline unchanged, so <64, 4, 2> stays.
+  // workgroups per CU): stage 3.36 vs 3.38 ms per 4096 VGA frames, pipeline unchanged; round 4 again, with <64, 16, 8> too, in
+  // the one-workgroup-per-CU configuration of the KITTI pipeline: 100.9 k (4, 2) / 99.5 k (8, 4) / 91.6 k (16, 8) stereo
+  // frames per second -- the registers and LDS the wide forms hold cost the co-running kernels more than the loads in
+  // flight gain.  <.., 4, 2> stays.
   const unsigned full = (total + 7u) / 8u * 8u;
   static const int kAblate = getenv("ORBFE_ORIENT_ABLATE") ? atoi(getenv("ORBFE_ORIENT_ABLATE")) : 0;
   static const int kInterleave = getenv("ORBFE_ORIENT_INTERLEAVE") ? atoi(getenv("ORBFE_ORIENT_INTERLEAVE")) : 1;
@@ -381,16 +390,13 @@ void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d
   } else {
     unsigned grid = full;
     if (kGridPerCu > 0 && (unsigned)kGridPerCu * 256u < full) grid = (unsigned)kGridPerCu * 256u;  // 256 CUs, multiple of 8
-    static const int kWide = getenv("ORBFE_ORIENT_WIDE") ? atoi(getenv("ORBFE_ORIENT_WIDE")) : 0;
-    if (kWide == 2)
-      hipLaunchKernelGGL((k_orient_desc<64, 16, 8>), dim3(grid), dim3(256), kPad, s, a, d_levelKp, d_levelCount,
-                         d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic, kAblate, kInterleave);
-    else if (kWide == 1)
-      hipLaunchKernelGGL((k_orient_desc<64, 8, 4>), dim3(grid), dim3(256), kPad, s, a, d_levelKp, d_levelCount,
-                         d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic, kAblate, kInterleave);
-    else
-    hipLaunchKernelGGL((k_orient_desc<64, 4, 2>), dim3(grid), dim3(256), kPad, s, a, d_levelKp, d_levelCount,
-                       d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic, kAblate, kInterleave);
+#define ORBFE_LAUNCH_ORIENT(KPB)                                                                                           \
+  hipLaunchKernelGGL((k_orient_desc<KPB, 4, 2>), dim3(grid), dim3(256), kPad, s, a, d_levelKp, d_levelCount, d_patternF,    \
+                     d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic, kAblate, kInterleave)
+    if (kpb == 256) ORBFE_LAUNCH_ORIENT(256);
+    else if (kpb == 128) ORBFE_LAUNCH_ORIENT(128);
+    else ORBFE_LAUNCH_ORIENT(64);
+#undef ORBFE_LAUNCH_ORIENT
   }
 }
 
