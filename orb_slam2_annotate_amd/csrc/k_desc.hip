@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
   __shared__ __attribute__((aligned(16))) uint32_t s_patch[4 * kUD * kPatchRows * kPatchDw];  // per wave: kUD patches
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  ORBFE_LATENCY_KERNEL_PRIO();
   // XCD-aware work mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, so the workgroups with
   // blockIdx % 8 == x walk the contiguous chunk x of the work items (work = frame * blocksPerFrame + slot chunk):
   // all workgroups of a frame run on ONE XCD, back to back, and that L2 fetches every line of the frame's pyramid

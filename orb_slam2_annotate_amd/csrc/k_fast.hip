@@ -652,6 +652,7 @@ __global__ __launch_bounds__(256) void k_gather_candidates(const CellDesc* __res
                                                            int32_t* __restrict__ cellPrefix,
                                                            int nlevels) {
   __shared__ int waveTot[4];
+  ORBFE_LATENCY_KERNEL_PRIO();
   // grid (nFrames, nlevels): consecutive workgroups -- which go to consecutive XCDs -- are consecutive frames of one
   // level.  With the level in blockIdx.x, level l of every frame ran on XCD l (8 levels, 8 XCDs) and the XCD with
   // the level-0 items decided the duration.

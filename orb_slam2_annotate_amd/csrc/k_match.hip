@@ -632,6 +632,7 @@ __global__ __launch_bounds__(256) void k_stereo_bucket(const float* __restrict__
                                                        int32_t* __restrict__ sortedBase, float4* __restrict__ recBase) {
   extern __shared__ int cnt[];  // rows + 1
   __shared__ int waveTot[4];
+  ORBFE_LATENCY_KERNEL_PRIO();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = blockIdx.x;
   const float* kpR = nArr ? kpBase + (size_t)(2 * p + 1) * capacity * 7 : kpBase;
   int Nr = nArr ? nArr[2 * p + 1] : nFixed;
@@ -697,6 +698,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a) {
 // Batched, device-resident form: pair p = frames (2p, 2p+1) of one extractor batch; the
 // keypoint counts are read from device memory (d_n of orbfe_extract_batch_device).
 __global__ __launch_bounds__(256) void k_stereo_match_batch(const StereoArgs a, const StereoBatch b) {
+  ORBFE_LATENCY_KERNEL_PRIO();
   __shared__ StereoLds lv;
   stereo_stage_views(a, lv);
   const int lane = threadIdx.x & 63;
@@ -733,6 +735,7 @@ __global__ __launch_bounds__(256) void k_stereo_median_cut(int N, const int32_t*
   __shared__ int hist[256];
   __shared__ int sel[3];  // hi bin, remaining k, total
   __shared__ int waveTot[4];
+  ORBFE_LATENCY_KERNEL_PRIO();
   const int tid = threadIdx.x;
   hist[tid] = 0;
   if (tid == 0) sel[2] = 0;

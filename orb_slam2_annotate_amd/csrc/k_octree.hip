@@ -564,6 +564,7 @@ __global__ __launch_bounds__(256) void k_octree(OctreeArgs a) {
   // with the level-0 items decided the duration: stage 1.15 -> 0.70 ms per 1024 KITTI frames, 2.05 -> 1.43 ms per 4096
   // VGA frames from the ordering alone.  With gridDim.x below the item count ($ORBFE_OCTREE_GRID workgroups per CU) the
   // grid size, not the LDS, bounds the workgroups in flight, and the rest of each CU stays free for the other streams.
+  ORBFE_LATENCY_KERNEL_PRIO();
   const int nItems = a.nlevels * a.nFrames;
   for (int it = blockIdx.x; it < nItems; it += gridDim.x) {
     const int l = it / a.nFrames, f = it - l * a.nFrames;

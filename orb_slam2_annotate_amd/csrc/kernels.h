@@ -18,6 +18,20 @@ __device__ __forceinline__ uint32_t udiv_magic(uint32_t n, uint32_t d, uint32_t 
   return q;
 }
 #endif
+// Wave issue priority of the latency-bound kernels (round 4).  The pipeline co-runs VALU-bound kernels (FAST, blur: 5-8
+// waves per SIMD, 0.55-0.87 VALU busy) with kernels that mostly wait -- k_orient_desc with ONE wave per SIMD, the octree, the
+// stereo matcher.  At equal priority the lone waiting wave queues for issue behind every busy wave each time it wakes up, its
+// kernel runs several times longer than alone (k_orient_desc: 170 us alone, 600-900 us in the pipeline) and holds its stream's
+// chain and hardware queue for that long.  s_setprio 3 lets such a wave issue as soon as it is ready: it has few instructions to
+// issue, so the busy kernels lose little.  -DORBFE_SETPRIO=0 builds without (same-box A/B in DESIGN.md 4).
+#ifndef ORBFE_SETPRIO
+#define ORBFE_SETPRIO 1
+#endif
+#if ORBFE_SETPRIO
+#define ORBFE_LATENCY_KERNEL_PRIO() __builtin_amdgcn_s_setprio(3)
+#else
+#define ORBFE_LATENCY_KERNEL_PRIO() ((void)0)
+#endif
 inline uint32_t udiv_magic_multiplier(uint32_t d) {
   return d <= 1 ? 0xffffffffu : (uint32_t)((1ULL << 32) / d);  // d = 1: umulhi gives n-1, the compare adds the 1
 }
