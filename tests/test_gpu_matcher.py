@@ -593,6 +593,45 @@ def test_frame_from_extractor_and_device(amd):
         r_.close()
 
 
+def test_resident_frame_used_on_another_thread_right_after_the_upload(amd):
+    """orbfe_frame_upload / orbfe_frame_from_extractor return WITHOUT waiting for the device (round 4): the slab is filled and
+    the grid built on the uploading thread's stream.  A search that uses the frame at once on ANOTHER thread (its own
+    stream) must be ordered behind that build by the frame's event -- 40 frames uploaded and consumed back to back, slabs
+    recycled through the pool in between, every result equal to the oracle's."""
+    from concurrent.futures import ThreadPoolExecutor
+    from orb_slam2_annotate_amd.matcher import ResidentFrame
+    k1, d1, k2, d2 = _two_frames(amd, 34)
+    n1, n2 = _nodes(d1, 13, 60), _nodes(d2, 13, 60)
+    rng = np.random.default_rng(34)
+    has1 = (rng.random(len(k1)) < 0.7).astype(np.uint8)
+    rn, r = orc.search_by_bow(d1, has1, k1["angle"], orc.FeatVec(n1), d2, k2["angle"], orc.FeatVec(n2), 0.7, True)
+    e = amd.ORBextractor(1000, 1.2, 8, 20, 7)
+    fr = synth.render_sequence(34, 2, 640, 480, step=3.0)
+    kx, dx = e(fr[1])  # the handle's output block = frame 2's records (same extractor settings as _two_frames)
+    assert np.array_equal(dx, d2)
+    v2 = amd.FrameView(k2["x"], k2["y"], k2["octave"], d2, (0.0, 640.0, 0.0, 480.0), angle=k2["angle"])
+    fv2 = amd.FeatureVector.from_node_of_feature(n2)
+    R1 = _resident(amd, k1, d1, n1)
+    m = amd.ORBmatcher(0.7, True)
+    qx = rng.uniform(0, 640, 64).astype(np.float32)
+    qy = rng.uniform(0, 480, 64).astype(np.float32)
+    qr = rng.uniform(5, 50, 64).astype(np.float32)
+    area_ref = [a.tolist() for a in v2.GetFeaturesInArea(qx, qy, qr)]
+
+    def consume(R):
+        gn, g = m.SearchByBoWResident(R1, has1, R)
+        area = [a.tolist() for a in R.GetFeaturesInArea(qx, qy, qr)]
+        return gn == rn and np.array_equal(g, r) and area == area_ref
+
+    with ThreadPoolExecutor(2) as pool:
+        for i in range(40):
+            R = v2.upload(fv2) if i % 2 == 0 else ResidentFrame(v2, fv2, extractor=e, frame=0)
+            ok = pool.submit(consume, R).result()  # used on a worker thread's stream right after the asynchronous build
+            R.close()                              # the slab goes back to the pool and is reused by the next upload
+            assert ok, i
+    R1.close()
+
+
 @pytest.mark.parametrize("only_stereo,ori", [(False, True), (True, False)])
 def test_search_for_triangulation_multi(amd, only_stereo, ori):
     """One key frame against K neighbours in ONE call (LocalMapping::CreateNewMapPoints, src/LocalMapping.cc:283-315): every
