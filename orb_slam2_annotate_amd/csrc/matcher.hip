@@ -482,6 +482,12 @@ void frames_settle() {  // call after the stream of the call has been synchronis
   for (const orbfe_frame* f : t_unsettled) f->settled.store(true, std::memory_order_release);
   t_unsettled.clear();
 }
+// an entry point that returns early (a HIP error between frame_use and its synchronisation) must not leave frames on the
+// list: they could be released before this thread's next call settles -- and writes to -- them
+struct UnsettledScope {
+  UnsettledScope() { t_unsettled.clear(); }
+  ~UnsettledScope() { t_unsettled.clear(); }
+};
 }  // namespace
 
 extern "C" void orbfe_frame_release(orbfe_frame* f) {
@@ -713,6 +719,7 @@ extern "C" int orbfe_frame_set_featvec(orbfe_frame* f, const orbfe_featvec* fv) 
 //      the result arrays travel ----
 static int bow_resident(const orbfe_frame* k1, const uint8_t* has_mp1, const orbfe_frame* k2, const uint8_t* has_mp2,
                         float nnratio, int check_ori, int kfkf, int32_t* match) {
+  UnsettledScope unsettledScope;
   if (!k1 || !k2 || !match) return mfail(ORBFE_ERR_INVALID, "search_by_bow_resident: NULL argument");
   if (k1->device != k2->device) return mfail(ORBFE_ERR_INVALID, "search_by_bow_resident: frames on different devices");
   const int n1 = k1->n, n2 = k2->n, nOut = kfkf ? n1 : n2;
@@ -777,6 +784,7 @@ extern "C" int orbfe_search_by_bow_kf_resident(const orbfe_frame* kf1, const uin
 static int bow_multi(const orbfe_frame* one, const uint8_t* has_mp_one, int K, const orbfe_frame* const* many,
                      const uint8_t* const* has_mp_k, float nnratio, int check_ori, int kfkf, int32_t* match,
                      int32_t* n_matches) {
+  UnsettledScope unsettledScope;
   if (!one || K < 0 || (K > 0 && (!many || !has_mp_k || !match || !n_matches)))
     return mfail(ORBFE_ERR_INVALID, "search_by_bow_multi: bad argument");
   const int nOut = one->n;
@@ -876,6 +884,7 @@ extern "C" int orbfe_search_for_triangulation_multi(const orbfe_frame* kf1, cons
                                                     const float* scale_factors2, const float* level_sigma2_2,
                                                     int n_levels2, int only_stereo, int check_orientation,
                                                     int32_t* match12, int32_t* n_matches) {
+  UnsettledScope unsettledScope;
   if (!kf1 || n_neighbours < 0 || (n_neighbours > 0 && (!kf2 || !has_mp2 || !F12 || !ex || !ey || !match12 || !n_matches)) ||
       !scale_factors2 || !level_sigma2_2 || n_levels2 <= 0 || n_levels2 > ORBFE_MAX_LEVELS)
     return mfail(ORBFE_ERR_INVALID, "search_for_triangulation_multi: bad argument");
@@ -1112,6 +1121,7 @@ struct WindowJob {
 // Upload frames (unless resident: keypoint arrays, descriptors and grid are on the device already) + queries, build the
 // grids, search every window; grows K until every list fits.
 int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
+  UnsettledScope unsettledScope;
   int K = K0 < 8 ? 8 : K0;
   struct Lay { size_t oX, oY, oOct, oUr, oDesc, oQx, oQy, oQr, oQmin, oQmax, oQact, oQur, oQdesc, oOut, oGur, oSig; bool withDesc, withUr, res; int frameOf; };
   std::vector<Lay> lay((size_t)nJobs);
