@@ -7,6 +7,9 @@ this script does it itself: with `--gpus N` and no WORLD_SIZE in the environment
 fresh `python bench.py` children (one per GPU, RCCL rendezvous on 127.0.0.1) BEFORE anything touches
 the GPU, relays rank 0's JSON line and exits non-zero if any rank failed.
 
+torch.distributed is initialised at the FIRST collective (LazyDist), after the extractor's HIP streams exist: a RCCL
+communicator created before them shifts their hardware-queue binding and costs every rank 11-15 %.
+
 A "step" is one pass of the hot path over the rank's resident batch.  Frames / stereo pairs are
 independent, so ranks share nothing: the only collectives are the barriers around the timed region
 and the MAX(elapsed) / SUM(frames) reductions of the report (RCCL) -- weak scaling.
@@ -774,6 +777,45 @@ def e2e_rate(g, args):
                     "host keypoints + descriptors (whole capacity-sized output blocks come back); oracle-checked on 3 images"}
 
 
+class LazyDist:
+    """torch.distributed, initialised at the FIRST collective instead of at start-up.  Round 4 measured that a live RCCL
+    communicator in the process costs the single-GPU pipeline 11 % when it is created BEFORE the extractor's HIP streams
+    (104.0 k -> 92.5 k stereo frames/s; gloo: no effect; tools/dist_ab.sh): the first collective of a workload is the
+    barrier in front of its timed region, i.e. after the warm-up passes have created every sub-batch stream."""
+
+    def __init__(self, dist, backend, rank, world, device, eager=False):
+        self.dist, self.backend, self.rank, self.world, self.device, self.up = dist, backend, rank, world, device, False
+        if eager:
+            self._ensure()
+
+    def _ensure(self):
+        if self.up:
+            return
+        if self.backend == "nccl":
+            self.dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.device)
+        else:
+            self.dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+        self.up = True
+
+    @property
+    def ReduceOp(self):
+        return self.dist.ReduceOp
+
+    def barrier(self):
+        self._ensure()
+        self.dist.barrier()
+
+    def all_reduce(self, t, op=None):
+        self._ensure()
+        self.dist.all_reduce(t, op=op)
+
+    def shutdown(self):
+        if self.up:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+            self.up = False
+
+
 def reduce_report(dt, units, torch, dist, use_dist, dev):
     if not use_dist:
         return dt, units
@@ -1036,6 +1078,8 @@ def main():
     ap.add_argument("--seq-scale", type=float, default=1.0, help="kitti_seq: scale factor on the sequence lengths")
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for 1 rank")
+    ap.add_argument("--eager-dist", action="store_true", help="create the process group at start-up (rounds 1-3) instead of at the first "
+                    "collective, i.e. after the extractor's streams exist (LazyDist: RCCL created first costs the pipeline 11 %%)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--full-line", action="store_true", help="print the FULL result dict as the stdout line (tens of KB: stage tables, "
                     "CPU variants, e2e, latency rows) instead of the compact contract line; what the tools/ scripts parse")
@@ -1089,10 +1133,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)  # before the process group: RCCL binds the communicator to the current device
     if use_dist:
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+        dist = LazyDist(dist, args.dist_backend, rank, world, torch.device("cuda", local_rank), eager=args.eager_dist)
 
     voc_arrays = None
     if "euroc" in names or "euroc_stereo" in names:
@@ -1153,8 +1194,7 @@ def main():
                                   "rows": rows}
             emit(out, args)
     if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        dist.shutdown()
 
 
 if __name__ == "__main__":

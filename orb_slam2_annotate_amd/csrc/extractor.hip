@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -194,12 +195,59 @@ void dfree(T** p) {
   *p = nullptr;
 }
 
+// HIP streams of destroyed handles are kept and handed to the next handle that asks for the same role (sub-batch i, the
+// two copy streams).  Two reasons.  (1) hipStreamCreate / Destroy are not free, and a process that makes one handle per
+// workload or per camera re-creates the same streams again and again.  (2) Round 4 measured that the ORDER in which a process
+// creates its streams matters: a HIP stream is bound to one of the GPU_MAX_HW_QUEUES hardware queues when it is created, and
+// a library that creates streams of its own in between -- RCCL, when torch.distributed is initialised -- shifts that
+// binding for every stream created after it: the 8-stream KITTI pipeline ran 11 % slower with the communicator created
+// first (104.0 k -> 92.5 k stereo frames/s; bench.py LazyDist, tools/dist_ab.sh).  A recycled stream keeps its queue.
+namespace {
+struct StreamPool {
+  std::mutex m;
+  struct Item { int device, role; hipStream_t s; };
+  std::vector<Item> items;
+};
+StreamPool g_streamPool;
+constexpr int kRoleH2D = 1000, kRoleD2H = 1001;
+hipError_t stream_get(int device, int role, hipStream_t* s) {
+  {
+    std::lock_guard<std::mutex> lk(g_streamPool.m);
+    auto& v = g_streamPool.items;
+    for (size_t i = 0; i < v.size(); i++)
+      if (v[i].device == device && v[i].role == role) { *s = v[i].s; v.erase(v.begin() + (long)i); return hipSuccess; }
+  }
+  // $ORBFE_STREAM_PRIORITY = high | low: the handle's streams in a priority class of their own (its own set of hardware
+  // queues in the HIP runtime), so that streams other libraries create at normal priority cannot shift their binding
+  static const int kPrioEnv = [] {
+    const char* v = getenv("ORBFE_STREAM_PRIORITY");
+    return !v ? 0 : (std::string(v) == "high" ? 1 : (std::string(v) == "low" ? 2 : 0));
+  }();
+  if (kPrioEnv) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+      return hipStreamCreateWithPriority(s, hipStreamNonBlocking, kPrioEnv == 1 ? greatest : least);
+    (void)hipGetLastError();
+  }
+  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+void stream_put(int device, int role, hipStream_t s) {
+  if (!s) return;
+  (void)hipStreamSynchronize(s);
+  {
+    std::lock_guard<std::mutex> lk(g_streamPool.m);
+    if (g_streamPool.items.size() < 256) { g_streamPool.items.push_back({device, role, s}); return; }
+  }
+  (void)hipStreamDestroy(s);
+}
+}  // namespace
+
 // Streams and events of sub-batches [e->subsReady, n) are created on first use: a handle for one live camera (1 stream)
 // costs 1 stream + 136 events to create instead of 32 streams + ~4 300 events.
 int ensure_subs(orbfe_extractor* e, int n) {
   if (n > orbfe_extractor::kMaxStreams) n = orbfe_extractor::kMaxStreams;
   for (int i = e->subsReady; i < n; i++) {
-    if (i > 0 && !e->extra[i - 1]) HIPCHK(hipStreamCreateWithFlags(&e->extra[i - 1], hipStreamNonBlocking));
+    if (i > 0 && !e->extra[i - 1]) HIPCHK(stream_get(e->device, i, &e->extra[i - 1]));
     HIPCHK(hipEventCreateWithFlags(&e->evStat[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->evChunkDone[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->evPyr[i], hipEventDisableTiming));
@@ -751,7 +799,7 @@ extern "C" int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlev
   if (!e) return fail(ORBFE_ERR_NOMEM, "out of memory");
   e->device = device;
   e->tab.init(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST);
-  hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  hipError_t err = stream_get(device, 0, &e->stream);
   if (const char* env = getenv("ORBFE_COPY_UNALIGNED")) e->copyUnaligned = atoi(env) != 0;
   if (const char* env = getenv("ORBFE_FAST_MODE")) {
     const std::string v(env);
@@ -807,7 +855,7 @@ extern "C" void orbfe_extractor_destroy(orbfe_extractor* e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (int i = 0; i < orbfe_extractor::kMaxStreams - 1; i++)
-    if (e->extra[i]) { (void)hipStreamSynchronize(e->extra[i]); (void)hipStreamDestroy(e->extra[i]); }
+    if (e->extra[i]) stream_put(e->device, i + 1, e->extra[i]);
   free_geometry(e);
   free_workspace(e);
   free_outputs(e);
@@ -823,8 +871,8 @@ extern "C" void orbfe_extractor_destroy(orbfe_extractor* e) {
     if (e->evComp[i]) (void)hipEventDestroy(e->evComp[i]);
     if (e->evOutDone[i]) (void)hipEventDestroy(e->evOutDone[i]);
   }
-  if (e->sH2D) { (void)hipStreamSynchronize(e->sH2D); (void)hipStreamDestroy(e->sH2D); }
-  if (e->sD2H) { (void)hipStreamSynchronize(e->sD2H); (void)hipStreamDestroy(e->sD2H); }
+  stream_put(e->device, kRoleH2D, e->sH2D);
+  stream_put(e->device, kRoleD2H, e->sD2H);
   dfree(&e->d_patternF);
   dfree(&e->d_stereoSad);
   dfree(&e->d_scaleTab);
@@ -848,7 +896,7 @@ extern "C" void orbfe_extractor_destroy(orbfe_extractor* e) {
     if (e->evTail[i]) (void)hipEventDestroy(e->evTail[i]);
   }
   if (e->evConsumerDone) (void)hipEventDestroy(e->evConsumerDone);
-  if (e->stream) (void)hipStreamDestroy(e->stream);
+  stream_put(e->device, 0, e->stream);
   delete e;
 }
 
@@ -1193,8 +1241,8 @@ extern "C" int orbfe_extract_batch_pipelined(orbfe_extractor* e, const uint8_t* 
   if (C > n_frames) C = n_frames;
   if ((rc = ensure_workspace(e, C))) return rc;
   if (!e->sH2D) {
-    HIPCHK(hipStreamCreateWithFlags(&e->sH2D, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&e->sD2H, hipStreamNonBlocking));
+    HIPCHK(stream_get(e->device, kRoleH2D, &e->sH2D));
+    HIPCHK(stream_get(e->device, kRoleD2H, &e->sD2H));
     for (int i = 0; i < 2; i++) {
       HIPCHK(hipEventCreateWithFlags(&e->evIn[i], hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&e->evComp[i], hipEventDisableTiming));
