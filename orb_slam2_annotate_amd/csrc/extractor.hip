@@ -246,6 +246,14 @@ void stream_put(int device, int role, hipStream_t s) {
 // costs 1 stream + 136 events to create instead of 32 streams + ~4 300 events.
 int ensure_subs(orbfe_extractor* e, int n) {
   if (n > orbfe_extractor::kMaxStreams) n = orbfe_extractor::kMaxStreams;
+  // $ORBFE_STREAM_SKEW = k (experiment, tools/skew_ab.sh): k idle streams are created in front of the handle's first extra
+  // stream, shifting the hardware-queue binding of everything created after them -- what a library like RCCL does by accident
+  static const int kSkew = getenv("ORBFE_STREAM_SKEW") ? atoi(getenv("ORBFE_STREAM_SKEW")) : 0;
+  static bool skewed = false;
+  if (kSkew > 0 && !skewed && n > 1) {
+    skewed = true;
+    for (int k = 0; k < kSkew; k++) { hipStream_t dummy; (void)hipStreamCreateWithFlags(&dummy, hipStreamNonBlocking); }
+  }
   for (int i = e->subsReady; i < n; i++) {
     if (i > 0 && !e->extra[i - 1]) HIPCHK(stream_get(e->device, i, &e->extra[i - 1]));
     HIPCHK(hipEventCreateWithFlags(&e->evStat[i], hipEventDisableTiming));
