@@ -629,6 +629,15 @@ int orbfe_search_by_sim3(int device, const orbfe_frame_view *KF1, const orbfe_fr
                          const int32_t *level2, const uint8_t *desc2, float th, int32_t *match12,
                          int32_t *n_found);
 
+/* cv::initUndistortRectifyMap(K, D, R, P.rowRange(0,3).colRange(0,3), cv::Size(cols, rows), CV_32F, M1, M2) as
+ * Examples/Stereo/stereo_euroc.cc:97-98 calls it once at start-up: the two CV_32F maps orbfe_rectifier_create takes, from the
+ * calibration of the settings file (Examples/Stereo/EuRoC.yaml: LEFT.K / LEFT.D / LEFT.R / LEFT.P).  K, R, P: row-major 3 x 3
+ * doubles (R NULL = identity, P NULL = K; pass the first three columns of a 3 x 4 projection); D: n_dist = 0, 4, 5 or 8
+ * coefficients (k1 k2 p1 p2 [k3 [k4 k5 k6]]); map_x / map_y: width * height floats each, written on the host.  Evaluated on the
+ * device, one thread per map row (a row is the reference's sequential running-sum chain in double precision). */
+int orbfe_init_undistort_rectify_map(int device, const double *K, const double *D, int n_dist, const double *R,
+                                     const double *P, int width, int height, float *map_x, float *map_y);
+
 /* cv::remap(im, imRect, M1, M2, cv::INTER_LINEAR) with CV_32F maps and the default constant-0
  * border, 8-bit single channel: the EuRoC rectification of Examples/Stereo/stereo_euroc.cc:136-137
  * (the maps come from cv::initUndistortRectifyMap at :97-98, once, and are handed over here once).

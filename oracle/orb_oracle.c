@@ -1794,6 +1794,62 @@ void orc_undistort_points(const float *xy, int n, const float *K4, const float *
   }
 }
 
+/* ------------------------------------------------------------------ */
+/* cv::initUndistortRectifyMap(K, D, R, P[:3,:3], size, CV_32F, M1, M2) */
+/* as Examples/Stereo/stereo_euroc.cc:97-98 calls it, once at start-up.  */
+/* Restated from the published imgproc/undistort.cpp (scalar path):      */
+/* iR = inv(P * R) by cv::invert's closed 3x3 form, the row-wise         */
+/* incremental _x += ir[0] sums, the rational radial + tangential model  */
+/* in double, (float) at the end.  Parity unpinned like every OpenCV     */
+/* primitive here (an AVX2 build of OpenCV 4.x evaluates the columns in  */
+/* lanes; not modelled).  D: 4, 5 or 8 coefficients (k1 k2 p1 p2 [k3     */
+/* [k4 k5 k6]]); R == NULL: identity; P == NULL: K.  Returns 0 / -1.     */
+/* ------------------------------------------------------------------ */
+int orc_init_undistort_rectify_map(const double *K, const double *D, int nD, const double *R, const double *P, int w,
+                                   int h, float *map_x, float *map_y) {
+  if (!K || w <= 0 || h <= 0 || !map_x || !map_y || !(nD == 0 || nD == 4 || nD == 5 || nD == 8) || (nD > 0 && !D)) return -1;
+  static const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  const double *Rm = R ? R : I3, *Ar = P ? P : K;
+  double M[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double acc = 0;
+      for (int k = 0; k < 3; k++) acc += Ar[3 * i + k] * Rm[3 * k + j];
+      M[3 * i + j] = acc;
+    }
+  /* cv::invert, n == 3: determinant by the first row, adjugate times 1/det */
+  double d = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+  if (d == 0) return -1;
+  d = 1. / d;
+  double ir[9];
+  ir[0] = (M[4] * M[8] - M[5] * M[7]) * d;
+  ir[1] = (M[2] * M[7] - M[1] * M[8]) * d;
+  ir[2] = (M[1] * M[5] - M[2] * M[4]) * d;
+  ir[3] = (M[5] * M[6] - M[3] * M[8]) * d;
+  ir[4] = (M[0] * M[8] - M[2] * M[6]) * d;
+  ir[5] = (M[2] * M[3] - M[0] * M[5]) * d;
+  ir[6] = (M[3] * M[7] - M[4] * M[6]) * d;
+  ir[7] = (M[1] * M[6] - M[0] * M[7]) * d;
+  ir[8] = (M[0] * M[4] - M[1] * M[3]) * d;
+  const double fx = K[0], fy = K[4], u0 = K[2], v0 = K[5];
+  const double k1 = nD > 0 ? D[0] : 0, k2 = nD > 1 ? D[1] : 0, p1 = nD > 2 ? D[2] : 0, p2 = nD > 3 ? D[3] : 0;
+  const double k3 = nD >= 5 ? D[4] : 0, k4 = nD >= 8 ? D[5] : 0, k5 = nD >= 8 ? D[6] : 0, k6 = nD >= 8 ? D[7] : 0;
+  for (int i = 0; i < h; i++) {
+    double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+    for (int j = 0; j < w; j++, _x += ir[0], _y += ir[3], _w += ir[6]) {
+      const double ww = 1. / _w, x = _x * ww, y = _y * ww;
+      const double x2 = x * x, y2 = y * y;
+      const double r2 = x2 + y2, _2xy = 2 * x * y;
+      const double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2);
+      const double xd = x * kr + p1 * _2xy + p2 * (r2 + 2 * x2);
+      const double yd = y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy;
+      map_x[(size_t)i * w + j] = (float)(fx * xd + u0);
+      map_y[(size_t)i * w + j] = (float)(fy * yd + v0);
+    }
+  }
+  return 0;
+}
+
 void orc_image_bounds(int cols, int rows, const float *K4, const float *dist, int n_dist, float *b) {
   if (n_dist > 0 && dist[0] != 0.0) {
     const float in[8] = {0.0f, 0.0f, (float)cols, 0.0f, 0.0f, (float)rows, (float)cols, (float)rows};

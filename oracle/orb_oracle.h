@@ -244,6 +244,8 @@ void orc_remap_linear(const uint8_t *src, int sw, int sh, int sstride, const flo
  * Parity unpinned. */
 void orc_undistort_points(const float *xy, int n, const float *K4, const float *dist, int n_dist, float *out_xy);
 /* Frame::ComputeImageBounds (src/Frame.cc:481-510) -> mnMinX, mnMaxX, mnMinY, mnMaxY */
+int orc_init_undistort_rectify_map(const double *K, const double *D, int nD, const double *R, const double *P, int w,
+                                   int h, float *map_x, float *map_y);
 void orc_image_bounds(int cols, int rows, const float *K4, const float *dist, int n_dist, float *bounds4);
 /* Frame::ComputeStereoFromRGBD (src/Frame.cc:689-713): d = imDepth.at<float>(v,u) with the float
  * coordinates of the DISTORTED keypoint truncated to int; mvuRight = kpU.x - mbf/d for d > 0. */

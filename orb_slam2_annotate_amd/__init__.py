@@ -7,4 +7,4 @@ from .extractor import ORBextractor, gaussian_blur7, resize_linear  # noqa: F401
 from .matcher import ComputeStereoMatches, FeatureVector, FrameView, ORBmatcher, ResidentFrame  # noqa: F401
 from .vocabulary import ORBVocabulary, synthetic_vocabulary_arrays, write_synthetic_vocabulary, write_vocabulary_text  # noqa: F401
 from .ingest import (ComputeDistinctiveDescriptors, ComputeImageBounds, ComputeStereoFromRGBD,  # noqa: F401
-                     Rectifier, UndistortKeyPoints, cvtColorToGray, undistortPoints)  # noqa: F401
+                     Rectifier, UndistortKeyPoints, cvtColorToGray, initUndistortRectifyMap, undistortPoints)  # noqa: F401

@@ -61,7 +61,7 @@ EXPORTS = [
     "orbfe_distinctive_descriptors", "orbfe_features_in_area", "orbfe_search_by_projection",
     "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_keyframe",
     "orbfe_search_by_projection_sim3", "orbfe_search_for_initialization", "orbfe_fuse_search", "orbfe_search_by_sim3",
-    "orbfe_rectifier_create", "orbfe_rectifier_destroy", "orbfe_remap", "orbfe_remap_batch_device", "orbfe_extract_stereo_rectified_batch_device_async",
+    "orbfe_init_undistort_rectify_map", "orbfe_rectifier_create", "orbfe_rectifier_destroy", "orbfe_remap", "orbfe_remap_batch_device", "orbfe_extract_stereo_rectified_batch_device_async",
     "orbfe_undistort_points", "orbfe_undistort_keypoints_batch_device", "orbfe_compute_image_bounds",
     "orbfe_stereo_from_rgbd",
 ]
@@ -184,6 +184,7 @@ def load():
     L.orbfe_frame_from_extractor.argtypes = [vp, ci, fwp, vp, ci, C.POINTER(C.c_void_p)]
     L.orbfe_frame_from_device.argtypes = [ci, vp, vp, fwp, vp, ci, C.POINTER(C.c_void_p)]
     L.orbfe_frame_set_featvec.argtypes = [vp, vp]
+    L.orbfe_init_undistort_rectify_map.argtypes = [ci, vp, vp, ci, vp, vp, ci, ci, vp, vp]
     L.orbfe_rectifier_create.argtypes = [ci, vp, vp, ci, ci, ci, C.POINTER(C.c_void_p)]
     L.orbfe_rectifier_destroy.argtypes = [vp]
     L.orbfe_rectifier_destroy.restype = None

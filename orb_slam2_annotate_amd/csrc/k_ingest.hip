@@ -416,6 +416,75 @@ bool undistort_params(const float* K4, const float* dist, int n_dist, UndistortP
 
 }  // namespace
 
+// cv::initUndistortRectifyMap(K, D, R, P[:3,:3], size, CV_32F, M1, M2) as Examples/Stereo/stereo_euroc.cc:97-98 calls it,
+// once at start-up: the two float maps orbfe_rectifier_create takes.  One THREAD per map row -- the reference walks a row
+// with running sums (_x += ir[0], ...), so a row is a sequential chain in double precision; rows are independent.  No FMA
+// contraction (the build's -ffp-contract=off), IEEE division.
+namespace {
+struct RectifyMapParams { double ir[9], fx, fy, u0, v0, k1, k2, p1, p2, k3, k4, k5, k6; int w, h; };
+__global__ __launch_bounds__(64) void k_init_rectify_map(const RectifyMapParams p, float* __restrict__ mapX, float* __restrict__ mapY) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= p.h) return;
+  double _x = __dadd_rn(__dmul_rn((double)i, p.ir[1]), p.ir[2]), _y = __dadd_rn(__dmul_rn((double)i, p.ir[4]), p.ir[5]),
+         _w = __dadd_rn(__dmul_rn((double)i, p.ir[7]), p.ir[8]);
+  float* mx = mapX + (size_t)i * p.w;
+  float* my = mapY + (size_t)i * p.w;
+  for (int j = 0; j < p.w; j++) {
+    const double ww = __ddiv_rn(1.0, _w), x = __dmul_rn(_x, ww), y = __dmul_rn(_y, ww);
+    const double x2 = __dmul_rn(x, x), y2 = __dmul_rn(y, y);
+    const double r2 = __dadd_rn(x2, y2), _2xy = __dmul_rn(__dmul_rn(2.0, x), y);
+    const double num = __dadd_rn(1.0, __dmul_rn(__dadd_rn(__dmul_rn(__dadd_rn(__dmul_rn(p.k3, r2), p.k2), r2), p.k1), r2));
+    const double den = __dadd_rn(1.0, __dmul_rn(__dadd_rn(__dmul_rn(__dadd_rn(__dmul_rn(p.k6, r2), p.k5), r2), p.k4), r2));
+    const double kr = __ddiv_rn(num, den);
+    const double xd = __dadd_rn(__dadd_rn(__dmul_rn(x, kr), __dmul_rn(p.p1, _2xy)), __dmul_rn(p.p2, __dadd_rn(r2, __dmul_rn(2.0, x2))));
+    const double yd = __dadd_rn(__dadd_rn(__dmul_rn(y, kr), __dmul_rn(p.p1, __dadd_rn(r2, __dmul_rn(2.0, y2)))), __dmul_rn(p.p2, _2xy));
+    mx[j] = (float)__dadd_rn(__dmul_rn(p.fx, xd), p.u0);
+    my[j] = (float)__dadd_rn(__dmul_rn(p.fy, yd), p.v0);
+    _x = __dadd_rn(_x, p.ir[0]); _y = __dadd_rn(_y, p.ir[3]); _w = __dadd_rn(_w, p.ir[6]);
+  }
+}
+}  // namespace
+
+extern "C" int orbfe_init_undistort_rectify_map(int device, const double* K, const double* D, int n_dist, const double* R,
+                                                const double* P, int width, int height, float* map_x, float* map_y) {
+  if (!K || width <= 0 || height <= 0 || !map_x || !map_y || !(n_dist == 0 || n_dist == 4 || n_dist == 5 || n_dist == 8) ||
+      (n_dist > 0 && !D))
+    return ifail(ORBFE_ERR_INVALID, "init_undistort_rectify_map: bad argument (K, the maps and 0 / 4 / 5 / 8 distortion coefficients are required)");
+  static const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  const double *Rm = R ? R : I3, *Ar = P ? P : K;
+  // iR = (P * R)^-1: nine dot products and cv::invert's closed 3 x 3 form -- a dozen double operations of set-up, evaluated
+  // here in the order the reference evaluates them (host: this translation unit is built with -ffp-contract=off)
+  double M[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double acc = 0;
+      for (int k = 0; k < 3; k++) acc += Ar[3 * i + k] * Rm[3 * k + j];
+      M[3 * i + j] = acc;
+    }
+  double d = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+  if (d == 0) return ifail(ORBFE_ERR_INVALID, "init_undistort_rectify_map: P * R is singular");
+  d = 1. / d;
+  RectifyMapParams p;
+  p.ir[0] = (M[4] * M[8] - M[5] * M[7]) * d; p.ir[1] = (M[2] * M[7] - M[1] * M[8]) * d; p.ir[2] = (M[1] * M[5] - M[2] * M[4]) * d;
+  p.ir[3] = (M[5] * M[6] - M[3] * M[8]) * d; p.ir[4] = (M[0] * M[8] - M[2] * M[6]) * d; p.ir[5] = (M[2] * M[3] - M[0] * M[5]) * d;
+  p.ir[6] = (M[3] * M[7] - M[4] * M[6]) * d; p.ir[7] = (M[1] * M[6] - M[0] * M[7]) * d; p.ir[8] = (M[0] * M[4] - M[1] * M[3]) * d;
+  p.fx = K[0]; p.fy = K[4]; p.u0 = K[2]; p.v0 = K[5];
+  p.k1 = n_dist > 0 ? D[0] : 0; p.k2 = n_dist > 1 ? D[1] : 0; p.p1 = n_dist > 2 ? D[2] : 0; p.p2 = n_dist > 3 ? D[3] : 0;
+  p.k3 = n_dist >= 5 ? D[4] : 0; p.k4 = n_dist >= 8 ? D[5] : 0; p.k5 = n_dist >= 8 ? D[6] : 0; p.k6 = n_dist >= 8 ? D[7] : 0;
+  p.w = width; p.h = height;
+  IHIP(hipSetDevice(device));
+  float* dmap = nullptr;
+  const size_t n = (size_t)width * height;
+  IHIP(hipMalloc((void**)&dmap, 2 * n * 4));
+  hipLaunchKernelGGL(k_init_rectify_map, dim3((height + 63) / 64), dim3(64), 0, 0, p, dmap, dmap + n);
+  hipError_t err = hipGetLastError();
+  if (err == hipSuccess) err = hipMemcpy(map_x, dmap, n * 4, hipMemcpyDeviceToHost);
+  if (err == hipSuccess) err = hipMemcpy(map_y, dmap + n, n * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(dmap);
+  if (err != hipSuccess) return ifail(ORBFE_ERR_HIP, std::string("init_undistort_rectify_map: ") + hipGetErrorString(err));
+  return ORBFE_OK;
+}
+
 extern "C" int orbfe_undistort_points(int device, const float* xy, int n, const float* K4, const float* dist,
                                       int n_dist, float* out_xy) {
   UndistortParams p;

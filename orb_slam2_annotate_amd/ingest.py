@@ -72,6 +72,22 @@ class Rectifier:
                                                    src_frame_stride, d_dst, dst_stride, dst_frame_stride))
 
 
+def initUndistortRectifyMap(K, D, R, P, size, device: int = 0):
+    """cv::initUndistortRectifyMap(K, D, R, P[:3, :3], (cols, rows), CV_32F) -> (map_x, map_y) as
+    Examples/Stereo/stereo_euroc.cc:97-98 builds the maps cv::remap takes.  K, R, P: 3x3 (P may be 3x4; R / P may be None);
+    D: 0, 4, 5 or 8 coefficients; size = (cols, rows)."""
+    K = np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(3, 3))
+    Dv = np.ascontiguousarray(np.asarray(D if D is not None else [], dtype=np.float64).reshape(-1))
+    Rm = None if R is None else np.ascontiguousarray(np.asarray(R, dtype=np.float64).reshape(3, 3))
+    Pm = None if P is None else np.ascontiguousarray(np.asarray(P, dtype=np.float64).reshape(3, -1)[:, :3])
+    cols, rows = int(size[0]), int(size[1])
+    mx = np.zeros((rows, cols), dtype=np.float32)
+    my = np.zeros((rows, cols), dtype=np.float32)
+    check(_lib.load().orbfe_init_undistort_rectify_map(device, ptr(K), ptr(Dv) if len(Dv) else None, len(Dv), ptr(Rm), ptr(Pm),
+                                                       cols, rows, ptr(mx), ptr(my)))
+    return mx, my
+
+
 def _cam(K, dist):
     K = np.asarray(K, dtype=np.float32)
     K4 = np.ascontiguousarray([K[0, 0], K[1, 1], K[0, 2], K[1, 2]] if K.ndim == 2 else K, dtype=np.float32)

@@ -495,6 +495,23 @@ def undistort_points(xy, K4, dist):
     return out
 
 
+def init_undistort_rectify_map(K, D, R, P, size):
+    """cv::initUndistortRectifyMap(K, D, R, P[:3,:3], (cols, rows), CV_32F) -> (map_x, map_y)"""
+    K = _f(np.asarray(K, np.float64).reshape(3, 3), np.float64)
+    Dv = _f(np.asarray(D if D is not None else [], np.float64).reshape(-1), np.float64)
+    Rm = None if R is None else _f(np.asarray(R, np.float64).reshape(3, 3), np.float64)
+    Pm = None if P is None else _f(np.asarray(P, np.float64).reshape(3, -1)[:, :3], np.float64)
+    cols, rows = int(size[0]), int(size[1])
+    mx, my = np.zeros((rows, cols), np.float32), np.zeros((rows, cols), np.float32)
+    L = lib()
+    L.orc_init_undistort_rectify_map.restype = C.c_int
+    L.orc_init_undistort_rectify_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    rc = L.orc_init_undistort_rectify_map(_p(K), _p(Dv) if len(Dv) else None, len(Dv), _p(Rm), _p(Pm), cols, rows, _p(mx), _p(my))
+    if rc != 0:
+        raise ValueError("orc_init_undistort_rectify_map: bad argument")
+    return mx, my
+
+
 def image_bounds(cols, rows, K4, dist):
     K4 = _f(K4, np.float32); d = _f(np.asarray(dist).reshape(-1), np.float32)
     b = np.zeros(4, np.float32)
