@@ -464,7 +464,7 @@ const orbfe_frame_view *orbfe_frame_get_view(const orbfe_frame *f);
  * when the Frame is built the extractor's keypoint records and descriptors are still in HBM.  These two build the
  * resident operands FROM THEM -- records split into the x / y / angle / octave arrays, descriptors copied device to device,
  * grid built on the device -- so of a frame's 60 bytes per keypoint only mvuRight (and, with ORBFE_FRAME_XY_FROM_VIEW, the
- * caller's undistorted positions) cross PCIe.  `view` holds the host arrays the claim loops and chi-square gates read
+ * caller's undistorted positions) cross PCIe.  `view` holds the host arrays the argument checks and the host-pointer forms read
  * (mvKeysUn / mvuRight / mDescriptors as the caller has them after its own constructor steps); view->n records are taken.
  *   orbfe_frame_from_extractor: frame `frame` of the handle's last orbfe_extract / small orbfe_extract_batch call
  *       (ORBFE_ERR_INVALID after a device-batch or pipelined call: those outputs are the caller's);
@@ -607,6 +607,11 @@ int orbfe_search_by_projection_sim3(int device, const orbfe_frame_view *KF, cons
 int orbfe_search_for_initialization(int device, const orbfe_frame_view *F1, const orbfe_frame_view *F2,
                                     float *prev_x, float *prev_y, int window_size, float nnratio,
                                     int check_orientation, int32_t *match12, int32_t *n_matches);
+
+/* Diagnostics: the projection searches above replay the reference's order-dependent claim loops on the device as a
+ * fixed-point iteration (csrc/k_window.hip: k_window_claim); this is the largest number of rounds a claim job of the calling
+ * thread's LAST such call took (1 + the longest chain of points that depend on each other; 2-3 on real frames). */
+int orbfe_debug_last_claim_rounds(void);
 
 /* The search ORBmatcher::Fuse runs per map point (src/ORBmatcher.cc:940-1110 with chi2_gate != 0,
  * the Sim3 overload :1112-1249 with chi2_gate == 0): best_idx[i] = keypoint of pKF with octave in

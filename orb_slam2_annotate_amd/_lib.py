@@ -60,7 +60,7 @@ EXPORTS = [
     "orbfe_bow_match_consecutive_batch_device", "orbfe_bow_match_consecutive_batch_device_async", "orbfe_bow_match_consecutive_stereo_batch_device_async", "orbfe_cvt_gray", "orbfe_cvt_gray_batch_device",
     "orbfe_distinctive_descriptors", "orbfe_features_in_area", "orbfe_search_by_projection",
     "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_keyframe",
-    "orbfe_search_by_projection_sim3", "orbfe_search_for_initialization", "orbfe_fuse_search", "orbfe_search_by_sim3",
+    "orbfe_search_by_projection_sim3", "orbfe_search_for_initialization", "orbfe_debug_last_claim_rounds", "orbfe_fuse_search", "orbfe_search_by_sim3",
     "orbfe_init_undistort_rectify_map", "orbfe_rectifier_create", "orbfe_rectifier_destroy", "orbfe_remap", "orbfe_remap_batch_device", "orbfe_extract_stereo_rectified_batch_device_async",
     "orbfe_undistort_points", "orbfe_undistort_keypoints_batch_device", "orbfe_compute_image_bounds",
     "orbfe_stereo_from_rgbd",
@@ -166,6 +166,8 @@ def load():
                                                         ci, cf, ci, vp, vp]
     L.orbfe_search_by_projection_keyframe.argtypes = [ci, fwp, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, cf, ci, ci, vp, vp]
     L.orbfe_search_by_projection_sim3.argtypes = [ci, fwp, vp, ci, vp, ci, vp, vp, vp, vp, vp, cf, vp, vp]
+    L.orbfe_debug_last_claim_rounds.argtypes = []
+    L.orbfe_debug_last_claim_rounds.restype = ci
     L.orbfe_search_for_initialization.argtypes = [ci, fwp, fwp, vp, vp, ci, cf, ci, vp, vp]
     L.orbfe_fuse_search.argtypes = [ci, fwp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, cf, ci, vp]
     L.orbfe_search_by_sim3.argtypes = [ci, fwp, fwp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, vp, vp]

@@ -171,7 +171,263 @@ __global__ __launch_bounds__(256) void k_window_search(GridFrame f, const uint32
   if (lane == 0) count[qi] = n;
 }
 
+// rotation-histogram bin, src/ORBmatcher.cc:1601-1610 (C round(): half away from zero)
+__device__ __forceinline__ int claim_rot_bin(float a1, float a2) {
+  float rot = __fsub_rn(a1, a2);
+  if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+  int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+  if (bin == 30) bin = 0;
+  return bin;
+}
+
+// The claim loops of SearchByProjection (map points :77-135, last frame :1572-1612, key frame :1726-1760, Sim3 :431-451) and
+// SearchForInitialization (:492-545) -- see ClaimJob (match_kernels.h).  One workgroup per job.  A round lets EVERY query
+// choose, in parallel, among the candidates that no query in front of it holds (according to the previous round's
+// choices); rounds repeat until no choice changes.  The fixed point is the reference's sequential result: query 0 never
+// depends on anyone, and once the queries in front of j have their final choices so has j -- at most nq + 1 rounds, in
+// practice two or three, because two map points rarely want the same feature.
+//   BEST / RATIO: a feature is hidden from query j when an earlier query whose match blocks (blockVal) chose it:
+//                 owner[feature] = the smallest such query (atomicMin), hidden <=> owner < j.
+//   INIT:         a feature is hidden from query j for candidates at distance >= the smallest distance at which an
+//                 earlier query took it (vMatchedDistance, :516-517): the choosers of a feature form a linked list
+//                 (owner = head, link = next), walked for the ones in front of j.
+__global__ __launch_bounds__(1024) void k_window_claim(const ClaimJob* __restrict__ jobs) {
+  extern __shared__ int32_t s_dyn[];
+  __shared__ int s_hist[30];
+  __shared__ int s_keep[3];
+  __shared__ int s_changed[2];
+  __shared__ int s_total, s_pruned, s_maxc, s_conflict;
+  const ClaimJob J = jobs[blockIdx.x];
+  const int tid = threadIdx.x;
+  int32_t* owner = J.owner ? J.owner : s_dyn;
+  constexpr int kNone = 0x7fffffff;
+  const bool init = J.mode == CLAIM_INIT;
+  const int ownerFree = init ? -1 : kNone;
+  if (tid < 30) s_hist[tid] = 0;
+  if (tid < 2) s_changed[tid] = 0;
+  if (tid == 0) { s_total = 0; s_pruned = 0; s_maxc = 0; s_conflict = 0; }
+  __syncthreads();
+  // What a thread needs of its FIRST query (nq <= 1024: its only one) stays in registers over the rounds -- the flags, the
+  // list length, the first eight candidates, the current choice: after round 0 a round of the BEST / RATIO forms touches LDS
+  // only, unless a list is longer than eight.  Further queries of the thread (tid + 1024, ...) and the INIT form take
+  // everything from memory every round.
+  uint8_t* s_oct = reinterpret_cast<uint8_t*>(s_dyn + (J.owner ? 0 : J.n));  // RATIO: octave bytes of the features (255: read HBM)
+  const bool has0 = !init && tid < J.nq;
+  bool act0 = false, bv0 = true;
+  int nc0 = 0, c0 = -2;
+  uint32_t e0[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  {
+    if (has0) {
+      const uint4* L4 = reinterpret_cast<const uint4*>(J.cand + (size_t)tid * J.K);  // K % 8 == 0, lists 256-byte aligned
+      const uint4 ea = L4[0], eb = L4[1];
+      e0[0] = ea.x; e0[1] = ea.y; e0[2] = ea.z; e0[3] = ea.w; e0[4] = eb.x; e0[5] = eb.y; e0[6] = eb.z; e0[7] = eb.w;
+      act0 = !J.active || J.active[tid];
+      bv0 = !J.blockVal || J.blockVal[tid];
+    }
+    int mc = 0;
+    for (int j = tid; j < J.nq; j += 1024) {
+      J.choice[j] = -2;  // (no choice computed yet: the first round counts as a change)
+      const int c = J.count[j];
+      mc = c > mc ? c : mc;
+      if (j == tid) nc0 = c < J.K ? c : J.K;
+    }
+    if (mc) atomicMax(&s_maxc, mc);
+    // (BEST / RATIO: a feature that is taken at entry is "owned by query -1", i.e. hidden from everyone)
+    for (int i = tid; i < J.n; i += 1024) owner[i] = (!init && J.blocked && J.blocked[i]) ? -1 : ownerFree;
+    if (J.mode == CLAIM_RATIO)
+      for (int i = tid; i < J.n; i += 1024) {
+        const int o = J.octave[i];
+        s_oct[i] = (uint8_t)((unsigned)o < 255u ? o : 255);
+      }
+  }
+  __syncthreads();
+  int rounds = 0;
+  for (;; rounds++) {
+    const int flag = rounds & 1;
+    if (tid == 0) s_changed[flag ^ 1] = 0;  // (everyone read it before the rebuild barriers of the previous round)
+    int changed = 0;
+    for (int j = tid; j < J.nq; j += 1024) {
+      int c = -1;
+      const bool slot0 = has0 && j == tid;
+      if (slot0 ? act0 : (!J.active || J.active[j])) {
+        int nc;
+        if (slot0) nc = nc0;
+        else { nc = J.count[j]; nc = nc < J.K ? nc : J.K; }
+        // the list is read eight entries (two 16-byte requests) at a time: one memory round trip per eight candidates instead
+        // of one per candidate -- a round is a handful of dependent round trips, and most lists are shorter than eight
+        const uint4* L4 = reinterpret_cast<const uint4*>(J.cand + (size_t)j * J.K);
+        if (init) {
+          int bestDist = kNone, bestDist2 = kNone, bestIdx = -1;
+          for (int k0 = 0; k0 < nc; k0 += 8) {
+            const uint4 ea = L4[k0 >> 2], eb = L4[(k0 >> 2) + 1];
+            const uint32_t ev8[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              if (k0 + u >= nc) break;
+              const uint32_t e = ev8[u];
+              const int i2 = (int)(e & 0xffffu), dist = (int)(e >> 16);
+              int held = kNone;  // vMatchedDistance[i2] as query j sees it
+              for (int i = owner[i2]; i >= 0; i = J.link[i])
+                if (i < j) {
+                  const int ci = J.choice[i];  // (may be this round's: only a consistent "i holds i2 at d" entry is used)
+                  if (ci >= 0 && (ci & 0xffff) == i2) held = (ci >> 16) < held ? (ci >> 16) : held;
+                }
+              if (held <= dist) continue;
+              if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx = i2; }
+              else if (dist < bestDist2) bestDist2 = dist;
+            }
+          }
+          if (bestIdx >= 0 && bestDist <= J.maxDist && (float)bestDist < __fmul_rn((float)bestDist2, J.nnratio))
+            c = (bestDist << 16) | bestIdx;
+        } else {
+          int bestDist = 256, bestDist2 = 256, bestIdx = -1, secIdx = -1;
+          // best and second best of eight entries, as selects (written with branches the compiler kept the four running
+          // values in scratch memory behind a computed store address)
+#define ORBFE_CLAIM_PROC8(EV, NVALID)                                                                                      \
+  do {                                                                                                                    \
+    int own_[8];                                                                                                          \
+    _Pragma("unroll") for (int u = 0; u < 8; u++) own_[u] = u < (NVALID) ? owner[(EV)[u] & 0xffffu] : -1; /* eight lookups in flight */ \
+    _Pragma("unroll") for (int u = 0; u < 8; u++) {                                                                       \
+      const bool free_ = own_[u] >= j; /* not held by an earlier query, not taken at entry, not past the end of the list */ \
+      const int idx_ = (int)((EV)[u] & 0xffffu), dist_ = (int)((EV)[u] >> 16);                                            \
+      const bool lt1_ = free_ && dist_ < bestDist, lt2_ = free_ && dist_ < bestDist2;                                     \
+      bestDist2 = lt1_ ? bestDist : (lt2_ ? dist_ : bestDist2);                                                           \
+      secIdx = lt1_ ? bestIdx : (lt2_ ? idx_ : secIdx);                                                                   \
+      bestDist = lt1_ ? dist_ : bestDist;                                                                                 \
+      bestIdx = lt1_ ? idx_ : bestIdx;                                                                                    \
+    }                                                                                                                     \
+  } while (0)
+          if (slot0) {
+            if (nc > 0) ORBFE_CLAIM_PROC8(e0, nc);
+          } else if (nc > 0) {
+            const uint4 ea = L4[0], eb = L4[1];
+            const uint32_t ev8[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
+            ORBFE_CLAIM_PROC8(ev8, nc);
+          }
+          for (int k0 = 8; k0 < nc; k0 += 8) {
+            const uint4 ea = L4[k0 >> 2], eb = L4[(k0 >> 2) + 1];
+            const uint32_t ev8[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
+            ORBFE_CLAIM_PROC8(ev8, nc - k0);
+          }
+#undef ORBFE_CLAIM_PROC8
+          if (bestIdx >= 0 && bestDist <= J.maxDist) {
+            c = bestIdx;
+            if (J.mode == CLAIM_RATIO && (float)bestDist > __fmul_rn(J.nnratio, (float)bestDist2)) {
+              // (:124-127: the ratio only counts between two candidates of the same level)
+              int bestLevel = s_oct[bestIdx], bestLevel2 = secIdx >= 0 ? (int)s_oct[secIdx] : -1;
+              if (bestLevel == 255) bestLevel = J.octave[bestIdx];
+              if (bestLevel2 == 255) bestLevel2 = J.octave[secIdx];
+              if (bestLevel == bestLevel2) c = -1;
+            }
+          }
+        }
+      }
+      if (slot0) {
+        if (c != c0) { c0 = c; J.choice[j] = c; changed = 1; }
+      } else if (c != J.choice[j]) { J.choice[j] = c; changed = 1; }
+    }
+    if (changed) s_changed[flag] = 1;
+    __syncthreads();
+    if (!s_changed[flag]) break;  // block-uniform: a round without a change is the fixed point
+    // (a feature taken at entry keeps its -1: atomicMin with a query index never lowers it)
+    for (int i = tid; i < J.n; i += 1024)
+      if (init || owner[i] != -1) owner[i] = ownerFree;
+    __syncthreads();
+    for (int j = tid; j < J.nq; j += 1024) {
+      const int c = (has0 && j == tid) ? c0 : J.choice[j];
+      if (c < 0) continue;
+      if (init) J.link[j] = atomicExch(&owner[c & 0xffff], j);
+      else if ((has0 && j == tid) ? bv0 : (!J.blockVal || J.blockVal[j])) atomicMin(&owner[c], j);
+    }
+    __syncthreads();
+    if (rounds == 0 && J.mode == CLAIM_BEST) {
+      // the usual case ends here: when no query's first choice is held by an earlier one, every query keeps the best of ALL
+      // its candidates and a second round would change nothing.  (Not so with the ratio test, whose outcome also depends on
+      // whether the SECOND best is still free.)
+      int conflict = 0;
+      for (int j = tid; j < J.nq; j += 1024) {
+        const int c = (has0 && j == tid) ? c0 : J.choice[j];
+        if (c >= 0 && owner[c] < j) conflict = 1;
+      }
+      if (conflict) s_conflict = 1;
+      __syncthreads();
+      if (!s_conflict) break;  // block-uniform
+    }
+  }
+  // ---- the match array, the rotation histogram (ComputeThreeMaxima, :1635-1690) and the count ----
+  const int nOut = init ? J.nq : J.n;
+  if (!init)
+    for (int i = tid; i < nOut; i += 1024) J.match[i] = -1;
+  __syncthreads();
+  int ev = 0;
+  for (int j = tid; j < J.nq; j += 1024) {
+    const int c = J.choice[j];
+    int m = -1;
+    if (c >= 0) {
+      const int f = init ? (c & 0xffff) : c;
+      if (J.checkOri) atomicAdd(&s_hist[claim_rot_bin(J.qAngle[j], J.fAngle[f])], 1);  // every take is pushed (:540-553, :1601-1610)
+      if (init) {
+        bool holder = true;  // a later query that took the feature replaced this one (:529-533)
+        for (int i = owner[f]; i >= 0; i = J.link[i])
+          if (i > j) { const int ci = J.choice[i]; if (ci >= 0 && (ci & 0xffff) == f) holder = false; }
+        if (holder) { m = f; ev++; }
+      } else {
+        atomicMax(&J.match[c], j);  // a feature whose holder does not block is overwritten by the later ones
+        ev++;
+      }
+    }
+    if (init) J.match[j] = m;
+  }
+  if (ev) atomicAdd(&s_total, ev);
+  __syncthreads();
+  if (J.checkOri) {
+    if (tid == 0) {
+      int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+      for (int i = 0; i < 30; i++) {
+        const int s = s_hist[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+        else if (s > max3) { max3 = s; i3 = i; }
+      }
+      if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { i2 = -1; i3 = -1; }
+      else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { i3 = -1; }
+      s_keep[0] = i1; s_keep[1] = i2; s_keep[2] = i3;
+    }
+    __syncthreads();
+    const int k0 = s_keep[0], k1 = s_keep[1], k2 = s_keep[2];
+    int pr = 0;
+    for (int j = tid; j < J.nq; j += 1024) {
+      const int c = J.choice[j];
+      if (c < 0) continue;
+      const int f = init ? (c & 0xffff) : c;
+      const int b = claim_rot_bin(J.qAngle[j], J.fAngle[f]);
+      if (b == k0 || b == k1 || b == k2) continue;
+      if (init) { if (J.match[j] >= 0) { J.match[j] = -1; pr++; } }   // :557-563: only a still-matched entry counts
+      else { J.match[c] = -1; pr++; }                                  // :1617-1625: every entry of a dropped bin counts
+    }
+    if (pr) atomicAdd(&s_pruned, pr);
+    __syncthreads();
+  }
+  if (init && J.prevX)
+    for (int j = tid; j < J.nq; j += 1024) {
+      const int m = J.match[j];
+      J.prevX[j] = m >= 0 ? J.fx[m] : J.qx[j];
+      J.prevY[j] = m >= 0 ? J.fy[m] : J.qy[j];
+    }
+  if (tid == 0) {
+    J.header[0] = s_maxc;
+    J.header[1] = s_total - s_pruned;
+    J.header[2] = rounds;
+    J.header[3] = 0;
+  }
+}
+
 }  // namespace
+
+void launch_window_claim(hipStream_t s, const ClaimJob* d_jobs, int nJobs, size_t ldsBytes) {
+  if (nJobs <= 0) return;
+  hipLaunchKernelGGL(k_window_claim, dim3(nJobs), dim3(1024), ldsBytes, s, d_jobs);
+}
 
 void launch_grid_build(hipStream_t s, const GridFrame& f, uint32_t* sortedKey, int32_t* cellOff) {
   int sortN = 64;

@@ -110,6 +110,31 @@ struct WindowQueries {
   // gate (gateUr = the projected ur of every query, invSigma2 = mvInvLevelSigma2), kept when its distance <= maxDist
   int32_t* best; const float* gateUr; const float* invSigma2; int gate; int maxDist;
 };
+// The claim loops of the projection searches on the device (k_window_claim): the reference walks its map points / key points
+// IN ORDER and a point that takes a feature hides it from the later ones (src/ORBmatcher.cc:77-78, 1572-1574, 1726-1727,
+// 431-432, 492-493).  One workgroup per job iterates "every query chooses among the features no EARLIER query holds" to its
+// fixed point -- which is the sequential result (query 0's choice is final after round 1, query 1's after round 2, ...; in
+// practice 2-3 rounds) -- so the candidate lists never leave the device: the match array comes back instead.
+enum { CLAIM_BEST = 0, CLAIM_RATIO = 1, CLAIM_INIT = 2 };
+struct ClaimJob {
+  const int32_t* count; const uint32_t* cand;  // k_window_search's lists: (dist << 16 | feature) in scan order
+  int K, nq, n;                 // list capacity, queries, features of the frame
+  const uint8_t* active;        // [nq] NULL: every query takes part
+  const uint8_t* blocked;       // [n] features that are taken at entry, NULL: none
+  const uint8_t* blockVal;      // [nq] whether query i's match hides its feature (MapPoint::Observations() > 0), NULL: always
+  const int32_t* octave;        // [n] (CLAIM_RATIO: the best / second-best level test, src/ORBmatcher.cc:100-127)
+  const float* qAngle; const float* fAngle;  // rotation histogram (checkOri)
+  const float* fx; const float* fy; const float* qx; const float* qy;  // CLAIM_INIT: "update prev matched" (:595-600):
+  float* prevX; float* prevY;   // out [nq]: the matched feature's position, else the query's own
+  int mode, maxDist, checkOri;
+  float nnratio;
+  int32_t* choice;  // [nq] scratch: the query's current choice (feature, or dist << 16 | feature in CLAIM_INIT), -1 none
+  int32_t* link;    // [nq] scratch (CLAIM_INIT: the other queries that chose the same feature)
+  int32_t* owner;   // [n]  scratch in HBM, NULL: the kernel's dynamic LDS holds it
+  int32_t* match;   // out.  BEST / RATIO: [n], query that holds feature i or -1.  INIT: [nq], feature of query i or -1
+  int32_t* header;  // out [4]: largest list length (> K: the lists were truncated, search again), matches, rounds, 0
+};
+void launch_window_claim(hipStream_t s, const ClaimJob* d_jobs, int nJobs, size_t ldsBytes);
 void launch_grid_build(hipStream_t s, const GridFrame& f, uint32_t* sortedKey, int32_t* cellOff);
 void launch_frame_from_records(hipStream_t s, const float* d_kp, const uint8_t* d_desc, int n, float* x, float* y, float* angle,
                                int32_t* octave, uint8_t* descOut, uint8_t* stereoZero);

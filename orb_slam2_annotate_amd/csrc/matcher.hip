@@ -1116,16 +1116,36 @@ struct WindowJob {
   const float* gur = nullptr;
   const float* invSigma2 = nullptr;
   int nLevels = 0, gate = 0, maxDist = 256;
+  // CLAIM mode (claim != NULL): the lists stay on the device and k_window_claim replays the reference's claim loop over
+  // them (match_kernels.h: ClaimJob); the match array, the count and -- SearchForInitialization -- the updated previous
+  // positions come back
+  struct ClaimSpec* claim = nullptr;
+};
+struct ClaimSpec {
+  int mode = CLAIM_BEST, maxDist = 100, checkOri = 0;
+  float nnratio = 0.0f;
+  const uint8_t* blocked = nullptr;   // [f->n] features taken at entry (NULL: none)
+  const uint8_t* blockVal = nullptr;  // [nq] does query i's match hide its feature (NULL: always)
+  const float* qAngle = nullptr;      // [nq] (checkOri)
+  int32_t* match = nullptr;           // out: [f->n] (BEST / RATIO) or [nq] (INIT)
+  int32_t* nMatches = nullptr;        // out
+  float* prevX = nullptr;             // INIT, out [nq]: the matched feature's position, else the query's own
+  float* prevY = nullptr;
+  int rounds = 0;                     // out: rounds the fixed point took
 };
 
 // Upload frames (unless resident: keypoint arrays, descriptors and grid are on the device already) + queries, build the
 // grids, search every window; grows K until every list fits.
+thread_local int t_lastClaimRounds = 0;
 int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
   UnsettledScope unsettledScope;
-  int K = K0 < 8 ? 8 : K0;
-  struct Lay { size_t oX, oY, oOct, oUr, oDesc, oQx, oQy, oQr, oQmin, oQmax, oQact, oQur, oQdesc, oOut, oGur, oSig; bool withDesc, withUr, res; int frameOf; };
+  t_lastClaimRounds = 0;
+  int K = ((K0 < 8 ? 8 : K0) + 7) & ~7;  // (k_window_claim reads the lists eight entries at a time)
+  struct Lay { size_t oX, oY, oOct, oUr, oDesc, oQx, oQy, oQr, oQmin, oQmax, oQact, oQur, oQdesc, oOut, oGur, oSig, oAng, oBlk, oBval, oQang, oScr;
+               bool withDesc, withUr, res; int frameOf; };
   std::vector<Lay> lay((size_t)nJobs);
   size_t off = 0;
+  int nClaim = 0;
   auto place = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
   for (int j = 0; j < nJobs; j++) {
     const WindowJob& J = jobs[j];
@@ -1135,7 +1155,7 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
     if (L.res && J.f->resident->device != device) return mfail(ORBFE_ERR_INVALID, "resident frame lives on another device");
     L.withDesc = J.f->desc && J.qdesc;
     L.withUr = J.qur && J.f->u_right;
-    L.oX = L.oY = L.oOct = L.oUr = L.oDesc = 0;
+    L.oX = L.oY = L.oOct = L.oUr = L.oDesc = L.oAng = L.oBlk = L.oBval = L.oQang = L.oScr = 0;
     L.frameOf = j;  // several jobs on the SAME host-array frame (one frame against K candidates): one upload, one grid
     if (!L.res)
       for (int k = 0; k < j; k++)
@@ -1160,17 +1180,38 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
         if (lay[k].withDesc && jobs[k].qdesc == J.qdesc && jobs[k].nq == J.nq) { shared = k; break; }
       L.oQdesc = shared >= 0 ? lay[shared].oQdesc : place(q * 32);
     }
+    if (J.claim) {
+      nClaim++;
+      if (J.claim->checkOri && !L.res) L.oAng = place(n * 4);  // (a resident frame has its angles on the device)
+      if (J.claim->blocked) L.oBlk = place(n);
+      if (J.claim->blockVal) L.oBval = place(q);
+      if (J.claim->checkOri) L.oQang = place(q * 4);
+    }
   }
+  const size_t oClaim = nClaim ? place((size_t)nClaim * sizeof(ClaimJob)) : 0;
   const size_t inBytes = off ? off : 256;
+  constexpr size_t kOwnerLds = 48 * 1024;  // owner[] of a frame with up to 12288 features lives in the claim kernel's LDS
   for (;;) {
     Arena* ar;
-    size_t outBytes = 0, gridBytes = 0;
+    size_t outBytes = 0, gridBytes = 0, scrBytes = 0, claimLds = 0;
     for (int j = 0; j < nJobs; j++) {
       lay[j].oOut = outBytes;
-      outBytes += pad((size_t)jobs[j].nq * 4) + (jobs[j].bestOut ? 0 : pad((size_t)jobs[j].nq * (size_t)K * 4));
-      if (!lay[j].res && lay[j].frameOf == j) gridBytes += pad((size_t)jobs[j].f->n * 4) + pad(3073 * 4);
+      const size_t q = (size_t)jobs[j].nq, n = (size_t)jobs[j].f->n;
+      if (jobs[j].claim) {
+        // comes back: header | match | (INIT: previous positions).  Stays: counts | lists | choice | link | (owner)
+        const bool ini = jobs[j].claim->mode == CLAIM_INIT;
+        outBytes += pad(16 + (ini ? q : n) * 4 + (ini ? 2 * q * 4 : 0));
+        lay[j].oScr = scrBytes;
+        scrBytes += pad(q * 4) + pad(q * (size_t)K * 4) + 2 * pad(q * 4) + (n * 4 > kOwnerLds ? pad(n * 4) : 0);
+        // the claim kernel's dynamic LDS: owner[] (unless in HBM) + the features' octave bytes (RATIO)
+        const size_t lds = (n * 4 <= kOwnerLds ? n * 4 : 0) + (jobs[j].claim->mode == CLAIM_RATIO ? n : 0);
+        if (lds > claimLds) claimLds = lds;
+      } else {
+        outBytes += pad(q * 4) + (jobs[j].bestOut ? 0 : pad(q * (size_t)K * 4));
+      }
+      if (!lay[j].res && lay[j].frameOf == j) gridBytes += pad(n * 4) + pad(3073 * 4);
     }
-    MHIP(arena_begin(device, pad(inBytes) + gridBytes + outBytes + 1024, &ar));
+    MHIP(arena_begin(device, pad(inBytes) + gridBytes + outBytes + scrBytes + 2048, &ar));
     for (int j = 0; j < nJobs; j++)
       if (lay[j].res) MHIP(frame_use(ar, jobs[j].f->resident));
     MHIP(staging_reserve(inBytes > outBytes ? inBytes : outBytes));
@@ -1193,11 +1234,51 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
         if (J.bestOut && J.gate && J.gur) std::memcpy(h + L.oGur, J.gur, q * 4);
         if (J.bestOut && J.gate) std::memcpy(h + L.oSig, J.invSigma2, (size_t)J.nLevels * 4);
       }
+      if (J.claim) {
+        if (L.oAng && n) std::memcpy(h + L.oAng, J.f->angle, n * 4);
+        if (J.claim->blocked && n) std::memcpy(h + L.oBlk, J.claim->blocked, n);
+        if (J.claim->blockVal && q) std::memcpy(h + L.oBval, J.claim->blockVal, q);
+        if (J.claim->checkOri && q) std::memcpy(h + L.oQang, J.claim->qAngle, q * 4);
+      }
     }
     uint8_t* din = carve<uint8_t>(ar, inBytes);
-    MHIP(hipMemcpyAsync(din, h, inBytes, hipMemcpyHostToDevice, ar->stream));
     uint8_t* dgrid = carve<uint8_t>(ar, gridBytes ? gridBytes : 1);
     uint8_t* dout = carve<uint8_t>(ar, outBytes ? outBytes : 1);
+    uint8_t* dscr = carve<uint8_t>(ar, scrBytes ? scrBytes : 1);
+    // the claim jobs' argument blocks travel with the inputs (their device addresses are known once the arena is carved)
+    for (int j = 0, c = 0; j < nJobs; j++) {
+      const WindowJob& J = jobs[j];
+      if (!J.claim) continue;
+      const Lay& L = lay[j];
+      const size_t q = (size_t)J.nq, n = (size_t)J.f->n;
+      const bool ini = J.claim->mode == CLAIM_INIT;
+      ClaimJob cj{};
+      uint8_t* sc = dscr + L.oScr;
+      cj.count = reinterpret_cast<const int32_t*>(sc); sc += pad(q * 4);
+      cj.cand = reinterpret_cast<const uint32_t*>(sc); sc += pad(q * (size_t)K * 4);
+      cj.choice = reinterpret_cast<int32_t*>(sc); sc += pad(q * 4);
+      cj.link = reinterpret_cast<int32_t*>(sc); sc += pad(q * 4);
+      cj.owner = n * 4 > kOwnerLds ? reinterpret_cast<int32_t*>(sc) : nullptr;
+      cj.K = K; cj.nq = J.nq; cj.n = J.f->n;
+      cj.active = J.qactive ? din + L.oQact : nullptr;
+      cj.blocked = J.claim->blocked ? din + L.oBlk : nullptr;
+      cj.blockVal = J.claim->blockVal ? din + L.oBval : nullptr;
+      const orbfe_frame* R = L.res ? J.f->resident : nullptr;
+      cj.octave = R ? R->doct : reinterpret_cast<const int32_t*>(din + L.oOct);
+      cj.qAngle = J.claim->checkOri ? reinterpret_cast<const float*>(din + L.oQang) : nullptr;
+      cj.fAngle = J.claim->checkOri ? (R ? R->dangle : reinterpret_cast<const float*>(din + L.oAng)) : nullptr;
+      cj.fx = R ? R->dx : reinterpret_cast<const float*>(din + L.oX);
+      cj.fy = R ? R->dy : reinterpret_cast<const float*>(din + L.oY);
+      cj.qx = reinterpret_cast<const float*>(din + L.oQx); cj.qy = reinterpret_cast<const float*>(din + L.oQy);
+      cj.mode = J.claim->mode; cj.maxDist = J.claim->maxDist; cj.checkOri = J.claim->checkOri; cj.nnratio = J.claim->nnratio;
+      cj.header = reinterpret_cast<int32_t*>(dout + L.oOut);
+      cj.match = cj.header + 4;
+      cj.prevX = ini ? reinterpret_cast<float*>(cj.match + q) : nullptr;
+      cj.prevY = ini ? cj.prevX + q : nullptr;
+      std::memcpy(h + oClaim + (size_t)c * sizeof(ClaimJob), &cj, sizeof(ClaimJob));
+      c++;
+    }
+    MHIP(hipMemcpyAsync(din, h, inBytes, hipMemcpyHostToDevice, ar->stream));
     size_t goff = 0;
     std::vector<const uint32_t*> keyOf((size_t)nJobs, nullptr);
     std::vector<const int32_t*> cellOf((size_t)nJobs, nullptr);
@@ -1252,7 +1333,15 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
       // counts and candidate lists of a job are adjacent, the jobs' blocks too: one copy back
       int32_t* dcount = reinterpret_cast<int32_t*>(dout + L.oOut);
       uint32_t* dcand = reinterpret_cast<uint32_t*>(dout + L.oOut + pad(q * 4));
+      if (J.claim) {  // the lists of a claim job stay in the scratch area
+        dcount = reinterpret_cast<int32_t*>(dscr + L.oScr);
+        dcand = reinterpret_cast<uint32_t*>(dscr + L.oScr + pad(q * 4));
+      }
       launch_window_search(ar->stream, g, dkey, dcell, wq, dcount, dcand);
+      MHIP(hipGetLastError());
+    }
+    if (nClaim) {
+      launch_window_claim(ar->stream, reinterpret_cast<const ClaimJob*>(din + oClaim), nClaim, claimLds);
       MHIP(hipGetLastError());
     }
     if (outBytes) MHIP(hipMemcpyAsync(h, dout, outBytes, hipMemcpyDeviceToHost, ar->stream));
@@ -1263,6 +1352,20 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
       const size_t q = (size_t)jobs[j].nq;
       if (jobs[j].bestOut) {
         if (q) std::memcpy(jobs[j].bestOut, h + lay[j].oOut, q * 4);
+        continue;
+      }
+      if (jobs[j].claim) {
+        ClaimSpec* C = jobs[j].claim;
+        const int32_t* hd = reinterpret_cast<const int32_t*>(h + lay[j].oOut);
+        mx = hd[0] > mx ? hd[0] : mx;
+        if (hd[0] > K) continue;  // truncated lists: the call searches again with room for the largest
+        const bool ini = C->mode == CLAIM_INIT;
+        const size_t nOut = ini ? q : (size_t)jobs[j].f->n;
+        if (nOut) std::memcpy(C->match, hd + 4, nOut * 4);
+        *C->nMatches = hd[1];
+        C->rounds = hd[2];
+        t_lastClaimRounds = hd[2] + 1 > t_lastClaimRounds ? hd[2] + 1 : t_lastClaimRounds;
+        if (ini && q) { std::memcpy(C->prevX, hd + 4 + q, q * 4); std::memcpy(C->prevY, hd + 4 + 2 * q, q * 4); }
         continue;
       }
       WindowResult* res = jobs[j].res;
@@ -1276,7 +1379,7 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
       for (size_t i = 0; i < q; i++) mx = res->count[i] > mx ? res->count[i] : mx;
     }
     if (mx <= K) return ORBFE_OK;
-    K = mx;  // a window held more features than the list: search again with room for the largest
+    K = (mx + 7) & ~7;  // a window held more features than the list: search again with room for the largest
   }
 }
 
@@ -1287,20 +1390,9 @@ int window_search(int device, const orbfe_frame_view* f, int nq, const float* qx
   return window_search_multi(device, &j, 1, K0);
 }
 
-// ComputeThreeMaxima, src/ORBmatcher.cc:1635-1690, over bin sizes
-void three_maxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3) {
-  int max1 = 0, max2 = 0, max3 = 0;
-  for (int i = 0; i < L; i++) {
-    const int s = (int)histo[i].size();
-    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-    else if (s > max3) { max3 = s; ind3 = i; }
-  }
-  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
-}
-
 }  // namespace
+
+extern "C" int orbfe_debug_last_claim_rounds(void) { return t_lastClaimRounds; }
 
 extern "C" int orbfe_features_in_area(int device, const orbfe_frame_view* frame, int n_queries, const float* x,
                                       const float* y, const float* r, const int32_t* min_level,
@@ -1352,36 +1444,15 @@ extern "C" int orbfe_search_by_projection(int device, const orbfe_frame_view* F,
     qmin[i] = lv - 1;
     qmax[i] = lv;
   }
-  WindowResult res;
-  const int rc = window_search(device, F, n_mp, proj_x, proj_y, qr.data(), qmin.data(), qmax.data(), in_view, proj_xr,
-                               mp_desc, 32, &res);
-  if (rc != ORBFE_OK) return rc;
-  std::vector<uint8_t> blk(F->n, 0);
-  if (blocked) std::memcpy(blk.data(), blocked, (size_t)F->n);
-  int nmatches = 0;
-  for (int i = 0; i < n_mp; i++) {
-    if (!in_view[i]) continue;
-    const int nc = res.count[i];
-    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
-    for (int c = 0; c < nc; c++) {
-      const uint32_t e = res.cand[(size_t)i * res.K + c];
-      const int idx = (int)(e & 0xffffu), dist = (int)(e >> 16);
-      if (blk[idx]) continue;
-      if (dist < bestDist) {
-        bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = F->octave[idx]; bestIdx = idx;
-      } else if (dist < bestDist2) {
-        bestLevel2 = F->octave[idx]; bestDist2 = dist;
-      }
-    }
-    if (bestDist <= 100) {  // TH_HIGH
-      if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
-      match[bestIdx] = i;
-      blk[bestIdx] = mp_obs_positive ? mp_obs_positive[i] : 1;
-      nmatches++;
-    }
-  }
-  *n_matches = nmatches;
-  return ORBFE_OK;
+  // the claim loop (:77-135: best / second best among the features no earlier map point holds, level + ratio test) runs on
+  // the device behind the window search (k_window_claim); the match array comes back
+  ClaimSpec C;
+  C.mode = CLAIM_RATIO; C.maxDist = 100 /* TH_HIGH */; C.nnratio = nnratio;
+  C.blocked = blocked; C.blockVal = mp_obs_positive;
+  C.match = match; C.nMatches = n_matches;
+  WindowJob job{F, n_mp, proj_x, proj_y, qr.data(), qmin.data(), qmax.data(), in_view, proj_xr, mp_desc, nullptr};
+  job.claim = &C;
+  return window_search_multi(device, &job, 1, 32);
 }
 
 extern "C" int orbfe_search_by_projection_last_frame(int device, const orbfe_frame_view* Cur, const float* scale_factors,
@@ -1415,49 +1486,16 @@ extern "C" int orbfe_search_by_projection_last_frame(int device, const orbfe_fra
     else { qmin[i] = o - 1; qmax[i] = o + 1; }
     if (Cur->u_right) qur[i] = u[i] - mbf * invzc[i];        // :1562
   }
-  WindowResult res;
-  const int rc = window_search(device, Cur, n_last, u, v, qr.data(), qmin.data(), qmax.data(), valid,
-                               Cur->u_right ? qur.data() : nullptr, mp_desc, 32, &res);
-  if (rc != ORBFE_OK) return rc;
-  constexpr int HISTO_LENGTH = 30;
-  std::vector<int> rotHist[HISTO_LENGTH];
-  const float factor = 1.0f / HISTO_LENGTH;
-  std::vector<uint8_t> blk(Cur->n, 0);
-  if (blocked) std::memcpy(blk.data(), blocked, (size_t)Cur->n);  // mvpMapPoints[i2] set with Observations() > 0 at entry (:1572-1574)
-  int nmatches = 0;
-  for (int i = 0; i < n_last; i++) {
-    if (!valid[i]) continue;
-    const int nc = res.count[i];
-    int bestDist = 256, bestIdx2 = -1;
-    for (int c = 0; c < nc; c++) {
-      const uint32_t e = res.cand[(size_t)i * res.K + c];
-      const int i2 = (int)(e & 0xffffu), dist = (int)(e >> 16);
-      if (blk[i2]) continue;
-      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
-    }
-    if (bestDist <= 100) {  // TH_HIGH
-      match_cur[bestIdx2] = i;
-      blk[bestIdx2] = obs_positive ? obs_positive[i] : 1;
-      nmatches++;
-      if (check_orientation) {
-        float rot = last_angle[i] - Cur->angle[bestIdx2];
-        if (rot < 0.0) rot += 360.0f;
-        int bin = (int)roundf(rot * factor);
-        if (bin == HISTO_LENGTH) bin = 0;
-        rotHist[bin].push_back(bestIdx2);
-      }
-    }
-  }
-  if (check_orientation) {
-    int ind1 = -1, ind2 = -1, ind3 = -1;
-    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
-    for (int i = 0; i < HISTO_LENGTH; i++) {
-      if (i == ind1 || i == ind2 || i == ind3) continue;
-      for (size_t j = 0; j < rotHist[i].size(); j++) { match_cur[rotHist[i][j]] = -1; nmatches--; }
-    }
-  }
-  *n_matches = nmatches;
-  return ORBFE_OK;
+  // claim loop :1572-1612 + rotation histogram :1614-1628 on the device (k_window_claim)
+  ClaimSpec C;
+  C.mode = CLAIM_BEST; C.maxDist = 100 /* TH_HIGH */; C.checkOri = check_orientation ? 1 : 0;
+  C.blocked = blocked;        // mvpMapPoints[i2] set with Observations() > 0 at entry (:1572-1574)
+  C.blockVal = obs_positive;
+  C.qAngle = last_angle;
+  C.match = match_cur; C.nMatches = n_matches;
+  WindowJob job{Cur, n_last, u, v, qr.data(), qmin.data(), qmax.data(), valid, Cur->u_right ? qur.data() : nullptr, mp_desc, nullptr};
+  job.claim = &C;
+  return window_search_multi(device, &job, 1, 32);
 }
 
 namespace {
@@ -1481,54 +1519,6 @@ int level_queries(const char* who, int n, const uint8_t* valid, const int32_t* l
   return ORBFE_OK;
 }
 
-struct RotHist {
-  static constexpr int L = 30;
-  std::vector<int> bins[L];
-  void push(float a1, float a2, int idx) {  // src/ORBmatcher.cc:1601-1610
-    float rot = a1 - a2;
-    if (rot < 0.0) rot += 360.0f;
-    int bin = (int)roundf(rot * (1.0f / L));
-    if (bin == L) bin = 0;
-    bins[bin].push_back(idx);
-  }
-};
-
-}  // namespace
-
-namespace {
-// the claim loop of SearchByProjection(CurrentFrame, pKF, ...) (src/ORBmatcher.cc:1700-1770) over the window lists of one job
-void keyframe_claim(const orbfe_frame_view* Cur, const WindowResult& res, const uint8_t* blocked, int n, const uint8_t* valid,
-                    const float* kf_angle, int orb_dist, int check_orientation, int32_t* match_cur, int32_t* n_matches) {
-  std::vector<uint8_t> blk(Cur->n, 0);
-  if (blocked) std::memcpy(blk.data(), blocked, (size_t)Cur->n);
-  RotHist rh;
-  int nmatches = 0;
-  for (int i = 0; i < n; i++) {
-    if (!valid[i]) continue;
-    int bestDist = 256, bestIdx2 = -1;
-    for (int c = 0; c < res.count[i]; c++) {
-      const uint32_t e = res.cand[(size_t)i * res.K + c];
-      const int i2 = (int)(e & 0xffffu), dist = (int)(e >> 16);
-      if (blk[i2]) continue;
-      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
-    }
-    if (bestDist <= orb_dist) {
-      match_cur[bestIdx2] = i;
-      blk[bestIdx2] = 1;
-      nmatches++;
-      if (check_orientation) rh.push(kf_angle[i], Cur->angle[bestIdx2], bestIdx2);
-    }
-  }
-  if (check_orientation) {
-    int ind1 = -1, ind2 = -1, ind3 = -1;
-    three_maxima(rh.bins, RotHist::L, ind1, ind2, ind3);
-    for (int i = 0; i < RotHist::L; i++) {
-      if (i == ind1 || i == ind2 || i == ind3) continue;
-      for (int idx : rh.bins[i]) { match_cur[idx] = -1; nmatches--; }
-    }
-  }
-  *n_matches = nmatches;
-}
 }  // namespace
 
 extern "C" int orbfe_search_by_projection_keyframe(int device, const orbfe_frame_view* Cur, const float* scale_factors,
@@ -1550,11 +1540,13 @@ extern "C" int orbfe_search_by_projection_keyframe(int device, const orbfe_frame
   for (int i = 0; i < Cur->n; i++) match_cur[i] = -1;
   *n_matches = 0;
   if (n == 0 || Cur->n == 0) return ORBFE_OK;
-  WindowResult res;
-  rc = window_search(device, Cur, n, u, v, qr.data(), qmin.data(), qmax.data(), valid, nullptr, mp_desc, 32, &res);
-  if (rc != ORBFE_OK) return rc;
-  keyframe_claim(Cur, res, blocked, n, valid, kf_angle, orb_dist, check_orientation, match_cur, n_matches);
-  return ORBFE_OK;
+  ClaimSpec C;  // claim loop :1726-1760 on the device
+  C.mode = CLAIM_BEST; C.maxDist = orb_dist; C.checkOri = check_orientation ? 1 : 0;
+  C.blocked = blocked; C.qAngle = kf_angle;
+  C.match = match_cur; C.nMatches = n_matches;
+  WindowJob job{Cur, n, u, v, qr.data(), qmin.data(), qmax.data(), valid, nullptr, mp_desc, nullptr};
+  job.claim = &C;
+  return window_search_multi(device, &job, 1, 32);
 }
 
 // The same search of ONE current frame against the projected map points of K candidate key frames in one call
@@ -1578,9 +1570,8 @@ extern "C" int orbfe_search_by_projection_keyframe_multi(int device, const orbfe
     return mfail(ORBFE_ERR_INVALID, "search_by_projection_keyframe_multi: bad argument");
   std::vector<std::vector<float>> qr((size_t)K);
   std::vector<std::vector<int32_t>> qmin((size_t)K), qmax((size_t)K);
-  std::vector<WindowResult> res((size_t)K);
+  std::vector<ClaimSpec> claims((size_t)K);
   std::vector<WindowJob> wj;
-  std::vector<int> jobOf;
   for (int k = 0; k < K; k++) {
     if (n[k] < 0 || (n[k] > 0 && (!valid[k] || !u[k] || !v[k] || !level[k] || !mp_desc[k] || (check_orientation && !kf_angle[k]))))
       return mfail(ORBFE_ERR_INVALID, "search_by_projection_keyframe_multi: NULL array of a candidate");
@@ -1590,16 +1581,18 @@ extern "C" int orbfe_search_by_projection_keyframe_multi(int device, const orbfe
     for (int i = 0; i < Cur->n; i++) match_cur[(size_t)k * Cur->n + i] = -1;
     n_matches[k] = 0;
     if (n[k] == 0 || Cur->n == 0) continue;
-    wj.push_back(WindowJob{Cur, n[k], u[k], v[k], qr[k].data(), qmin[k].data(), qmax[k].data(), valid[k], nullptr, mp_desc[k], &res[k]});
-    jobOf.push_back(k);
+    ClaimSpec& C = claims[k];
+    C.mode = CLAIM_BEST; C.maxDist = orb_dist[k]; C.checkOri = check_orientation ? 1 : 0;
+    C.blocked = blocked ? blocked[k] : nullptr;
+    C.qAngle = check_orientation ? kf_angle[k] : nullptr;
+    C.match = match_cur + (size_t)k * Cur->n; C.nMatches = &n_matches[k];
+    WindowJob job{Cur, n[k], u[k], v[k], qr[k].data(), qmin[k].data(), qmax[k].data(), valid[k], nullptr, mp_desc[k], nullptr};
+    job.claim = &C;
+    wj.push_back(job);
   }
   if (wj.empty()) return ORBFE_OK;
-  int rc = window_search_multi(device, wj.data(), (int)wj.size(), 32);
-  if (rc != ORBFE_OK) return rc;
-  for (int k : jobOf)
-    keyframe_claim(Cur, res[k], blocked ? blocked[k] : nullptr, n[k], valid[k], check_orientation ? kf_angle[k] : nullptr, orb_dist[k],
-                   check_orientation, match_cur + (size_t)k * Cur->n, &n_matches[k]);
-  return ORBFE_OK;
+  // one claim workgroup per candidate behind the K window searches: one upload, one launch group, one download
+  return window_search_multi(device, wj.data(), (int)wj.size(), 32);
 }
 
 extern "C" int orbfe_search_by_projection_sim3(int device, const orbfe_frame_view* KF, const float* scale_factors,
@@ -1620,25 +1613,13 @@ extern "C" int orbfe_search_by_projection_sim3(int device, const orbfe_frame_vie
   for (int i = 0; i < KF->n; i++) match[i] = -1;
   *n_matches = 0;
   if (n == 0 || KF->n == 0) return ORBFE_OK;
-  WindowResult res;
-  rc = window_search(device, KF, n, u, v, qr.data(), qmin.data(), qmax.data(), valid, nullptr, mp_desc, 32, &res);
-  if (rc != ORBFE_OK) return rc;
-  std::vector<uint8_t> blk(KF->n, 0);
-  if (matched) std::memcpy(blk.data(), matched, (size_t)KF->n);
-  int nmatches = 0;
-  for (int i = 0; i < n; i++) {
-    if (!valid[i]) continue;
-    int bestDist = 256, bestIdx = -1;
-    for (int c = 0; c < res.count[i]; c++) {
-      const uint32_t e = res.cand[(size_t)i * res.K + c];
-      const int idx = (int)(e & 0xffffu), dist = (int)(e >> 16);
-      if (blk[idx]) continue;
-      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
-    }
-    if (bestDist <= 50) { match[bestIdx] = i; blk[bestIdx] = 1; nmatches++; }  // TH_LOW
-  }
-  *n_matches = nmatches;
-  return ORBFE_OK;
+  ClaimSpec C;  // claim loop :431-451 on the device
+  C.mode = CLAIM_BEST; C.maxDist = 50 /* TH_LOW */;
+  C.blocked = matched;
+  C.match = match; C.nMatches = n_matches;
+  WindowJob job{KF, n, u, v, qr.data(), qmin.data(), qmax.data(), valid, nullptr, mp_desc, nullptr};
+  job.claim = &C;
+  return window_search_multi(device, &job, 1, 32);
 }
 
 extern "C" int orbfe_search_for_initialization(int device, const orbfe_frame_view* F1, const orbfe_frame_view* F2,
@@ -1659,47 +1640,16 @@ extern "C" int orbfe_search_for_initialization(int device, const orbfe_frame_vie
   std::vector<uint8_t> active(n1);
   for (int i = 0; i < n1; i++) active[i] = F1->octave[i] > 0 ? 0 : 1;  // only level-0 keypoints (:482-484)
   for (int i = 0; i < n1; i++) qlv[i] = active[i] ? F1->octave[i] : 0;
-  WindowResult res;
-  const int rc = window_search(device, F2, n1, prev_x, prev_y, qr.data(), qlv.data(), qlv.data(), active.data(), nullptr,
-                               F1->desc, 128, &res);
-  if (rc != ORBFE_OK) return rc;
-  std::vector<int> vMatchedDistance(F2->n, INT_MAX), vnMatches21(F2->n, -1);
-  RotHist rh;
-  int nmatches = 0;
-  for (int i1 = 0; i1 < n1; i1++) {
-    if (!active[i1]) continue;
-    int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
-    for (int c = 0; c < res.count[i1]; c++) {
-      const uint32_t e = res.cand[(size_t)i1 * res.K + c];
-      const int i2 = (int)(e & 0xffffu), dist = (int)(e >> 16);
-      if (vMatchedDistance[i2] <= dist) continue;
-      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
-      else if (dist < bestDist2) bestDist2 = dist;
-    }
-    if (bestDist <= 50) {  // TH_LOW
-      if ((float)bestDist < (float)bestDist2 * nnratio) {
-        if (vnMatches21[bestIdx2] >= 0) { match12[vnMatches21[bestIdx2]] = -1; nmatches--; }
-        match12[i1] = bestIdx2;
-        vnMatches21[bestIdx2] = i1;
-        vMatchedDistance[bestIdx2] = bestDist;
-        nmatches++;
-        if (check_orientation) rh.push(F1->angle[i1], F2->angle[bestIdx2], i1);
-      }
-    }
-  }
-  if (check_orientation) {
-    int ind1 = -1, ind2 = -1, ind3 = -1;
-    three_maxima(rh.bins, RotHist::L, ind1, ind2, ind3);
-    for (int i = 0; i < RotHist::L; i++) {
-      if (i == ind1 || i == ind2 || i == ind3) continue;
-      for (int idx1 : rh.bins[i])
-        if (match12[idx1] >= 0) { match12[idx1] = -1; nmatches--; }
-    }
-  }
-  for (int i1 = 0; i1 < n1; i1++)  // "Update prev matched" (:595-600)
-    if (match12[i1] >= 0) { prev_x[i1] = F2->x[match12[i1]]; prev_y[i1] = F2->y[match12[i1]]; }
-  *n_matches = nmatches;
-  return ORBFE_OK;
+  // the claim loop (:492-545: vMatchedDistance, the nnratio test, a later better match replaces the earlier one), the rotation
+  // histogram (:557-563) and "update prev matched" (:595-600) run on the device (k_window_claim, CLAIM_INIT)
+  ClaimSpec C;
+  C.mode = CLAIM_INIT; C.maxDist = 50 /* TH_LOW */; C.nnratio = nnratio; C.checkOri = check_orientation ? 1 : 0;
+  C.qAngle = F1->angle;
+  C.match = match12; C.nMatches = n_matches;
+  C.prevX = prev_x; C.prevY = prev_y;
+  WindowJob job{F2, n1, prev_x, prev_y, qr.data(), qlv.data(), qlv.data(), active.data(), nullptr, F1->desc, nullptr};
+  job.claim = &C;
+  return window_search_multi(device, &job, 1, 128);
 }
 
 namespace {

@@ -376,3 +376,72 @@ def test_search_by_projection_keyframe_multi(amd):
     for k, (n_ref, ref) in enumerate(refs):
         assert (int(cnt[k]), got[k].tolist()) == (n_ref, ref.tolist()), k
     assert sum(r[0] for r in refs) > 400
+
+
+def _cluster(rng, n, base, octave, bits):
+    """n features inside a 6-px disc around (320, 240), descriptors a few bits away from `base`"""
+    a = rng.uniform(0, 2 * np.pi, n)
+    rr = rng.uniform(0, 6, n)
+    x = (320 + rr * np.cos(a)).astype(np.float32)
+    y = (240 + rr * np.sin(a)).astype(np.float32)
+    d = np.repeat(base[None, :], n, axis=0).copy()
+    for i in range(n):
+        for b in rng.integers(0, 256, bits):
+            d[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    return x, y, np.full(n, octave, np.int32), rng.uniform(0, 360, n).astype(np.float32), d
+
+
+def test_claim_loops_with_long_dependency_chains(amd):
+    """The claim loops run on the device as a fixed-point iteration (k_window_claim): worst case for it are queries that
+    ALL want the same few features -- every one of them depends on every earlier one (src/ORBmatcher.cc:77-78, 1572-1574,
+    1726-1727, 431-432, 516-533).  60 features in one 6-px cluster, 400 queries on top of it."""
+    rng = np.random.default_rng(90)
+    base = rng.integers(0, 256, 32, dtype=np.uint8)
+    x, y, octv, ang, desc = _cluster(rng, 60, base, 2, 20)
+    F, Fo = _both(amd, x, y, octv, ang, desc, None)
+    nq = 400
+    u, v, lv, qa, md = _cluster(rng, nq, base, 2, 24)
+    valid = np.ones(nq, np.uint8)
+    # key frame (reloc) form, with and without the rotation histogram
+    for check_ori in (True, False):
+        m = amd.ORBmatcher(0.9, check_ori)
+        n_ref, ref = orc.search_by_projection_reloc(Fo, SF, valid, u, v, lv, qa, md, None, 10.0, 100, check_ori)
+        n_got, got = m.SearchByProjectionKeyFrame(F, SF, valid, u, v, lv, qa, md, 10.0, 100)
+        assert (n_got, got.tolist()) == (n_ref, ref.tolist())
+    assert (ref >= 0).sum() > 10
+    from orb_slam2_annotate_amd import _lib
+    assert _lib.load().orbfe_debug_last_claim_rounds() > 10  # (the chains are really there: random frames take 2-4 rounds)
+    # Sim3 form (TH_LOW)
+    n_ref, ref = orc.search_by_projection_sim3(Fo, SF, valid, u, v, lv, md, None, 10.0)
+    n_got, got = amd.ORBmatcher(0.75, True).SearchByProjectionSim3(F, SF, valid, u, v, lv, md, 10.0)
+    assert (n_got, got.tolist()) == (n_ref, ref.tolist())
+    # last-frame form: a third of the matches do not hide their feature (MapPoint::Observations() == 0), so later points
+    # overwrite them and a feature is pushed into the rotation histogram more than once
+    obs = (rng.random(nq) < 0.66).astype(np.uint8)
+    invzc = np.zeros(nq, np.float32)
+    for check_ori in (True, False):
+        n_ref, ref = orc.search_by_projection_lastframe(Fo, SF, 40.0, valid, u, v, invzc, lv, qa, md, obs, 0, 15.0, check_ori)
+        n_got, got = amd.ORBmatcher(0.9, check_ori).SearchByProjectionLastFrame(F, SF, valid, u, v, lv, qa, md, 15.0, mode=0, mbf=40.0,
+                                                                               invzc=invzc, obs_positive=obs)
+        assert (n_got, got.tolist()) == (n_ref, ref.tolist())
+    # map-point form (best / second-best level + ratio test)
+    view_cos = np.full(nq, 0.9, np.float32)
+    for o in (obs, None):
+        n_ref, ref = orc.search_by_projection_mappoints(Fo, SF, None, valid, lv, view_cos, u, v, None, md, o, 3.0, 0.8)
+        n_got, got = amd.ORBmatcher(0.8, True).SearchByProjection(F, SF, valid, lv, view_cos, u, v, md, th=3.0, mp_obs_positive=o)
+        assert (n_got, got.tolist()) == (n_ref, ref.tolist())
+    # SearchForInitialization: 300 level-0 key points of F1 over the same 60 key points of F2 -- a later, closer key point
+    # takes a feature back from an earlier one (:529-533)
+    x2, y2, o2, a2, d2 = _cluster(rng, 60, base, 0, 12)
+    x1, y1, o1, a1, d1 = _cluster(rng, 300, base, 0, 16)
+    o1[rng.random(300) < 0.1] = 1  # (not level 0: skipped, :482-484)
+    F1, O1 = _both(amd, x1, y1, o1, a1, d1, None)
+    F2, O2 = _both(amd, x2, y2, o2, a2, d2, None)
+    prev = np.stack([x1, y1], axis=1).astype(np.float32)
+    for check_ori in (True, False):
+        n_ref, ref, prev_ref = orc.search_for_initialization(O1, O2, prev.copy(), 100, 0.9, check_ori)
+        prev_got = prev.copy()
+        n_got, got = amd.ORBmatcher(0.9, check_ori).SearchForInitialization(F1, F2, prev_got, 100)
+        assert (n_got, got.tolist()) == (n_ref, ref.tolist())
+        assert np.array_equal(prev_got, prev_ref)
+    assert n_ref > 5

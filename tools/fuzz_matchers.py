@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential test of the projection-search family (device frame grid + window search +
-host claim loops) against the CPU oracle.
+device claim loops, k_window_claim) against the CPU oracle.
     python tools/fuzz_matchers.py [seconds] [seed]"""
 import sys
 import time
