@@ -9,6 +9,8 @@
 // exactly the reference's scan order (ix outer, iy inner, index ascending inside a cell).
 // HBM-light integer work: a 64-lane wavefront owns one query, takes a span 64 entries at a
 // time, and a ballot keeps the survivors in scan order.
+#include <cstdlib>
+
 #include "kernels.h"
 #include "match_kernels.h"
 
@@ -58,6 +60,94 @@ __global__ __launch_bounds__(1024) void k_grid_build(GridFrame f, int sortN, uin
     }
     cellOff[c] = lo;
   }
+}
+
+// The same arrays by COUNTING instead of sorting (frames of up to 8192 features: every Frame / KeyFrame of the reference's
+// settings).  The bitonic network above is 66 passes with a workgroup barrier each for 2048 keys -- 29 us, half of a
+// host-array projection search and most of orbfe_frame_upload.  Here: cell counts with LDS atomics, one block scan over the
+// 3072 cells (= cellOff), an unordered scatter of the keys into their cell's segment, and every key's rank inside its
+// segment by counting the smaller keys there (segments hold ~1 feature; the order inside a cell is ascending feature
+// index, as mGrid's push_back order, src/Frame.cc:246-259).  Seven barriers.  A frame that piles more than kGridRankMax
+// features into one cell (synthetic clusters) would make that last step quadratic: the workgroup then runs the bitonic
+// network instead -- same result.
+constexpr int kGridRankMax = 64;
+__global__ __launch_bounds__(1024) void k_grid_build_count(GridFrame f, int sortN, uint32_t* __restrict__ sortedKey,
+                                                           int32_t* __restrict__ cellOff) {
+  extern __shared__ uint32_t keys[];       // [sortN] scatter target / bitonic array
+  __shared__ int s_off[GRID_CELLS + 1];    // counts, then first position of each cell
+  __shared__ int s_cur[GRID_CELLS];        // scatter cursors
+  __shared__ int s_wave[16];
+  __shared__ int s_max;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int c = t; c < GRID_CELLS; c += 1024) { s_off[c] = 0; s_cur[c] = 0; }
+  if (t == 0) s_max = 0;
+  __syncthreads();
+  auto key_of = [&](int i) -> uint32_t {
+    // PosInGrid, src/Frame.cc:417-427: round() half away from zero
+    const int px = (int)roundf((f.x[i] - f.minX) * f.wInv);
+    const int py = (int)roundf((f.y[i] - f.minY) * f.hInv);
+    if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) return KEY_NONE;
+    return ((uint32_t)(px * GRID_ROWS + py) << 16) | (uint32_t)i;
+  };
+  for (int i = t; i < f.n; i += 1024) {
+    const uint32_t k = key_of(i);
+    if (k != KEY_NONE) atomicAdd(&s_off[k >> 16], 1);
+  }
+  __syncthreads();
+  // exclusive scan over the cells: thread t owns cells 3t .. 3t+2
+  const int c0 = s_off[3 * t], c1 = s_off[3 * t + 1], c2 = s_off[3 * t + 2];
+  {
+    int m = c0 > c1 ? c0 : c1;
+    m = m > c2 ? m : c2;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(m, o, 64); m = v > m ? v : m; }
+    if (lane == 0) atomicMax(&s_max, m);
+  }
+  int incl = c0 + c1 + c2;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; w++) base += s_wave[w];
+  const int excl = base + incl - (c0 + c1 + c2);
+  __syncthreads();  // (everyone has read its three counts)
+  s_off[3 * t] = excl; s_off[3 * t + 1] = excl + c0; s_off[3 * t + 2] = excl + c0 + c1;
+  cellOff[3 * t] = excl; cellOff[3 * t + 1] = excl + c0; cellOff[3 * t + 2] = excl + c0 + c1;
+  if (t == 1023) { s_off[GRID_CELLS] = excl + c0 + c1 + c2; cellOff[GRID_CELLS] = excl + c0 + c1 + c2; }
+  __syncthreads();
+  if (s_max <= kGridRankMax) {  // block-uniform
+    for (int i = t; i < f.n; i += 1024) {
+      const uint32_t k = key_of(i);
+      if (k != KEY_NONE) keys[s_off[k >> 16] + atomicAdd(&s_cur[k >> 16], 1)] = k;
+    }
+    __syncthreads();
+    for (int i = t; i < f.n; i += 1024) {
+      const uint32_t k = key_of(i);
+      if (k == KEY_NONE) continue;
+      const int s = s_off[k >> 16], e = s_off[(k >> 16) + 1];
+      int rank = 0;
+      for (int p = s; p < e; p++) rank += keys[p] < k ? 1 : 0;
+      sortedKey[s + rank] = k;
+    }
+    return;
+  }
+  // ---- a crowded cell: the bitonic network of k_grid_build (cellOff is already written) ----
+  for (int i = t; i < sortN; i += 1024) keys[i] = i < f.n ? key_of(i) : KEY_NONE;
+  __syncthreads();
+  for (int k = 2; k <= sortN; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < sortN; i += 1024) {
+        const int p = i ^ j;
+        if (p > i) {
+          const uint32_t a = keys[i], b = keys[p];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) { keys[i] = b; keys[p] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = t; i < f.n; i += 1024) sortedKey[i] = keys[i];
 }
 
 // One wavefront per query, 4 per block.
@@ -180,39 +270,74 @@ __device__ __forceinline__ int claim_rot_bin(float a1, float a2) {
   return bin;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
 // The claim loops of SearchByProjection (map points :77-135, last frame :1572-1612, key frame :1726-1760, Sim3 :431-451) and
 // SearchForInitialization (:492-545) -- see ClaimJob (match_kernels.h).  One workgroup per job.  A round lets EVERY query
 // choose, in parallel, among the candidates that no query in front of it holds (according to the previous round's
 // choices); rounds repeat until no choice changes.  The fixed point is the reference's sequential result: query 0 never
 // depends on anyone, and once the queries in front of j have their final choices so has j -- at most nq + 1 rounds, in
-// practice two or three, because two map points rarely want the same feature.
-//   BEST / RATIO: a feature is hidden from query j when an earlier query whose match blocks (blockVal) chose it:
-//                 owner[feature] = the smallest such query (atomicMin), hidden <=> owner < j.
-//   INIT:         a feature is hidden from query j for candidates at distance >= the smallest distance at which an
-//                 earlier query took it (vMatchedDistance, :516-517): the choosers of a feature form a linked list
-//                 (owner = head, link = next), walked for the ones in front of j.
-__global__ __launch_bounds__(1024) void k_window_claim(const ClaimJob* __restrict__ jobs) {
+// practice three or four, because two map points rarely want the same feature.
+// ---------------------------------------------------------------------------------------------------------------------
+
+// three dominant bins (ComputeThreeMaxima, src/ORBmatcher.cc:1635-1690): the 30 counts come into registers at once
+__device__ __forceinline__ void claim_three_maxima(const int* hist, int* keep) {
+  int h[30];
+#pragma unroll
+  for (int i = 0; i < 30; i++) h[i] = hist[i];
+  int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+#pragma unroll
+  for (int i = 0; i < 30; i++) {
+    const int s = h[i];
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+    else if (s > max3) { max3 = s; i3 = i; }
+  }
+  if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { i2 = -1; i3 = -1; }
+  else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { i3 = -1; }
+  keep[0] = i1; keep[1] = i2; keep[2] = i3;
+}
+
+// BEST / RATIO forms.  A feature is hidden from query j when an EARLIER query whose match blocks (blockVal) chose it in the
+// previous round.  own[2][n] hold, per feature, a stamp (round << 21 | 0x1fffff - query) written with atomicMax by every
+// blocking chooser of a round: the newest round wins, inside a round the smallest query index; a round reads the array the
+// previous round wrote and writes the other one, so a round is ONE barrier and nothing is ever cleared (an entry whose round
+// is not the previous one is "free"; 0xffffffff = taken at entry, hidden from everyone).  What a thread needs of its FIRST
+// query (nq <= 1024: its only one) stays in registers over the rounds -- flags, list length, the first eight candidates, the
+// current choice -- so a round touches LDS only unless a list is longer than eight; further queries of a thread (tid + 1024,
+// ...) take everything from memory every round.  The match array is built in LDS (the stamp arrays are free by then) and
+// written out once.
+constexpr int kClaimRoundBits = 11, kClaimJBits = 21;
+constexpr uint32_t kClaimJMask = (1u << kClaimJBits) - 1u, kClaimTaken = 0xffffffffu;
+// wave64 sum / max through the DPP network; every lane returns the wave's value
+__device__ __forceinline__ int claim_wave_sum(int x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+__device__ __forceinline__ int claim_wave_max(int x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(x, o, 64); x = t > x ? t : x; }
+  return x;
+}
+
+// kOneJob: the (usual) single job travels as the kernel argument -- no dependent load of a block that the input copy has
+// just put into HBM in front of the kernel's first memory request
+template <bool kOneJob>
+__global__ __launch_bounds__(1024) void k_window_claim(const ClaimJob job, const ClaimJob* __restrict__ jobs) {
   extern __shared__ int32_t s_dyn[];
-  __shared__ int s_hist[30];
+  __shared__ int s_hist[16][32];  // per wave: a thousand atomics on thirty shared counters would queue behind each other
   __shared__ int s_keep[3];
-  __shared__ int s_changed[2];
-  __shared__ int s_total, s_pruned, s_maxc, s_conflict;
-  const ClaimJob J = jobs[blockIdx.x];
-  const int tid = threadIdx.x;
-  int32_t* owner = J.owner ? J.owner : s_dyn;
-  constexpr int kNone = 0x7fffffff;
-  const bool init = J.mode == CLAIM_INIT;
-  const int ownerFree = init ? -1 : kNone;
-  if (tid < 30) s_hist[tid] = 0;
-  if (tid < 2) s_changed[tid] = 0;
-  if (tid == 0) { s_total = 0; s_pruned = 0; s_maxc = 0; s_conflict = 0; }
-  __syncthreads();
-  // What a thread needs of its FIRST query (nq <= 1024: its only one) stays in registers over the rounds -- the flags, the
-  // list length, the first eight candidates, the current choice: after round 0 a round of the BEST / RATIO forms touches LDS
-  // only, unless a list is longer than eight.  Further queries of the thread (tid + 1024, ...) and the INIT form take
-  // everything from memory every round.
-  uint8_t* s_oct = reinterpret_cast<uint8_t*>(s_dyn + (J.owner ? 0 : J.n));  // RATIO: octave bytes of the features (255: read HBM)
-  const bool has0 = !init && tid < J.nq;
+  __shared__ int s_changed[3];
+  __shared__ int s_total, s_pruned, s_maxc;
+  const ClaimJob J = kOneJob ? job : jobs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t* own0 = reinterpret_cast<uint32_t*>(J.owner ? J.owner : s_dyn);
+  uint32_t* own1 = own0 + J.n;
+  uint8_t* s_oct = reinterpret_cast<uint8_t*>(s_dyn + (J.owner ? 0 : 2 * J.n));  // RATIO: octave bytes of the features (255: read HBM)
+  if (tid < 512) s_hist[tid >> 5][tid & 31] = 0;
+  if (tid < 3) s_changed[tid] = 0;
+  if (tid == 0) { s_total = 0; s_pruned = 0; s_maxc = 0; }
+  const bool has0 = tid < J.nq;
   bool act0 = false, bv0 = true;
   int nc0 = 0, c0 = -2;
   uint32_t e0[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
@@ -226,19 +351,198 @@ __global__ __launch_bounds__(1024) void k_window_claim(const ClaimJob* __restric
     }
     int mc = 0;
     for (int j = tid; j < J.nq; j += 1024) {
-      J.choice[j] = -2;  // (no choice computed yet: the first round counts as a change)
       const int c = J.count[j];
       mc = c > mc ? c : mc;
       if (j == tid) nc0 = c < J.K ? c : J.K;
+      else J.choice[j] = -2;  // (no choice computed yet: the first round counts as a change)
     }
-    if (mc) atomicMax(&s_maxc, mc);
-    // (BEST / RATIO: a feature that is taken at entry is "owned by query -1", i.e. hidden from everyone)
-    for (int i = tid; i < J.n; i += 1024) owner[i] = (!init && J.blocked && J.blocked[i]) ? -1 : ownerFree;
+    for (int i = tid; i < J.n; i += 1024) {
+      const uint32_t v = (J.blocked && J.blocked[i]) ? kClaimTaken : 0u;
+      own0[i] = v;
+      own1[i] = v;
+    }
     if (J.mode == CLAIM_RATIO)
       for (int i = tid; i < J.n; i += 1024) {
         const int o = J.octave[i];
         s_oct[i] = (uint8_t)((unsigned)o < 255u ? o : 255);
       }
+    __syncthreads();
+    mc = claim_wave_max(mc);
+    if (lane == 0 && mc) atomicMax(&s_maxc, mc);
+  }
+  int rounds = 0;          // rounds run so far
+  uint32_t stampR = 0;     // round field of the stamps the PREVIOUS round wrote (0: nothing written yet)
+  for (;; rounds++) {
+    if (stampR >= (1u << kClaimRoundBits) - 2u) {  // (round 2047 is never used: its stamp of query 0 would read "taken at entry")
+      // the round field is about to wrap (only chains of thousands of queries that all want the same features get here):
+      // clear the arrays and write the current choices again under round 1
+      __syncthreads();
+      for (int i = tid; i < J.n; i += 1024) {
+        if (own0[i] != kClaimTaken) own0[i] = 0u;
+        if (own1[i] != kClaimTaken) own1[i] = 0u;
+      }
+      __syncthreads();
+      uint32_t* rd = (rounds & 1) ? own1 : own0;  // the array this round is going to read
+      for (int j = tid; j < J.nq; j += 1024) {
+        const int c = j == tid ? c0 : J.choice[j];
+        const bool bv = j == tid ? bv0 : (!J.blockVal || J.blockVal[j]);
+        if (c >= 0 && bv) atomicMax(&rd[c], (1u << kClaimJBits) | (kClaimJMask - (uint32_t)j));
+      }
+      stampR = 1;
+      __syncthreads();
+    }
+    const uint32_t* rd = (rounds & 1) ? own1 : own0;
+    uint32_t* wr = (rounds & 1) ? own0 : own1;
+    const uint32_t stampW = stampR + 1;
+    const int flag = rounds % 3;
+    if (tid == 0) s_changed[(rounds + 1) % 3] = 0;  // (last read two barriers ago)
+    int changed = 0;
+    for (int j = tid; j < J.nq; j += 1024) {
+      int c = -1;
+      const bool slot0 = j == tid;
+      if (slot0 ? act0 : (!J.active || J.active[j])) {
+        int nc;
+        if (slot0) nc = nc0;
+        else { nc = J.count[j]; nc = nc < J.K ? nc : J.K; }
+        // the list is read eight entries (two 16-byte requests) at a time: one memory round trip per eight candidates
+        const uint4* L4 = reinterpret_cast<const uint4*>(J.cand + (size_t)j * J.K);
+        int bestDist = 256, bestDist2 = 256, bestIdx = -1, secIdx = -1;
+        // best and second best of eight entries, as selects (written with branches the compiler kept the four running
+        // values in scratch memory behind a computed store address).  `free`: not taken at entry, not held by an earlier
+        // query in the previous round, not past the end of the list
+#define ORBFE_CLAIM_PROC8(EV, NVALID)                                                                                      \
+  do {                                                                                                                    \
+    uint32_t own_[8];                                                                                                     \
+    _Pragma("unroll") for (int u = 0; u < 8; u++) own_[u] = u < (NVALID) ? rd[(EV)[u] & 0xffffu] : kClaimTaken;           \
+    _Pragma("unroll") for (int u = 0; u < 8; u++) {                                                                       \
+      const bool held_ = own_[u] == kClaimTaken ||                                                                        \
+                         ((own_[u] >> kClaimJBits) == stampR && stampR != 0u && (int)(kClaimJMask - (own_[u] & kClaimJMask)) < j); \
+      const int idx_ = (int)((EV)[u] & 0xffffu), dist_ = (int)((EV)[u] >> 16);                                            \
+      const bool lt1_ = !held_ && dist_ < bestDist, lt2_ = !held_ && dist_ < bestDist2;                                   \
+      bestDist2 = lt1_ ? bestDist : (lt2_ ? dist_ : bestDist2);                                                           \
+      secIdx = lt1_ ? bestIdx : (lt2_ ? idx_ : secIdx);                                                                   \
+      bestDist = lt1_ ? dist_ : bestDist;                                                                                 \
+      bestIdx = lt1_ ? idx_ : bestIdx;                                                                                    \
+    }                                                                                                                     \
+  } while (0)
+        if (slot0) {
+          if (nc > 0) ORBFE_CLAIM_PROC8(e0, nc);
+        } else if (nc > 0) {
+          const uint4 ea = L4[0], eb = L4[1];
+          const uint32_t ev8[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
+          ORBFE_CLAIM_PROC8(ev8, nc);
+        }
+        for (int k0 = 8; k0 < nc; k0 += 8) {
+          const uint4 ea = L4[k0 >> 2], eb = L4[(k0 >> 2) + 1];
+          const uint32_t ev8[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
+          ORBFE_CLAIM_PROC8(ev8, nc - k0);
+        }
+#undef ORBFE_CLAIM_PROC8
+        if (bestIdx >= 0 && bestDist <= J.maxDist) {
+          c = bestIdx;
+          if (J.mode == CLAIM_RATIO && (float)bestDist > __fmul_rn(J.nnratio, (float)bestDist2)) {
+            // (:124-127: the ratio only counts between two candidates of the same level)
+            int bestLevel = s_oct[bestIdx], bestLevel2 = secIdx >= 0 ? (int)s_oct[secIdx] : -1;
+            if (bestLevel == 255) bestLevel = J.octave[bestIdx];
+            if (bestLevel2 == 255) bestLevel2 = J.octave[secIdx];
+            if (bestLevel == bestLevel2) c = -1;
+          }
+        }
+      }
+      bool bv;
+      if (slot0) {
+        if (c != c0) { c0 = c; changed = 1; }
+        bv = bv0;
+      } else {
+        if (c != J.choice[j]) { J.choice[j] = c; changed = 1; }
+        bv = !J.blockVal || J.blockVal[j];
+      }
+      if (c >= 0 && bv) atomicMax(&wr[c], (stampW << kClaimJBits) | (kClaimJMask - (uint32_t)j));
+    }
+    if (changed) s_changed[flag] = 1;
+    __syncthreads();
+    stampR = stampW;
+    if (!s_changed[flag]) break;  // block-uniform: a round without a change is the fixed point
+  }
+  // ---- the match array (in LDS, over the stamp arrays), the rotation histogram (:1614-1628) and the count ----
+  int* match = reinterpret_cast<int*>(own0);
+  for (int i = tid; i < J.n; i += 1024) match[i] = -1;
+  __syncthreads();
+  int ev = 0, bin0 = -1;
+  for (int j = tid; j < J.nq; j += 1024) {
+    const int c = j == tid ? c0 : J.choice[j];
+    if (c < 0) continue;
+    atomicMax(&match[c], j);  // a feature whose holder does not block is overwritten by the later ones
+    ev++;
+    if (J.checkOri) {
+      const int b = claim_rot_bin(J.qAngle[j], J.fAngle[c]);  // every take is pushed (:1601-1610)
+      atomicAdd(&s_hist[wave][b], 1);
+      if (j == tid) bin0 = b;
+    }
+  }
+  ev = claim_wave_sum(ev);
+  if (lane == 0 && ev) atomicAdd(&s_total, ev);
+  __syncthreads();
+  if (J.checkOri) {
+    if (tid < 30) {
+      int t = 0;
+#pragma unroll
+      for (int w = 0; w < 16; w++) t += s_hist[w][tid];
+      s_hist[0][tid] = t;
+    }
+    __syncthreads();
+    if (tid == 0) claim_three_maxima(s_hist[0], s_keep);
+    __syncthreads();
+    const int k0 = s_keep[0], k1 = s_keep[1], k2 = s_keep[2];
+    int pr = 0;
+    for (int j = tid; j < J.nq; j += 1024) {
+      const int c = j == tid ? c0 : J.choice[j];
+      if (c < 0) continue;
+      const int b = j == tid ? bin0 : claim_rot_bin(J.qAngle[j], J.fAngle[c]);
+      if (b == k0 || b == k1 || b == k2) continue;
+      match[c] = -1;  // :1617-1625: every entry of a dropped bin clears its feature and counts
+      pr++;
+    }
+    pr = claim_wave_sum(pr);
+    if (lane == 0 && pr) atomicAdd(&s_pruned, pr);
+    __syncthreads();
+  }
+  for (int i = tid; i < J.n; i += 1024) J.match[i] = match[i];
+  if (tid == 0) {
+    J.header[0] = s_maxc;
+    J.header[1] = s_total - s_pruned;
+    J.header[2] = rounds;
+    J.header[3] = 0;
+  }
+}
+
+// SearchForInitialization (:492-545).  A feature is hidden from query j only for candidates at distance >= the smallest
+// distance at which an earlier query took it (vMatchedDistance, :516-517): the choosers of a feature form a linked list
+// (owner = head, link = next), walked for the ones in front of j; the last taker keeps the feature (:529-533).  Called once
+// per initialisation attempt: the plain form (everything re-read every round, three barriers per round).
+__global__ __launch_bounds__(1024) void k_window_claim_init(const ClaimJob* __restrict__ jobs) {
+  extern __shared__ int32_t s_dyn[];
+  __shared__ int s_hist[30];
+  __shared__ int s_keep[3];
+  __shared__ int s_changed[2];
+  __shared__ int s_total, s_pruned, s_maxc;
+  const ClaimJob J = jobs[blockIdx.x];
+  const int tid = threadIdx.x;
+  int32_t* owner = J.owner ? J.owner : s_dyn;
+  constexpr int kNone = 0x7fffffff;
+  if (tid < 30) s_hist[tid] = 0;
+  if (tid < 2) s_changed[tid] = 0;
+  if (tid == 0) { s_total = 0; s_pruned = 0; s_maxc = 0; }
+  __syncthreads();
+  {
+    int mc = 0;
+    for (int j = tid; j < J.nq; j += 1024) {
+      J.choice[j] = -2;  // (no choice computed yet: the first round counts as a change)
+      const int c = J.count[j];
+      mc = c > mc ? c : mc;
+    }
+    if (mc) atomicMax(&s_maxc, mc);
+    for (int i = tid; i < J.n; i += 1024) owner[i] = -1;
   }
   __syncthreads();
   int rounds = 0;
@@ -248,167 +552,79 @@ __global__ __launch_bounds__(1024) void k_window_claim(const ClaimJob* __restric
     int changed = 0;
     for (int j = tid; j < J.nq; j += 1024) {
       int c = -1;
-      const bool slot0 = has0 && j == tid;
-      if (slot0 ? act0 : (!J.active || J.active[j])) {
-        int nc;
-        if (slot0) nc = nc0;
-        else { nc = J.count[j]; nc = nc < J.K ? nc : J.K; }
-        // the list is read eight entries (two 16-byte requests) at a time: one memory round trip per eight candidates instead
-        // of one per candidate -- a round is a handful of dependent round trips, and most lists are shorter than eight
+      if (!J.active || J.active[j]) {
+        int nc = J.count[j];
+        nc = nc < J.K ? nc : J.K;
         const uint4* L4 = reinterpret_cast<const uint4*>(J.cand + (size_t)j * J.K);
-        if (init) {
-          int bestDist = kNone, bestDist2 = kNone, bestIdx = -1;
-          for (int k0 = 0; k0 < nc; k0 += 8) {
-            const uint4 ea = L4[k0 >> 2], eb = L4[(k0 >> 2) + 1];
-            const uint32_t ev8[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
+        int bestDist = kNone, bestDist2 = kNone, bestIdx = -1;
+        for (int k0 = 0; k0 < nc; k0 += 8) {
+          const uint4 ea = L4[k0 >> 2], eb = L4[(k0 >> 2) + 1];
+          const uint32_t ev8[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-              if (k0 + u >= nc) break;
-              const uint32_t e = ev8[u];
-              const int i2 = (int)(e & 0xffffu), dist = (int)(e >> 16);
-              int held = kNone;  // vMatchedDistance[i2] as query j sees it
-              for (int i = owner[i2]; i >= 0; i = J.link[i])
-                if (i < j) {
-                  const int ci = J.choice[i];  // (may be this round's: only a consistent "i holds i2 at d" entry is used)
-                  if (ci >= 0 && (ci & 0xffff) == i2) held = (ci >> 16) < held ? (ci >> 16) : held;
-                }
-              if (held <= dist) continue;
-              if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx = i2; }
-              else if (dist < bestDist2) bestDist2 = dist;
-            }
-          }
-          if (bestIdx >= 0 && bestDist <= J.maxDist && (float)bestDist < __fmul_rn((float)bestDist2, J.nnratio))
-            c = (bestDist << 16) | bestIdx;
-        } else {
-          int bestDist = 256, bestDist2 = 256, bestIdx = -1, secIdx = -1;
-          // best and second best of eight entries, as selects (written with branches the compiler kept the four running
-          // values in scratch memory behind a computed store address)
-#define ORBFE_CLAIM_PROC8(EV, NVALID)                                                                                      \
-  do {                                                                                                                    \
-    int own_[8];                                                                                                          \
-    _Pragma("unroll") for (int u = 0; u < 8; u++) own_[u] = u < (NVALID) ? owner[(EV)[u] & 0xffffu] : -1; /* eight lookups in flight */ \
-    _Pragma("unroll") for (int u = 0; u < 8; u++) {                                                                       \
-      const bool free_ = own_[u] >= j; /* not held by an earlier query, not taken at entry, not past the end of the list */ \
-      const int idx_ = (int)((EV)[u] & 0xffffu), dist_ = (int)((EV)[u] >> 16);                                            \
-      const bool lt1_ = free_ && dist_ < bestDist, lt2_ = free_ && dist_ < bestDist2;                                     \
-      bestDist2 = lt1_ ? bestDist : (lt2_ ? dist_ : bestDist2);                                                           \
-      secIdx = lt1_ ? bestIdx : (lt2_ ? idx_ : secIdx);                                                                   \
-      bestDist = lt1_ ? dist_ : bestDist;                                                                                 \
-      bestIdx = lt1_ ? idx_ : bestIdx;                                                                                    \
-    }                                                                                                                     \
-  } while (0)
-          if (slot0) {
-            if (nc > 0) ORBFE_CLAIM_PROC8(e0, nc);
-          } else if (nc > 0) {
-            const uint4 ea = L4[0], eb = L4[1];
-            const uint32_t ev8[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
-            ORBFE_CLAIM_PROC8(ev8, nc);
-          }
-          for (int k0 = 8; k0 < nc; k0 += 8) {
-            const uint4 ea = L4[k0 >> 2], eb = L4[(k0 >> 2) + 1];
-            const uint32_t ev8[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
-            ORBFE_CLAIM_PROC8(ev8, nc - k0);
-          }
-#undef ORBFE_CLAIM_PROC8
-          if (bestIdx >= 0 && bestDist <= J.maxDist) {
-            c = bestIdx;
-            if (J.mode == CLAIM_RATIO && (float)bestDist > __fmul_rn(J.nnratio, (float)bestDist2)) {
-              // (:124-127: the ratio only counts between two candidates of the same level)
-              int bestLevel = s_oct[bestIdx], bestLevel2 = secIdx >= 0 ? (int)s_oct[secIdx] : -1;
-              if (bestLevel == 255) bestLevel = J.octave[bestIdx];
-              if (bestLevel2 == 255) bestLevel2 = J.octave[secIdx];
-              if (bestLevel == bestLevel2) c = -1;
-            }
+          for (int u = 0; u < 8; u++) {
+            if (k0 + u >= nc) break;
+            const uint32_t e = ev8[u];
+            const int i2 = (int)(e & 0xffffu), dist = (int)(e >> 16);
+            int held = kNone;  // vMatchedDistance[i2] as query j sees it
+            for (int i = owner[i2]; i >= 0; i = J.link[i])
+              if (i < j) {
+                const int ci = J.choice[i];  // (may be this round's: only a consistent "i holds i2 at d" entry is used)
+                if (ci >= 0 && (ci & 0xffff) == i2) held = (ci >> 16) < held ? (ci >> 16) : held;
+              }
+            if (held <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
           }
         }
+        if (bestIdx >= 0 && bestDist <= J.maxDist && (float)bestDist < __fmul_rn((float)bestDist2, J.nnratio))
+          c = (bestDist << 16) | bestIdx;
       }
-      if (slot0) {
-        if (c != c0) { c0 = c; J.choice[j] = c; changed = 1; }
-      } else if (c != J.choice[j]) { J.choice[j] = c; changed = 1; }
+      if (c != J.choice[j]) { J.choice[j] = c; changed = 1; }
     }
     if (changed) s_changed[flag] = 1;
     __syncthreads();
     if (!s_changed[flag]) break;  // block-uniform: a round without a change is the fixed point
-    // (a feature taken at entry keeps its -1: atomicMin with a query index never lowers it)
-    for (int i = tid; i < J.n; i += 1024)
-      if (init || owner[i] != -1) owner[i] = ownerFree;
+    for (int i = tid; i < J.n; i += 1024) owner[i] = -1;
     __syncthreads();
     for (int j = tid; j < J.nq; j += 1024) {
-      const int c = (has0 && j == tid) ? c0 : J.choice[j];
-      if (c < 0) continue;
-      if (init) J.link[j] = atomicExch(&owner[c & 0xffff], j);
-      else if ((has0 && j == tid) ? bv0 : (!J.blockVal || J.blockVal[j])) atomicMin(&owner[c], j);
+      const int c = J.choice[j];
+      if (c >= 0) J.link[j] = atomicExch(&owner[c & 0xffff], j);
     }
     __syncthreads();
-    if (rounds == 0 && J.mode == CLAIM_BEST) {
-      // the usual case ends here: when no query's first choice is held by an earlier one, every query keeps the best of ALL
-      // its candidates and a second round would change nothing.  (Not so with the ratio test, whose outcome also depends on
-      // whether the SECOND best is still free.)
-      int conflict = 0;
-      for (int j = tid; j < J.nq; j += 1024) {
-        const int c = (has0 && j == tid) ? c0 : J.choice[j];
-        if (c >= 0 && owner[c] < j) conflict = 1;
-      }
-      if (conflict) s_conflict = 1;
-      __syncthreads();
-      if (!s_conflict) break;  // block-uniform
-    }
   }
-  // ---- the match array, the rotation histogram (ComputeThreeMaxima, :1635-1690) and the count ----
-  const int nOut = init ? J.nq : J.n;
-  if (!init)
-    for (int i = tid; i < nOut; i += 1024) J.match[i] = -1;
-  __syncthreads();
+  // ---- vnMatches12, the rotation histogram (:557-563), the count, "update prev matched" (:595-600) ----
   int ev = 0;
   for (int j = tid; j < J.nq; j += 1024) {
     const int c = J.choice[j];
     int m = -1;
     if (c >= 0) {
-      const int f = init ? (c & 0xffff) : c;
-      if (J.checkOri) atomicAdd(&s_hist[claim_rot_bin(J.qAngle[j], J.fAngle[f])], 1);  // every take is pushed (:540-553, :1601-1610)
-      if (init) {
-        bool holder = true;  // a later query that took the feature replaced this one (:529-533)
-        for (int i = owner[f]; i >= 0; i = J.link[i])
-          if (i > j) { const int ci = J.choice[i]; if (ci >= 0 && (ci & 0xffff) == f) holder = false; }
-        if (holder) { m = f; ev++; }
-      } else {
-        atomicMax(&J.match[c], j);  // a feature whose holder does not block is overwritten by the later ones
-        ev++;
-      }
+      const int f = c & 0xffff;
+      if (J.checkOri) atomicAdd(&s_hist[claim_rot_bin(J.qAngle[j], J.fAngle[f])], 1);  // every take is pushed (:540-553)
+      bool holder = true;  // a later query that took the feature replaced this one (:529-533)
+      for (int i = owner[f]; i >= 0; i = J.link[i])
+        if (i > j) { const int ci = J.choice[i]; if (ci >= 0 && (ci & 0xffff) == f) holder = false; }
+      if (holder) { m = f; ev++; }
     }
-    if (init) J.match[j] = m;
+    J.match[j] = m;
   }
   if (ev) atomicAdd(&s_total, ev);
   __syncthreads();
   if (J.checkOri) {
-    if (tid == 0) {
-      int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
-      for (int i = 0; i < 30; i++) {
-        const int s = s_hist[i];
-        if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
-        else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
-        else if (s > max3) { max3 = s; i3 = i; }
-      }
-      if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { i2 = -1; i3 = -1; }
-      else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { i3 = -1; }
-      s_keep[0] = i1; s_keep[1] = i2; s_keep[2] = i3;
-    }
+    if (tid == 0) claim_three_maxima(s_hist, s_keep);
     __syncthreads();
     const int k0 = s_keep[0], k1 = s_keep[1], k2 = s_keep[2];
     int pr = 0;
     for (int j = tid; j < J.nq; j += 1024) {
       const int c = J.choice[j];
       if (c < 0) continue;
-      const int f = init ? (c & 0xffff) : c;
-      const int b = claim_rot_bin(J.qAngle[j], J.fAngle[f]);
+      const int b = claim_rot_bin(J.qAngle[j], J.fAngle[c & 0xffff]);
       if (b == k0 || b == k1 || b == k2) continue;
-      if (init) { if (J.match[j] >= 0) { J.match[j] = -1; pr++; } }   // :557-563: only a still-matched entry counts
-      else { J.match[c] = -1; pr++; }                                  // :1617-1625: every entry of a dropped bin counts
+      if (J.match[j] >= 0) { J.match[j] = -1; pr++; }  // :557-563: only a still-matched entry counts
     }
     if (pr) atomicAdd(&s_pruned, pr);
     __syncthreads();
   }
-  if (init && J.prevX)
+  if (J.prevX)
     for (int j = tid; j < J.nq; j += 1024) {
       const int m = J.match[j];
       J.prevX[j] = m >= 0 ? J.fx[m] : J.qx[j];
@@ -424,15 +640,19 @@ __global__ __launch_bounds__(1024) void k_window_claim(const ClaimJob* __restric
 
 }  // namespace
 
-void launch_window_claim(hipStream_t s, const ClaimJob* d_jobs, int nJobs, size_t ldsBytes) {
+void launch_window_claim(hipStream_t s, const ClaimJob* d_jobs, const ClaimJob* h_first, int nJobs, size_t ldsBytes, bool initForm) {
   if (nJobs <= 0) return;
-  hipLaunchKernelGGL(k_window_claim, dim3(nJobs), dim3(1024), ldsBytes, s, d_jobs);
+  if (initForm) hipLaunchKernelGGL(k_window_claim_init, dim3(nJobs), dim3(1024), ldsBytes, s, d_jobs);
+  else if (nJobs == 1 && h_first) hipLaunchKernelGGL((k_window_claim<true>), dim3(1), dim3(1024), ldsBytes, s, *h_first, d_jobs);
+  else hipLaunchKernelGGL((k_window_claim<false>), dim3(nJobs), dim3(1024), ldsBytes, s, ClaimJob{}, d_jobs);
 }
 
 void launch_grid_build(hipStream_t s, const GridFrame& f, uint32_t* sortedKey, int32_t* cellOff) {
   int sortN = 64;
   while (sortN < f.n) sortN <<= 1;
-  hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(1024), (size_t)sortN * 4, s, f, sortN, sortedKey, cellOff);
+  static const int kForceSort = getenv("ORBFE_GRID_SORT") ? atoi(getenv("ORBFE_GRID_SORT")) : 0;  // 1: the bitonic kernel for every frame
+  if (f.n <= 8192 && !kForceSort) hipLaunchKernelGGL(k_grid_build_count, dim3(1), dim3(1024), (size_t)sortN * 4, s, f, sortN, sortedKey, cellOff);
+  else hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(1024), (size_t)sortN * 4, s, f, sortN, sortedKey, cellOff);
 }
 
 // orbfe_frame_from_device: the extractor's 28-byte cv::KeyPoint records -> the resident frame's arrays, descriptors copied

@@ -130,11 +130,12 @@ struct ClaimJob {
   float nnratio;
   int32_t* choice;  // [nq] scratch: the query's current choice (feature, or dist << 16 | feature in CLAIM_INIT), -1 none
   int32_t* link;    // [nq] scratch (CLAIM_INIT: the other queries that chose the same feature)
-  int32_t* owner;   // [n]  scratch in HBM, NULL: the kernel's dynamic LDS holds it
+  int32_t* owner;   // [2 n] ([n] for CLAIM_INIT) scratch in HBM, NULL: the kernel's dynamic LDS holds it
   int32_t* match;   // out.  BEST / RATIO: [n], query that holds feature i or -1.  INIT: [nq], feature of query i or -1
   int32_t* header;  // out [4]: largest list length (> K: the lists were truncated, search again), matches, rounds, 0
 };
-void launch_window_claim(hipStream_t s, const ClaimJob* d_jobs, int nJobs, size_t ldsBytes);
+void launch_window_claim(hipStream_t s, const ClaimJob* d_jobs, const ClaimJob* h_first /* host copy of job 0 */, int nJobs, size_t ldsBytes,
+                         bool initForm /* all jobs CLAIM_INIT, or none */);
 void launch_grid_build(hipStream_t s, const GridFrame& f, uint32_t* sortedKey, int32_t* cellOff);
 void launch_frame_from_records(hipStream_t s, const float* d_kp, const uint8_t* d_desc, int n, float* x, float* y, float* angle,
                                int32_t* octave, uint8_t* descOut, uint8_t* stereoZero);

@@ -1146,6 +1146,7 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
   std::vector<Lay> lay((size_t)nJobs);
   size_t off = 0;
   int nClaim = 0;
+  bool claimInit = false;
   auto place = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
   for (int j = 0; j < nJobs; j++) {
     const WindowJob& J = jobs[j];
@@ -1181,6 +1182,9 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
       L.oQdesc = shared >= 0 ? lay[shared].oQdesc : place(q * 32);
     }
     if (J.claim) {
+      if (J.nq > 0x1fffff) return mfail(ORBFE_ERR_INVALID, "more than 2097151 points in one projection search");
+      if (nClaim && claimInit != (J.claim->mode == CLAIM_INIT)) return mfail(ORBFE_ERR_INVALID, "mixed claim forms in one call");
+      claimInit = J.claim->mode == CLAIM_INIT;
       nClaim++;
       if (J.claim->checkOri && !L.res) L.oAng = place(n * 4);  // (a resident frame has its angles on the device)
       if (J.claim->blocked) L.oBlk = place(n);
@@ -1190,7 +1194,7 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
   }
   const size_t oClaim = nClaim ? place((size_t)nClaim * sizeof(ClaimJob)) : 0;
   const size_t inBytes = off ? off : 256;
-  constexpr size_t kOwnerLds = 48 * 1024;  // owner[] of a frame with up to 12288 features lives in the claim kernel's LDS
+  constexpr size_t kOwnerLds = 60 * 1024;  // the claim kernel's per-feature arrays live in its LDS up to this size (~6800 features)
   for (;;) {
     Arena* ar;
     size_t outBytes = 0, gridBytes = 0, scrBytes = 0, claimLds = 0;
@@ -1202,9 +1206,12 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
         const bool ini = jobs[j].claim->mode == CLAIM_INIT;
         outBytes += pad(16 + (ini ? q : n) * 4 + (ini ? 2 * q * 4 : 0));
         lay[j].oScr = scrBytes;
-        scrBytes += pad(q * 4) + pad(q * (size_t)K * 4) + 2 * pad(q * 4) + (n * 4 > kOwnerLds ? pad(n * 4) : 0);
-        // the claim kernel's dynamic LDS: owner[] (unless in HBM) + the features' octave bytes (RATIO)
-        const size_t lds = (n * 4 <= kOwnerLds ? n * 4 : 0) + (jobs[j].claim->mode == CLAIM_RATIO ? n : 0);
+        // the claim kernel's dynamic LDS: the per-feature owner array(s) -- in HBM when they do not fit -- + the features'
+        // octave bytes (RATIO)
+        const size_t ownBytes = (ini ? 1 : 2) * n * 4, octBytes = jobs[j].claim->mode == CLAIM_RATIO ? n : 0;
+        const bool ownInLds = ownBytes + octBytes <= kOwnerLds;
+        scrBytes += pad(q * 4) + pad(q * (size_t)K * 4) + 2 * pad(q * 4) + (ownInLds ? 0 : pad(ownBytes));
+        const size_t lds = (ownInLds ? ownBytes : 0) + octBytes;
         if (lds > claimLds) claimLds = lds;
       } else {
         outBytes += pad(q * 4) + (jobs[j].bestOut ? 0 : pad(q * (size_t)K * 4));
@@ -1258,7 +1265,8 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
       cj.cand = reinterpret_cast<const uint32_t*>(sc); sc += pad(q * (size_t)K * 4);
       cj.choice = reinterpret_cast<int32_t*>(sc); sc += pad(q * 4);
       cj.link = reinterpret_cast<int32_t*>(sc); sc += pad(q * 4);
-      cj.owner = n * 4 > kOwnerLds ? reinterpret_cast<int32_t*>(sc) : nullptr;
+      const size_t ownBytes = (ini ? 1 : 2) * n * 4, octBytes = J.claim->mode == CLAIM_RATIO ? n : 0;
+      cj.owner = ownBytes + octBytes > kOwnerLds ? reinterpret_cast<int32_t*>(sc) : nullptr;
       cj.K = K; cj.nq = J.nq; cj.n = J.f->n;
       cj.active = J.qactive ? din + L.oQact : nullptr;
       cj.blocked = J.claim->blocked ? din + L.oBlk : nullptr;
@@ -1341,7 +1349,8 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
       MHIP(hipGetLastError());
     }
     if (nClaim) {
-      launch_window_claim(ar->stream, reinterpret_cast<const ClaimJob*>(din + oClaim), nClaim, claimLds);
+      launch_window_claim(ar->stream, reinterpret_cast<const ClaimJob*>(din + oClaim), reinterpret_cast<const ClaimJob*>(h + oClaim), nClaim,
+                          claimLds, claimInit);
       MHIP(hipGetLastError());
     }
     if (outBytes) MHIP(hipMemcpyAsync(h, dout, outBytes, hipMemcpyDeviceToHost, ar->stream));

@@ -445,3 +445,25 @@ def test_claim_loops_with_long_dependency_chains(amd):
         assert (n_got, got.tolist()) == (n_ref, ref.tolist())
         assert np.array_equal(prev_got, prev_ref)
     assert n_ref > 5
+
+
+def test_claim_loops_on_a_frame_too_large_for_lds(amd):
+    """more than 12288 key points: k_window_claim keeps owner[] in HBM instead of LDS (and a thread owns several points)"""
+    rng = np.random.default_rng(91)
+    x, y, octv, ang, desc, _ = _random_frame(rng, 14000, spread=0.0)
+    F, Fo = _both(amd, x, y, octv, ang, desc, None)
+    n_mp = 5000
+    src, px, py, md = _map_points(rng, x, y, octv, desc, n_mp, 1.5)
+    level = np.clip(octv[src] + rng.integers(0, 2, n_mp), 0, 7).astype(np.int32)
+    in_view = (rng.random(n_mp) < 0.9).astype(np.uint8)
+    view_cos = rng.uniform(0.99, 1.0, n_mp).astype(np.float32)
+    obs = (rng.random(n_mp) < 0.8).astype(np.uint8)
+    blocked = (rng.random(14000) < 0.1).astype(np.uint8)
+    n_ref, ref = orc.search_by_projection_mappoints(Fo, SF, blocked, in_view, level, view_cos, px, py, None, md, obs, 3.0, 0.8)
+    n_got, got = amd.ORBmatcher(0.8, True).SearchByProjection(F, SF, in_view, level, view_cos, px, py, md, th=3.0, blocked=blocked,
+                                                              mp_obs_positive=obs)
+    assert (n_got, got.tolist()) == (n_ref, ref.tolist()) and n_ref > 1000
+    ka = ((ang[src] + rng.normal(0, 6, n_mp)) % 360).astype(np.float32)
+    n_ref, ref = orc.search_by_projection_reloc(Fo, SF, in_view, px, py, level, ka, md, blocked, 10.0, 100, True)
+    n_got, got = amd.ORBmatcher(0.9, True).SearchByProjectionKeyFrame(F, SF, in_view, px, py, level, ka, md, 10.0, 100, blocked=blocked)
+    assert (n_got, got.tolist()) == (n_ref, ref.tolist()) and n_ref > 1000
