@@ -151,11 +151,9 @@ __global__ __launch_bounds__(1024) void k_grid_build_count(GridFrame f, int sort
 }
 
 // One wavefront per query, 4 per block.
-__global__ __launch_bounds__(256) void k_window_search(GridFrame f, const uint32_t* __restrict__ sortedKey,
-                                                       const int32_t* __restrict__ cellOff, WindowQueries q,
-                                                       int32_t* __restrict__ count, uint32_t* __restrict__ cand) {
-  const int lane = threadIdx.x & 63;
-  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void window_search_one(const GridFrame& f, const uint32_t* __restrict__ sortedKey,
+                                                  const int32_t* __restrict__ cellOff, const WindowQueries& q,
+                                                  int32_t* __restrict__ count, uint32_t* __restrict__ cand, int qi, int lane) {
   if (qi >= q.n) return;
   const float x = q.x[qi], y = q.y[qi], r = q.r[qi];
   const int minLevel = q.minLevel[qi], maxLevel = q.maxLevel[qi];
@@ -259,6 +257,24 @@ __global__ __launch_bounds__(256) void k_window_search(GridFrame f, const uint32
     return;
   }
   if (lane == 0) count[qi] = n;
+}
+
+__global__ __launch_bounds__(256) void k_window_search(GridFrame f, const uint32_t* __restrict__ sortedKey,
+                                                       const int32_t* __restrict__ cellOff, WindowQueries q,
+                                                       int32_t* __restrict__ count, uint32_t* __restrict__ cand) {
+  window_search_one(f, sortedKey, cellOff, q, count, cand, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
+// The window searches of ALL jobs of a call in one launch (Fuse into K key frames, one frame against K relocalisation
+// candidates, the two directions of SearchBySim3): K launches of ~250 workgroups each ran one after the other on the
+// call's stream, 8 us apiece.  A workgroup finds its job by its block range (scalar search) and reads the job's block.
+__global__ __launch_bounds__(256) void k_window_search_multi(const WindowSearchJob* __restrict__ jobs, int nJobs) {
+  int j = 0;
+  for (int k = 1; k < nJobs; k++)
+    if ((int)blockIdx.x >= jobs[k].blockStart) j = k;  // block-uniform
+  const WindowSearchJob J = jobs[j];
+  window_search_one(J.f, J.sortedKey, J.cellOff, J.q, J.count, J.cand, ((int)blockIdx.x - J.blockStart) * 4 + (threadIdx.x >> 6),
+                    threadIdx.x & 63);
 }
 
 // rotation-histogram bin, src/ORBmatcher.cc:1601-1610 (C round(): half away from zero)
@@ -680,6 +696,11 @@ void launch_frame_from_records(hipStream_t s, const float* d_kp, const uint8_t* 
   if (n <= 0) return;
   hipLaunchKernelGGL(k_frame_from_records, dim3((n + 255) / 256), dim3(256), 0, s, d_kp, d_desc, n, x, y, angle, octave, descOut,
                      stereoZero);
+}
+
+void launch_window_search_multi(hipStream_t s, const WindowSearchJob* d_jobs, int nJobs, int totalBlocks) {
+  if (nJobs <= 0 || totalBlocks <= 0) return;
+  hipLaunchKernelGGL(k_window_search_multi, dim3(totalBlocks), dim3(256), 0, s, d_jobs, nJobs);
 }
 
 void launch_window_search(hipStream_t s, const GridFrame& f, const uint32_t* sortedKey, const int32_t* cellOff,

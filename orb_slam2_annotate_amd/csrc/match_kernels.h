@@ -139,6 +139,10 @@ void launch_window_claim(hipStream_t s, const ClaimJob* d_jobs, const ClaimJob* 
 void launch_grid_build(hipStream_t s, const GridFrame& f, uint32_t* sortedKey, int32_t* cellOff);
 void launch_frame_from_records(hipStream_t s, const float* d_kp, const uint8_t* d_desc, int n, float* x, float* y, float* angle,
                                int32_t* octave, uint8_t* descOut, uint8_t* stereoZero);
+struct WindowSearchJob {  // one job of k_window_search_multi; blockStart = first workgroup of the job (4 queries per workgroup)
+  GridFrame f; const uint32_t* sortedKey; const int32_t* cellOff; WindowQueries q; int32_t* count; uint32_t* cand; int blockStart;
+};
+void launch_window_search_multi(hipStream_t s, const WindowSearchJob* d_jobs, int nJobs, int totalBlocks);
 void launch_window_search(hipStream_t s, const GridFrame& f, const uint32_t* sortedKey, const int32_t* cellOff,
                           const WindowQueries& q, int32_t* count, uint32_t* cand);
 

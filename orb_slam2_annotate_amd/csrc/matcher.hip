@@ -1193,6 +1193,7 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
     }
   }
   const size_t oClaim = nClaim ? place((size_t)nClaim * sizeof(ClaimJob)) : 0;
+  const size_t oWs = nJobs > 1 ? place((size_t)nJobs * sizeof(WindowSearchJob)) : 0;
   const size_t inBytes = off ? off : 256;
   constexpr size_t kOwnerLds = 60 * 1024;  // the claim kernel's per-feature arrays live in its LDS up to this size (~6800 features)
   for (;;) {
@@ -1286,10 +1287,13 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
       std::memcpy(h + oClaim + (size_t)c * sizeof(ClaimJob), &cj, sizeof(ClaimJob));
       c++;
     }
-    MHIP(hipMemcpyAsync(din, h, inBytes, hipMemcpyHostToDevice, ar->stream));
+    // the search jobs: every device address is known once the arena is carved, so the job blocks travel with the inputs too
     size_t goff = 0;
     std::vector<const uint32_t*> keyOf((size_t)nJobs, nullptr);
     std::vector<const int32_t*> cellOf((size_t)nJobs, nullptr);
+    std::vector<WindowSearchJob> wsj((size_t)nJobs);
+    std::vector<char> buildsGrid((size_t)nJobs, 0);
+    int totalBlocks = 0;
     for (int j = 0; j < nJobs; j++) {
       const WindowJob& J = jobs[j];
       const Lay& L = lay[j];
@@ -1319,8 +1323,7 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
         goff += pad(n * 4);
         int32_t* c = reinterpret_cast<int32_t*>(dgrid + goff);
         goff += pad(3073 * 4);
-        launch_grid_build(ar->stream, g, k, c);
-        MHIP(hipGetLastError());
+        buildsGrid[j] = 1;
         dkey = k; dcell = c;
         keyOf[j] = k; cellOf[j] = c;
       }
@@ -1345,9 +1348,22 @@ int window_search_multi(int device, WindowJob* jobs, int nJobs, int K0) {
         dcount = reinterpret_cast<int32_t*>(dscr + L.oScr);
         dcand = reinterpret_cast<uint32_t*>(dscr + L.oScr + pad(q * 4));
       }
-      launch_window_search(ar->stream, g, dkey, dcell, wq, dcount, dcand);
-      MHIP(hipGetLastError());
+      wsj[j] = WindowSearchJob{g, dkey, dcell, wq, dcount, dcand, totalBlocks};
+      totalBlocks += (J.nq + 3) / 4;
     }
+    if (nJobs > 1) std::memcpy(h + oWs, wsj.data(), (size_t)nJobs * sizeof(WindowSearchJob));
+    MHIP(hipMemcpyAsync(din, h, inBytes, hipMemcpyHostToDevice, ar->stream));
+    for (int j = 0; j < nJobs; j++)
+      if (buildsGrid[j]) {
+        launch_grid_build(ar->stream, wsj[j].f, const_cast<uint32_t*>(wsj[j].sortedKey), const_cast<int32_t*>(wsj[j].cellOff));
+        MHIP(hipGetLastError());
+      }
+    if (nJobs > 1) {  // ONE launch for the window searches of all jobs
+      launch_window_search_multi(ar->stream, reinterpret_cast<const WindowSearchJob*>(din + oWs), nJobs, totalBlocks);
+    } else {
+      launch_window_search(ar->stream, wsj[0].f, wsj[0].sortedKey, wsj[0].cellOff, wsj[0].q, wsj[0].count, wsj[0].cand);
+    }
+    MHIP(hipGetLastError());
     if (nClaim) {
       launch_window_claim(ar->stream, reinterpret_cast<const ClaimJob*>(din + oClaim), reinterpret_cast<const ClaimJob*>(h + oClaim), nClaim,
                           claimLds, claimInit);
