@@ -288,9 +288,7 @@ __global__ __launch_bounds__(64) void k_search_by_bow_batch(BowBatch b) {
 // never written, :774,827) -> one wavefront per KF1 feature.  A candidate replaces the best
 // when dist <= bestDist, so among equal distances the LAST scanned one wins (:840).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_search_triangulation(TriArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void search_triangulation_one(const TriArgs& a, int q, int lane) {
   if (q >= a.nQueries) return;
   const TriQuery tq = a.queries[q];
   const uint32_t idx1 = tq.idx1;
@@ -333,6 +331,24 @@ __global__ __launch_bounds__(256) void k_search_triangulation(TriArgs a) {
       a.bin[idx1] = (int8_t)rot_bin(a.angle1[idx1], a.angle2[idx2]);
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_search_triangulation(TriArgs a) {
+  search_triangulation_one(a, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+// K (key frame, neighbour) problems in ONE launch (orbfe_search_for_triangulation_multi, LocalMapping::CreateNewMapPoints:
+// 20 neighbours): blockStart[k] = first workgroup of problem k (4 queries per workgroup), args[k] its operands.  The K
+// launches ran one after the other on the call's stream, ~10 us apiece for a few hundred wavefronts each.
+__global__ __launch_bounds__(256) void k_search_triangulation_multi(const TriArgs* __restrict__ args, const int32_t* __restrict__ blockStart,
+                                                                    int K) {
+  const int g = blockIdx.x;
+  int lo = 0, hi = K;  // last k with blockStart[k] <= g (block-uniform: scalar loads)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (blockStart[mid] <= g) lo = mid; else hi = mid;
+  }
+  const TriArgs a = args[lo];
+  search_triangulation_one(a, (g - blockStart[lo]) * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
 }
 
 // Rotation-consistency pruning shared by the three searches (:303-322, ComputeThreeMaxima
@@ -398,6 +414,10 @@ void launch_search_by_bow_multi(hipStream_t s, const BowArgs* d_args, const int3
 void launch_search_triangulation(hipStream_t s, const TriArgs& a) {
   if (a.nQueries <= 0) return;
   hipLaunchKernelGGL(k_search_triangulation, dim3((a.nQueries + 3) / 4), dim3(256), 0, s, a);
+}
+void launch_search_triangulation_multi(hipStream_t s, const TriArgs* d_args, const int32_t* d_blockStart, int K, int totalBlocks) {
+  if (K <= 0 || totalBlocks <= 0) return;
+  hipLaunchKernelGGL(k_search_triangulation_multi, dim3(totalBlocks), dim3(256), 0, s, d_args, d_blockStart, K);
 }
 void launch_rot_prune(hipStream_t s, int32_t* match, const int8_t* bin, int n, int checkOri, int32_t* nMatches) {
   hipLaunchKernelGGL(k_rot_prune, dim3(1), dim3(256), 0, s, match, bin, n, checkOri, nMatches, 0);

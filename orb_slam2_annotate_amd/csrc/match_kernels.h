@@ -151,6 +151,7 @@ void launch_search_by_bow_multi(hipStream_t s, const BowArgs* d_args, const int3
 void launch_search_by_bow_batch(hipStream_t s, const BowBatch& b, int nPairs, int checkOri, int32_t* d_nMatches,
                                 int maxNodes /* bound on FeatureVector entries per frame, 0: capacity */);
 void launch_search_triangulation(hipStream_t s, const TriArgs& a);
+void launch_search_triangulation_multi(hipStream_t s, const TriArgs* d_args, const int32_t* d_blockStart, int K, int totalBlocks);
 void launch_rot_prune(hipStream_t s, int32_t* match, const int8_t* bin, int n, int checkOri, int32_t* nMatches);
 void launch_rot_prune_batch(hipStream_t s, int32_t* match, const int8_t* bin, int n, int nArrays, int checkOri, int32_t* nMatches);
 void launch_stereo(hipStream_t s, const StereoArgs& a, int32_t* d_nStereo);

@@ -896,7 +896,8 @@ extern "C" int orbfe_search_for_triangulation_multi(const orbfe_frame* kf1, cons
     return mfail(ORBFE_ERR_INVALID, "search_for_triangulation_multi: key frame uploaded without FeatureVector / angles, or NULL mask");
   // host: the shared nodes and the query list of every neighbour (:787-811)
   std::vector<std::vector<TriQuery>> queries((size_t)K);
-  size_t bytes = pad((size_t)K * 9 * 4) + 2 * pad((size_t)n_levels2 * 4) + 2 * pad((size_t)K * n1 * 4) + pad((size_t)K * 4) + 8192;
+  size_t bytes = pad((size_t)K * 9 * 4) + 2 * pad((size_t)n_levels2 * 4) + 2 * pad((size_t)K * n1 * 4) + pad((size_t)K * 4) + 8192 +
+                 pad((size_t)K * sizeof(TriArgs)) + pad((size_t)K * 4);
   std::vector<NodePair> pairs;
   for (int k = 0; k < K; k++) {
     const orbfe_frame* k2 = kf2[k];
@@ -940,7 +941,10 @@ extern "C" int orbfe_search_for_triangulation_multi(const orbfe_frame* kf1, cons
   int32_t* dcount;
   MHIP(up_fill(ar, &dcount, (size_t)K, 0));
   MHIP(up_fill(ar, &dbin, (size_t)K * n1, 0));
-  MHIP(flush(ar));
+  // the K problems run as ONE launch: their argument blocks and first workgroups travel with the inputs
+  std::vector<TriArgs> targs;
+  std::vector<int32_t> blockStart;
+  int totalBlocks = 0;
   for (int k = 0; k < K; k++) {
     if (queries[k].empty()) continue;
     const orbfe_frame* k2 = kf2[k];
@@ -951,8 +955,19 @@ extern "C" int orbfe_search_for_triangulation_multi(const orbfe_frame* kf1, cons
     a.stereo2 = k2->dstereo; a.indices2 = k2->dindices;
     a.F12 = dF + (size_t)k * 9; a.ex = ex[k]; a.ey = ey[k]; a.scaleFactors2 = dsf; a.levelSigma2_2 = dsg;
     a.onlyStereo = only_stereo; a.match = dmatch + (size_t)k * n1; a.bin = dbin + (size_t)k * n1;
-    launch_search_triangulation(ar->stream, a);
+    targs.push_back(a);
+    blockStart.push_back(totalBlocks);
+    totalBlocks += (a.nQueries + 3) / 4;
   }
+  TriArgs* dargs = nullptr;
+  int32_t* dstart = nullptr;
+  if (!targs.empty()) {
+    MHIP(up(ar, &dargs, targs.data(), targs.size()));
+    MHIP(up(ar, &dstart, blockStart.data(), blockStart.size()));
+  }
+  MHIP(flush(ar));
+  if (targs.size() == 1) launch_search_triangulation(ar->stream, targs[0]);
+  else if (!targs.empty()) launch_search_triangulation_multi(ar->stream, dargs, dstart, (int)targs.size(), totalBlocks);
   launch_rot_prune_batch(ar->stream, dmatch, dbin, n1, K, check_orientation, dcount);  // all K histograms in one launch
   MHIP(hipGetLastError());
   MHIP(down_range(ar, dmatch, dcount + K));
