@@ -108,7 +108,7 @@ __device__ __forceinline__ Rect child_rect(const Rect r, int q) {
 // take the global-memory form of the same loops.
 constexpr int kRegCand = 16;
 
-template <bool REG, int T, bool HYB = false>
+template <bool REG, int T, bool HYB = false, int RC = kRegCand>
 __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, int* waveTot, int* sh, const int l, const int f) {
   const int tid = threadIdx.x;
   const LevelGeom g = a.lvg[l];
@@ -143,11 +143,11 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
   int cur = 0;
   for (int i = tid; i < nIni; i += T) scanB[i] = 0;
   __syncthreads();
-  uint32_t kxy[kRegCand];   // REG: candidate coordinates / current node of candidate j*256 + tid
-  uint32_t knode[kRegCand];
+  uint32_t kxy[RC];   // REG: candidate coordinates / current node of candidate j*256 + tid
+  uint32_t knode[RC];
   if constexpr (REG) {
 #pragma unroll
-    for (int j = 0; j < kRegCand; j++) {
+    for (int j = 0; j < RC; j++) {
       const int k = j * T + tid;
       kxy[j] = 0; knode[j] = 0;
       if (k < n) {
@@ -196,7 +196,7 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
   __syncthreads();
   if constexpr (REG) {
 #pragma unroll
-    for (int j = 0; j < kRegCand; j++) knode[j] = (uint32_t)scanA[knode[j]];
+    for (int j = 0; j < RC; j++) knode[j] = (uint32_t)scanA[knode[j]];
   } else {
     for (int k = tid; k < n; k += T) nodeOf[k] = (uint16_t)scanA[nodeOf[k]];
   }
@@ -216,12 +216,12 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
     }
     __syncthreads();
     // B. speculative 4-way histogram of the candidates' keys (DivideNode :531-546)
-    int kbin[kRegCand];  // REG: child counter this candidate voted for in this pass (-1: its node is not split)
+    int kbin[RC];  // REG: child counter this candidate voted for in this pass (-1: its node is not split)
     if constexpr (REG) {
       // four candidates at a time: their node flags and rectangles are requested together, so a pass
       // is 4 x (one LDS round trip + 4 atomics) instead of 16 dependent round trips
 #pragma unroll
-      for (int j0 = 0; j0 < kRegCand; j0 += 4) {
+      for (int j0 = 0; j0 < RC; j0 += 4) {
         uint8_t in4[4];
         Rect r4[4];
 #pragma unroll
@@ -450,7 +450,7 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
       // a split that the early break cancelled (inS cleared in C) keeps its node; the vote of pass B
       // already names the child otherwise
 #pragma unroll
-      for (int j0 = 0; j0 < kRegCand; j0 += 4) {
+      for (int j0 = 0; j0 < RC; j0 += 4) {
         uint8_t in4[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) in4[u] = inS[knode[j0 + u]];
@@ -501,7 +501,7 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
   __syncthreads();
   if constexpr (REG) {
 #pragma unroll
-    for (int j = 0; j < kRegCand; j++) {
+    for (int j = 0; j < RC; j++) {
       const int k = j * T + tid;
       if (k < n)
         atomicMax(reinterpret_cast<unsigned int*>(&best[knode[j]]), (cand[k].score << 24) | (0xffffffu - (unsigned)k));
@@ -586,6 +586,18 @@ __global__ __launch_bounds__(256) void k_octree_reg(OctreeArgs a) {
   else octree_body<false, 256, true>(a, smem, waveTot, sh, blockIdx.x, blockIdx.y);
 }
 
+// The latency form with 1024 threads and up to 8192 candidates in registers (8 per thread): level 0 of a 1241 x 376 frame
+// lists ~5000 candidates -- more than 256 x 16 -- and fell back to the global-memory sweeps, two dependent HBM round trips
+// per pass: 82 of the 167 us of kernel time of a single KITTI frame.
+__global__ __launch_bounds__(1024) void k_octree_reg1024(OctreeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ int waveTot[16];
+  __shared__ int sh[4];
+  const int n = a.candCount[(size_t)blockIdx.y * a.nlevels + blockIdx.x];  // block-uniform
+  if (n <= 1024 * 8) octree_body<true, 1024, true, 8>(a, smem, waveTot, sh, blockIdx.x, blockIdx.y);
+  else octree_body<false, 1024, true>(a, smem, waveTot, sh, blockIdx.x, blockIdx.y);
+}
+
 // Third build: the node list does not fit in LDS (a level asked for more than ~2 890 keypoints, e.g. 3000 features
 // on a 1-level pyramid): the same generation passes with the per-workgroup arrays in a global-memory slab.  Every
 // array access becomes a flat load / store / atomic and __syncthreads() orders them inside the workgroup -- slow
@@ -616,14 +628,19 @@ hipError_t launch_octree(hipStream_t s, const OctreeArgs& args, int nlevels, int
   const bool latencyForm = nFrames <= 8;  // too few workgroups to fill the GPU anyway
   static const size_t pad = occupancy_pad_bytes("OCTREE", 0);
   if (!latencyForm && lds + pad <= 64 * 1024) lds += pad;
-  static thread_local size_t configured[2] = {0, 0};
-  const void* fn = latencyForm ? reinterpret_cast<const void*>(k_octree_reg) : reinterpret_cast<const void*>(k_octree);
-  if (lds > 64 * 1024 && lds > configured[latencyForm]) {
+  static thread_local size_t configured[3] = {0, 0, 0};
+  static const int kLatT = getenv("ORBFE_OCTREE_T") ? atoi(getenv("ORBFE_OCTREE_T")) : 1024;
+  const bool wide = latencyForm && kLatT == 1024;
+  const void* fn = wide ? reinterpret_cast<const void*>(k_octree_reg1024)
+                        : (latencyForm ? reinterpret_cast<const void*>(k_octree_reg) : reinterpret_cast<const void*>(k_octree));
+  const int which = wide ? 2 : (latencyForm ? 1 : 0);
+  if (lds > 64 * 1024 && lds > configured[which]) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    configured[latencyForm] = lds;
+    configured[which] = lds;
   }
-  if (latencyForm) hipLaunchKernelGGL(k_octree_reg, dim3(nlevels, nFrames), dim3(256), lds, s, a);
+  if (wide) hipLaunchKernelGGL(k_octree_reg1024, dim3(nlevels, nFrames), dim3(1024), lds, s, a);
+  else if (latencyForm) hipLaunchKernelGGL(k_octree_reg, dim3(nlevels, nFrames), dim3(256), lds, s, a);
   else {
     // workgroups per CU of the persistent grid; 0 = one workgroup per (frame, level).  Round 2 capped it at 4; with the
     // round-3 kernels the pipelines measure the same with any cap (KITTI 105.6 k vs 104.0 k, TUM 379.9 k vs 382.9 k, EuRoC
