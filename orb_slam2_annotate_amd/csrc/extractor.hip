@@ -638,9 +638,15 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
     // one launch and one global round trip fewer per chain; KITTI 100.6 k vs 101.4 k, TUM 361.9 k vs 360.1 k stereo frames /
     // frames per second for separate vs fused in a same-box A/B: the launch is not what the chain waits for)
     StageTimer t(e, ORBFE_STAGE_OCTREE, 2, nFrames, sub, sT);
-    launch_gather_candidates(sT, e->d_cells, e->d_lvgeom, g.nlevels, nFrames, slots, g.totalSlots, cellCount,
-                             nCells, cand, candCount, cellPrefix);
+    const bool octGathers = octree_gathers(nFrames, e->octreeMaxL);  // a few frames: the octree workgroups gather their own level
+    if (!octGathers)
+      launch_gather_candidates(sT, e->d_cells, e->d_lvgeom, g.nlevels, nFrames, slots, g.totalSlots, cellCount,
+                               nCells, cand, candCount, cellPrefix);
     OctreeArgs oa = {};
+    if (octGathers) {
+      oa.gCells = e->d_cells; oa.gSlots = slots; oa.gCellCount = cellCount; oa.gCellsPerFrame = nCells; oa.gCellPrefix = cellPrefix;
+      oa.gCand = cand; oa.gCandCount = candCount;
+    }
     oa.cand = cand;
     oa.slotsPerFrame = g.totalSlots;
     oa.candCount = candCount;

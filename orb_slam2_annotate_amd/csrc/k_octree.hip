@@ -593,6 +593,44 @@ __global__ __launch_bounds__(1024) void k_octree_reg1024(OctreeArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ int waveTot[16];
   __shared__ int sh[4];
+  if (a.gCells) {
+    // ---- the ordered compaction of k_gather_candidates (k_fast.hip) for this (frame, level): cells in cell-row-major
+    //      order, raster inside each cell ----
+    const int l = blockIdx.x, f = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const LevelGeom g = a.lvg[l];
+    const uint16_t* cnt = a.gCellCount + (size_t)f * a.gCellsPerFrame + g.cellStart;
+    int32_t* pre = a.gCellPrefix + (size_t)f * a.gCellsPerFrame + g.cellStart;
+    int run = 0;  // identical in every thread
+    for (int cb = 0; cb < g.nCells; cb += 1024) {
+      const int c = cb + tid;
+      const int v = c < g.nCells ? cnt[c] : 0;
+      int x = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+      }
+      if (lane == 63) waveTot[wave] = x;
+      __syncthreads();
+      int base = run;
+      for (int w = 0; w < wave; w++) base += waveTot[w];
+#pragma unroll
+      for (int w = 0; w < 16; w++) run += waveTot[w];
+      if (c < g.nCells) pre[c] = base + x - v;
+      __syncthreads();
+    }
+    if (tid == 0) a.gCandCount[(size_t)f * a.nlevels + l] = run;
+    const Candidate* sl = a.gSlots + (size_t)f * a.slotsPerFrame;
+    Candidate* out = a.gCand + (size_t)f * a.slotsPerFrame + g.slotStart;
+    for (int t = tid; t < 4 * g.nCells; t += 1024) {  // four threads per cell
+      const int c = t >> 2, part = t & 3;
+      const int n = cnt[c], b = pre[c];
+      const Candidate* src = sl + a.gCells[g.cellStart + c].slotBase;
+      for (int i = part; i < n; i += 4) out[b + i] = src[i];
+    }
+    __syncthreads();  // (the workgroup's own stores to cand / candCount are visible to it behind the barrier)
+  }
   const int n = a.candCount[(size_t)blockIdx.y * a.nlevels + blockIdx.x];  // block-uniform
   if (n <= 1024 * 8) octree_body<true, 1024, true, 8>(a, smem, waveTot, sh, blockIdx.x, blockIdx.y);
   else octree_body<false, 1024, true>(a, smem, waveTot, sh, blockIdx.x, blockIdx.y);
@@ -615,6 +653,17 @@ size_t octree_lds_bytes(int maxL) {
   return (size_t)maxL * (2 * 8 + 2 * 4 + 16 + 4 + 4 + 2 + 2 + 1) + 64;
 }
 
+namespace {
+int octree_latency_threads() {
+  static const int t = getenv("ORBFE_OCTREE_T") ? atoi(getenv("ORBFE_OCTREE_T")) : 1024;
+  return t;
+}
+}  // namespace
+bool octree_gathers(int nFrames, int maxL) {
+  static const bool off = getenv("ORBFE_OCTREE_GATHER") && atoi(getenv("ORBFE_OCTREE_GATHER")) == 0;
+  return !off && nFrames > 0 && nFrames <= 8 && octree_lds_bytes(maxL) <= kOctreeLdsLimit && octree_latency_threads() == 1024;
+}
+
 hipError_t launch_octree(hipStream_t s, const OctreeArgs& args, int nlevels, int nFrames) {
   if (nFrames <= 0) return hipSuccess;
   OctreeArgs a = args;
@@ -629,8 +678,8 @@ hipError_t launch_octree(hipStream_t s, const OctreeArgs& args, int nlevels, int
   static const size_t pad = occupancy_pad_bytes("OCTREE", 0);
   if (!latencyForm && lds + pad <= 64 * 1024) lds += pad;
   static thread_local size_t configured[3] = {0, 0, 0};
-  static const int kLatT = getenv("ORBFE_OCTREE_T") ? atoi(getenv("ORBFE_OCTREE_T")) : 1024;
-  const bool wide = latencyForm && kLatT == 1024;
+  const bool wide = latencyForm && octree_latency_threads() == 1024;
+  if (a.gCells && !wide) return hipErrorInvalidValue;  // (only the wide single-frame form gathers)
   const void* fn = wide ? reinterpret_cast<const void*>(k_octree_reg1024)
                         : (latencyForm ? reinterpret_cast<const void*>(k_octree_reg) : reinterpret_cast<const void*>(k_octree));
   const int which = wide ? 2 : (latencyForm ? 1 : 0);

@@ -108,7 +108,12 @@ struct OctreeArgs {
   int maxL;                   // node capacity (>= every level's kpCap and nIni, multiple of 4)
   uint8_t* work;              // global-memory node lists, one slab of workStride bytes per (frame, level);
   size_t workStride;          //   only read when octree_lds_bytes(maxL) > kOctreeLdsLimit
+  // the single-frame form gathers the level's candidates itself (octree_gathers(): k_gather_candidates's work at the head of
+  // the (frame, level) workgroup -- one launch and its gap less in a chain that is nothing but launches): inputs of the gather
+  const CellDesc* gCells; const Candidate* gSlots; const uint16_t* gCellCount; int gCellsPerFrame; int32_t* gCellPrefix;
+  Candidate* gCand; int32_t* gCandCount;   // = cand / candCount, writable
 };
+bool octree_gathers(int nFrames, int maxL);  // launch_octree(..., nFrames) will run the form that gathers: fill the g* fields, skip launch_gather_candidates
 constexpr size_t kOctreeLdsLimit = 150 * 1024;  // beyond it the node list lives in global memory (k_octree_global)
 size_t octree_lds_bytes(int maxL);
 hipError_t launch_octree(hipStream_t s, const OctreeArgs& a, int nlevels, int nFrames);
