@@ -28,3 +28,29 @@ for _ in range(reps):
     ts.append(time.perf_counter() - t0)
 ts = np.array(ts) * 1e3
 print(f"{kind}: {img.shape[1]}x{img.shape[0]}, {len(k)} keypoints: median {np.median(ts):.3f} ms, min {ts.min():.3f} ms over {reps} calls", flush=True)
+if len(sys.argv) > 3 and sys.argv[3] == "pinned":  # the same frame from page-locked memory (orbfe_host_alloc), outputs page-locked too
+    import ctypes as C
+    from orb_slam2_annotate_amd import _lib
+    H, W = img.shape
+    pimg, pk, pd, pn = e.pinned_buffers(1, H, W)
+    np.copyto(pimg[0], img)
+    L = _lib.load()
+    n = C.c_int(0)
+    call = lambda: _lib.check(L.orbfe_extract(e._h, _lib.ptr(pimg), W, H, W, _lib.ptr(pk), _lib.ptr(pd), pk.shape[1], C.byref(n)))
+    call()
+    tp = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        call()
+        tp.append(time.perf_counter() - t0)
+    tp = np.array(tp) * 1e3
+    print(f"  page-locked image and outputs, C-ABI call only: median {np.median(tp):.3f} ms, min {tp.min():.3f} ms ({n.value} keypoints)", flush=True)
+if len(sys.argv) > 3 and sys.argv[3] == "stages":  # HIP-event time per stage of the same calls (the events cost a few microseconds themselves)
+    e.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        e(img)
+    wall = (time.perf_counter() - t0) / reps * 1e3
+    st = e.profile_get()
+    print(f"  with stage events: {wall:.3f} ms per call; " + "  ".join(f"{s} {v[0] / reps:.3f}" for s, v in st.items() if v[1]) +
+          f"  | sum {sum(v[0] for v in st.values()) / reps:.3f} ms", flush=True)

@@ -10,5 +10,5 @@ timeout -k 10 260 python tools/fuzz_stereo_bow.py 200 64 | tail -1 >> gpurun_out
 cat gpurun_out/r04_fuzz.txt
 python tools/matcher_latency.py > gpurun_out/r04_matcher_latency.txt 2>&1 || exit 1
 python tools/claim_probe.py 100 > gpurun_out/r04_claim_probe.txt 2>&1 || exit 1
-{ python tools/single_frame_latency.py 300 kitti; python tools/single_frame_latency.py 300 vga; } > gpurun_out/r04_single_frame_latency.txt 2>&1 || exit 1
+{ python tools/single_frame_latency.py 300 kitti pinned; python tools/single_frame_latency.py 300 vga pinned; python tools/single_frame_latency.py 300 kitti stages; python tools/single_frame_latency.py 300 vga stages; } > gpurun_out/r04_single_frame_latency.txt 2>&1 || exit 1
 tail -3 gpurun_out/r04_single_frame_latency.txt
