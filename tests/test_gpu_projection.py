@@ -467,3 +467,45 @@ def test_claim_loops_on_a_frame_too_large_for_lds(amd):
     n_ref, ref = orc.search_by_projection_reloc(Fo, SF, in_view, px, py, level, ka, md, blocked, 10.0, 100, True)
     n_got, got = amd.ORBmatcher(0.9, True).SearchByProjectionKeyFrame(F, SF, in_view, px, py, level, ka, md, 10.0, 100, blocked=blocked)
     assert (n_got, got.tolist()) == (n_ref, ref.tolist()) and n_ref > 1000
+
+
+def test_claim_chain_longer_than_the_round_stamp(amd):
+    """A dependency chain of 2100 points: point k sees key points k and k+1 and prefers k; a point in front of all takes key
+    point 0, so point 0 moves to 1, which pushes point 1 to 2, ... one link per round of k_window_claim -- more rounds than
+    the 11-bit round field of its owner stamps counts, so the re-basing path runs (BEST and RATIO form)."""
+    n = 2101
+    bounds = (-8.0, 8.0 * n + 8.0, 0.0, 480.0)
+    base = np.random.default_rng(92).integers(0, 256, 32, dtype=np.uint8)
+
+    def onehot(k):
+        d = np.zeros(32, np.uint8)
+        d[(k % 256) >> 3] = 1 << (k & 7)
+        return d
+
+    D = np.stack([base ^ onehot(k) for k in range(n)])
+    fdesc = np.stack([D[k] ^ onehot(k + 128) for k in range(n)])          # key point k: one bit from D[k]
+    fx = (8.0 * np.arange(n)).astype(np.float32)
+    fy = np.full(n, 240.0, np.float32)
+    octv = np.zeros(n, np.int32)
+    ang = np.zeros(n, np.float32)
+    F, Fo = _both(amd, fx, fy, octv, ang, fdesc, None, bounds)
+    # point 0 sits left of key point 0 and sees only it; point k+1 sits between key points k and k+1
+    u = np.concatenate([[-3.0], 8.0 * np.arange(n - 1) + 4.0]).astype(np.float32)
+    v = np.full(n, 240.0, np.float32)
+    md = np.concatenate([D[:1], D[: n - 1]])
+    lv = np.zeros(n, np.int32)
+    valid = np.ones(n, np.uint8)
+    qa = np.zeros(n, np.float32)
+    from orb_slam2_annotate_amd import _lib
+    n_ref, ref = orc.search_by_projection_reloc(Fo, SF, valid, u, v, lv, qa, md, None, 5.0, 100, False)
+    n_got, got = amd.ORBmatcher(0.9, False).SearchByProjectionKeyFrame(F, SF, valid, u, v, lv, qa, md, 5.0, 100)
+    assert (n_got, got.tolist()) == (n_ref, ref.tolist())
+    # key point k went to point k -- the shifted chain (the key points of the last half grid cell are not in the grid:
+    # PosInGrid rounds, src/Frame.cc:417-427)
+    assert n_ref > 2060 and ref[:2060].tolist() == list(range(2060))
+    assert _lib.load().orbfe_debug_last_claim_rounds() > 2046
+    view_cos = np.full(n, 0.9, np.float32)                                  # radius 4 * th
+    n_ref, ref = orc.search_by_projection_mappoints(Fo, SF, None, valid, lv, view_cos, u, v, None, md, None, 1.25, 0.8)
+    n_got, got = amd.ORBmatcher(0.8, True).SearchByProjection(F, SF, valid, lv, view_cos, u, v, md, th=1.25)
+    assert (n_got, got.tolist()) == (n_ref, ref.tolist()) and n_ref > 2060
+    assert _lib.load().orbfe_debug_last_claim_rounds() > 2046
