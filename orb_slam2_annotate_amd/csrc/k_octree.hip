@@ -632,6 +632,8 @@ __global__ __launch_bounds__(1024) void k_octree_reg1024(OctreeArgs a) {
     __syncthreads();  // (the workgroup's own stores to cand / candCount are visible to it behind the barrier)
   }
   const int n = a.candCount[(size_t)blockIdx.y * a.nlevels + blockIdx.x];  // block-uniform
+  // (node-list phases on wave 0, as in the other forms: shared by all sixteen waves -- HYB = false -- the stage takes 70
+  // instead of 55 us per KITTI frame, 52 instead of 37 per VGA frame, same box)
   if (n <= 1024 * 8) octree_body<true, 1024, true, 8>(a, smem, waveTot, sh, blockIdx.x, blockIdx.y);
   else octree_body<false, 1024, true>(a, smem, waveTot, sh, blockIdx.x, blockIdx.y);
 }
