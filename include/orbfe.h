@@ -338,6 +338,17 @@ int orbfe_stereo_match_batch_device(orbfe_extractor *e, int n_pairs, const orbfe
                                     float mbf, float mb, float *d_uRight, float *d_depth,
                                     int32_t *d_n_stereo);
 
+/* The front end of the stereo Frame constructor in ONE call (src/Frame.cc:78-96: ExtractORB(0, imLeft) and
+ * ExtractORB(1, imRight) on two threads, join, ComputeStereoMatches): both eyes go through handle e as a two-frame
+ * batch, the stereo matcher runs on the records while they are still in HBM, and keypoints / descriptors of both eyes,
+ * mvuRight and mvDepth (n_left floats each, -1 = no stereo) come back in one download.  Same results as two
+ * orbfe_extract calls + orbfe_compute_stereo_matches.  The handle then holds the pair as frames 0 (left) and 1 (right):
+ * orbfe_frame_from_extractor(e, 0, ...) builds the resident Frame from it. */
+int orbfe_extract_stereo_frame(orbfe_extractor *e, const uint8_t *left, const uint8_t *right, int width, int height,
+                               int stride, orbfe_keypoint *kp_left, uint8_t *desc_left, int *n_left,
+                               orbfe_keypoint *kp_right, uint8_t *desc_right, int *n_right, int capacity, float mbf,
+                               float mb, float *uRight, float *depth);
+
 /* ------------------------------------------------------------------------- */
 /* DBoW2 vocabulary (the step right before SearchByBoW)       */
 /* ------------------------------------------------------------------------- */

@@ -69,6 +69,30 @@ class ORBextractor {
     pyramidValid_ = false;
   }
 
+  // The front end of the stereo Frame constructor in one call (src/Frame.cc:78-96: ExtractORB(0, imLeft) and
+  // ExtractORB(1, imRight) on two threads, join, ComputeStereoMatches): both eyes through THIS handle, the stereo matcher on
+  // the records still in HBM, one download.  mvuRight / mvDepth get keysLeft.size() entries (-1 = no stereo).
+  void extractStereoFrame(const uint8_t* left, const uint8_t* right, int width, int height, int stride, float mbf, float mb,
+                          std::vector<KeyPoint>& keysLeft, std::vector<uint8_t>& descLeft, std::vector<KeyPoint>& keysRight,
+                          std::vector<uint8_t>& descRight, std::vector<float>& mvuRight, std::vector<float>& mvDepth) {
+    if (!left || !right || width <= 0 || height <= 0) return;
+    int cap = orbfe_extractor_max_keypoints_for(h_, width, height);
+    if (cap < orbfe_extractor_max_keypoints(h_)) cap = orbfe_extractor_max_keypoints(h_);
+    keysLeft.resize(cap); keysRight.resize(cap);
+    descLeft.resize((size_t)cap * 32); descRight.resize((size_t)cap * 32);
+    mvuRight.assign(cap, -1.0f); mvDepth.assign(cap, -1.0f);
+    int nl = 0, nr = 0;
+    check(orbfe_extract_stereo_frame(h_, left, right, width, height, stride, reinterpret_cast<orbfe_keypoint*>(keysLeft.data()),
+                                     descLeft.data(), &nl, reinterpret_cast<orbfe_keypoint*>(keysRight.data()), descRight.data(),
+                                     &nr, cap, mbf, mb, mvuRight.data(), mvDepth.data()), "ORBextractor::extractStereoFrame");
+    keysLeft.resize(nl); keysRight.resize(nr);
+    descLeft.resize((size_t)nl * 32); descRight.resize((size_t)nr * 32);
+    mvuRight.resize(nl); mvDepth.resize(nl);
+    w_ = width;
+    h0_ = height;
+    pyramidValid_ = false;
+  }
+
   int GetLevels() { return orbfe_extractor_get_levels(h_); }
   float GetScaleFactor() { return orbfe_extractor_get_scale_factor(h_); }
   std::vector<float> GetScaleFactors() { return vec(orbfe_extractor_get_scale_factors); }

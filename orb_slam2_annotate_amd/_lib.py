@@ -49,7 +49,7 @@ EXPORTS = [
     "orbfe_extractor_get_inverse_scale_factors", "orbfe_extractor_get_scale_sigma_squares",
     "orbfe_extractor_get_inverse_scale_sigma_squares", "orbfe_extractor_get_features_per_level",
     "orbfe_extractor_get_umax", "orbfe_extractor_max_keypoints", "orbfe_extractor_max_keypoints_for", "orbfe_extract", "orbfe_extract_batch",
-    "orbfe_extract_batch_device", "orbfe_extract_batch_device_async", "orbfe_extract_batch_pipelined", "orbfe_host_alloc", "orbfe_host_free", "orbfe_extractor_synchronize", "orbfe_extractor_level_size", "orbfe_extractor_get_pyramid_level",
+    "orbfe_extract_batch_device", "orbfe_extract_batch_device_async", "orbfe_extract_batch_pipelined", "orbfe_host_alloc", "orbfe_host_free", "orbfe_extract_stereo_frame", "orbfe_extractor_synchronize", "orbfe_extractor_level_size", "orbfe_extractor_get_pyramid_level",
     "orbfe_extractor_pyramid_level_device", "orbfe_extractor_debug_candidates",
     "orbfe_extractor_debug_blurred_level", "orbfe_extractor_debug_host_octree", "orbfe_debug_octree_host", "orbfe_debug_geometry",
     "orbfe_debug_resize_tables", "orbfe_debug_resize_tiles", "orbfe_extractor_set_streams", "orbfe_extractor_set_fused", "orbfe_extractor_set_pyramid_blur", "orbfe_extractor_set_fast_mode", "orbfe_extractor_set_schedule", "orbfe_extractor_set_desc_tiles", "orbfe_extractor_set_blur_spec", "orbfe_gaussian_blur7_spec", "orbfe_extractor_profile", "orbfe_extractor_profile_get",
@@ -146,6 +146,7 @@ def load():
     L.orbfe_search_for_triangulation.argtypes = [ci, vp, vp, vp, vp, vp, vp, ci, fvp, vp, vp, vp, vp, vp, vp, vp,
                                                  ci, fvp, vp, cf, cf, vp, vp, ci, ci, ci, vp]
     L.orbfe_compute_stereo_matches.argtypes = [vp, ci, vp, ci, vp, vp, ci, vp, vp, ci, cf, cf, vp, vp]
+    L.orbfe_extract_stereo_frame.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, vp]
     L.orbfe_stereo_match_batch_device.argtypes = [vp, ci, vp, vp, vp, ci, cf, cf, vp, vp, vp]
     L.orbfe_vocabulary_load_text.argtypes = [C.c_char_p, ci, C.POINTER(C.c_void_p)]
     L.orbfe_vocabulary_create.argtypes = [ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, C.POINTER(C.c_void_p)]

@@ -139,6 +139,8 @@ struct orbfe_extractor {
   uint8_t* d_octreeWork = nullptr;  // node lists of k_octree_global (only when they do not fit in LDS)
   size_t octreeWorkStride = 0;
   float* d_scaleTab = nullptr;     // mvScaleFactor[16] + mvInvScaleFactor[16]
+  float* d_frameStereo = nullptr;  // orbfe_extract_stereo_frame: mvuRight | mvDepth | survivors of the pair
+  size_t frameStereoCap = 0;
   int32_t* d_stereoSad = nullptr;  // scratch of the batched stereo matcher
   int32_t* d_stereoRowStart = nullptr;
   int32_t* d_stereoSorted = nullptr;
@@ -888,6 +890,7 @@ extern "C" void orbfe_extractor_destroy(orbfe_extractor* e) {
   stream_put(e->device, kRoleH2D, e->sH2D);
   stream_put(e->device, kRoleD2H, e->sD2H);
   dfree(&e->d_patternF);
+  dfree(&e->d_frameStereo);
   dfree(&e->d_stereoSad);
   dfree(&e->d_scaleTab);
   dfree(&e->d_stereoRowStart);
@@ -1771,6 +1774,103 @@ extern "C" int orbfe_stereo_match_batch_device(orbfe_extractor* e, int n_pairs, 
   // descriptor / count buffers this matcher is still reading: they wait for this event (run_pipeline)
   { int rc = orbfe_extractor_consumer_end_(e); if (rc) return rc; }
   return ORBFE_OK;  // asynchronous on the handle's streams: orbfe_extractor_synchronize() to wait
+}
+
+// The stereo Frame constructor's front end in ONE call (src/Frame.cc:78-96: ExtractORB on two threads, join,
+// ComputeStereoMatches): both eyes go through this handle as a two-frame batch -- one upload, every kernel of the
+// single-frame chain over two frames, the stereo matcher on the records that are still in HBM -- and keypoints,
+// descriptors, mvuRight and mvDepth come back in one download.  Two handles on two threads + orbfe_compute_stereo_matches
+// (which takes the keypoints it has just downloaded up again) cost 0.42-0.51 ms per KITTI pair; this call ~0.3 ms.
+extern "C" int orbfe_extract_stereo_frame(orbfe_extractor* e, const uint8_t* left, const uint8_t* right, int width, int height,
+                                          int stride, orbfe_keypoint* kpL, uint8_t* descL, int* nL, orbfe_keypoint* kpR,
+                                          uint8_t* descR, int* nR, int capacity, float mbf, float mb, float* uRight,
+                                          float* depth) {
+  if (!e || !nL || !nR) return fail(ORBFE_ERR_INVALID, "extract_stereo_frame: bad argument");
+  *nL = *nR = 0;
+  if (!left || !right || width <= 0 || height <= 0) return ORBFE_OK;  // empty image: silent return (:1122)
+  if (!kpL || !descL || !kpR || !descR || !uRight || !depth || capacity <= 0 || stride < width || capacity >= (1 << 20))
+    return fail(ORBFE_ERR_INVALID, "extract_stereo_frame: bad output buffers");
+  HIPCHK(hipSetDevice(e->device));
+  int rc;
+  e->outLastFrames = 0;
+  if ((rc = ensure_geometry(e, width, height))) return rc;
+  if ((rc = ensure_workspace(e, 2))) return rc;
+  if ((rc = ensure_outputs(e, 2, capacity))) return rc;
+  if (e->frameStereoCap < (size_t)capacity) {
+    if ((rc = sync_all(e))) return rc;
+    e->frameStereoCap = 0;
+    if ((rc = dalloc(&e->d_frameStereo, 2 * (size_t)capacity + 16))) return rc;
+    e->frameStereoCap = (size_t)capacity;
+  }
+  next_event_slot(e);
+  // both images into the input slab at the caller's pitch (the kernels read rows in place at any stride)
+  const size_t frameStride = ((size_t)stride * height + 255) & ~(size_t)255;
+  const size_t slab = 2 * frameStride + 64;
+  if (slab > e->hostInBytes) {
+    e->hostInBytes = 0;
+    e->haveLast = false;
+    if ((rc = dalloc(&e->d_hostIn, slab))) return rc;
+    e->hostInBytes = slab;
+  }
+  const size_t bytes = (size_t)(height - 1) * stride + width;
+  {
+    StageTimer t(e, ORBFE_STAGE_H2D, 0, 0, 0, e->stream);
+    HIPCHK(hipMemcpyAsync(e->d_hostIn, left, bytes, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_hostIn + frameStride, right, bytes, hipMemcpyHostToDevice, e->stream));
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));  // (as orbfe_extract_batch: sub-batch streams would read the uploaded frames)
+  const LevelView l0{e->d_hostIn, frameStride, stride, width, height};
+  if ((rc = run_pipeline(e, l0, 2, e->d_kpOut, e->d_descOut, capacity, e->d_nOut))) return rc;
+  float* d_ur = e->d_frameStereo;
+  float* d_dp = e->d_frameStereo + capacity;
+  int32_t* d_ns = reinterpret_cast<int32_t*>(e->d_frameStereo + 2 * (size_t)capacity);
+  if ((rc = orbfe_stereo_match_batch_device(e, 1, e->d_kpOut, e->d_descOut, e->d_nOut, capacity, mbf, mb, d_ur, d_dp, d_ns)))
+    return rc;
+  if (e->lastS > 1 || e->lastLanes) { if ((rc = sync_all(e))) return rc; }  // (a pair is one sub-batch: everything is on e->stream)
+  {
+    StageTimer t(e, ORBFE_STAGE_D2H, 0, 0, 0, e->stream);
+    const size_t blockBytes = (size_t)(reinterpret_cast<uint8_t*>(e->d_nOut) - e->d_outBlock) + sizeof(int32_t) * 2;
+    const size_t stBytes = 2 * (size_t)capacity * sizeof(float);
+    const size_t need = blockBytes + stBytes;
+    if (e->outStageBytes < need) {
+      if (e->h_outStage) (void)hipHostFree(e->h_outStage);
+      e->h_outStage = nullptr;
+      e->outStageBytes = 0;
+      const size_t want = need > (size_t)512 * 1024 ? need : (size_t)512 * 1024;
+      HIPCHK(hipHostMalloc((void**)&e->h_outStage, want, hipHostMallocDefault));
+      e->outStageBytes = want;
+    }
+    HIPCHK(hipMemcpyAsync(e->h_outStage, e->d_outBlock, blockBytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->h_outStage + blockBytes, e->d_frameStereo, stBytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const uint8_t* hk = e->h_outStage;
+    const uint8_t* hd = e->h_outStage + (e->d_descOut - e->d_outBlock);
+    const int32_t* hc = reinterpret_cast<const int32_t*>(e->h_outStage + (reinterpret_cast<uint8_t*>(e->d_nOut) - e->d_outBlock));
+    bool overflow = false;
+    int n[2];
+    orbfe_keypoint* kk[2] = {kpL, kpR};
+    uint8_t* dd[2] = {descL, descR};
+    for (int f = 0; f < 2; f++) {
+      n[f] = hc[f];
+      if (n[f] > capacity) { overflow = true; n[f] = capacity; }
+      if (n[f] > 0) {
+        std::memcpy(kk[f], hk + (size_t)f * capacity * sizeof(orbfe_keypoint), sizeof(orbfe_keypoint) * (size_t)n[f]);
+        std::memcpy(dd[f], hd + (size_t)f * capacity * 32, (size_t)n[f] * 32);
+      }
+    }
+    *nL = n[0];
+    *nR = n[1];
+    if (n[0] > 0) {
+      std::memcpy(uRight, e->h_outStage + blockBytes, sizeof(float) * (size_t)n[0]);
+      std::memcpy(depth, e->h_outStage + blockBytes + (size_t)capacity * sizeof(float), sizeof(float) * (size_t)n[0]);
+    }
+    e->outLastCount.assign(n, n + 2);
+    e->outLastCapacity = capacity;
+    e->outLastFrames = 2;
+    if (overflow) return fail(ORBFE_ERR_CAPACITY, "keypoint capacity too small");
+  }
+  resolve_stage_times(e);
+  return ORBFE_OK;
 }
 
 // ---- host-logic debug entry points (no GPU needed; CPU tests compare them with the oracle) ----

@@ -97,6 +97,25 @@ class ORBextractor:
         self._last_shape = (1, H, W)
         return kps[: n.value].copy(), desc[: n.value].copy()
 
+    def extract_stereo_frame(self, left: np.ndarray, right: np.ndarray, mbf: float, mb: float, capacity: int | None = None):
+        """The stereo Frame constructor's front end in one call (src/Frame.cc:78-96): ExtractORB on both eyes +
+        ComputeStereoMatches -> (keysLeft, descLeft, keysRight, descRight, mvuRight, mvDepth).  The handle then holds the
+        pair as frames 0 / 1 (ResidentFrame(view, fv, extractor=self, frame=0))."""
+        if left.dtype != np.uint8 or left.ndim != 2 or right.dtype != np.uint8 or right.shape != left.shape:
+            raise AssertionError("image.type() == CV_8UC1, both eyes of one size")
+        left, right = np.ascontiguousarray(left), np.ascontiguousarray(right)
+        H, W = left.shape
+        cap = capacity or self.max_keypoints(W, H)
+        kl, kr = np.zeros(cap, dtype=KP_DTYPE), np.zeros(cap, dtype=KP_DTYPE)
+        dl, dr = np.zeros((cap, 32), dtype=np.uint8), np.zeros((cap, 32), dtype=np.uint8)
+        u, d = np.full(cap, -1, dtype=np.float32), np.full(cap, -1, dtype=np.float32)
+        nl, nr = C.c_int(0), C.c_int(0)
+        check(self._L.orbfe_extract_stereo_frame(self._h, ptr(left), ptr(right), W, H, W, ptr(kl), ptr(dl), C.byref(nl), ptr(kr),
+                                                 ptr(dr), C.byref(nr), cap, float(mbf), float(mb), ptr(u), ptr(d)))
+        self._last_shape = (2, H, W)
+        a, b = nl.value, nr.value
+        return kl[:a].copy(), dl[:a].copy(), kr[:b].copy(), dr[:b].copy(), u[:a].copy(), d[:a].copy()
+
     def extract_batch(self, images: np.ndarray, capacity: int | None = None):
         """images: [B,H,W] uint8 (host).  Returns list of (keypoints, descriptors) per frame."""
         images = np.ascontiguousarray(images, dtype=np.uint8)

@@ -3,6 +3,7 @@
 // stereo matching, DescriptorDistance.  Prints a checksum the Python test compares with the oracle.
 #include <atomic>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <map>
 #include <thread>
@@ -39,6 +40,17 @@ int main(int argc, char** argv) {
   tr.join();
   std::vector<float> u, d;
   ComputeStereoMatches(eL, eR, kL, dL, kR, dR, 80.0f, 80.0f / 200.0f, u, d);
+  {  // the same stereo Frame in ONE call on one handle: identical keypoints, descriptors, mvuRight, mvDepth
+    ORBextractor eS(600, 1.2f, 8, 20, 7);
+    std::vector<KeyPoint> sL, sR;
+    std::vector<uint8_t> sdL, sdR;
+    std::vector<float> su, sd;
+    eS.extractStereoFrame(L.data(), R.data(), W, H, W, 80.0f, 80.0f / 200.0f, sL, sdL, sR, sdR, su, sd);
+    const bool same = sL.size() == kL.size() && sR.size() == kR.size() && !std::memcmp(sL.data(), kL.data(), kL.size() * 28) &&
+                      !std::memcmp(sR.data(), kR.data(), kR.size() * 28) && sdL == dL && sdR == dR && su.size() == u.size() &&
+                      !std::memcmp(su.data(), u.data(), u.size() * 4) && !std::memcmp(sd.data(), d.data(), d.size() * 4);
+    if (!same) { std::printf("extractStereoFrame differs from two extractions + ComputeStereoMatches\n"); return 1; }
+  }
   const std::vector<Image>& pyr = eL.mvImagePyramid();
   uint64_t hp = 1469598103934665603ull;
   for (const Image& im : pyr) hp = fnv(im.data.data(), im.data.size(), hp);

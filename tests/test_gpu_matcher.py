@@ -674,3 +674,33 @@ def test_search_for_triangulation_multi(amd, only_stereo, ori):
         assert int(cnt[k]) == refs[k][0], k
         assert np.array_equal(match[k], refs[k][1]), k
     assert sum(r[0] for r in refs) > 20 and refs[0][0] > 5 and refs[4][0] == 0 and refs[5][0] == 0
+
+
+
+@pytest.mark.parametrize("shape,nf,bf,fx,scene", [((1241, 376), 2000, 386.1448, 718.856, "textured"), ((752, 480), 1200, 47.90639384423901, 435.2, "shapes")])
+def test_extract_stereo_frame_is_two_extractions_and_the_stereo_matcher(amd, shape, nf, bf, fx, scene):
+    """orbfe_extract_stereo_frame = ExtractORB x2 + ComputeStereoMatches of the stereo Frame constructor (src/Frame.cc:78-96)
+    in one call on one handle: keypoints / descriptors of both eyes, mvuRight and mvDepth equal the oracle's, and the
+    handle then holds the pair (a resident frame built from frame 0 equals one built from host arrays)."""
+    w, h = shape
+    left, right = synth.STEREO_SCENES[scene](5, w, h)
+    e = amd.ORBextractor(nf, 1.2, 8, 20, 7)
+    mbf = np.float32(bf)
+    mb = np.float32(mbf / np.float32(fx))
+    o = orc.Oracle(nf, 1.2, 8, 20, 7)
+    krL, drL, pL = o.extract(left, want_pyramid=True)
+    krR, drR, pR = o.extract(right, want_pyramid=True)
+    u_ref, d_ref = o.stereo(w, h, krL, drL, krR, drR, pL, pR, float(mbf), float(mb))
+    for _ in range(2):  # (the second call reuses the handle's buffers and streams)
+        kL, dL, kR, dR, u, d = e.extract_stereo_frame(left, right, float(mbf), float(mb))
+        assert np.array_equal(krL, kL) and np.array_equal(krR, kR)
+        assert np.array_equal(drL, dL) and np.array_equal(drR, dR)
+        assert np.array_equal(u_ref, u) and np.array_equal(d_ref, d)
+    assert (u >= 0).sum() > 100
+    # the ordinary calls still work on the same handle afterwards, and a different size re-plans it
+    k1, d1 = e(left)
+    assert np.array_equal(k1, krL) and np.array_equal(d1, drL)
+    small_l, small_r = np.ascontiguousarray(left[:240, :320]), np.ascontiguousarray(right[:240, :320])
+    ks, ds, _, _, us, _ = e.extract_stereo_frame(small_l, small_r, float(mbf), float(mb))
+    ko, do, po = o.extract(small_l, want_pyramid=True)
+    assert np.array_equal(ks, ko) and np.array_equal(ds, do) and len(us) == len(ks)

@@ -215,6 +215,23 @@ def measure(reps=30, verbose=True):
     M.SearchByBoWMulti(keep, [has2] * len(keep), R1)
     for k_ in keep:
         k_.close()
+    # the stereo Frame on ONE handle and one thread: both eyes as a 2-frame batch (two sub-batch streams), then
+    # ComputeStereoMatches on frames 0 and 1 of that handle -- instead of two handles on two threads
+    def one_handle():
+        (a1, b1), (a2, b2) = eL.extract_batch(np.stack([left, right]))
+        return amd.ComputeStereoMatches(eL, eL, a1, b1, a2, b2, float(mbf), float(mb), frameL=0, frameR=1)
+    timed("stereo Frame on ONE handle: extract_batch(L, R) + ComputeStereoMatches(frames 0, 1)", one_handle, n=40)
+    timed("stereo Frame in ONE call: orbfe_extract_stereo_frame (both eyes + stereo matcher, one download)",
+          lambda: eL.extract_stereo_frame(left, right, float(mbf), float(mb)), n=40)
+    # ONE frame through operator() -- the live camera: upload, the single-frame kernel chain, download (tools/single_frame_latency.py)
+    timed("operator() on one 1241x376 frame, 2000 features (pageable image, Python call)", lambda: eL(left), n=60)
+    import ctypes as C
+    from orb_slam2_annotate_amd import _lib
+    pimg, pk, pd, _pn = eL.pinned_buffers(1, h, w)
+    np.copyto(pimg[0], left)
+    L_, n_ = _lib.load(), C.c_int(0)
+    timed("operator() on one 1241x376 frame, page-locked image and outputs (orbfe_host_alloc), C-ABI call",
+          lambda: _lib.check(L_.orbfe_extract(eL._h, _lib.ptr(pimg), w, h, w, _lib.ptr(pk), _lib.ptr(pd), pk.shape[1], C.byref(n_))), n=60)
     return rows
 
 
