@@ -68,6 +68,12 @@ def main():
                 print("STEREO MISMATCH", cfg, f"mbf={mbf} mb={mb} first bad {bad[:5]}", u_ref[bad[:5]], u[bad[:5]])
                 sys.exit(1)
             n_st += 1
+            if rng.random() < 0.5:  # round 4: the same stereo frame in ONE call on the left handle (orbfe_extract_stereo_frame)
+                k1, d1, k2, d2, u1, dd1 = eL.extract_stereo_frame(left, right, float(mbf), float(mb))
+                if not (np.array_equal(k1, krL) and np.array_equal(k2, krR) and np.array_equal(d1, drL) and np.array_equal(d2, drR) and
+                        np.array_equal(u1, u_ref) and np.array_equal(dd1, d_ref)):
+                    print("STEREO FRAME (one call) MISMATCH", cfg, f"mbf={mbf} mb={mb}")
+                    sys.exit(1)
         if len(kL) > 4 and len(kR) > 4:
             n_nodes = int(rng.choice([1, 2, 5, 8, 12, 20, 100, 150]))  # round 4: 8 / 12 / 20 land in the 2- and 4-slot register paths
             n1, n2 = nodes_of(dL, rng, n_nodes), nodes_of(dR, rng, n_nodes)
