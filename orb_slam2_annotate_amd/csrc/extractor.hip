@@ -123,6 +123,9 @@ struct orbfe_extractor {
   int16_t* d_beta[kMaxLevels] = {};
   uint32_t* d_colrec[kMaxLevels] = {};
   uint32_t* d_rowrec[kMaxLevels] = {};
+  ChainTile* d_chainTiles = nullptr;    // the one-launch pyramid of the single-frame form (k_pyramid_chain): tiles + what each needs
+  int nChainTiles = 0, chainBufA = 0, chainBufB = 0, chainMaxW = 0, chainMaxH = 0;
+  bool chainOk = false;
   int32_t* d_tileGx[kMaxLevels] = {};   // ownership tables of the fused blur + resize kernel (ResizeTables::tileGx / tileDy)
   int32_t* d_tileDy[kMaxLevels] = {};
   bool pyrBlur = true;                  // blur level l and write level l+1 from the same staged tiles ($ORBFE_PYRBLUR,
@@ -279,6 +282,9 @@ void free_geometry(orbfe_extractor* e) {
   dfree(&e->d_lvgeom);
   dfree(&e->d_descTiles);
   e->nDescTiles = 0;
+  dfree(&e->d_chainTiles);
+  e->nChainTiles = 0;
+  e->chainOk = false;
   for (int l = 0; l < kMaxLevels; l++) { dfree(&e->d_xofs[l]); dfree(&e->d_alpha[l]); dfree(&e->d_yofs[l]); dfree(&e->d_beta[l]); dfree(&e->d_colrec[l]); dfree(&e->d_rowrec[l]); dfree(&e->d_tileGx[l]); dfree(&e->d_tileDy[l]); }
 }
 void free_workspace(orbfe_extractor* e) {
@@ -329,6 +335,49 @@ int ensure_geometry(orbfe_extractor* e, int W, int H) {
     if (!tiles.empty()) {
       if ((rc = dalloc(&e->d_descTiles, tiles.size()))) return rc;
       HIPCHK(hipMemcpy(e->d_descTiles, tiles.data(), tiles.size() * sizeof(DescTile), hipMemcpyHostToDevice));
+    }
+  }
+  {
+    // k_pyramid_chain: 32 x 32 tiles of levels 1 .. n-1, each with the rectangles it needs of the levels below it
+    // (walking the cv::resize tables back to level 0); usable while the two LDS rectangle buffers fit
+    std::vector<ChainTile> tiles;
+    size_t bufA = 0, bufB = 0;
+    int maxW = 0, maxH = 0;
+    bool ok = g.nlevels > 1;
+    for (int l = 1; l < g.nlevels && ok; l++)
+      for (int y0 = 0; y0 < g.lv[l].h && ok; y0 += 32)
+        for (int x0 = 0; x0 < g.lv[l].w; x0 += 32) {
+          ChainTile t = {};
+          t.level = l;
+          int rx0 = x0, ry0 = y0, rx1 = std::min(x0 + 32, g.lv[l].w) - 1, ry1 = std::min(y0 + 32, g.lv[l].h) - 1;  // inclusive
+          for (int k = l; k >= 0; k--) {
+            const int w = rx1 - rx0 + 1, h = ry1 - ry0 + 1;
+            if (w > 255 || h > 255) { ok = false; break; }
+            t.r[k] = ChainRect{(int16_t)rx0, (int16_t)ry0, (int16_t)w, (int16_t)h};
+            const size_t bytes = (size_t)((w + 3) & ~3) * h;
+            if (k & 1) bufB = std::max(bufB, bytes); else bufA = std::max(bufA, bytes);
+            if (k > 0) { maxW = std::max(maxW, w); maxH = std::max(maxH, h); }  // (table entries of the level-k output rectangle)
+            if (k == 0) break;
+            const ResizeTables& z = g.rz[k];
+            const int Wp = g.lv[k - 1].w, Hp = g.lv[k - 1].h;
+            auto clampr = [&](int v) { return v < 0 ? 0 : (v >= Hp ? Hp - 1 : v); };
+            const int sx0 = z.xofs[rx0], sx1 = std::min(z.xofs[rx1] + 1, Wp - 1);
+            const int sy0 = clampr(z.yofs[ry0]), sy1 = clampr(z.yofs[ry1] + 1);
+            rx0 = sx0; rx1 = std::max(sx1, sx0); ry0 = sy0; ry1 = std::max(sy1, sy0);
+          }
+          if (!ok) break;
+          tiles.push_back(t);
+        }
+    bufA = (bufA + 15) & ~(size_t)15;
+    bufB = (bufB + 15) & ~(size_t)15;
+    if (ok && bufA + bufB + (size_t)(maxW + maxH) * 8 > (size_t)60 * 1024) ok = false;
+    e->chainOk = false;
+    if (ok && !tiles.empty()) {
+      if ((rc = dalloc(&e->d_chainTiles, tiles.size()))) return rc;
+      HIPCHK(hipMemcpy(e->d_chainTiles, tiles.data(), tiles.size() * sizeof(ChainTile), hipMemcpyHostToDevice));
+      e->nChainTiles = (int)tiles.size();
+      e->chainBufA = (int)bufA; e->chainBufB = (int)bufB; e->chainMaxW = maxW; e->chainMaxH = maxH;
+      e->chainOk = true;
     }
   }
   for (int l = 1; l < g.nlevels; l++) {
@@ -558,6 +607,23 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
   // (not for the few-frame launches of a live camera: there the 8 dependent blur + resize launches are a longer critical
   // path than 7 small resize launches followed by one blur launch -- 0.195 vs 0.167 ms per single frame)
   const bool pyrBlur = e->pyrBlur && !fused && !lanes && nFrames > 8;
+  // a few frames (the live camera): the whole pyramid in ONE launch -- every tile recomputes its chain from level 0 in LDS
+  // (k_pyramid_chain) -- instead of n-1 dependent launches of a few microseconds each
+  static const bool kChainOff = getenv("ORBFE_PYR_CHAIN") && atoi(getenv("ORBFE_PYR_CHAIN")) == 0;
+  const bool chain = !kChainOff && e->chainOk && !pyrBlur && !fused && nFrames <= 8 && !(ko & 1);
+  if (chain) {
+    StageTimer t(e, ORBFE_STAGE_PYRAMID, 1, nFrames, sub, s);
+    PyrChainArgs ca = {};
+    ca.l0 = pyr.lv[0];
+    for (int l = 0; l < g.nlevels; l++) { ca.w[l] = g.lv[l].w; ca.h[l] = g.lv[l].h; }
+    for (int l = 1; l < g.nlevels; l++) {
+      ca.lv[l] = LevelViewMut{const_cast<uint8_t*>(pyr.lv[l].base), g.pyrBytes, g.lv[l].pitch, g.lv[l].w, g.lv[l].h};
+      ca.xofs[l] = e->d_xofs[l]; ca.alpha[l] = e->d_alpha[l]; ca.yofs[l] = e->d_yofs[l]; ca.beta[l] = e->d_beta[l];
+    }
+    ca.tiles = e->d_chainTiles;
+    ca.bufA = e->chainBufA; ca.bufB = e->chainBufB; ca.maxW = e->chainMaxW; ca.maxH = e->chainMaxH;
+    launch_pyramid_chain(s, ca, e->nChainTiles, nFrames);
+  } else
   {  // ComputePyramid, :1203-1234
     StageTimer t(e, ORBFE_STAGE_PYRAMID, pyrBlur ? g.nlevels : g.nlevels - 1, nFrames, sub, s);
     for (int l = 1; l <= g.nlevels && !(ko & 1); l++) {

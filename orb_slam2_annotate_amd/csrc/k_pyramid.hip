@@ -342,4 +342,103 @@ void launch_copy2d(hipStream_t s, LevelView src, LevelViewMut dst, int nFrames) 
   hipLaunchKernelGGL(k_copy2d, dim3((unsigned)((total + 255) / 256), nFrames), dim3(256), 0, s, src, dst, chunks, magic, total);
 }
 
+
+// ---- k_pyramid_chain: see kernels.h (PyrChainArgs) ----
+// i / d for i < 2^24, 1 <= d < 256 by multiply-high (2^32 / d + 1: the error term i * (m * d - 2^32) stays below 2^32)
+__device__ __forceinline__ uint32_t chain_div(uint32_t i, uint32_t d, uint32_t magic) { return d == 1u ? i : __umulhi(i, magic); }
+__device__ __forceinline__ uint32_t chain_magic(uint32_t d) { return d <= 1u ? 0u : (uint32_t)(0x100000000ull / d) + 1u; }
+__global__ __launch_bounds__(256) void k_pyramid_chain(const PyrChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const ChainTile T = a.tiles[blockIdx.x];  // block-uniform (scalar loads)
+  const int f = blockIdx.y, tid = threadIdx.x;
+  uint8_t* bufIn = lds;
+  uint8_t* bufOut = lds + a.bufA;
+  uint2* colrec = reinterpret_cast<uint2*>(lds + a.bufA + a.bufB);  // per column of the output rectangle: taps | weights
+  uint2* rowrec = colrec + a.maxW;                                   // per row
+  // ---- the level-0 rectangle, 4 bytes per request where the row allows ----
+  ChainRect rIn = T.r[0];
+  int pitchIn = (rIn.w + 3) & ~3;
+  {
+    const uint8_t* S = a.l0.base + (size_t)f * a.l0.frameStride + (size_t)rIn.y0 * a.l0.pitch + rIn.x0;
+    const int dwPerRow = pitchIn >> 2;
+    const uint32_t inv = chain_magic((uint32_t)dwPerRow);
+    struct __attribute__((packed, aligned(1))) U1u { uint32_t x; };
+    for (int i = tid; i < rIn.h * dwPerRow; i += 256) {
+      const int y = (int)chain_div((uint32_t)i, (uint32_t)dwPerRow, inv), c = i - y * dwPerRow;
+      const uint8_t* p = S + (size_t)y * a.l0.pitch + 4 * c;
+      uint32_t v;
+      if (rIn.x0 + 4 * c + 3 < a.w[0]) v = reinterpret_cast<const U1u*>(p)->x;
+      else {  // the last dword of a row at the right image border: stay inside the row
+        v = 0;
+        for (int b = 0; b < 4; b++)
+          if (rIn.x0 + 4 * c + b < a.w[0]) v |= (uint32_t)p[b] << (8 * b);
+      }
+      *reinterpret_cast<uint32_t*>(bufIn + y * pitchIn + 4 * c) = v;
+    }
+  }
+  // ---- level k from level k-1, k = 1 .. T.level (cv::resize INTER_LINEAR in 11-bit fixed point, the arithmetic of
+  //      k_resize_generic: rows and the second tap clamped at use) ----
+  for (int k = 1; k <= T.level; k++) {
+    const ChainRect rOut = T.r[k];
+    const int Wp = a.w[k - 1], Hp = a.h[k - 1];
+    const int32_t* xo = a.xofs[k];
+    const int16_t* al = a.alpha[k];
+    const int32_t* yo = a.yofs[k];
+    const int16_t* be = a.beta[k];
+    for (int x = tid; x < rOut.w; x += 256) {
+      const int dx = rOut.x0 + x;
+      const int sx = xo[dx];
+      const int sx1 = sx + 1 < Wp ? sx + 1 : sx;
+      colrec[x] = make_uint2((uint32_t)(sx - rIn.x0) | ((uint32_t)(sx1 - rIn.x0) << 16),
+                             (uint32_t)(uint16_t)al[2 * dx] | ((uint32_t)(uint16_t)al[2 * dx + 1] << 16));
+    }
+    for (int y = tid; y < rOut.h; y += 256) {
+      const int dy = rOut.y0 + y;
+      const int sy = yo[dy];
+      const int r0 = sy < 0 ? 0 : (sy >= Hp ? Hp - 1 : sy);
+      const int r1 = sy + 1 < 0 ? 0 : (sy + 1 >= Hp ? Hp - 1 : sy + 1);
+      rowrec[y] = make_uint2((uint32_t)(r0 - rIn.y0) | ((uint32_t)(r1 - rIn.y0) << 16),
+                             (uint32_t)(uint16_t)be[2 * dy] | ((uint32_t)(uint16_t)be[2 * dy + 1] << 16));
+    }
+    __syncthreads();  // (also: the previous level's stores to bufIn)
+    const int pitchOut = (rOut.w + 3) & ~3;
+    const uint32_t invW = chain_magic((uint32_t)rOut.w);
+    for (int i = tid; i < rOut.w * rOut.h; i += 256) {
+      const int y = (int)chain_div((uint32_t)i, (uint32_t)rOut.w, invW), x = i - y * rOut.w;
+      const uint2 c = colrec[x], r = rowrec[y];
+      const uint8_t* S0 = bufIn + (r.x & 0xffffu) * pitchIn;
+      const uint8_t* S1 = bufIn + (r.x >> 16) * pitchIn;
+      const int o0 = (int)(c.x & 0xffffu), o1 = (int)(c.x >> 16);
+      const int a0 = (int)(c.y & 0xffffu), a1 = (int)(c.y >> 16);
+      const int b0 = (int)(r.y & 0xffffu), b1 = (int)(r.y >> 16);
+      const int h0 = S0[o0] * a0 + S0[o1] * a1;
+      const int h1 = S1[o0] * a0 + S1[o1] * a1;
+      bufOut[y * pitchOut + x] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+    }
+    __syncthreads();
+    uint8_t* t = bufIn; bufIn = bufOut; bufOut = t;
+    rIn = rOut;
+    pitchIn = pitchOut;
+  }
+  // ---- the tile itself (owned levels: pitch % 64 == 0, tile origin % 32 == 0) ----
+  const LevelViewMut D = a.lv[T.level];
+  uint8_t* out = D.base + (size_t)f * D.frameStride + (size_t)rIn.y0 * D.pitch + rIn.x0;
+  const int dwPerRow = pitchIn >> 2;  // <= 8
+  for (int i = tid; i < rIn.h * dwPerRow; i += 256) {
+    const int y = i / dwPerRow, c = i - y * dwPerRow;
+    const uint32_t v = *reinterpret_cast<const uint32_t*>(bufIn + y * pitchIn + 4 * c);
+    uint8_t* p = out + (size_t)y * D.pitch + 4 * c;
+    if (4 * c + 3 < rIn.w) *reinterpret_cast<uint32_t*>(p) = v;
+    else
+      for (int b = 0; 4 * c + b < rIn.w; b++) p[b] = (uint8_t)(v >> (8 * b));
+  }
+}
+
+size_t pyramid_chain_lds_bytes(const PyrChainArgs& a) { return (size_t)a.bufA + a.bufB + (size_t)(a.maxW + a.maxH) * sizeof(uint2); }
+
+void launch_pyramid_chain(hipStream_t s, const PyrChainArgs& a, int nTiles, int nFrames) {
+  if (nTiles <= 0 || nFrames <= 0) return;
+  hipLaunchKernelGGL(k_pyramid_chain, dim3(nTiles, nFrames), dim3(256), pyramid_chain_lds_bytes(a), s, a);
+}
+
 }  // namespace orbfe

@@ -77,6 +77,24 @@ struct LevelKp {
 };
 
 // ---- pyramid (ComputePyramid, :1203-1234) ----
+// ---- the whole pyramid of a few frames in ONE launch (single-frame form, k_pyramid_chain) ----
+// A workgroup owns one 32 x 32 tile of one level l >= 1 and produces it from LEVEL 0: it stages the level-0 rectangle its
+// tile depends on and walks the chain level 1, 2, ... l in LDS, recomputing the (slightly larger) rectangle of every
+// intermediate level -- the same fixed-point bilinear step from the same inputs, so every pixel equals the one the
+// level-by-level kernels write.  Seven dependent launches of a few microseconds each (+ the gaps between them) become one.
+struct ChainRect { int16_t x0, y0, w, h; };
+struct ChainTile { int32_t level; ChainRect r[kMaxLevels]; };  // r[k], k = 0 .. level: what the tile needs of level k; r[level] = the tile
+struct PyrChainArgs {
+  LevelView l0;                       // level 0 (the caller's pitch)
+  LevelViewMut lv[kMaxLevels];        // destinations, levels 1 .. nlevels-1
+  const int32_t* xofs[kMaxLevels]; const int16_t* alpha[kMaxLevels];   // cv::resize tables of level k-1 -> k
+  const int32_t* yofs[kMaxLevels]; const int16_t* beta[kMaxLevels];
+  int w[kMaxLevels], h[kMaxLevels];   // level sizes
+  const ChainTile* tiles;
+  int bufA, bufB, maxW, maxH;         // LDS carve: bytes of the two rectangle buffers, longest rectangle side (table entries)
+};
+size_t pyramid_chain_lds_bytes(const PyrChainArgs& a);
+void launch_pyramid_chain(hipStream_t s, const PyrChainArgs& a, int nTiles, int nFrames);
 void launch_resize(hipStream_t s, LevelView src, LevelViewMut dst, const int32_t* d_xofs,
                    const int16_t* d_alpha, const int32_t* d_yofs, const int16_t* d_beta,
                    const uint32_t* d_colrec, const uint32_t* d_rowrec, int nFrames);
