@@ -226,6 +226,12 @@ int orbfe_extractor_set_fused(orbfe_extractor *e, int enable);
  * orbfe_extractor_set_fused(1). */
 int orbfe_extractor_set_pyramid_blur(orbfe_extractor *e, int enable);
 
+/* Calls of at most 8 frames (the live camera) build the pyramid with n-1 dependent resize launches of a few microseconds
+ * each.  1: ONE launch instead -- a workgroup owns a tile of one level and recomputes, in LDS, the rectangles of the levels
+ * below it from level 0 (k_pyramid_chain: same fixed-point step from the same inputs, identical pixels).  0 (default;
+ * $ORBFE_PYR_CHAIN): the launches -- the one-launch form measured no faster (32 vs 29 us per KITTI frame). */
+int orbfe_extractor_set_pyramid_chain(orbfe_extractor *e, int enable);
+
 /* A call's frames are split into n consecutive sub-batches that run concurrently on n HIP
  * streams with private workspace slices (1..32, default 1 or $ORBFE_STREAMS); results do not
  * depend on n.  Stage timing covers the kernels of sub-batch 0 (frames_out reports how many

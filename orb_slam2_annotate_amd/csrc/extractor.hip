@@ -126,6 +126,8 @@ struct orbfe_extractor {
   ChainTile* d_chainTiles = nullptr;    // the one-launch pyramid of the single-frame form (k_pyramid_chain): tiles + what each needs
   int nChainTiles = 0, chainBufA = 0, chainBufB = 0, chainMaxW = 0, chainMaxH = 0;
   bool chainOk = false;
+  bool pyrChain = false;                // use it for calls of <= 8 frames ($ORBFE_PYR_CHAIN, orbfe_extractor_set_pyramid_chain): off,
+                                        // it measured no faster than the seven launches
   int32_t* d_tileGx[kMaxLevels] = {};   // ownership tables of the fused blur + resize kernel (ResizeTables::tileGx / tileDy)
   int32_t* d_tileDy[kMaxLevels] = {};
   bool pyrBlur = true;                  // blur level l and write level l+1 from the same staged tiles ($ORBFE_PYRBLUR,
@@ -344,12 +346,13 @@ int ensure_geometry(orbfe_extractor* e, int W, int H) {
     size_t bufA = 0, bufB = 0;
     int maxW = 0, maxH = 0;
     bool ok = g.nlevels > 1;
-    for (int l = 1; l < g.nlevels && ok; l++)
-      for (int y0 = 0; y0 < g.lv[l].h && ok; y0 += 32)
-        for (int x0 = 0; x0 < g.lv[l].w; x0 += 32) {
+    for (int l = g.nlevels - 1; l >= 1 && ok; l--) {  // the longest chains first
+      const int TS = l >= 4 ? 16 : 32;  // (deep levels: smaller tiles, i.e. smaller rectangles to recompute -- 16 measured best of 32 / 16 / 8)
+      for (int y0 = 0; y0 < g.lv[l].h && ok; y0 += TS)
+        for (int x0 = 0; x0 < g.lv[l].w; x0 += TS) {
           ChainTile t = {};
           t.level = l;
-          int rx0 = x0, ry0 = y0, rx1 = std::min(x0 + 32, g.lv[l].w) - 1, ry1 = std::min(y0 + 32, g.lv[l].h) - 1;  // inclusive
+          int rx0 = x0, ry0 = y0, rx1 = std::min(x0 + TS, g.lv[l].w) - 1, ry1 = std::min(y0 + TS, g.lv[l].h) - 1;  // inclusive
           for (int k = l; k >= 0; k--) {
             const int w = rx1 - rx0 + 1, h = ry1 - ry0 + 1;
             if (w > 255 || h > 255) { ok = false; break; }
@@ -368,6 +371,7 @@ int ensure_geometry(orbfe_extractor* e, int W, int H) {
           if (!ok) break;
           tiles.push_back(t);
         }
+    }
     bufA = (bufA + 15) & ~(size_t)15;
     bufB = (bufB + 15) & ~(size_t)15;
     if (ok && bufA + bufB + (size_t)(maxW + maxH) * 8 > (size_t)60 * 1024) ok = false;
@@ -609,8 +613,7 @@ int run_chunk(orbfe_extractor* e, hipStream_t s, int sub, LevelView level0, int 
   const bool pyrBlur = e->pyrBlur && !fused && !lanes && nFrames > 8;
   // a few frames (the live camera): the whole pyramid in ONE launch -- every tile recomputes its chain from level 0 in LDS
   // (k_pyramid_chain) -- instead of n-1 dependent launches of a few microseconds each
-  static const bool kChainOff = getenv("ORBFE_PYR_CHAIN") && atoi(getenv("ORBFE_PYR_CHAIN")) == 0;
-  const bool chain = !kChainOff && e->chainOk && !pyrBlur && !fused && nFrames <= 8 && !(ko & 1);
+  const bool chain = e->pyrChain && e->chainOk && !pyrBlur && !fused && nFrames <= 8 && !(ko & 1);
   if (chain) {
     StageTimer t(e, ORBFE_STAGE_PYRAMID, 1, nFrames, sub, s);
     PyrChainArgs ca = {};
@@ -893,6 +896,7 @@ extern "C" int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlev
   if (const char* env = getenv("ORBFE_LANES")) e->laneMode = atoi(env) != 0;
   if (const char* env = getenv("ORBFE_FUSED")) e->fused = atoi(env) != 0;
   if (const char* env = getenv("ORBFE_PYRBLUR")) e->pyrBlur = atoi(env) != 0;
+  if (const char* env = getenv("ORBFE_PYR_CHAIN")) e->pyrChain = atoi(env) != 0;
   if (const char* env = getenv("ORBFE_BLUR_SPEC")) {
     const int v = atoi(env);
     if (v >= 0 && v <= 2) e->blurSpec = v;
@@ -1714,6 +1718,17 @@ extern "C" int orbfe_extractor_set_pyramid_blur(orbfe_extractor* e, int enable) 
   int rc = sync_all(e);
   if (rc) return rc;
   e->pyrBlur = enable != 0;
+  return ORBFE_OK;
+}
+
+// The pyramid of a call of <= 8 frames in ONE launch (k_pyramid_chain) instead of n-1 dependent resize launches.  Identical
+// results; off by default (measured: no faster).
+extern "C" int orbfe_extractor_set_pyramid_chain(orbfe_extractor* e, int enable) {
+  if (!e) return fail(ORBFE_ERR_INVALID, "NULL handle");
+  HIPCHK(hipSetDevice(e->device));
+  int rc = sync_all(e);
+  if (rc) return rc;
+  e->pyrChain = enable != 0;
   return ORBFE_OK;
 }
 

@@ -284,6 +284,10 @@ class ORBextractor:
         """ComputePyramid + GaussianBlur as one kernel per level (default) or as separate launches; identical results."""
         check(self._L.orbfe_extractor_set_pyramid_blur(self._h, int(bool(enable))))
 
+    def set_pyramid_chain(self, enable: bool):
+        """calls of <= 8 frames: the whole pyramid in one launch (k_pyramid_chain) instead of n-1 resize launches; identical results."""
+        check(self._L.orbfe_extractor_set_pyramid_chain(self._h, int(bool(enable))))
+
     def set_fused(self, enable: bool):
         """GaussianBlur inside the FAST kernel (default) or as its own launch; identical results."""
         check(self._L.orbfe_extractor_set_fused(self._h, int(bool(enable))))

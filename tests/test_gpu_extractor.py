@@ -645,3 +645,27 @@ def test_pipelined_host_batch_keeps_the_last_chunk_only(amd):
     assert np.array_equal(e.pyramid_level(2, frame=519), o.split_pyramid(pyr, w, h)[2])
     with pytest.raises(amd.OrbfeError, match="not retained"):
         e.pyramid_level(0, frame=0)
+
+
+
+@pytest.mark.parametrize("shape,cfg", [((1241, 376), (2000, 1.2, 8, 20, 7)), ((640, 480), (1000, 1.2, 8, 20, 7)), ((333, 217), (500, 1.2, 8, 20, 7)),
+                                       ((752, 480), (1200, 1.1, 10, 20, 7)), ((640, 480), (800, 1.4, 6, 20, 7))])
+def test_pyramid_in_one_launch_matches_the_level_by_level_form(amd, shape, cfg):
+    """orbfe_extractor_set_pyramid_chain(1): every tile of every level recomputed from level 0 in LDS (k_pyramid_chain) --
+    the pyramid levels, keypoints and descriptors of single-frame calls equal the oracle's (scale 1.4 / deep pyramids whose
+    rectangles do not fit LDS fall back to the launches: same results either way)."""
+    w, h = shape
+    img = synth.render_frame(31, w, h)
+    e = amd.ORBextractor(*cfg)
+    e.set_pyramid_chain(True)
+    o = orc.Oracle(*cfg)
+    kr, dr, pyr = o.extract(img, want_pyramid=True)
+    for _ in range(2):
+        k, d = e(img)
+        assert np.array_equal(k, kr) and np.array_equal(d, dr)
+    for l, ref in enumerate(o.split_pyramid(pyr, w, h)):
+        assert np.array_equal(e.pyramid_level(l), ref), l
+    (k2, d2), (k3, d3) = e.extract_batch(np.stack([img, img[::-1].copy()]))  # two frames: still the one-launch form
+    assert np.array_equal(k2, kr) and np.array_equal(d2, dr)
+    kf, df, _ = o.extract(np.ascontiguousarray(img[::-1]), want_pyramid=True)
+    assert np.array_equal(k3, kf) and np.array_equal(d3, df)
