@@ -666,6 +666,7 @@ __global__ __launch_bounds__(256) void k_gather_candidates(const CellDesc* __res
     const int c = cb + tid;
     const int v = c < g.nCells ? cnt[c] : 0;
     // wave inclusive scan
+    // wave inclusive scan (LDS permutes: this kernel runs next to the VALU-bound ones, see k_octree.hip octree_wave_incl_scan)
     int x = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {

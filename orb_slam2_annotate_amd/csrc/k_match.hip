@@ -27,14 +27,7 @@ __device__ __forceinline__ int hdist(const Desc& a, const Desc& b) {
   for (int i = 0; i < 8; i++) d += __popc(a.w[i] ^ b.w[i]);
   return d;
 }
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64);
-    v = t < v ? t : v;
-  }
-  return v;
-}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { return wave_min_u32_dpp(v); }  // (kernels.h: DPP, not ds_bpermute)
 // rotation-histogram bin, src/ORBmatcher.cc:272-279 (C round(): half away from zero)
 __device__ __forceinline__ int rot_bin(float a1, float a2) {
   const float factor = 1.0f / 30;
@@ -100,15 +93,7 @@ __device__ __forceinline__ void bow_node(const BowArgs& a, const NodePair np, in
       else if (dist < best2) best2 = dist;
     }
     // two smallest of the multiset, first position of the minimum
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const uint32_t ok1 = (uint32_t)__shfl_xor((int)key1, o, 64);
-      const uint32_t ob2 = (uint32_t)__shfl_xor((int)best2, o, 64);
-      const uint32_t lo = ok1 < key1 ? ok1 : key1, hi = ok1 < key1 ? key1 : ok1;
-      const uint32_t m2 = ob2 < best2 ? ob2 : best2;
-      key1 = lo;
-      best2 = (hi >> 16) < m2 ? (hi >> 16) : m2;
-    }
+    wave_top2_dpp(key1, best2);
     const uint32_t bestDist1 = key1 >> 16, pos = key1 & 0xffffu;
     const bool pass1 = a.strictLow ? (bestDist1 < 50u) : (bestDist1 <= 50u);  // :263 vs :686
     if (pass1 && (float)bestDist1 < __fmul_rn(a.nnratio, (float)best2)) {
@@ -137,7 +122,27 @@ __device__ __forceinline__ void bow_node(const BowArgs& a, const NodePair np, in
 // (three dependent round trips, ~40 us per node -- and the LARGEST node of a pair decides how long the launch takes);
 // here a node is two round trips plus ~100 ALU cycles per query.  Same scan order, same claims: the key carries the
 // candidate's position in the node, so the minimum over lanes and slots is the reference's first minimum.
-template <int NC>
+// the wave's two smallest distances: DPP (kernels.h) in the single-call kernels, whose launch lasts as long as the queries of
+// its largest node walk this reduction one after the other (129 queries: 74 -> 54 us); LDS permutes in the batch kernel of the
+// device-resident pipelines, where thousands of node waves overlap and the VALU port is what they share with the extractor's
+// kernels (EuRoC stereo, same box: 99.8 k with the permutes, 98.8 k with DPP)
+template <bool kDpp>
+__device__ __forceinline__ void bow_top2(uint32_t& key1, uint32_t& best2) {
+  if constexpr (kDpp) { wave_top2_dpp(key1, best2); return; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t ok1k = (uint32_t)__shfl_xor((int)key1, o, 64);
+    const uint32_t ob2 = (uint32_t)__shfl_xor((int)best2, o, 64);
+    const uint32_t lo = ok1k < key1 ? ok1k : key1, hi = ok1k < key1 ? key1 : ok1k;
+    const uint32_t m2 = ob2 < best2 ? ob2 : best2;
+    key1 = lo;
+    best2 = (hi >> 16) < m2 ? (hi >> 16) : m2;
+  }
+  key1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)key1);
+  best2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)best2);
+}
+
+template <int NC, bool kDpp>
 __device__ __forceinline__ void bow_node_regs(const BowArgs& a, const NodePair np, int lane) {
   uint32_t idx2[NC];
   bool free2[NC];
@@ -179,17 +184,7 @@ __device__ __forceinline__ void bow_node_regs(const BowArgs& a, const NodePair n
           if (dist < (key1 >> 16)) { best2 = key1 >> 16; key1 = (dist << 16) | (uint32_t)(lane + 64 * c); }
           else if (dist < best2) best2 = dist;
         }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t ok1k = (uint32_t)__shfl_xor((int)key1, o, 64);
-        const uint32_t ob2 = (uint32_t)__shfl_xor((int)best2, o, 64);
-        const uint32_t lo = ok1k < key1 ? ok1k : key1, hi = ok1k < key1 ? key1 : ok1k;
-        const uint32_t m2 = ob2 < best2 ? ob2 : best2;
-        key1 = lo;
-        best2 = (hi >> 16) < m2 ? (hi >> 16) : m2;
-      }
-      key1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)key1);
-      best2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)best2);
+      bow_top2<kDpp>(key1, best2);
       const uint32_t bestDist1 = key1 >> 16, pos = key1 & 0xffffu;
       const bool pass1 = a.strictLow ? (bestDist1 < 50u) : (bestDist1 <= 50u);  // :263 vs :686
       if (pass1 && (float)bestDist1 < __fmul_rn(a.nnratio, (float)best2)) {  // wave-uniform; pos < cnt2 here
@@ -217,11 +212,11 @@ __device__ __forceinline__ void bow_node_regs(const BowArgs& a, const NodePair n
 
 // NCMAX = candidate slots per lane the launch was built for (the host knows the largest node of the call): nodes beyond
 // 64 * NCMAX candidates take the LDS-claim path
-template <int NCMAX>
+template <int NCMAX, bool kDpp = true>
 __device__ __forceinline__ void bow_node_any(const BowArgs& a, const NodePair np, int lane, uint8_t* claimed) {
-  if (np.cnt2 <= 64) bow_node_regs<1>(a, np, lane);
-  else if (NCMAX >= 2 && np.cnt2 <= 128) bow_node_regs<2>(a, np, lane);
-  else if (NCMAX >= 4 && np.cnt2 <= 256) bow_node_regs<4>(a, np, lane);
+  if (np.cnt2 <= 64) bow_node_regs<1, kDpp>(a, np, lane);
+  else if (NCMAX >= 2 && np.cnt2 <= 128) bow_node_regs<2, kDpp>(a, np, lane);
+  else if (NCMAX >= 4 && np.cnt2 <= 256) bow_node_regs<4, kDpp>(a, np, lane);
   else bow_node(a, np, lane, claimed);
 }
 
@@ -280,7 +275,7 @@ __global__ __launch_bounds__(64) void k_search_by_bow_batch(BowBatch b) {
   a.match = b.match + (size_t)p * c;
   a.bin = b.bin + (size_t)p * c;
   const NodePair np = {off1[i], off1[i + 1] - off1[i], off2[lo], off2[lo + 1] - off2[lo]};
-  bow_node_any<1>(a, np, lane, claimed);
+  bow_node_any<1, false>(a, np, lane, claimed);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -672,7 +667,7 @@ __global__ __launch_bounds__(256) void k_stereo_bucket(const float* __restrict__
   for (int base = 0; base <= rows; base += 256) {  // exclusive scan over the rows
     const int i = base + tid;
     const int v = i <= rows ? cnt[i] : 0;
-    int x = v;
+    int x = v;  // (LDS permutes on purpose: part of the batch pipeline, see k_octree.hip octree_wave_incl_scan)
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const int y = __shfl_up(x, o, 64);
@@ -774,7 +769,7 @@ __global__ __launch_bounds__(256) void k_stereo_median_cut(int N, const int32_t*
   auto pick = [&](int k) {
     const int lane = tid & 63, wave = tid >> 6;
     const int v = hist[tid];
-    int x = v;
+    int x = v;  // (LDS permutes on purpose: part of the batch pipeline, see k_octree.hip octree_wave_incl_scan)
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const int y = __shfl_up(x, o, 64);

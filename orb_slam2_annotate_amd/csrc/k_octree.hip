@@ -25,19 +25,30 @@ namespace {
 struct Rect { int16_t x0, x1, y0, y1; };
 
 // exclusive scan of a[0..len) in place (LDS) by the T threads of the workgroup; returns the total to every thread
-template <int T>
+// kDpp: the wave scan in the DPP network (kernels.h) instead of six ds_bpermute steps.  The single-frame forms take it (their
+// critical path is these scans: gather + octree 55 -> 50 us per KITTI frame); the throughput form keeps the LDS permutes -- with
+// DPP its stage was 6 % shorter alone (0.633 -> 0.596 ms per 1024 KITTI frames) but the pipelined step 1.5 % LONGER in a same-box
+// A/B (104.7 k vs 103.0 k stereo frames/s, twice): a wave that waits for the LDS crossbar leaves the VALU port to the FAST and
+// blur waves next to it, a wave walking a DPP chain (with its wait states, at s_setprio 3) does not.
+template <bool kDpp>
+__device__ __forceinline__ int octree_wave_incl_scan(int v, int lane) {
+  if constexpr (kDpp) return wave_incl_scan_dpp(v);
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  return x;
+}
+template <int T, bool kDpp>
 __device__ int block_scan_excl(int* a, int len, int* waveTot) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int run = 0;
   for (int base = 0; base < len; base += T) {
     const int i = base + tid;
     const int v = i < len ? a[i] : 0;
-    int x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int y = __shfl_up(x, o, 64);
-      if (lane >= o) x += y;
-    }
+    const int x = octree_wave_incl_scan<kDpp>(v, lane);
     if (T == 64) {  // one wavefront: the running total lives in a register
       const int tot = __builtin_amdgcn_readlane(x, 63);
       if (i < len) a[i] = run + x - v;
@@ -65,17 +76,13 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 // exclusive scan of a[0..len) in place by ONE wavefront (lane = 0..63); returns the total to every lane
+template <bool kDpp>
 __device__ __forceinline__ int wave_scan_excl(int* a, int len, int lane) {
   int run = 0;
   for (int base = 0; base < len; base += 64) {
     const int i = base + lane;
     const int v = i < len ? a[i] : 0;
-    int x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int y = __shfl_up(x, o, 64);
-      if (lane >= o) x += y;
-    }
+    const int x = octree_wave_incl_scan<kDpp>(v, lane);
     if (i < len) a[i] = run + x - v;
     run += __builtin_amdgcn_readlane(x, 63);
   }
@@ -111,6 +118,7 @@ constexpr int kRegCand = 16;
 template <bool REG, int T, bool HYB = false, int RC = kRegCand>
 __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, int* waveTot, int* sh, const int l, const int f) {
   const int tid = threadIdx.x;
+  constexpr bool kDpp = REG || T == 1024;  // the single-frame forms (see octree_wave_incl_scan)
   const LevelGeom g = a.lvg[l];
   const int M = a.maxL;
   // LDS carve (M entries each)
@@ -181,7 +189,7 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
   __syncthreads();
   for (int i = tid; i < nIni; i += T) { scanA[i] = scanB[i] > 0 ? 1 : 0; }
   __syncthreads();
-  int L = block_scan_excl<T>(scanA, nIni, waveTot);  // scanA[i] = list position of root i (if non-empty)
+  int L = block_scan_excl<T, kDpp>(scanA, nIni, waveTot);  // scanA[i] = list position of root i (if non-empty)
   for (int i = tid; i < nIni; i += T) {
     if (scanB[i] > 0) {
       Rect r;
@@ -289,7 +297,7 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
         if (!phase2) {
           for (int p = lane; p < L; p += 64) scanA[p] = inS[p];
           wave_sync();
-          m = wave_scan_excl(scanA, L, lane);
+          m = wave_scan_excl<kDpp>(scanA, L, lane);
           for (int p = lane; p < L; p += 64)
             if (inS[p]) { order[scanA[p]] = (uint16_t)p; rankOf[p] = (uint16_t)scanA[p]; }
           wave_sync();
@@ -302,7 +310,7 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
             scanA[j] = (child[4 * p] > 0) + (child[4 * p + 1] > 0) + (child[4 * p + 2] > 0) + (child[4 * p + 3] > 0) - 1;
           }
           wave_sync();
-          wave_scan_excl(scanA, E, lane);  // scanA[j] = growth before split j
+          wave_scan_excl<kDpp>(scanA, E, lane);  // scanA[j] = growth before split j
           // split j happens iff the list is still < N before it: L + scanA[j] < N (early break :774)
           m = 0;
           for (int j0 = 0; j0 < E; j0 += 64) m += __popcll(__ballot(j0 + lane < E && L + scanA[j0 + lane] < N));
@@ -316,8 +324,8 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
         }
         for (int p = lane; p < L; p += 64) scanB[p] = inS[p] ? 0 : 1;
         wave_sync();
-        const int cn0 = wave_scan_excl(scanA, m, lane);
-        const int ns0 = wave_scan_excl(scanB, L, lane);
+        const int cn0 = wave_scan_excl<kDpp>(scanA, m, lane);
+        const int ns0 = wave_scan_excl<kDpp>(scanB, L, lane);
         // E. write the next list: reverse(created) ++ survivors
         int expand = 0;
         for (int j = lane; j < m; j += 64) {
@@ -344,8 +352,11 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
             cnn[np] = cn[p];
             scanB[p] = np;
           }
+        if constexpr (kDpp) expand = wave_sum_dpp(expand);
+        else {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) expand += __shfl_xor(expand, o, 64);
+          for (int o = 32; o > 0; o >>= 1) expand += __shfl_xor(expand, o, 64);
+        }
         if (lane == 0) { sh[0] = cn0; sh[1] = ns0; sh[2] = expand; }
       }
       __syncthreads();
@@ -357,7 +368,7 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
       if (!phase2) {
         for (int p = tid; p < L; p += T) scanA[p] = inS[p];
         __syncthreads();
-        m = block_scan_excl<T>(scanA, L, waveTot);
+        m = block_scan_excl<T, kDpp>(scanA, L, waveTot);
         for (int p = tid; p < L; p += T)
           if (inS[p]) { order[scanA[p]] = (uint16_t)p; rankOf[p] = (uint16_t)scanA[p]; }
         __syncthreads();
@@ -392,7 +403,7 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
           scanA[j] = (child[4 * p] > 0) + (child[4 * p + 1] > 0) + (child[4 * p + 2] > 0) + (child[4 * p + 3] > 0) - 1;
         }
         __syncthreads();
-        block_scan_excl<T>(scanA, E, waveTot);  // scanA[j] = growth before split j
+        block_scan_excl<T, kDpp>(scanA, E, waveTot);  // scanA[j] = growth before split j
         // split j happens iff the list is still < N before it: L + scanA[j] < N (early break :774)
         if (tid == 0) sh[1] = 0;
         __syncthreads();
@@ -412,8 +423,8 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
       }
       for (int p = tid; p < L; p += T) scanB[p] = inS[p] ? 0 : 1;
       __syncthreads();
-      Cn = block_scan_excl<T>(scanA, m, waveTot);
-      nSurv = block_scan_excl<T>(scanB, L, waveTot);
+      Cn = block_scan_excl<T, kDpp>(scanA, m, waveTot);
+      nSurv = block_scan_excl<T, kDpp>(scanB, L, waveTot);
       // E. write the next list: reverse(created) ++ survivors
       if (tid == 0) sh[2] = 0;
       __syncthreads();
@@ -605,12 +616,7 @@ __global__ __launch_bounds__(1024) void k_octree_reg1024(OctreeArgs a) {
     for (int cb = 0; cb < g.nCells; cb += 1024) {
       const int c = cb + tid;
       const int v = c < g.nCells ? cnt[c] : 0;
-      int x = v;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int y = __shfl_up(x, o, 64);
-        if (lane >= o) x += y;
-      }
+      const int x = wave_incl_scan_dpp(v);
       if (lane == 63) waveTot[wave] = x;
       __syncthreads();
       int base = run;

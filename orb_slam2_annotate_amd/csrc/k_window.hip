@@ -99,13 +99,10 @@ __global__ __launch_bounds__(1024) void k_grid_build_count(GridFrame f, int sort
   {
     int m = c0 > c1 ? c0 : c1;
     m = m > c2 ? m : c2;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(m, o, 64); m = v > m ? v : m; }
+    m = wave_max_i32_dpp(m);
     if (lane == 0) atomicMax(&s_max, m);
   }
-  int incl = c0 + c1 + c2;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+  const int incl = wave_incl_scan_dpp(c0 + c1 + c2);
   if (lane == 63) s_wave[wave] = incl;
   __syncthreads();
   int base = 0;
@@ -245,12 +242,7 @@ __device__ __forceinline__ void window_search_one(const GridFrame& f, const uint
     }
   }
   if (q.best) {
-    uint32_t k = bestKey;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const uint32_t t = (uint32_t)__shfl_xor((int)k, o, 64);
-      k = t < k ? t : k;
-    }
+    const uint32_t k = wave_min_u32_dpp(bestKey);
     // (keys are unique: they carry the scan position) the owner of the minimum writes its keypoint
     if (k == 0xffffffffu) { if (lane == 0) q.best[qi] = -1; }
     else if (bestKey == k) q.best[qi] = (int)(k >> 16) <= q.maxDist ? (int32_t)bestId : -1;
@@ -325,16 +317,8 @@ __device__ __forceinline__ void claim_three_maxima(const int* hist, int* keep) {
 constexpr int kClaimRoundBits = 11, kClaimJBits = 21;
 constexpr uint32_t kClaimJMask = (1u << kClaimJBits) - 1u, kClaimTaken = 0xffffffffu;
 // wave64 sum / max through the DPP network; every lane returns the wave's value
-__device__ __forceinline__ int claim_wave_sum(int x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-  return x;
-}
-__device__ __forceinline__ int claim_wave_max(int x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(x, o, 64); x = t > x ? t : x; }
-  return x;
-}
+__device__ __forceinline__ int claim_wave_sum(int x) { return wave_sum_dpp(x); }
+__device__ __forceinline__ int claim_wave_max(int x) { return wave_max_i32_dpp(x); }
 
 // kOneJob: the (usual) single job travels as the kernel argument -- no dependent load of a block that the input copy has
 // just put into HBM in front of the kernel's first memory request

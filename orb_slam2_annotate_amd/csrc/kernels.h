@@ -12,6 +12,67 @@ namespace orbfe {
 // n / d for a run-time invariant d with the host-built multiplier M = floor(2^32 / d): the estimate
 // umulhi(n, M) is q or q-1 for EVERY 32-bit n, one compare fixes it (block-uniform operands: scalar ALU).
 #if defined(__HIPCC__)
+// ---- wave64 scans and reductions in the DPP network (row shifts / rotations inside the 16-lane rows, then the two row
+// broadcasts; checked on gfx950 by tools/ubench/dpp_scan.hip).  __shfl_up / __shfl_xor compile to ds_bpermute_b32 -- a trip
+// through the LDS crossbar, ~100 cycles of latency per step of a dependent six-step chain; a DPP step is a VALU operand
+// modifier.  Round 4 found 216 ds_bpermute in k_octree and 273 in the matcher kernels: every scan and min-reduction of the
+// latency-bound kernels went that way. ----
+__device__ __forceinline__ int wave_incl_scan_dpp(int x) {  // inclusive prefix sum over the 64 lanes
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1, 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2, 3
+  return x;
+}
+__device__ __forceinline__ int wave_sum_dpp(int x) { return __builtin_amdgcn_readlane(wave_incl_scan_dpp(x), 63); }  // -> every lane (scalar)
+__device__ __forceinline__ uint32_t wave_min_u32_dpp(uint32_t v) {  // -> every lane (scalar)
+  uint32_t t;
+  t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xf, 0xf, false); v = t < v ? t : v;  // row_ror:1
+  t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xf, 0xf, false); v = t < v ? t : v;  // row_ror:2
+  t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xf, 0xf, false); v = t < v ? t : v;  // row_ror:4
+  t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false); v = t < v ? t : v;  // row_ror:8: every lane = its row's minimum
+  t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x142, 0xa, 0xf, false); v = t < v ? t : v;      // rows 1, 3 += rows 0, 2
+  t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x143, 0xc, 0xf, false); v = t < v ? t : v;      // rows 2, 3 += rows 0..1
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ int wave_max_i32_dpp(int v) {  // -> every lane (scalar)
+  int t;
+  t = __builtin_amdgcn_update_dpp(v, v, 0x121, 0xf, 0xf, false); v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(v, v, 0x122, 0xf, 0xf, false); v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false); v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false); v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;
+  return __builtin_amdgcn_readlane(v, 63);
+}
+// The two smallest distances of the wave and the position of the first minimum (SearchByBoW's best / second best): every lane
+// brings key1 = (distance << 16 | position) of its own minimum and best2 = its own second-smallest distance; merging two
+// disjoint sets keeps the smaller key and, as second, the smallest of (the other key's distance, the two seconds).
+__device__ __forceinline__ void wave_top2_dpp(uint32_t& key1, uint32_t& best2) {  // -> every lane (scalar)
+#define ORBFE_TOP2_STEP(CTRL, RMASK, IDK, IDB)                                                                   \
+  {                                                                                                             \
+    const uint32_t ok_ = (uint32_t)__builtin_amdgcn_update_dpp((int)(IDK), (int)key1, CTRL, RMASK, 0xf, false);  \
+    const uint32_t ob_ = (uint32_t)__builtin_amdgcn_update_dpp((int)(IDB), (int)best2, CTRL, RMASK, 0xf, false); \
+    const uint32_t lo_ = ok_ < key1 ? ok_ : key1, hi_ = ok_ < key1 ? key1 : ok_;                                 \
+    const uint32_t m2_ = ob_ < best2 ? ob_ : best2;                                                              \
+    key1 = lo_;                                                                                                  \
+    best2 = (hi_ >> 16) < m2_ ? (hi_ >> 16) : m2_;                                                               \
+  }
+  // rotations inside a row: after step k a lane holds the top two of 2^k consecutive lanes of its row (disjoint halves)
+  ORBFE_TOP2_STEP(0x121, 0xf, key1, best2)
+  ORBFE_TOP2_STEP(0x122, 0xf, key1, best2)
+  ORBFE_TOP2_STEP(0x124, 0xf, key1, best2)
+  ORBFE_TOP2_STEP(0x128, 0xf, key1, best2)
+  // row broadcasts: the lanes that receive nothing merge with the identity (no candidate: distance 0xffff)
+  ORBFE_TOP2_STEP(0x142, 0xa, 0xffffffffu, 0xffffu)
+  ORBFE_TOP2_STEP(0x143, 0xc, 0xffffffffu, 0xffffu)
+#undef ORBFE_TOP2_STEP
+  key1 = (uint32_t)__builtin_amdgcn_readlane((int)key1, 63);
+  best2 = (uint32_t)__builtin_amdgcn_readlane((int)best2, 63);
+}
+
 __device__ __forceinline__ uint32_t udiv_magic(uint32_t n, uint32_t d, uint32_t M) {
   uint32_t q = __umulhi(n, M);
   if (n - q * d >= d) q++;
