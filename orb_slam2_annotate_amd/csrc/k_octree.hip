@@ -293,6 +293,11 @@ __device__ __forceinline__ void octree_body(const OctreeArgs& a, uint8_t* smem, 
         __syncthreads();
       }
       if (wave == 0) {
+        // (round 4, measured and NOT kept: these loops with FOUR entries per lane and trip, loads in front of any use, so that
+        // the two or three dependent LDS round trips of an entry overlap -- this section is 13 k of the 26 k cycles of a pass
+        // at level 0 of a KITTI frame.  Bit-equal, and slower everywhere: stage 0.62 -> 0.78 ms per 1024 KITTI frames, 1.19 ->
+        // 1.64 per 4096 VGA frames, single frame 50 -> 54 us: most passes walk lists shorter than one trip, and the
+        // unrolled, predicated form issues four entries' instructions for them)
         int m;
         if (!phase2) {
           for (int p = lane; p < L; p += 64) scanA[p] = inS[p];
