@@ -509,3 +509,30 @@ def test_claim_chain_longer_than_the_round_stamp(amd):
     n_got, got = amd.ORBmatcher(0.8, True).SearchByProjection(F, SF, valid, lv, view_cos, u, v, md, th=1.25)
     assert (n_got, got.tolist()) == (n_ref, ref.tolist()) and n_ref > 2060
     assert _lib.load().orbfe_debug_last_claim_rounds() > 2046
+
+
+@pytest.mark.parametrize("n_crowd", [40, 65, 700])
+def test_grid_with_a_crowded_cell(amd, n_crowd):
+    """The frame grid is built by counting (k_grid_build_count) up to 64 key points per cell and by the bitonic network
+    beyond: n_crowd key points in ONE 10 x 10 px cell plus a spread-out rest -- the windows come back in the reference's
+    scan order either way (mGrid's push_back order inside a cell, src/Frame.cc:246-259)."""
+    rng = np.random.default_rng(93 + n_crowd)
+    n_rest = 900
+    x = np.concatenate([rng.uniform(301.0, 309.0, n_crowd), rng.uniform(0, 640, n_rest)]).astype(np.float32)
+    y = np.concatenate([rng.uniform(201.0, 209.0, n_crowd), rng.uniform(0, 480, n_rest)]).astype(np.float32)
+    perm = rng.permutation(len(x))  # the crowd is not contiguous in index order
+    x, y = x[perm], y[perm]
+    n = len(x)
+    octv = rng.integers(0, 8, n).astype(np.int32)
+    ang = rng.uniform(0, 360, n).astype(np.float32)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    F, Fo = _both(amd, x, y, octv, ang, desc, None)
+    qx = np.array([305.0, 305.0, 100.0, 320.0, 304.0], np.float32)
+    qy = np.array([205.0, 205.0, 100.0, 240.0, 206.0], np.float32)
+    r = np.array([3.0, 60.0, 30.0, 500.0, 12.0], np.float32)
+    lo = np.array([-1, 0, -1, 2, 1], np.int32)
+    hi = np.array([-1, 3, -1, -1, 5], np.int32)
+    got = F.GetFeaturesInArea(qx, qy, r, lo, hi, capacity=16)
+    for q in range(len(qx)):
+        assert got[q].tolist() == Fo.features_in_area(qx[q], qy[q], r[q], lo[q], hi[q]).tolist(), q
+    assert len(got[1]) > n_crowd // 3
