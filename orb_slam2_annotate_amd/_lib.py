@@ -52,7 +52,7 @@ EXPORTS = [
     "orbfe_extract_batch_device", "orbfe_extract_batch_device_async", "orbfe_extract_batch_pipelined", "orbfe_host_alloc", "orbfe_host_free", "orbfe_extract_stereo_frame", "orbfe_extractor_synchronize", "orbfe_extractor_level_size", "orbfe_extractor_get_pyramid_level",
     "orbfe_extractor_pyramid_level_device", "orbfe_extractor_debug_candidates",
     "orbfe_extractor_debug_blurred_level", "orbfe_extractor_debug_host_octree", "orbfe_debug_octree_host", "orbfe_debug_geometry",
-    "orbfe_debug_resize_tables", "orbfe_debug_resize_tiles", "orbfe_extractor_set_streams", "orbfe_extractor_set_fused", "orbfe_extractor_set_pyramid_blur", "orbfe_extractor_set_pyramid_chain", "orbfe_extractor_set_fast_mode", "orbfe_extractor_set_schedule", "orbfe_extractor_set_desc_tiles", "orbfe_extractor_set_blur_spec", "orbfe_gaussian_blur7_spec", "orbfe_extractor_profile", "orbfe_extractor_profile_get",
+    "orbfe_debug_resize_tables", "orbfe_debug_resize_tiles", "orbfe_extractor_set_streams", "orbfe_extractor_set_fused", "orbfe_extractor_set_pyramid_blur", "orbfe_extractor_set_pyramid_chain", "orbfe_set_blur_pass_order", "orbfe_extractor_set_fast_mode", "orbfe_extractor_set_schedule", "orbfe_extractor_set_desc_tiles", "orbfe_extractor_set_blur_spec", "orbfe_gaussian_blur7_spec", "orbfe_extractor_profile", "orbfe_extractor_profile_get",
     "orbfe_stage_name", "orbfe_resize_linear", "orbfe_gaussian_blur7", "orbfe_descriptor_distance",
     "orbfe_hamming_matrix", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",
     "orbfe_search_for_triangulation", "orbfe_frame_upload", "orbfe_frame_release", "orbfe_frame_get_view", "orbfe_search_by_bow_resident", "orbfe_search_by_bow_kf_resident", "orbfe_search_for_triangulation_multi", "orbfe_fuse_search_multi", "orbfe_search_by_bow_multi", "orbfe_search_by_bow_kf_multi", "orbfe_search_by_projection_keyframe_multi", "orbfe_frame_from_extractor", "orbfe_frame_from_device", "orbfe_frame_set_featvec", "orbfe_compute_stereo_matches", "orbfe_stereo_match_batch_device", "orbfe_vocabulary_load_text", "orbfe_vocabulary_create", "orbfe_vocabulary_destroy",
@@ -167,6 +167,8 @@ def load():
                                                         ci, cf, ci, vp, vp]
     L.orbfe_search_by_projection_keyframe.argtypes = [ci, fwp, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, cf, ci, ci, vp, vp]
     L.orbfe_search_by_projection_sim3.argtypes = [ci, fwp, vp, ci, vp, ci, vp, vp, vp, vp, vp, cf, vp, vp]
+    L.orbfe_set_blur_pass_order.argtypes = [ci]
+    L.orbfe_set_blur_pass_order.restype = ci
     L.orbfe_debug_last_claim_rounds.argtypes = []
     L.orbfe_debug_last_claim_rounds.restype = ci
     L.orbfe_search_for_initialization.argtypes = [ci, fwp, fwp, vp, vp, ci, cf, ci, vp, vp]

@@ -1732,6 +1732,12 @@ extern "C" int orbfe_extractor_set_pyramid_chain(orbfe_extractor* e, int enable)
   return ORBFE_OK;
 }
 
+// Order of the blur kernel's two passes (process-wide, k_blur.hip); the blurred bytes are the same either way.
+extern "C" int orbfe_set_blur_pass_order(int order) {
+  if (order >= 0) set_blur_pass_order(order);
+  return blur_pass_order();
+}
+
 // Schedule of the sub-batches of a call: 0 = one independent stream per sub-batch, 1 = three lanes shared by all
 // sub-batches (pyramid | FAST + blur | gather + octree + orientation/descriptors) as a software pipeline.
 extern "C" int orbfe_extractor_set_desc_tiles(orbfe_extractor* e, int enable) {

@@ -20,6 +20,14 @@
 //      accumulate), rounding, one 32-bit coalesced store per 4 pixels.
 // Every source byte is read once per tile (+ halo), every output written once; measured: 61 % VALU
 // issue, the rest is waiting for the tile's own staging loads.
+// HF = true (round 4, second half) swaps the passes -- both are exact integer sums, so the bytes are the same:
+//   2'. HORIZONTAL pass on the staged BYTES with v_dot4_u32_u8 (four taps per instruction: 10 per 4 pixels; the 8.8
+//       row sums <= 255 * 257 fit 16 bits), a thread takes 4 columns of a ROW PAIR and leaves one dword per column in
+//       LDS = (h[2p][c], h[2p+1][c]);
+//   3'. VERTICAL pass with v_dot2_u32_u16 on those row pairs (two taps per instruction, 32-bit accumulate), a thread
+//       owns 4 columns x 4 rows: five 16-byte LDS reads, 64 dot2, rounding, one 32-bit store per row.
+//   6.4 VALU per pixel instead of 9.9 for the two passes (no byte -> u16 split, no repacking between the passes).
+#include <atomic>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -59,7 +67,7 @@ struct BlurBatch {
   int ablate;  // 0; $ORBFE_BLUR_ABLATE, timing experiments (tools/ablate_blur.sh): 1 no blur stores, 2 no next-level stores, 4 no staging loads, 8 no resize at all
 };
 
-template <int SPEC, int kBW, int kBH, bool RESIZE>
+template <int SPEC, int kBW, int kBH, bool RESIZE, bool HF>
 __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   constexpr int kVDW = (kBW + 8) / 4;  // dword columns the blur needs: bx-4 .. bx+kBW+3
   // RESIZE: one more staged dword per row -- an 8-byte tap window that starts in the tile's last column ends at bx+kBW+6
@@ -73,7 +81,9 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   constexpr int kVR = 5;                             // output rows per vertical-pass item (see phase 2)
   constexpr int kVB = (kBH + kVR - 1) / kVR;         // row blocks of a full tile: 13 / 7 -- the last one runs past the tile
   __shared__ __attribute__((aligned(16))) uint32_t tin[(kVB * kVR + 6) * kTDW];  // source bytes: kTH staged rows (+ the last block's overhang)
-  __shared__ uint2 vbuf[kVB * kVR * kVDW];         // vertical sums, 4 u16 per entry
+  constexpr int kPairs = (kTH + 1) / 2;            // HF: row pairs of the staged tile (35 / 19)
+  __shared__ uint2 vbuf[HF ? 1 : kVB * kVR * kVDW];  // vertical sums, 4 u16 per entry
+  __shared__ __attribute__((aligned(16))) uint32_t hpair[HF ? kPairs * kBW : 4];  // HF: horizontal sums, (row 2p, row 2p+1) of a column per dword
   __shared__ uint4 s_col[RESIZE ? 48 : 1];         // RESIZE: column records of the groups this tile owns
   __shared__ uint4 s_row[RESIZE ? 80 : 1];         //         and row records of the output rows it owns (<= 65 at scale >= 1)
   __shared__ int s_g0, s_nG, s_d0, s_d1;
@@ -241,6 +251,96 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
       }
     }
   }
+  uint8_t* D = dst.base + (size_t)f * dst.frameStride + (size_t)by * dst.pitch + bx;
+  // rounding of four 16.16 sums (the four columns of a group in one row) and their bytes as one dword
+  auto finish = [&](uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, const bool simdCols) -> uint32_t {
+    if (SPEC != 0) {
+      if (SPEC == 2 && simdCols) {  // round-half-to-even of x / 2^16: + 0x7fff + (bit 16 of x)
+        o0 += 0x7fffu + ((o0 >> 16) & 1u); o1 += 0x7fffu + ((o1 >> 16) & 1u);
+        o2 += 0x7fffu + ((o2 >> 16) & 1u); o3 += 0x7fffu + ((o3 >> 16) & 1u);
+      }
+      // the taps sum to 257: 255 * 257 * 257 + 2^15 reaches 257 << 16 -- saturate_cast<uchar>
+      o0 = min(o0, 0xffffffu); o1 = min(o1, 0xffffffu); o2 = min(o2, 0xffffffu); o3 = min(o3, 0xffffffu);
+    }
+    // the rounded sums are < 2^24: byte 2 of each is the result; two v_perm gather them
+    const uint32_t lo = __builtin_amdgcn_perm(o1, o0, 0x0c0c0602u);   // (o0.b2, o1.b2, 0, 0)
+    const uint32_t hi = __builtin_amdgcn_perm(o3, o2, 0x06020c0cu);   // (0, 0, o2.b2, o3.b2)
+    return lo | hi;
+  };
+  if constexpr (HF) {
+    // ---- 2'. horizontal pass on bytes: item = (row pair p, 4-pixel group g); output x of the tile takes the staged bytes
+    //          x+1 .. x+7, i.e. the group's three dwords d0 d1 d2 hold every tap of its four outputs ----
+    constexpr uint32_t W0a = K0 << 8 | K1 << 16 | K2 << 24, W0b = K3 | K2 << 8 | K1 << 16 | K0 << 24;       // o0: d0 bytes 1-3, d1 bytes 0-3
+    constexpr uint32_t W1a = K0 << 16 | K1 << 24, W1b = K2 | K3 << 8 | K2 << 16 | K1 << 24, W1c = K0;       // o1: d0 2-3, d1, d2 byte 0
+    constexpr uint32_t W2a = K0 << 24, W2b = K1 | K2 << 8 | K3 << 16 | K2 << 24, W2c = K1 | K0 << 8;       // o2: d0 3, d1, d2 0-1
+    constexpr uint32_t W3b = K0 | K1 << 8 | K2 << 16 | K3 << 24, W3c = K2 | K1 << 8 | K0 << 16;            // o3: d1, d2 0-2
+    const int nPairs = (stageRows + 1) >> 1;  // (an odd last row pairs with a stale one; the sums of rows past the staged ones are never read)
+    for (int i = tid; i < nPairs * kGX; i += 256) {
+      const int p = (int)((uint32_t)i / (uint32_t)kGX), g = i - p * kGX;
+      const uint32_t* tp = &tin[(2 * p) * kTDW + g];
+      uint32_t hs[2][4];
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        const uint32_t d0 = tp[r * kTDW], d1 = tp[r * kTDW + 1], d2 = tp[r * kTDW + 2];
+        hs[r][0] = __builtin_amdgcn_udot4(d1, W0b, __builtin_amdgcn_udot4(d0, W0a, 0u, false), false);
+        hs[r][1] = __builtin_amdgcn_udot4(d2, W1c, __builtin_amdgcn_udot4(d1, W1b, __builtin_amdgcn_udot4(d0, W1a, 0u, false), false), false);
+        hs[r][2] = __builtin_amdgcn_udot4(d2, W2c, __builtin_amdgcn_udot4(d1, W2b, __builtin_amdgcn_udot4(d0, W2a, 0u, false), false), false);
+        hs[r][3] = __builtin_amdgcn_udot4(d2, W3c, __builtin_amdgcn_udot4(d1, W3b, 0u, false), false);
+      }
+      *reinterpret_cast<uint4*>(&hpair[p * kBW + 4 * g]) =
+          make_uint4(hs[0][0] | hs[1][0] << 16, hs[0][1] | hs[1][1] << 16, hs[0][2] | hs[1][2] << 16, hs[0][3] | hs[1][3] << 16);
+    }
+    __syncthreads();
+    // ---- 3'. vertical pass on the row pairs: item = (4-row block rb, group g); output row t of the tile takes the staged rows
+    //          t .. t+6: for even t the pairs t/2 .. t/2+3 weighted (K0,K1) (K2,K3) (K2,K1) (K0,0), for odd t the pairs
+    //          (t-1)/2 .. with (0,K0) (K1,K2) (K3,K2) (K1,K0) ----
+    const int rowBlocks4 = (rowsValid + 3) >> 2;   // rowBlocks4 * kGX <= 256: one item per thread
+    const int rb = (int)((uint32_t)tid / (uint32_t)kGX), g = tid - rb * kGX;
+    if (rb < rowBlocks4 && bx + 4 * g < dst.w) {
+      const uint4* hp = reinterpret_cast<const uint4*>(&hpair[(2 * rb) * kBW + 4 * g]);
+      uint32_t q[5][4];
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        const uint4 v = hp[k * (kBW / 4)];
+        q[k][0] = v.x; q[k][1] = v.y; q[k][2] = v.z; q[k][3] = v.w;
+      }
+      const bool simd = SPEC == 2 && bx + 4 * g < (dst.w & ~3);
+      const uint32_t R = (SPEC == 2 && simd) ? 0u : (1u << 15);
+      uint32_t hv[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int k0 = r >> 1;
+        uint32_t o[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          uint32_t a;
+          if ((r & 1) == 0) {
+            a = dot2(q[k0][c], pk(K0, K1), R);
+            a = dot2(q[k0 + 1][c], pk(K2, K3), a);
+            a = dot2(q[k0 + 2][c], pk(K2, K1), a);
+            a = dot2(q[k0 + 3][c], pk(K0, 0), a);
+          } else {
+            a = dot2(q[k0][c], pk(0, K0), R);
+            a = dot2(q[k0 + 1][c], pk(K1, K2), a);
+            a = dot2(q[k0 + 2][c], pk(K3, K2), a);
+            a = dot2(q[k0 + 3][c], pk(K1, K0), a);
+          }
+          o[c] = a;
+        }
+        hv[r] = finish(o[0], o[1], o[2], o[3], simd);
+      }
+      const uint32_t off = (uint32_t)(4 * rb) * (uint32_t)dst.pitch + 4u * (uint32_t)g;
+      const int nr = rowsValid - 4 * rb;  // >= 1 rows of the block lie inside the level
+      if (nr >= 4) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) *reinterpret_cast<uint32_t*>(D + (off + (uint32_t)r * (uint32_t)dst.pitch)) = hv[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+          if (r < nr) *reinterpret_cast<uint32_t*>(D + (off + (uint32_t)r * (uint32_t)dst.pitch)) = hv[r];
+      }
+    }
+  } else {
   // ---- 2. vertical pass: a thread owns 4 adjacent columns x kVR output rows; the kVR + 6 source dwords are
   //         split into u16 pairs once and shared by the rows; 8.8 sums, two pixels per lane-op ----
   for (int i = tid; i < rowBlocks * kVDW; i += 256) {
@@ -276,7 +376,6 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   // ---- 3. horizontal pass on u16 pairs: out[x] = (sum_i K[i] * v[x+4+i-3] + 2^15) >> 16 ----
   // thread = (row mod kHR, column group): the tile origin D is block-uniform (scalar), the thread keeps a
   // 32-bit byte offset and an LDS pointer and steps both by kHR rows per iteration
-  uint8_t* D = dst.base + (size_t)f * dst.frameStride + (size_t)by * dst.pitch + bx;
   // one 4-pixel group from three consecutive vbuf entries (d_k = (v'[2k], v'[2k+1]) with v' indexed from the group's column)
   auto hgroup = [&](const uint2 e0, const uint2 e1, const uint2 e2, const bool simdCols) -> uint32_t {
     const uint32_t d0 = e0.x, d1 = e0.y, d2 = e1.x, d3 = e1.y, d4 = e2.x, d5 = e2.y;
@@ -298,18 +397,7 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
     o3 = dot2(d3, pk(K2, K3), o3);
     o3 = dot2(d4, pk(K2, K1), o3);
     o3 = dot2(d5, pk(K0, 0), o3);
-    if (SPEC != 0) {
-      if (SPEC == 2 && simdCols) {  // round-half-to-even of x / 2^16: + 0x7fff + (bit 16 of x)
-        o0 += 0x7fffu + ((o0 >> 16) & 1u); o1 += 0x7fffu + ((o1 >> 16) & 1u);
-        o2 += 0x7fffu + ((o2 >> 16) & 1u); o3 += 0x7fffu + ((o3 >> 16) & 1u);
-      }
-      // the taps sum to 257: 255 * 257 * 257 + 2^15 reaches 257 << 16 -- saturate_cast<uchar>
-      o0 = min(o0, 0xffffffu); o1 = min(o1, 0xffffffu); o2 = min(o2, 0xffffffu); o3 = min(o3, 0xffffffu);
-    }
-    // the rounded sums are < 2^24: byte 2 of each is the result; two v_perm gather them
-    const uint32_t lo = __builtin_amdgcn_perm(o1, o0, 0x0c0c0602u);   // (o0.b2, o1.b2, 0, 0)
-    const uint32_t hi = __builtin_amdgcn_perm(o3, o2, 0x06020c0cu);   // (0, 0, o2.b2, o3.b2)
-    return lo | hi;
+    return finish(o0, o1, o2, o3, simdCols);
   };
   {
     // (measured and dropped: 16 pixels per thread from three ds_read_b128 with one 16-byte store -- KITTI +0.8 %, TUM -1.9 %,
@@ -324,7 +412,23 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
       if (!(bb.ablate & 1) || hv == 0x12345678u) *reinterpret_cast<uint32_t*>(D + off) = hv;
     }
   }
+  }
 }
+
+// Order of the two separable passes (process-wide; the bytes do not depend on it): 1 = horizontal on bytes, then vertical
+// on row pairs (HF, the default), 0 = vertical packed-16, then horizontal on u16 pairs (rounds 1-3).
+// $ORBFE_BLUR_HFIRST / orbfe_set_blur_pass_order.
+static std::atomic<int> g_blurPassOrder{-1};
+int blur_pass_order() {
+  int v = g_blurPassOrder.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* env = getenv("ORBFE_BLUR_HFIRST");
+    v = env ? (atoi(env) != 0) : 1;
+    g_blurPassOrder.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+void set_blur_pass_order(int order) { g_blurPassOrder.store(order != 0, std::memory_order_relaxed); }
 
 namespace {
 template <int kBW, int kBH>
@@ -348,9 +452,15 @@ void launch_blur_tiles(hipStream_t s, const LevelView* src, const LevelViewMut* 
   if (total == 0) return;
   const dim3 grid((total + 7u) / 8u * 8u);
   static const size_t pad = occupancy_pad_bytes("BLUR", 0);
-  if (spec == kBlurSpecCv2Scalar) hipLaunchKernelGGL((k_blur7<1, kBW, kBH, false>), grid, dim3(256), pad, s, bb);
-  else if (spec == kBlurSpecCv2Sse2) hipLaunchKernelGGL((k_blur7<2, kBW, kBH, false>), grid, dim3(256), pad, s, bb);
-  else hipLaunchKernelGGL((k_blur7<0, kBW, kBH, false>), grid, dim3(256), pad, s, bb);
+  if (blur_pass_order() != 0) {
+    if (spec == kBlurSpecCv2Scalar) hipLaunchKernelGGL((k_blur7<1, kBW, kBH, false, true>), grid, dim3(256), pad, s, bb);
+    else if (spec == kBlurSpecCv2Sse2) hipLaunchKernelGGL((k_blur7<2, kBW, kBH, false, true>), grid, dim3(256), pad, s, bb);
+    else hipLaunchKernelGGL((k_blur7<0, kBW, kBH, false, true>), grid, dim3(256), pad, s, bb);
+  } else {
+    if (spec == kBlurSpecCv2Scalar) hipLaunchKernelGGL((k_blur7<1, kBW, kBH, false, false>), grid, dim3(256), pad, s, bb);
+    else if (spec == kBlurSpecCv2Sse2) hipLaunchKernelGGL((k_blur7<2, kBW, kBH, false, false>), grid, dim3(256), pad, s, bb);
+    else hipLaunchKernelGGL((k_blur7<0, kBW, kBH, false, false>), grid, dim3(256), pad, s, bb);
+  }
 }
 }  // namespace
 
@@ -386,9 +496,15 @@ void launch_blur7_resize(hipStream_t s, LevelView src, LevelViewMut dst, LevelVi
   static const int kAblate = getenv("ORBFE_BLUR_ABLATE") ? atoi(getenv("ORBFE_BLUR_ABLATE")) : 0;
   bb.ablate = kAblate;
   const dim3 grid((total + 7u) / 8u * 8u);
-  if (spec == kBlurSpecCv2Scalar) hipLaunchKernelGGL((k_blur7<1, 64, 64, true>), grid, dim3(256), 0, s, bb);
-  else if (spec == kBlurSpecCv2Sse2) hipLaunchKernelGGL((k_blur7<2, 64, 64, true>), grid, dim3(256), 0, s, bb);
-  else hipLaunchKernelGGL((k_blur7<0, 64, 64, true>), grid, dim3(256), 0, s, bb);
+  if (blur_pass_order() != 0) {
+    if (spec == kBlurSpecCv2Scalar) hipLaunchKernelGGL((k_blur7<1, 64, 64, true, true>), grid, dim3(256), 0, s, bb);
+    else if (spec == kBlurSpecCv2Sse2) hipLaunchKernelGGL((k_blur7<2, 64, 64, true, true>), grid, dim3(256), 0, s, bb);
+    else hipLaunchKernelGGL((k_blur7<0, 64, 64, true, true>), grid, dim3(256), 0, s, bb);
+  } else {
+    if (spec == kBlurSpecCv2Scalar) hipLaunchKernelGGL((k_blur7<1, 64, 64, true, false>), grid, dim3(256), 0, s, bb);
+    else if (spec == kBlurSpecCv2Sse2) hipLaunchKernelGGL((k_blur7<2, 64, 64, true, false>), grid, dim3(256), 0, s, bb);
+    else hipLaunchKernelGGL((k_blur7<0, 64, 64, true, false>), grid, dim3(256), 0, s, bb);
+  }
 }
 
 void launch_blur7(hipStream_t s, LevelView src, LevelViewMut dst, int nFrames, int spec) {

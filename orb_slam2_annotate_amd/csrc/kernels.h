@@ -203,6 +203,8 @@ void launch_blur7_resize(hipStream_t s, LevelView src, LevelViewMut dst, LevelVi
                          const uint32_t* d_rowrec, const int32_t* d_tileGx, const int32_t* d_tileDy, int nFrames, int spec);
 void launch_blur7_levels(hipStream_t s, const LevelView* src, const LevelViewMut* dst, int nlevels, int nFrames,
                          int spec = kBlurSpecCv4);
+int blur_pass_order();              // 1: horizontal pass on bytes first (default), 0: vertical packed-16 first; same bytes
+void set_blur_pass_order(int order);
 
 // ---- orientation + descriptor + final keypoint record (:78-152, :905-916, :1187-1195) ----
 struct OrientDescArgs {

@@ -301,6 +301,12 @@ def resize_linear(src: np.ndarray, dw: int, dh: int, device: int = 0) -> np.ndar
     return dst
 
 
+def set_blur_pass_order(order: int) -> int:
+    """Process-wide order of the blur kernel's two separable passes (1: horizontal on bytes first, the default; 0: the
+    rounds 1-3 form, vertical packed-16 first; a negative value only queries).  Identical bytes; returns the order in force."""
+    return int(_lib.load().orbfe_set_blur_pass_order(int(order)))
+
+
 def gaussian_blur7(src: np.ndarray, device: int = 0, spec: int = 0) -> np.ndarray:
     src = np.ascontiguousarray(src, dtype=np.uint8)
     h, w = src.shape

@@ -409,6 +409,44 @@ def test_blur_spec_variants_match_the_oracle(amd, spec):
     assert d0.shape == ds.shape and not np.array_equal(d0, ds)
 
 
+def test_blur_pass_orders_give_the_oracle_bytes(amd):
+    """k_blur7 runs its two separable passes horizontal-first (bytes through v_dot4, then row pairs through v_dot2: the
+    default since round 4) or vertical-first (rounds 1-3), orbfe_set_blur_pass_order / $ORBFE_BLUR_HFIRST.  Both are exact
+    integer sums: every spec, every tile shape case (partial tiles, one-tile images, odd last row pair, images narrower than a
+    group) and the fused pyramid + blur form give the oracle's bytes in both orders."""
+    rng = np.random.default_rng(11)
+    was = amd.set_blur_pass_order(-1)
+    try:
+        for order in (0, 1):
+            assert amd.set_blur_pass_order(order) == order
+            for spec in (0, 1, 2):
+                for (w, h) in ((640, 480), (1241, 376), (333, 217), (130, 65), (70, 66), (64, 64), (65, 7), (5, 9), (7, 9)):
+                    imgs = [rng.integers(0, 256, (h, w), dtype=np.uint8), np.full((h, w), 255, np.uint8)]
+                    if spec:
+                        imgs.append(rng.integers(250, 256, (h, w), dtype=np.uint8))
+                    for img in imgs:
+                        assert np.array_equal(orc.gaussian_blur7(img, spec), amd.gaussian_blur7(img, spec=spec)), (order, spec, w, h)
+            # the extractor: single frame (separate launches) and a 12-frame batch (fused pyramid + blur kernel per level)
+            for (w, h), params in (((1241, 376), (2000, 1.2, 8, 20, 7)), ((333, 217), (500, 1.2, 8, 20, 7))):
+                nf, sf, nl, ini, mn = params
+                frames = np.stack([synth.render_frame(900 + i, w, h) for i in range(12)])
+                o = orc.Oracle(nf, sf, nl, ini, mn)
+                e = amd.ORBextractor(nf, sf, nl, ini, mn)
+                kps, desc = e(frames[0])
+                kr, dr, pyr = o.extract(frames[0], want_pyramid=True)
+                for l, ref in enumerate(o.split_pyramid(pyr, w, h)):
+                    assert np.array_equal(orc.gaussian_blur7(ref), e.debug_blurred_level(l)), (order, l)
+                _kp_equal(kr, kps)
+                assert np.array_equal(dr, desc)
+                res = e.extract_batch(frames)
+                for f in range(len(frames)):
+                    kr, dr = o.extract(frames[f])
+                    _kp_equal(kr, res[f][0])
+                    assert np.array_equal(dr, res[f][1]), (order, f)
+    finally:
+        amd.set_blur_pass_order(was)
+
+
 def test_pipelined_host_batch_equals_oracle(amd):
     """orbfe_extract_batch_pipelined: chunks of the host batch move H2D / through the kernels / D2H on separate streams.
     Several chunks + a short tail, 1 and 3 sub-batch streams, pinned and ordinary (page-locked for the call) buffers,
