@@ -822,6 +822,8 @@ class LazyDist:
 def reduce_report(dt, units, torch, dist, use_dist, dev):
     if not use_dist:
         return dt, units
+    if getattr(dist, "backend", "nccl") != "nccl":
+        dev = "cpu"  # gloo (ranks sharing one GPU in the rehearsal test): host tensors
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     n = torch.tensor([units], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1134,6 +1136,11 @@ def main():
     use_dist = world > 1 or args.force_dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # one rank per GPU; with fewer devices than ranks (the 2-rank rehearsal of configs[4] on a one-GPU box, gloo backend:
+    # RCCL refuses two ranks on one device) the ranks share the devices round-robin and the line says so
+    n_dev = max(1, torch.cuda.device_count())
+    ranks_per_gpu = (world + n_dev - 1) // n_dev
+    local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)  # before the process group: RCCL binds the communicator to the current device
     if use_dist:
         dist = LazyDist(dist, args.dist_backend, rank, world, torch.device("cuda", local_rank), eager=args.eager_dist)
@@ -1181,6 +1188,8 @@ def main():
                            "sharding": f"independent frames, one resident batch per GPU x{world}, no data-path collective"},
                 "roofline": head["roofline"], "parity_check": head["parity_check"],
             }
+            if ranks_per_gpu > 1:
+                out["config"]["ranks_per_gpu"] = ranks_per_gpu  # oversubscribed rehearsal: the value is not a rate of N GPUs
             for k in ("repeats", "cpu_baseline", "vs_cpu_baseline", "e2e", "stereo_matches_per_frame", "matching_work"):
                 if head.get(k) is not None:
                     out[k] = head[k]
