@@ -331,7 +331,11 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
       }
       const uint32_t off = (uint32_t)(4 * rb) * (uint32_t)dst.pitch + 4u * (uint32_t)g;
       const int nr = rowsValid - 4 * rb;  // >= 1 rows of the block lie inside the level
-      if (nr >= 4) {
+      if (bb.ablate & 1) {  // (block-uniform timing switch of tools/ablate_blur.sh: the sums stay live, nothing is stored)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (hv[r] == 0x12345678u && r < nr) *reinterpret_cast<uint32_t*>(D + (off + (uint32_t)r * (uint32_t)dst.pitch)) = hv[r];
+      } else if (nr >= 4) {
 #pragma unroll
         for (int r = 0; r < 4; r++) *reinterpret_cast<uint32_t*>(D + (off + (uint32_t)r * (uint32_t)dst.pitch)) = hv[r];
       } else {

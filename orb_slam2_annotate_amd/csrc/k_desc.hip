@@ -48,7 +48,11 @@ __device__ __forceinline__ void wave_sync_lds() {
 // launches of a few frames (4 per wavefront, 4x the workgroups: the serial chain per wave is 4x shorter).
 // kUM / kUD: keypoints whose row loads (moments) / patch loads (descriptors) a wave keeps in flight at once (4 / 2;
 // 8 / 4 measured no faster, see launch_orient_desc).
-template <int kKpPerBlock, int kUM, int kUD>
+// kAbl: the $ORBFE_ORIENT_ABLATE hooks are compiled in (tools/ablate_orient.sh).  As a run-time argument alone the
+// sampling switch (bit 4) put TWO scalar branches around every one of the 16 samples a lane takes per keypoint -- 32 taken
+// or skipped branches and ~80 SALU instructions per keypoint in a kernel whose cost IS its per-wave chain -- so the
+// product build instantiates kAbl = false, where `ablate` is the constant 0.
+template <int kKpPerBlock, int kUM, int kUD, bool kAbl>
 __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
                                                      const LevelKp* __restrict__ levelKp,
                                                      const int32_t* __restrict__ levelCount,
@@ -59,8 +63,9 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
                                                      uint8_t* __restrict__ descOut,
                                                      int32_t* __restrict__ nOut, int blocksPerFrame,
                                                      int nFrames, uint32_t blocksMagic,
-                                                     int ablate /* 0; $ORBFE_ORIENT_ABLATE, timing experiments: 1 no moment loads, 2 no patch loads, 4 no sampling */,
+                                                     int ablateArg /* 0; $ORBFE_ORIENT_ABLATE, timing experiments: 1 no moment loads, 2 no patch loads, 4 no sampling */,
                                                      int interleave) {
+  const int ablate = kAbl ? ablateArg : 0;
   __shared__ int s_m10[kKpPerBlock], s_m01[kKpPerBlock];
   __shared__ int s_x[kKpPerBlock], s_y[kKpPerBlock], s_level[kKpPerBlock], s_out[kKpPerBlock];
   __shared__ unsigned s_score[kKpPerBlock];
@@ -314,23 +319,30 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
         // the four ballots are the 32 descriptor bytes: lane t stores ballot t (ONE 8-byte store instruction of 4 lanes
         // instead of four single-lane ones), lanes 0..6 store the seven words of the cv::KeyPoint record (one
         // instruction instead of seven) -- the kernel's memory instructions per keypoint drop from 14 to 5
-        unsigned long long bits = 0;
+        // (branch-free: `if (lane == t) bits = bt` / `if (lane == k) w = ...` compiled into twelve exec-mask branches per
+        // keypoint around LDS reads the compiler will not speculate; the ballots go to their lanes through selects on loop-invariant lane masks, the record
+        // words are read / computed by every lane -- broadcast LDS reads -- and selected)
+        uint32_t bitsLo = 0, bitsHi = 0;
 #pragma unroll
         for (int t = 0; t < 4; t++) {
           const unsigned long long bt = __ballot(t0v[u][t] < t1v[u][t]);
-          if (lane == t) bits = bt;
+          bitsLo = lane == t ? (uint32_t)bt : bitsLo;
+          bitsHi = lane == t ? (uint32_t)(bt >> 32) : bitsHi;
         }
-        if (lane < 4) dout[lane] = bits;
+        if (lane < 4) dout[lane] = (unsigned long long)bitsLo | ((unsigned long long)bitsHi << 32);
         {
           const int l = __builtin_amdgcn_readfirstlane(s_level[j]);
           const float sc = a.scale[l];
+          const uint32_t wx = __float_as_uint(__fmul_rn((float)s_x[j], sc)), wy = __float_as_uint(__fmul_rn((float)s_y[j], sc));
+          const uint32_t wa = __float_as_uint(s_angle[j]), ws = __float_as_uint((float)s_score[j]);
+          const uint32_t wz = __float_as_uint(a.kpSize[l]);
           uint32_t w = 0xffffffffu;  // class_id = -1 (lane 6)
-          if (lane == 0) w = __float_as_uint(__fmul_rn((float)s_x[j], sc));
-          if (lane == 1) w = __float_as_uint(__fmul_rn((float)s_y[j], sc));
-          if (lane == 2) w = __float_as_uint(a.kpSize[l]);
-          if (lane == 3) w = __float_as_uint(s_angle[j]);
-          if (lane == 4) w = __float_as_uint((float)s_score[j]);
-          if (lane == 5) w = (uint32_t)l;
+          w = lane == 5 ? (uint32_t)l : w;
+          w = lane == 4 ? ws : w;
+          w = lane == 3 ? wa : w;
+          w = lane == 2 ? wz : w;
+          w = lane == 1 ? wy : w;
+          w = lane == 0 ? wx : w;
           if (lane < 7) reinterpret_cast<uint32_t*>(kpOut + ((size_t)f * a.outCapacity + outIdx) * 7)[lane] = w;
         }
       }
@@ -386,17 +398,22 @@ void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d
   static const int kAblate = getenv("ORBFE_ORIENT_ABLATE") ? atoi(getenv("ORBFE_ORIENT_ABLATE")) : 0;
   static const int kInterleave = getenv("ORBFE_ORIENT_INTERLEAVE") ? atoi(getenv("ORBFE_ORIENT_INTERLEAVE")) : 1;
   if (latencyForm) {
-    hipLaunchKernelGGL((k_orient_desc<16, 4, 2>), dim3(full), dim3(256), 0, s, a, d_levelKp, d_levelCount,
-                       d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic, kAblate, kInterleave);
+    if (kAblate)
+      hipLaunchKernelGGL((k_orient_desc<16, 4, 2, true>), dim3(full), dim3(256), 0, s, a, d_levelKp, d_levelCount,
+                         d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic, kAblate, kInterleave);
+    else
+      hipLaunchKernelGGL((k_orient_desc<16, 4, 2, false>), dim3(full), dim3(256), 0, s, a, d_levelKp, d_levelCount,
+                         d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic, 0, kInterleave);
   } else {
     unsigned grid = full;
     if (kGridPerCu > 0 && (unsigned)kGridPerCu * 256u < full) grid = (unsigned)kGridPerCu * 256u;  // 256 CUs, multiple of 8
-#define ORBFE_LAUNCH_ORIENT(KPB)                                                                                           \
-  hipLaunchKernelGGL((k_orient_desc<KPB, 4, 2>), dim3(grid), dim3(256), kPad, s, a, d_levelKp, d_levelCount, d_patternF,    \
+#define ORBFE_LAUNCH_ORIENT(KPB, ABL)                                                                                      \
+  hipLaunchKernelGGL((k_orient_desc<KPB, 4, 2, ABL>), dim3(grid), dim3(256), kPad, s, a, d_levelKp, d_levelCount, d_patternF, \
                      d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic, kAblate, kInterleave)
-    if (kpb == 256) ORBFE_LAUNCH_ORIENT(256);
-    else if (kpb == 128) ORBFE_LAUNCH_ORIENT(128);
-    else ORBFE_LAUNCH_ORIENT(64);
+    if (kAblate) ORBFE_LAUNCH_ORIENT(64, true);  // (the ablation build exists for the default workgroup size only)
+    else if (kpb == 256) ORBFE_LAUNCH_ORIENT(256, false);
+    else if (kpb == 128) ORBFE_LAUNCH_ORIENT(128, false);
+    else ORBFE_LAUNCH_ORIENT(64, false);
 #undef ORBFE_LAUNCH_ORIENT
   }
 }
