@@ -352,6 +352,17 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrientDescArgs a,
   }  // work items of this workgroup
 }
 
+// keypoints whose moment-row / patch loads a wave keeps in flight at once (template kUM / kUD): 4 / 2.  A/B builds override
+// (tools/ab_build.sh um2 -DORBFE_ORIENT_UM=2 -DORBFE_ORIENT_UD=1): measured at the end of round 4, (4, 2) / (2, 1) / (1, 1) give
+// 107.0 k / 107.2 k / 106.9 k KITTI stereo frames/s and 1.28 / 1.26 / 1.27 ms exclusive -- the kernel does not wait for its
+// loads; see DESIGN.md 4 for the forms with MORE loads in flight (slower in the pipeline)
+#ifndef ORBFE_ORIENT_UM
+#define ORBFE_ORIENT_UM 4
+#endif
+#ifndef ORBFE_ORIENT_UD
+#define ORBFE_ORIENT_UD 2
+#endif
+
 void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d_levelKp,
                         const int32_t* d_levelCount, const float4* d_patternF, const uint4* d_momentTab,
                         const int32_t* d_umax, int nFrames, void* d_kpOut, uint8_t* d_descOut,
@@ -399,16 +410,16 @@ void launch_orient_desc(hipStream_t s, const OrientDescArgs& a, const LevelKp* d
   static const int kInterleave = getenv("ORBFE_ORIENT_INTERLEAVE") ? atoi(getenv("ORBFE_ORIENT_INTERLEAVE")) : 1;
   if (latencyForm) {
     if (kAblate)
-      hipLaunchKernelGGL((k_orient_desc<16, 4, 2, true>), dim3(full), dim3(256), 0, s, a, d_levelKp, d_levelCount,
+      hipLaunchKernelGGL((k_orient_desc<16, ORBFE_ORIENT_UM, ORBFE_ORIENT_UD, true>), dim3(full), dim3(256), 0, s, a, d_levelKp, d_levelCount,
                          d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic, kAblate, kInterleave);
     else
-      hipLaunchKernelGGL((k_orient_desc<16, 4, 2, false>), dim3(full), dim3(256), 0, s, a, d_levelKp, d_levelCount,
+      hipLaunchKernelGGL((k_orient_desc<16, ORBFE_ORIENT_UM, ORBFE_ORIENT_UD, false>), dim3(full), dim3(256), 0, s, a, d_levelKp, d_levelCount,
                          d_patternF, d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic, 0, kInterleave);
   } else {
     unsigned grid = full;
     if (kGridPerCu > 0 && (unsigned)kGridPerCu * 256u < full) grid = (unsigned)kGridPerCu * 256u;  // 256 CUs, multiple of 8
 #define ORBFE_LAUNCH_ORIENT(KPB, ABL)                                                                                      \
-  hipLaunchKernelGGL((k_orient_desc<KPB, 4, 2, ABL>), dim3(grid), dim3(256), kPad, s, a, d_levelKp, d_levelCount, d_patternF, \
+  hipLaunchKernelGGL((k_orient_desc<KPB, ORBFE_ORIENT_UM, ORBFE_ORIENT_UD, ABL>), dim3(grid), dim3(256), kPad, s, a, d_levelKp, d_levelCount, d_patternF, \
                      d_momentTab, d_umax, (float*)d_kpOut, d_descOut, d_nOut, blocksPerFrame, nFrames, blocksMagic, kAblate, kInterleave)
     if (kAblate) ORBFE_LAUNCH_ORIENT(64, true);  // (the ablation build exists for the default workgroup size only)
     else if (kpb == 256) ORBFE_LAUNCH_ORIENT(256, false);
