@@ -67,8 +67,11 @@ struct BlurBatch {
   int ablate;  // 0; $ORBFE_BLUR_ABLATE, timing experiments (tools/ablate_blur.sh): 1 no blur stores, 2 no next-level stores, 4 no staging loads, 8 no resize at all
 };
 
-template <int SPEC, int kBW, int kBH, bool RESIZE, bool HF>
+// ABL: the $ORBFE_BLUR_ABLATE hooks are compiled in (tools/ablate_blur.sh); the product build has `ablate` = constant 0 -- as a
+// run-time field the store switch cost a compare, three scalar instructions and a branch per trip of the resize loop (cf. k_desc.hip)
+template <int SPEC, int kBW, int kBH, bool RESIZE, bool HF, bool ABL = false>
 __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
+  const int ablate = ABL ? bb.ablate : 0;
   constexpr int kVDW = (kBW + 8) / 4;  // dword columns the blur needs: bx-4 .. bx+kBW+3
   // RESIZE: one more staged dword per row -- an 8-byte tap window that starts in the tile's last column ends at bx+kBW+6
   constexpr int kTDW = kVDW + (RESIZE ? 2 : 0);  // (19 dwords are needed; 20 keep the rows 16-byte aligned for b128 staging)
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
   constexpr int kParts = kTDW / 4;  // 5 x 16 bytes per tile row
   constexpr int kPieces = (kTH * kParts + 255) / 256;
   U4u q[kPieces] = {};
-  if (wideCols && !(bb.ablate & 4)) {
+  if (wideCols && !(ablate & 4)) {
     // 16-byte requests (any byte address, profiles/r02_unaligned.txt) and ds_write_b128, 2 staging instructions per thread
     // instead of 6 -- the memory instructions of a wave, not the bytes, are what the texture addresser meters; top /
     // bottom tiles reflect the row
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
     // now 58).  256 - nG * rowsPerPass < nG threads idle (nG = 13, 14: 9, 4).
     const int nG = s_nG, nRows = s_d1 - s_d0;
     uint8_t* Nf = bb.next.base + (size_t)f * bb.next.frameStride;
-    if (nG > 0 && nRows > 0 && !(bb.ablate & 8)) {
+    if (nG > 0 && nRows > 0 && !(ablate & 8)) {
       const uint32_t invG = 65536u / (uint32_t)nG + 1u;      // exact t / nG for t < 4096 (nG <= 16)
       const int rowsPerPass = (int)((256u * invG) >> 16);   // 256 / nG (block-uniform)
       int r = (int)(((uint32_t)tid * invG) >> 16);
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
             const uint32_t v = (__umulhi(hA, rr.z) + __umulhi(hB, rr.w) + 2u) >> 2;
             packed |= v << (8 * k);
           }
-          if (!(bb.ablate & 2) || packed == 0x12345678u) *reinterpret_cast<uint32_t*>(Nf + off) = packed;
+          if (!(ablate & 2) || packed == 0x12345678u) *reinterpret_cast<uint32_t*>(Nf + off) = packed;
         }
       }
     }
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
       }
       const uint32_t off = (uint32_t)(4 * rb) * (uint32_t)dst.pitch + 4u * (uint32_t)g;
       const int nr = rowsValid - 4 * rb;  // >= 1 rows of the block lie inside the level
-      if (bb.ablate & 1) {  // (block-uniform timing switch of tools/ablate_blur.sh: the sums stay live, nothing is stored)
+      if (ablate & 1) {  // (block-uniform timing switch of tools/ablate_blur.sh: the sums stay live, nothing is stored)
 #pragma unroll
         for (int r = 0; r < 4; r++)
           if (hv[r] == 0x12345678u && r < nr) *reinterpret_cast<uint32_t*>(D + (off + (uint32_t)r * (uint32_t)dst.pitch)) = hv[r];
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(256) void k_blur7(const BlurBatch bb) {
     for (int row = tid / kGX; row < rowsValid; row += kHR, off += (uint32_t)kHR * (uint32_t)dst.pitch, vp += kHR * kVDW) {
       if (!colIn) continue;
       const uint32_t hv = hgroup(vp[0], vp[1], vp[2], SPEC == 2 && bx + 4 * gx < (dst.w & ~3));
-      if (!(bb.ablate & 1) || hv == 0x12345678u) *reinterpret_cast<uint32_t*>(D + off) = hv;
+      if (!(ablate & 1) || hv == 0x12345678u) *reinterpret_cast<uint32_t*>(D + off) = hv;
     }
   }
   }
@@ -500,7 +503,10 @@ void launch_blur7_resize(hipStream_t s, LevelView src, LevelViewMut dst, LevelVi
   static const int kAblate = getenv("ORBFE_BLUR_ABLATE") ? atoi(getenv("ORBFE_BLUR_ABLATE")) : 0;
   bb.ablate = kAblate;
   const dim3 grid((total + 7u) / 8u * 8u);
-  if (blur_pass_order() != 0) {
+  if (kAblate) {  // (the ablation build exists for the default arithmetic only)
+    if (blur_pass_order() != 0) hipLaunchKernelGGL((k_blur7<0, 64, 64, true, true, true>), grid, dim3(256), 0, s, bb);
+    else hipLaunchKernelGGL((k_blur7<0, 64, 64, true, false, true>), grid, dim3(256), 0, s, bb);
+  } else if (blur_pass_order() != 0) {
     if (spec == kBlurSpecCv2Scalar) hipLaunchKernelGGL((k_blur7<1, 64, 64, true, true>), grid, dim3(256), 0, s, bb);
     else if (spec == kBlurSpecCv2Sse2) hipLaunchKernelGGL((k_blur7<2, 64, 64, true, true>), grid, dim3(256), 0, s, bb);
     else hipLaunchKernelGGL((k_blur7<0, 64, 64, true, true>), grid, dim3(256), 0, s, bb);
