@@ -234,8 +234,8 @@ int orbfe_extractor_set_pyramid_chain(orbfe_extractor *e, int enable);
 
 /* Order of the two separable passes of the 7x7 GaussianBlur kernel (src/ORBextractor.cc:1169-1175), process-wide.  Both
  * passes are exact integer sums, so the blurred bytes do not depend on it.  1 (default; $ORBFE_BLUR_HFIRST): horizontal
- * pass on the staged bytes with v_dot4_u32_u8, vertical pass on row pairs with v_dot2_u32_u16 (6.4 VALU instructions per
- * pixel); 0: the rounds 1-3 form, vertical packed-16 pass first (9.9 per pixel).  Returns the order now in force; a
+ * pass on the staged bytes with v_dot4_u32_u8, vertical pass on row pairs with v_dot2_u32_u16 (~160 VALU instructions per
+ * wave for the two passes); 0: the rounds 1-3 form, vertical packed-16 pass first (216 per wave).  Returns the order now in force; a
  * negative argument only queries.  Takes effect at the next launch. */
 int orbfe_set_blur_pass_order(int order);
 
