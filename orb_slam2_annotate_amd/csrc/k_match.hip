@@ -471,6 +471,9 @@ constexpr uint32_t selpair(int o) { return (uint32_t)o | 0x0c00u | ((uint32_t)(o
 // `lv` = per-level views of both pyramids in LDS (a vector level index into the kernel argument would go through scratch)
 struct StereoLds { LevelView L[kMaxLevels], R[kMaxLevels]; float scale[2 * kMaxLevels]; };  // scale: mvScaleFactor | mvInvScaleFactor
 
+// kRec: the right keypoints' sorted 16-byte records exist (pp.sortedRec; every batch call and every host call with row
+// buckets) -- a template parameter, so the candidate scan does not test a loop-invariant pointer on every trip
+template <bool kRec>
 __device__ __forceinline__ void stereo_row16(const StereoArgs& a, const StereoLds& lv, const StereoPair& pp, int iL, bool alive,
                                              int lane) {
   const int sub = lane & 15, rowBase = lane & 48;
@@ -516,7 +519,7 @@ __device__ __forceinline__ void stereo_row16(const StereoArgs& a, const StereoLd
     if (p < pEnd) {
       int iR, octR;
       float yR, uR;
-      if (pp.sortedRec) {
+      if (kRec) {
         const float4 rc = pp.sortedRec[p];
         uR = rc.x; yR = rc.y; octR = __float_as_int(rc.z); iR = __float_as_int(rc.w);
       } else {
@@ -546,7 +549,12 @@ __device__ __forceinline__ void stereo_row16(const StereoArgs& a, const StereoLd
   const uint32_t winRow = (uint32_t)(win >> rowBase) & 0xffffu;
   const int src = rowBase + (winRow ? __builtin_ctz(winRow) : 0);
   const float uR0 = __shfl(bestU, src, 64);
+  float oU = -1.0f, oD = -1.0f;
+  int oS = -1;
   // ---- SAD refinement on the left keypoint's pyramid level (:600-638) ----
+  // (wave-uniform: skipped when none of the wave's four left keypoints found a candidate below thOrbDist -- the block is
+  // 403 of the kernel's 920 VALU instructions per wave)
+  if (__builtin_amdgcn_ballot_w64(live) != 0ull) {
   const float sf = lv.scale[kMaxLevels + levelL];
   const float scaleduL = roundf(__fmul_rn(uL, sf));
   const float scaledvL = roundf(__fmul_rn(vL, sf));
@@ -624,8 +632,6 @@ __device__ __forceinline__ void stereo_row16(const StereoArgs& a, const StereoLd
   if (deltaR < -1 || deltaR > 1) live = false;
   float bestuR = __fmul_rn(lv.scale[levelL], __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));
   float disparity = __fsub_rn(uL, bestuR);
-  float oU = -1.0f, oD = -1.0f;
-  int oS = -1;
   if (live && disparity >= 0 && disparity < a.maxD) {
     if (disparity <= 0) {
       disparity = 0.01f;
@@ -635,6 +641,7 @@ __device__ __forceinline__ void stereo_row16(const StereoArgs& a, const StereoLd
     oU = bestuR;
     oS = bestSad;
   }
+  }  // any keypoint of the wave alive
   if (alive && sub == 0) { pp.uRight[iL] = oU; pp.depth[iL] = oD; pp.sad[iL] = oS; }
 }
 
@@ -707,7 +714,8 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a) {
   const int iL = blockIdx.x * 16 + (threadIdx.x >> 4);
   StereoPair pp = {a.kpL, a.descL, a.N, a.kpR, a.descR, a.Nr, a.frameL, a.frameR, a.uRight, a.depth, a.sad,
                    a.rowStart, a.sortedIdx, a.rowStart ? a.sortedRec : nullptr};
-  stereo_row16(a, lv, pp, iL, iL < a.N, lane);
+  if (pp.sortedRec) stereo_row16<true>(a, lv, pp, iL, iL < a.N, lane);
+  else stereo_row16<false>(a, lv, pp, iL, iL < a.N, lane);
 }
 
 // Batched, device-resident form: pair p = frames (2p, 2p+1) of one extractor batch; the
@@ -735,7 +743,8 @@ __global__ __launch_bounds__(256) void k_stereo_match_batch(const StereoArgs a, 
   pp.rowStart = a.rowStart ? a.rowStart + (size_t)p * (a.rows + 1) : nullptr;
   pp.sortedIdx = a.rowStart ? a.sortedIdx + (size_t)p * b.capacity : nullptr;
   pp.sortedRec = (a.rowStart && a.sortedRec) ? a.sortedRec + (size_t)p * b.capacity : nullptr;
-  stereo_row16(a, lv, pp, iL, iL < N, lane);
+  if (pp.sortedRec) stereo_row16<true>(a, lv, pp, iL, iL < N, lane);  // block-uniform
+  else stereo_row16<false>(a, lv, pp, iL, iL < N, lane);
 }
 
 // Median cut (:672-685): drop matches whose SAD >= 1.5*1.4*median, median = sorted[size/2].
